@@ -1,0 +1,141 @@
+"""The oracle's hand-derived backward passes vs an INDEPENDENT float64 autograd.
+
+The Theano graphs (public/GRU_Spatial.py:127-229, public/GRU.py:313-385, public/BPR.py:201-237)
+define a scalar cost and let T.grad differentiate it.  Theano cannot run here, so the closest
+available pin is: restate only the *forward cost* in torch float64, let torch.autograd produce the
+gradients, apply the reference's update rule and compare with oracle.*_step.  This file imports
+the oracle (it is a test) and torch CPU only.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import poi_oracle as O
+
+torch.set_default_dtype(torch.float64)
+
+
+def _toy_spatial(seed, N=23, B=7, D=5, LM=9, L=6):
+    rng = np.random.default_rng(seed)
+    P = O.init_spatial_params(rng, N, B, D)
+    P['bi'] = rng.uniform(-0.3, 0.3, (3, D)); P['bs'] = rng.uniform(-0.3, 0.3, B + 1)
+    P['h0'] = np.zeros(D)
+    p = np.full(LM, N); q = np.full(LM, N); dp = np.full(LM, B); dq = np.full(LM, B)
+    # repeated POIs on purpose (multiplicity-weighted L2, duplicate scatter)
+    p[:L] = rng.integers(0, 6, L); q[:L] = rng.integers(4, N, L)
+    dp[1:L] = rng.integers(0, B + 1, L - 1); dq[1:L] = rng.integers(0, B + 1, L - 1)
+    mask = np.array([1] * L + [0] * (LM - L))
+    return P, p, q, dp, dq, mask
+
+
+def _torch_spatial_cost(T, p, q, dp, dq, L, lam):
+    lt, di, ui, wh, bi, vs, bs, wd, lw = (T[k] for k in ('lt', 'di', 'ui', 'wh', 'bi', 'vs', 'bs', 'wd', 'loss_weight'))
+    xps, xqs, xds = lt[p], lt[q], di[dp]
+    xs = torch.cat((xps, xds), 1)
+    ls = torch.softmax(lw, 0)
+    h = torch.zeros(lt.shape[1])
+    sur = 0.0; bpr = 0.0
+    for t in range(L - 1):
+        zr = torch.sigmoid(torch.einsum('gij,j->gi', ui[:2], xs[t]) + torch.einsum('gij,j->gi', wh[:2], h) + bi[:2])
+        z, r = zr[0], zr[1]
+        c = torch.tanh(ui[2] @ xs[t] + wh[2] @ (r * h) + bi[2])
+        h = (1 - z) * h + z * c
+        s = torch.softmax(vs @ h + bs, 0)
+        u = h @ (xps[t + 1] - xqs[t + 1]) + wd * (s[dp[t + 1]] - s[dq[t + 1]])
+        bpr = bpr + torch.log(torch.sigmoid(u))
+        sur = sur + s[:dp[t + 1] + 1].sum() - torch.log(s[dp[t + 1]])
+    upq = -bpr
+    los = ls[0] * sur + ls[1] * upq
+    l2 = sum((v ** 2).sum() for v in (xps, xqs, ui, wh, bi, xds, vs, bs, wd, ls))
+    return los + 0.5 * lam * l2, los, sur, upq, ls
+
+
+@pytest.mark.parametrize("seed,L", [(0, 6), (1, 4), (2, 9)])
+def test_spatial_step_matches_autograd(seed, L):
+    alpha, lam = 0.01, 0.001
+    P, p, q, dp, dq, mask = _toy_spatial(seed, L=L)
+    T = {k: torch.tensor(np.asarray(v, float), requires_grad=True) for k, v in P.items() if k != 'h0'}
+    cost, los, sur, upq, ls = _torch_spatial_cost(T, p, q, dp, dq, L, lam)
+    cost.backward()
+    Pn, out = O.spatial_step(P, p, q, dp, dq, mask, alpha, lam)
+    assert np.isclose(out[0], los.item(), rtol=1e-13)
+    assert np.isclose(out[1], float(sur.detach()), rtol=1e-13) and np.isclose(out[2], float(upq.detach()), rtol=1e-13)
+    assert np.allclose(out[3], ls.detach().numpy(), rtol=1e-13)
+    for k in ('ui', 'wh', 'bi', 'vs', 'bs', 'wd', 'loss_weight'):
+        exp = T[k].detach().numpy() - alpha * T[k].grad.numpy()
+        assert np.allclose(np.asarray(Pn[k]), exp, rtol=1e-11, atol=1e-14), k
+    R = np.unique(np.concatenate((p, q))); S = np.unique(dp)
+    lt_exp = P['lt'].copy(); lt_exp[R] -= alpha * T['lt'].grad.numpy()[R]
+    di_exp = P['di'].copy(); di_exp[S] -= alpha * T['di'].grad.numpy()[S]
+    assert np.allclose(Pn['lt'], lt_exp, rtol=1e-11, atol=1e-14)
+    assert np.allclose(Pn['di'], di_exp, rtol=1e-11, atol=1e-14)
+    # rows outside R / S untouched, including gradient-free rows
+    untouched = np.setdiff1d(np.arange(P['lt'].shape[0]), R)
+    assert np.array_equal(Pn['lt'][untouched], P['lt'][untouched])
+
+
+def test_spatial_forward_cost_consistent_and_fd():
+    alpha, lam = 0.01, 0.001
+    P, p, q, dp, dq, mask = _toy_spatial(5)
+    c0, los, sur, upq, ls = O.spatial_forward_cost(P, p, q, dp, dq, mask, lam)
+    Pn, out = O.spatial_step(P, p, q, dp, dq, mask, alpha, lam)
+    assert np.isclose(out[0], los, rtol=1e-14)
+    # finite-difference probe on a few wh / vs entries through the update rule
+    eps = 1e-6
+    for name, idx in (('wh', (1, 2, 3)), ('vs', (2, 1)), ('ui', (2, 0, 7))):
+        Pp = {k: np.array(v, float, copy=True) for k, v in P.items()}
+        Pm = {k: np.array(v, float, copy=True) for k, v in P.items()}
+        Pp[name][idx] += eps; Pm[name][idx] -= eps
+        gfd = (O.spatial_forward_cost(Pp, p, q, dp, dq, mask, lam)[0] - O.spatial_forward_cost(Pm, p, q, dp, dq, mask, lam)[0]) / (2 * eps)
+        gor = (P[name][idx] - Pn[name][idx]) / alpha
+        assert np.isclose(gfd, gor, rtol=1e-6, atol=1e-9), (name, gfd, gor)
+
+
+def _torch_gru_cost(T, p, q, L, lam):
+    lt, ui, wh, bi = T['lt'], T['ui'], T['wh'], T['bi']
+    xps, xqs = lt[p], lt[q]
+    h = torch.zeros(lt.shape[1]); tot = 0.0
+    for t in range(L):
+        tot = tot + torch.log(torch.sigmoid(h @ (xps[t] - xqs[t])))
+        z = torch.sigmoid(ui[0] @ xps[t] + wh[0] @ h + bi[0])
+        r = torch.sigmoid(ui[1] @ xps[t] + wh[1] @ h + bi[1])
+        c = torch.tanh(ui[2] @ xps[t] + wh[2] @ (r * h) + bi[2])
+        h = (1 - z) * h + z * c
+    return -tot + 0.5 * lam * sum((v ** 2).sum() for v in (xps, xqs, ui, wh, bi)), -tot
+
+
+@pytest.mark.parametrize("seed,L", [(0, 5), (3, 8)])
+def test_gru_step_matches_autograd(seed, L):
+    alpha, lam = 0.01, 0.001
+    rng = np.random.default_rng(seed)
+    N, D, LM = 19, 6, 8
+    P = O.init_gru_params(rng, N, D); P['bi'] = rng.uniform(-0.2, 0.2, (3, D))
+    p = np.full(LM, N); q = np.full(LM, N)
+    p[:L] = rng.integers(0, 5, L); q[:L] = rng.integers(3, N, L)
+    mask = np.array([1] * L + [0] * (LM - L))
+    T = {k: torch.tensor(v, requires_grad=True) for k, v in P.items() if k != 'h0'}
+    cost, loss = _torch_gru_cost(T, p, q, L, lam)
+    cost.backward()
+    Pn, out = O.gru_step(P, p, q, mask, alpha, lam)
+    assert np.isclose(out, loss.item(), rtol=1e-13)
+    for k in ('ui', 'wh', 'bi'):
+        assert np.allclose(Pn[k], P[k] - alpha * T[k].grad.numpy(), rtol=1e-11, atol=1e-14), k
+    R = np.unique(np.concatenate((p, q)))
+    lt_exp = P['lt'].copy(); lt_exp[R] -= alpha * T['lt'].grad.numpy()[R]
+    assert np.allclose(Pn['lt'], lt_exp, rtol=1e-11, atol=1e-14)
+
+
+def test_bpr_step_matches_autograd():
+    alpha, lam = 0.01, 0.001
+    rng = np.random.default_rng(7)
+    P = O.init_bpr_params(rng, 11, 13, 8)
+    u, pi, qi = 4, 2, 9
+    T = {k: torch.tensor(v, requires_grad=True) for k, v in P.items()}
+    usr, xpq = T['ux'][u], T['lt'][[pi, qi]]
+    upq = torch.log(torch.sigmoid(usr @ (xpq[0] - xpq[1])))
+    cost = -upq + 0.5 * lam * ((usr ** 2).sum() + (xpq ** 2).sum())
+    cost.backward()
+    Pn, loss = O.bpr_step(P, u, pi, qi, alpha, lam)
+    assert np.isclose(loss, -upq.item(), rtol=1e-13)
+    assert np.allclose(Pn['ux'], P['ux'] - alpha * T['ux'].grad.numpy(), rtol=1e-12, atol=1e-15)
+    assert np.allclose(Pn['lt'], P['lt'] - alpha * T['lt'].grad.numpy(), rtol=1e-12, atol=1e-15)
