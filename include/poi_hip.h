@@ -1,0 +1,154 @@
+/*
+ * poi_hip.h - C-ABI of libpoi_hip.so: the MI355X (gfx950) implementation of the next-POI hot path
+ * of tangrizzly/Point-of-Interest-Recommendation.
+ *
+ * The reference has no FFI of its own: the hot path sits behind the duck-typed Theano model object
+ * that prog_bpr_gru_spatial.py and public/Valuate.py call.  Each entry point below
+ * names the reference method whose arithmetic it replaces (file:line relative to /root/reference);
+ * the Python classes in point-of-interest-recommendation_amd/models.py mirror those methods and
+ * reach this library through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless its name ends in _host.
+ *    Nothing is allocated for the caller; scratch memory is owned by the poi_ctx.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work;
+ *    the caller synchronises (outputs are device buffers).
+ *  - Return value: 0 on success, a negative POI_E* code otherwise; poi_last_error() returns the text.
+ *  - Index data is CSR-packed, never padded on the device: sequence u occupies positions
+ *    off[u] .. off[u+1]-1 of the flat int32 arrays p/q/dp/dq.  The reference pads every user to
+ *    len_max (public/Load_Data_by_length.py:115-124); the only arithmetic effect of the padding -
+ *    the L2 decay of the padding rows lt[n_item] / di[n_dist] (public/GRU_Spatial.py:202-203) - is
+ *    reproduced analytically from `len_max`.
+ *  - Table element type: float32 (POI_F32).  All arithmetic is float32 (reference: float64).
+ *
+ * Batch semantics (n_seq > 1, "throughput mode"; n_seq == 1 is exactly the reference step):
+ *    every sequence's reference update is evaluated at the launch-entry parameter values; each
+ *    parameter row then moves by the MEAN of the updates of the sequences that touch it (dense
+ *    tensors are touched by all n_seq sequences).  See DESIGN.md "Batch semantics".
+ */
+#ifndef POI_HIP_H
+#define POI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POI_ABI_VERSION 1
+
+enum {
+  POI_OK = 0,
+  POI_EINVAL = -1,   /* bad argument (NULL pointer, D % 4 != 0, n < 0, ...) */
+  POI_ENOMEM = -2,   /* scratch allocation failed */
+  POI_EHIP = -3,     /* a HIP runtime call failed */
+  POI_ENOTSUP = -4   /* configuration not supported by this build */
+};
+
+typedef struct poi_ctx poi_ctx;
+
+/* Parameter block of the recurrent models.
+ *   OboSpatialGru (public/GRU_Spatial.py:42-90): all fields; ui is (3, D, 2D).
+ *   OboGru        (public/GRU.py:301-311):        di/vs/bs/wd/lw NULL, n_dist 0; ui is (3, D, D).
+ * lt (n_item+1, D)  di (n_dist+1, D)  wh (3, D, D)  bi (3, D)  vs (n_dist+1, D)  bs (n_dist+1)
+ * wd (1)  lw = loss_weight (2).  h0 is the zero vector (never trained, public/GRU_Spatial.py:80-82). */
+typedef struct poi_gru_params {
+  float* lt; float* di; float* ui; float* wh; float* bi; float* vs; float* bs; float* wd; float* lw;
+  int32_t n_item; int32_t n_dist; int32_t dim;
+} poi_gru_params;
+
+/* CSR view of the reference's shared index tables tra_buys_masks / tra_buys_neg_masks /
+ * tra_dist_masks / tra_dist_neg_masks / tra_masks (public/GRU.py:50-55, public/GRU_Spatial.py:46-49).
+ * dp/dq may be NULL for OboGru.  len_max = padded row length of the reference tables. */
+typedef struct poi_seq_tables {
+  const int32_t* off; const int32_t* p; const int32_t* q; const int32_t* dp; const int32_t* dq;
+  int32_t n_user; int32_t len_max; int32_t max_len; /* max_len = longest real sequence */
+} poi_seq_tables;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int poi_abi_version(void);
+int poi_ctx_create(poi_ctx** out, int device);
+int poi_ctx_destroy(poi_ctx* ctx);
+const char* poi_last_error(const poi_ctx* ctx);   /* also valid with ctx == NULL (last global error) */
+/* number of CUs / name of the device the ctx is bound to (host-side queries) */
+int poi_ctx_num_cu(const poi_ctx* ctx);
+
+/* ---- a5: BPR-MF step - OboBpr.bpr_train(uidx, [p, q]), public/BPR.py:201-241 ----------------
+ * n independent (user, positive, negative) triples.  ux (n_user, D), lt (n_item+1, D).
+ * loss_out[n] = -log sigmoid(u).  mode: POI_BPR_SNAPSHOT = batch semantics above;
+ * POI_BPR_HOGWILD = in-place racy update (one pass over the three rows; identical to the
+ * reference whenever no row is shared inside the launch, e.g. n == 1). */
+enum { POI_BPR_SNAPSHOT = 0, POI_BPR_HOGWILD = 1 };
+int poi_bpr_step(poi_ctx* ctx, float* ux, float* lt, int32_t n_user, int32_t n_item, int32_t dim,
+                 const int32_t* uidx, const int32_t* p, const int32_t* q, int32_t n,
+                 float alpha, float lambda, float* loss_out, int mode, void* stream);
+
+/* ---- a2: Distance2Pre step - OboSpatialGru.seq_train(uidx), public/GRU_Spatial.py:127-229 ---
+ * uidx[n_seq] = user ids (rows of the CSR tables) trained in this launch.
+ * out[5*k .. 5*k+4] = [los, sur, upq, ls0, ls1] of sequence k (the 4-tuple the reference returns,
+ * public/GRU_Spatial.py:222, with ls flattened). */
+int poi_spatial_step(poi_ctx* ctx, const poi_gru_params* prm, const poi_seq_tables* tab,
+                     const int32_t* uidx, int32_t n_seq, float alpha, float lambda,
+                     float* out, void* stream);
+
+/* ---- a4: plain GRU + BPR step - OboGru.seq_train(uidx), public/GRU.py:313-389 ---------------
+ * out[k] = -sum_t log sigmoid(u_t) (public/GRU.py:380). */
+int poi_gru_step(poi_ctx* ctx, const poi_gru_params* prm, const poi_seq_tables* tab,
+                 const int32_t* uidx, int32_t n_seq, float alpha, float lambda,
+                 float* out, void* stream);
+
+/* ---- a6: predict - seq_predict(start_end), public/GRU_Spatial.py:231-288, public/GRU.py:154-205
+ * prm->lt / prm->di must point at the SNAPSHOTS trained_items / trained_dists.
+ * hts (n, D) = hidden state after the user's whole train sequence; sts (n, n_dist+1) =
+ * softmax(vs.h + bs) (spatial only; pass NULL for OboGru). */
+int poi_gru_predict(poi_ctx* ctx, const poi_gru_params* prm, const poi_seq_tables* tab,
+                    const int32_t* uidx, int32_t n, float* hts, float* sts, void* stream);
+
+/* ---- a8: all-POI scoring - compute_sub_all_scores(start_end) --------------------------------
+ * public/GRU.py:93-96, public/BPR.py:76-79; spatial variant adds wd*prob, public/GRU_Spatial.py:117-125.
+ * users (n, D) rows already selected (trained_users[start_end]); items (n_item+1, D) = trained_items
+ * (padding row dropped); prob (n, n_item) or NULL; wd read from device (NULL with prob NULL).
+ * scores_out (n, n_item) row-major. */
+int poi_score_all(poi_ctx* ctx, const float* users, const float* items, int32_t n, int32_t n_item,
+                  int32_t dim, const float* wd, const float* prob, float* scores_out, void* stream);
+
+/* ---- a8+a9 fused: scoring + top-K - public/Valuate.py:91-100,132-146 -----------------------
+ * Same score definition as poi_score_all; the (n, n_item) matrix is never materialised.
+ * idx_out (n, k) int32 sorted by descending score, ties by ascending index; score_out (n, k) or NULL. */
+int poi_score_topk(poi_ctx* ctx, const float* users, const float* items, int32_t n, int32_t n_item,
+                   int32_t dim, const float* wd, const float* prob, int32_t k,
+                   int32_t* idx_out, float* score_out, void* stream);
+
+/* ---- a9 alone: top-K of a given score matrix (checks the selection independently of the GEMM) */
+int poi_topk(poi_ctx* ctx, const float* scores, int32_t n, int32_t n_item, int32_t k,
+             int32_t* idx_out, float* score_out, void* stream);
+
+/* ---- a10: AUC preference - compute_sub_auc_preference(start_end), public/GRU.py:98-110 ------
+ * users (n, D); tes_p/tes_q/tes_mask (n, len_tes) int32; out (n, len_tes) uint8 = (u.(xp-xq))*mask > 0 */
+int poi_auc_preference(poi_ctx* ctx, const float* users, const float* items, int32_t n, int32_t dim,
+                       const int32_t* tes_p, const int32_t* tes_q, const int32_t* tes_mask,
+                       int32_t len_tes, uint8_t* out, void* stream);
+
+/* ---- model.l2.eval(): sum of squares of a flat buffer (public/GRU_Spatial.py:83-88) ----------
+ * out[0] += sum x^2 (out is a device float64 accumulator the caller zeroes). */
+int poi_sumsq(poi_ctx* ctx, const float* x, int64_t n, double* out, void* stream);
+
+/* ---- last-train-POI -> all-POI distance-bin probability rows (8f rank 2) ---------------------
+ * public/Load_Data_by_length.py:183-235 (fun_compute_distance + fun_acquire_prob) for a user batch:
+ * prob_out[k][j] = sts[k][bin] * (bin < n_dist), bin = cal_dis(coord[last_poi[k]], coord[j]).
+ * coords (n_item, 2) float64 lat,lon; sts (n, n_dist+1) float32; dd in metres. */
+int poi_dist_prob(poi_ctx* ctx, const double* coords, const int32_t* last_poi, const float* sts,
+                  int32_t n, int32_t n_item, int32_t n_dist, double dd, float* prob_out, void* stream);
+
+/* ---- multi-GPU reconciliation helpers (8e): delta = cur - base ; cur = base + sum_delta ------ */
+int poi_delta_make(poi_ctx* ctx, const float* cur, const float* base, float* delta, int64_t n, void* stream);
+int poi_delta_apply(poi_ctx* ctx, float* cur, const float* base, const float* delta_sum, int64_t n, void* stream);
+
+/* ---- primitive self-test (wave reductions, atomics) used by tests/ and smoke() --------------- */
+int poi_selftest(poi_ctx* ctx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POI_HIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libpoi_hip.so (include/poi_hip.h).  The library is the product: if it is not
+built, or a call fails, this module raises - there is no CPU fallback."""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpoi_hip.so")
+ABI_VERSION = 1
+
+BPR_SNAPSHOT, BPR_HOGWILD = 0, 1
+
+
+class PoiError(RuntimeError):
+    pass
+
+
+class GruParams(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "lw")] + \
+               [("n_item", c_int32), ("n_dist", c_int32), ("dim", c_int32)]
+
+
+class SeqTables(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("off", "p", "q", "dp", "dq")] + \
+               [("n_user", c_int32), ("len_max", c_int32), ("max_len", c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/poi_hip.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "poi_abi_version": (c_int, []),
+    "poi_ctx_create": (c_int, [POINTER(c_void_p), c_int]),
+    "poi_ctx_destroy": (c_int, [c_void_p]),
+    "poi_last_error": (c_char_p, [c_void_p]),
+    "poi_ctx_num_cu": (c_int, [c_void_p]),
+    "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                             c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
+                                 c_void_p, c_void_p]),
+    "poi_gru_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
+                             c_void_p, c_void_p]),
+    "poi_gru_predict": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_void_p, c_void_p,
+                                c_void_p]),
+    "poi_score_all": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
+    "poi_score_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                               c_void_p, c_void_p, c_void_p]),
+    "poi_topk": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "poi_auc_preference": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                   c_void_p, c_void_p]),
+    "poi_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "poi_dist_prob": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double, c_void_p,
+                              c_void_p]),
+    "poi_delta_make": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "poi_delta_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "poi_selftest": (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every exported symbol.  Raises PoiError when missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PoiError("%s is not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(no CPU fallback exists for the hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError -> missing export
+        fn.restype = res
+        fn.argtypes = args
+    if lib.poi_abi_version() != ABI_VERSION:
+        raise PoiError("libpoi_hip.so ABI %d != binding %d" % (lib.poi_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+class Context:
+    """Owns one poi_ctx (device scratch + error text) bound to a HIP device."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = c_void_p()
+        rc = self.lib.poi_ctx_create(ctypes.byref(h), int(device))
+        if rc != 0:
+            raise PoiError("poi_ctx_create(%d) failed: %s" % (device, self.lib.poi_last_error(None).decode()))
+        self.handle = h
+        self.device = int(device)
+
+    def check(self, rc):
+        if rc != 0:
+            raise PoiError("libpoi_hip error %d: %s" % (rc, self.lib.poi_last_error(self.handle).decode()))
+
+    @property
+    def num_cu(self):
+        return self.lib.poi_ctx_num_cu(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.poi_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def context(device=0):
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]

@@ -1,0 +1,335 @@
+// C-ABI of libpoi_hip.so (see include/poi_hip.h): context, scratch ownership, argument checks,
+// kernel dispatch.  No torch types, no host allocation handed to the caller.
+#include "../../include/poi_hip.h"
+#include "poi_kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+namespace {
+thread_local std::string g_err;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct poi_ctx {
+  int device = 0;
+  int num_cu = 0;
+  int wg_per_cu = 4;
+  std::string err;
+  // per-sequence engine
+  DevBuf ws, slab;
+  DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
+  // BPR
+  DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
+  // scoring
+  DevBuf cand_s, cand_i;
+  // selftest
+  DevBuf st;
+};
+
+static int fail(poi_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(c, POI_EHIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+  } while (0)
+
+// Grow-only zero-initialised device buffer.  Contents are all-zero after (re)allocation; users
+// of gradient tables rely on that and restore the zeros themselves after each launch.
+static int ensure(poi_ctx* c, DevBuf& b, size_t bytes, hipStream_t st) {
+  if (bytes <= b.bytes) return POI_OK;
+  if (b.p) { HIPCHK(c, hipStreamSynchronize(st)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+  size_t want = bytes + bytes / 8;
+  if (hipMalloc(&b.p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    want = bytes;
+    if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return fail(c, POI_ENOMEM, "hipMalloc(%zu) failed", bytes); }
+  }
+  b.bytes = want;
+  HIPCHK(c, hipMemsetAsync(b.p, 0, want, st));
+  return POI_OK;
+}
+
+extern "C" {
+
+int poi_abi_version(void) { return POI_ABI_VERSION; }
+
+const char* poi_last_error(const poi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int poi_ctx_create(poi_ctx** out, int device) {
+  if (!out) return fail(nullptr, POI_EINVAL, "poi_ctx_create: out is NULL");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, POI_EHIP, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(nullptr, POI_EINVAL, "device %d out of range (%d visible)", device, ndev);
+  poi_ctx* c = new poi_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipGetDeviceProperties failed"); }
+  c->num_cu = prop.multiProcessorCount;
+  if (const char* e = getenv("POI_SEQ_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
+  if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
+  *out = c;
+  return POI_OK;
+}
+
+int poi_ctx_destroy(poi_ctx* c) {
+  if (!c) return POI_OK;
+  DevBuf* all[] = {&c->ws, &c->slab, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di,
+                   &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->st};
+  (void)hipDeviceSynchronize();
+  for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
+  delete c;
+  return POI_OK;
+}
+
+int poi_ctx_num_cu(const poi_ctx* c) { return c ? c->num_cu : POI_EINVAL; }
+
+// ---------------------------------------------------------------------------------------------
+static int check_gru(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, bool spatial, bool need_q) {
+  if (!c || !P || !T) return fail(c, POI_EINVAL, "NULL ctx/params/tables");
+  if (P->dim <= 0 || P->dim % 4 != 0 || P->dim > 256) return fail(c, POI_ENOTSUP, "dim must be a multiple of 4 in [4, 256] (got %d)", P->dim);
+  if (!P->lt || !P->ui || !P->wh || !P->bi) return fail(c, POI_EINVAL, "lt/ui/wh/bi must be non-NULL");
+  if (spatial && (!P->di || !P->vs || !P->bs || !P->wd || !P->lw || P->n_dist <= 0)) return fail(c, POI_EINVAL, "spatial model needs di/vs/bs/wd/lw and n_dist > 0");
+  if (!T->off || !T->p) return fail(c, POI_EINVAL, "tables: off/p must be non-NULL");
+  if (need_q && !T->q) return fail(c, POI_EINVAL, "tables: q must be non-NULL");
+  if (spatial && (!T->dp || (need_q && !T->dq))) return fail(c, POI_EINVAL, "tables: dp/dq must be non-NULL for the spatial model");
+  if (T->max_len <= 0 || T->len_max < T->max_len) return fail(c, POI_EINVAL, "tables: need 0 < max_len <= len_max");
+  return POI_OK;
+}
+
+static void fill_args(poi::SeqArgs& A, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int n) {
+  memset(&A, 0, sizeof A);
+  A.lt = P->lt; A.di = P->di; A.ui = P->ui; A.wh = P->wh; A.bi = P->bi; A.vs = P->vs; A.bs = P->bs; A.wd = P->wd; A.lw = P->lw;
+  A.n_item = P->n_item; A.n_dist = P->n_dist; A.dim = P->dim;
+  A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq;
+  A.len_max = T->len_max; A.cap = T->max_len;
+  A.uidx = uidx; A.n_seq = n;
+}
+
+static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
+                    float alpha, float lambda, float* out, void* stream, bool spatial) {
+  int rc = check_gru(c, P, T, spatial, true);
+  if (rc) return rc;
+  if (!uidx || !out || n < 0) return fail(c, POI_EINVAL, "uidx/out NULL or n < 0");
+  if (n == 0) return POI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int D = P->dim, XW = spatial ? 2 * D : D, NB = spatial ? P->n_dist + 1 : 0;
+  int grid = c->num_cu * c->wg_per_cu;
+  if (grid > n) grid = n;
+  const poi::DenseLayout dl = poi::dense_layout(D, XW, NB);
+  const size_t wsf = poi::seq_ws_floats(D, NB, T->max_len);
+  if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
+  if ((rc = ensure(c, c->slab, sizeof(float) * (size_t)dl.total * grid, st))) return rc;
+  if ((rc = ensure(c, c->g_lt, sizeof(float) * (size_t)(P->n_item + 1) * D, st))) return rc;
+  if ((rc = ensure(c, c->mult_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
+  if ((rc = ensure(c, c->nseq_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
+  if (spatial) {
+    if ((rc = ensure(c, c->g_di, sizeof(float) * (size_t)(P->n_dist + 1) * D, st))) return rc;
+    if ((rc = ensure(c, c->mult_di, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
+    if ((rc = ensure(c, c->nseq_di, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
+  }
+  poi::SeqArgs A;
+  fill_args(A, P, T, uidx, n);
+  A.out = out;
+  A.ws = (float*)c->ws.p; A.ws_stride = wsf;
+  A.slab = (float*)c->slab.p;
+  A.g_lt = (float*)c->g_lt.p; A.mult_lt = (int*)c->mult_lt.p; A.nseq_lt = (int*)c->nseq_lt.p;
+  A.g_di = (float*)c->g_di.p; A.mult_di = (int*)c->mult_di.p; A.nseq_di = (int*)c->nseq_di.p;
+  HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st));
+  return POI_OK;
+}
+
+int poi_spatial_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
+                     float alpha, float lambda, float* out, void* stream) {
+  return seq_step(c, P, T, uidx, n, alpha, lambda, out, stream, true);
+}
+
+int poi_gru_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
+                 float alpha, float lambda, float* out, void* stream) {
+  return seq_step(c, P, T, uidx, n, alpha, lambda, out, stream, false);
+}
+
+int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
+                    float* hts, float* sts, void* stream) {
+  const bool spatial = P && P->di != nullptr;
+  int rc = check_gru(c, P, T, spatial, false);
+  if (rc) return rc;
+  if (!uidx || !hts || n < 0) return fail(c, POI_EINVAL, "uidx/hts NULL or n < 0");
+  if (n == 0) return POI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  poi::SeqArgs A;
+  fill_args(A, P, T, uidx, n);
+  A.hts = hts; A.sts = sts;
+  int grid = c->num_cu * c->wg_per_cu;
+  if (grid > n) grid = n;
+  HIPCHK(c, poi::launch_seq_predict(A, spatial, grid, (hipStream_t)stream));
+  return POI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_item, int32_t dim,
+                 const int32_t* uidx, const int32_t* p, const int32_t* q, int32_t n,
+                 float alpha, float lambda, float* loss_out, int mode, void* stream) {
+  if (!c || !ux || !lt || !uidx || !p || !q || !loss_out) return fail(c, POI_EINVAL, "poi_bpr_step: NULL argument");
+  if (dim <= 0 || dim % 4 != 0) return fail(c, POI_ENOTSUP, "dim must be a positive multiple of 4 (got %d)", dim);
+  if (n < 0 || n_user <= 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
+  if (mode != POI_BPR_SNAPSHOT && mode != POI_BPR_HOGWILD) return fail(c, POI_EINVAL, "unknown mode %d", mode);
+  if (n == 0) return POI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  poi::BprArgs A;
+  memset(&A, 0, sizeof A);
+  A.ux = ux; A.lt = lt; A.n_user = n_user; A.n_item = n_item; A.dim = dim;
+  A.uidx = uidx; A.p = p; A.q = q; A.n = n; A.alpha = alpha; A.lambda = lambda; A.loss = loss_out;
+  if (mode == POI_BPR_SNAPSHOT) {
+    int rc;
+    if ((rc = ensure(c, c->g_ux, sizeof(float) * (size_t)n_user * dim, st))) return rc;
+    if ((rc = ensure(c, c->cnt_ux, sizeof(int) * (size_t)n_user, st))) return rc;
+    if ((rc = ensure(c, c->g_blt, sizeof(float) * (size_t)(n_item + 1) * dim, st))) return rc;
+    if ((rc = ensure(c, c->cnt_blt, sizeof(int) * (size_t)(n_item + 1), st))) return rc;
+    A.g_ux = (float*)c->g_ux.p; A.cnt_ux = (int*)c->cnt_ux.p; A.g_lt = (float*)c->g_blt.p; A.cnt_lt = (int*)c->cnt_blt.p;
+  }
+  HIPCHK(c, poi::launch_bpr(A, mode, st));
+  return POI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int score_common(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
+                        const float* wd, const float* prob, float* scores, int32_t k, int32_t* idx_out, float* score_out,
+                        void* stream) {
+  if (!c || !users || !items) return fail(c, POI_EINVAL, "score: NULL argument");
+  if (dim <= 0 || dim % 4 != 0 || dim > 256) return fail(c, POI_ENOTSUP, "dim must be a multiple of 4 in [4, 256] (got %d)", dim);
+  if (n < 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
+  if (prob && !wd) return fail(c, POI_EINVAL, "prob given without wd");
+  if (k < 0 || k > 32 || (k > 0 && k > n_item)) return fail(c, POI_ENOTSUP, "top-K supports 1 <= k <= min(32, n_item) (got %d)", k);
+  if (n == 0) return POI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  poi::ScoreArgs A;
+  memset(&A, 0, sizeof A);
+  A.users = users; A.items = items; A.n = n; A.n_item = n_item; A.dim = dim; A.wd = wd; A.prob = prob;
+  A.scores = scores; A.k = k; A.idx_out = idx_out; A.score_out = score_out;
+  const int n_utile = (n + 31) / 32, ntile = (n_item + 31) / 32;
+  int want = (c->num_cu * 8 + n_utile - 1) / n_utile;     // aim for >= 8 wavefronts per CU
+  if (want > ntile) want = ntile;
+  int n_split = ((want + 3) / 4) * 4;
+  if (n_split < 4) n_split = 4;
+  A.n_split = n_split;
+  if (k > 0) {
+    const size_t cand = (size_t)n_split * n_utile * 32 * k;
+    int rc;
+    if ((rc = ensure(c, c->cand_s, sizeof(float) * cand, st))) return rc;
+    if ((rc = ensure(c, c->cand_i, sizeof(int) * cand, st))) return rc;
+    A.cand_score = (float*)c->cand_s.p; A.cand_idx = (int*)c->cand_i.p;
+  }
+  HIPCHK(c, poi::launch_score(A, st));
+  if (k > 0) HIPCHK(c, poi::launch_topk_merge(A, n_split, st));
+  return POI_OK;
+}
+
+int poi_score_all(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
+                  const float* wd, const float* prob, float* scores_out, void* stream) {
+  if (!scores_out) return fail(c, POI_EINVAL, "scores_out is NULL");
+  return score_common(c, users, items, n, n_item, dim, wd, prob, scores_out, 0, nullptr, nullptr, stream);
+}
+
+int poi_score_topk(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
+                   const float* wd, const float* prob, int32_t k, int32_t* idx_out, float* score_out, void* stream) {
+  if (!idx_out || k <= 0) return fail(c, POI_EINVAL, "idx_out NULL or k <= 0");
+  return score_common(c, users, items, n, n_item, dim, wd, prob, nullptr, k, idx_out, score_out, stream);
+}
+
+int poi_topk(poi_ctx* c, const float* scores, int32_t n, int32_t n_item, int32_t k, int32_t* idx_out, float* score_out,
+             void* stream) {
+  if (!c || !scores || !idx_out) return fail(c, POI_EINVAL, "poi_topk: NULL argument");
+  if (k <= 0 || k > 32 || k > n_item) return fail(c, POI_ENOTSUP, "top-K supports 1 <= k <= min(32, n_item) (got %d)", k);
+  if (n < 0) return fail(c, POI_EINVAL, "n < 0");
+  if (n == 0) return POI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, poi::launch_topk_rows(scores, n, n_item, k, idx_out, score_out, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_auc_preference(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t dim,
+                       const int32_t* tp, const int32_t* tq, const int32_t* tm, int32_t len, uint8_t* out, void* stream) {
+  if (!c || !users || !items || !tp || !tq || !tm || !out) return fail(c, POI_EINVAL, "poi_auc_preference: NULL argument");
+  if (dim <= 0 || dim % 4 != 0) return fail(c, POI_ENOTSUP, "dim must be a positive multiple of 4");
+  if (n < 0 || len < 0) return fail(c, POI_EINVAL, "bad sizes");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, poi::launch_auc(users, items, n, dim, tp, tq, tm, len, out, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_sumsq(poi_ctx* c, const float* x, int64_t n, double* out, void* stream) {
+  if (!c || !x || !out || n < 0) return fail(c, POI_EINVAL, "poi_sumsq: bad argument");
+  if (n == 0) return POI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, poi::launch_sumsq(x, n, out, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_dist_prob(poi_ctx* c, const double* coords, const int32_t* last_poi, const float* sts, int32_t n, int32_t n_item,
+                  int32_t n_dist, double dd, float* prob_out, void* stream) {
+  if (!c || !coords || !last_poi || !sts || !prob_out) return fail(c, POI_EINVAL, "poi_dist_prob: NULL argument");
+  if (n < 0 || n_item <= 0 || n_dist <= 0 || !(dd > 0)) return fail(c, POI_EINVAL, "bad sizes");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int32_t o = 0; o < n; o += 32768) {
+    const int32_t m = n - o < 32768 ? n - o : 32768;
+    HIPCHK(c, poi::launch_dist_prob(coords, last_poi + o, sts + (size_t)o * (n_dist + 1), m, n_item, n_dist, dd,
+                                    prob_out + (size_t)o * n_item, (hipStream_t)stream));
+  }
+  return POI_OK;
+}
+
+int poi_delta_make(poi_ctx* c, const float* cur, const float* base, float* delta, int64_t n, void* stream) {
+  if (!c || !cur || !base || !delta || n < 0) return fail(c, POI_EINVAL, "poi_delta_make: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, poi::launch_delta_make(cur, base, delta, n, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delta_sum, int64_t n, void* stream) {
+  if (!c || !cur || !base || !delta_sum || n < 0) return fail(c, POI_EINVAL, "poi_delta_apply: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, poi::launch_delta_apply(cur, base, delta_sum, n, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_selftest(poi_ctx* c, void* stream) {
+  if (!c) return fail(c, POI_EINVAL, "NULL ctx");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->st, 64, st);
+  if (rc) return rc;
+  HIPCHK(c, hipMemsetAsync(c->st.p, 0, 64, st));
+  float* buf = (float*)c->st.p;
+  int* flag = (int*)((char*)c->st.p + 32);
+  HIPCHK(c, poi::launch_selftest(buf, flag, st));
+  float hb[8]; int hf = -1;
+  HIPCHK(c, hipMemcpyAsync(hb, buf, sizeof hb, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(&hf, flag, sizeof hf, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (hf != 0) return fail(c, POI_EHIP, "selftest: %d wave/block reduction mismatches", hf);
+  for (int i = 0; i < 8; ++i) if (hb[i] != 256.0f) return fail(c, POI_EHIP, "selftest: float atomic count %g != 256", hb[i]);
+  return POI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Small kernels around the hot path: AUC preference, sum of squares, last-POI distance-bin
+// probabilities, replica-delta helpers, primitive self-test.
+#include "poi_common.h"
+#include "poi_kernels.h"
+
+namespace poi {
+
+// compute_sub_auc_preference (public/GRU.py:98-110): one wavefront per (user, test position).
+__global__ __launch_bounds__(POI_BLOCK) void auc_kernel(const float* __restrict__ users, const float* __restrict__ items,
+                                                         int n, int D, const int* __restrict__ tp, const int* __restrict__ tq,
+                                                         const int* __restrict__ tm, int len, uint8_t* __restrict__ out) {
+  const int e = blockIdx.x * POI_NWAVE + wave_id();
+  if (e >= n * len) return;
+  const int u = e / len;
+  const float* ur = users + (size_t)u * D;
+  const float* pr = items + (size_t)tp[e] * D;
+  const float* qr = items + (size_t)tq[e] * D;
+  float acc = 0.f;
+  for (int j = lane_id() * 4; j < D; j += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(ur + j);
+    const float4 b = *reinterpret_cast<const float4*>(pr + j);
+    const float4 c = *reinterpret_cast<const float4*>(qr + j);
+    acc += a.x * (b.x - c.x) + a.y * (b.y - c.y) + a.z * (b.z - c.z) + a.w * (b.w - c.w);
+  }
+  acc = wave_sum(acc);
+  if (lane_id() == 0) out[e] = (acc * (float)tm[e] > 0.f) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(POI_BLOCK) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* out) {
+  __shared__ double red[POI_NWAVE];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * POI_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * POI_BLOCK) {
+    const double v = (double)x[i];
+    acc += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane_id() == 0) red[wave_id()] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// cal_dis (public/Load_Data_by_length.py:24-42) in float64, operation order as written there;
+// contraction off so that products and sums round separately like the Python expression.
+__device__ __forceinline__ int cal_dis_bin(double lat1, double lon1, double lat2, double lon2, double dd, int dist_num) {
+#pragma clang fp contract(off)
+  const double d = 12742.0;
+  const double p = 0.017453292519943295;
+  const double a = (lat1 - lat2) * p;
+  const double b = (lon1 - lon2) * p;
+  const double c = (1.0 - cos(a)) / 2 + cos(lat1 * p) * cos(lat2 * p) * (1.0 - cos(b)) / 2;
+  const double dist = d * asin(sqrt(c));
+  const double q = dist * 1000 / dd;
+  int interval = q >= 2147483647.0 ? 2147483647 : (int)q;
+  return interval < dist_num ? interval : dist_num;
+}
+
+// fun_compute_distance + fun_acquire_prob (public/Load_Data_by_length.py:183-235) for a user batch.
+__global__ __launch_bounds__(POI_BLOCK) void dist_prob_kernel(const double* __restrict__ coords, const int* __restrict__ last_poi,
+                                                               const float* __restrict__ sts, int n, int N, int n_dist,
+                                                               double dd, float* __restrict__ prob) {
+  const int k = blockIdx.y;
+  const int lp = last_poi[k];
+  const double lat1 = coords[2 * lp], lon1 = coords[2 * lp + 1];
+  const float* s = sts + (size_t)k * (n_dist + 1);
+  for (int j = blockIdx.x * POI_BLOCK + threadIdx.x; j < N; j += gridDim.x * POI_BLOCK) {
+    const int bin = cal_dis_bin(lat1, lon1, coords[2 * j], coords[2 * j + 1], dd, n_dist);
+    prob[(size_t)k * N + j] = bin < n_dist ? s[bin] : 0.f;
+  }
+}
+
+__global__ void delta_make_kernel(const float* __restrict__ cur, const float* __restrict__ base, float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = cur[i] - base[i];
+}
+__global__ void delta_apply_kernel(float* __restrict__ cur, const float* __restrict__ base, const float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) cur[i] = base[i] + d[i];
+}
+
+// Self-test: DPP wave_sum/wave_max vs the ds_bpermute versions, block_sum, float atomics.
+__global__ __launch_bounds__(POI_BLOCK) void selftest_kernel(float* buf, int* fail) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  // pseudo-random but exactly representable values so that sums are order-independent
+  const float v = (float)(((tid * 2654435761u) >> 20) & 1023) - 512.0f;
+  const float a = wave_sum(v), b = wave_sum_shfl(v);
+  if (a != b) atomicAdd(fail, 1);
+  float m = v;
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (wave_max(v) != m) atomicAdd(fail, 1);
+  const float bs = block_sum(v, red);
+  float ref = 0.f;
+  for (int t = 0; t < POI_BLOCK; ++t) ref += (float)(((t * 2654435761u) >> 20) & 1023) - 512.0f;
+  if (bs != ref) atomicAdd(fail, 1);
+  atomicAdd(&buf[tid & 7], 1.0f);
+}
+
+hipError_t launch_auc(const float* users, const float* items, int n, int dim, const int* tp, const int* tq,
+                      const int* tm, int len, uint8_t* out, hipStream_t st) {
+  const int e = n * len;
+  if (e <= 0) return hipSuccess;
+  hipLaunchKernelGGL(auc_kernel, dim3((e + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, users, items, n, dim, tp, tq, tm, len, out);
+  return hipGetLastError();
+}
+hipError_t launch_sumsq(const float* x, int64_t n, double* out, hipStream_t st) {
+  int64_t g = (n + POI_BLOCK * 8 - 1) / (POI_BLOCK * 8);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)g), dim3(POI_BLOCK), 0, st, x, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_dist_prob(const double* coords, const int* last_poi, const float* sts, int n, int n_item,
+                            int n_dist, double dd, float* prob, hipStream_t st) {
+  int gx = (n_item + POI_BLOCK - 1) / POI_BLOCK;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(dist_prob_kernel, dim3(gx, n), dim3(POI_BLOCK), 0, st, coords, last_poi, sts, n, n_item, n_dist, dd, prob);
+  return hipGetLastError();
+}
+hipError_t launch_delta_make(const float* cur, const float* base, float* delta, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(delta_make_kernel, dim3(2048), dim3(256), 0, st, cur, base, delta, n);
+  return hipGetLastError();
+}
+hipError_t launch_delta_apply(float* cur, const float* base, const float* dsum, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(delta_apply_kernel, dim3(2048), dim3(256), 0, st, cur, base, dsum, n);
+  return hipGetLastError();
+}
+hipError_t launch_selftest(float* buf, int* fail, hipStream_t st) {
+  hipLaunchKernelGGL(selftest_kernel, dim3(8), dim3(POI_BLOCK), 0, st, buf, fail);
+  return hipGetLastError();
+}
+
+}  // namespace poi

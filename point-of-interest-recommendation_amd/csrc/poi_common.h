@@ -1,0 +1,149 @@
+// Device-side helpers shared by the gfx950 kernels: 64-lane wavefront reductions (DPP), block
+// reductions through LDS, and the two GEMV shapes the per-sequence engine uses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define POI_WAVE 64
+#define POI_BLOCK 256
+#define POI_NWAVE (POI_BLOCK / POI_WAVE)
+
+namespace poi {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// Sum over the 64 lanes of a wavefront; result is wave-uniform (returned in every lane).
+// Four DPP adds reduce each 16-lane row (quad swap, quad-pair swap, half-mirror, mirror), then the
+// four row sums are read through SGPRs.
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);  // row_half_mirror
+  v += dpp_f<0x140>(v);  // row_mirror
+  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+// Reference implementation through ds_bpermute, used only by the self-test.
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide (256 threads) reductions; `red` is an LDS array of >= POI_NWAVE floats.  Contains barriers.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane_id() == 0) red[wave_id()] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if (lane_id() == 0) red[wave_id()] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// log(sigmoid(x)) = -softplus(-x), stable on both sides.
+__device__ __forceinline__ float log_sigmoidf_(float x) {
+  return x >= 0.f ? -log1pf(expf(-x)) : x - log1pf(expf(x));
+}
+
+// Row-parallel GEMV: out[r] = act(W1[r,:K1].x1 + W2[r,:K2].x2 + bias[r]) for r in [0, nrows).
+// One wavefront per row (4 rows in flight per wave), lanes stride the row in float4 (coalesced
+// 1-KiB row segments from HBM/L2), wave_sum closes the dot product.  x1/x2 live in LDS.
+// ACT: 0 none, 1 sigmoid, 2 tanh.  W2 may be nullptr (K2 = 0).
+template <int ACT>
+__device__ __forceinline__ void gemv_rows(const float* __restrict__ W1, int K1, const float* x1,
+                                          const float* __restrict__ W2, int K2, const float* x2,
+                                          const float* __restrict__ bias, int nrows, float* out) {
+  const int lane = lane_id(), w = wave_id();
+  for (int r0 = w * 4; r0 < nrows; r0 += POI_NWAVE * 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u;
+      if (r < nrows) {
+        const float* w1 = W1 + (size_t)r * K1;
+        for (int j = lane * 4; j < K1; j += 256)
+          acc[u] += dot4(*reinterpret_cast<const float4*>(w1 + j), *reinterpret_cast<const float4*>(x1 + j));
+        if (W2) {
+          const float* w2 = W2 + (size_t)r * K2;
+          for (int j = lane * 4; j < K2; j += 256)
+            acc[u] += dot4(*reinterpret_cast<const float4*>(w2 + j), *reinterpret_cast<const float4*>(x2 + j));
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s = wave_sum(acc[u]);
+      const int r = r0 + u;
+      if (lane == 0 && r < nrows) {
+        float v = s + (bias ? bias[r] : 0.f);
+        if (ACT == 1) v = sigmoidf_(v);
+        if (ACT == 2) v = tanhf(v);
+        out[r] = v;
+      }
+    }
+  }
+}
+
+// Column-parallel transposed GEMV: out[j] (+)= sum_i W[i, j] * v[i], W row-major (rows x cols),
+// cols % 4 == 0, cols <= 1024.  Thread t owns the float4 column c = t % (cols/4) for the row group
+// rg = t / (cols/4); the RG partial sums meet in LDS `part` (>= 1024 floats).  v and out are LDS.
+// Contains barriers; `out` is overwritten (ACCUM=false) or incremented (ACCUM=true).
+template <bool ACCUM>
+__device__ __forceinline__ void gemv_cols(const float* __restrict__ W, int rows, int cols,
+                                          const float* v, float* out, float* part) {
+  const int c4n = cols >> 2;
+  const int RG = POI_BLOCK / c4n > 0 ? POI_BLOCK / c4n : 1;
+  const int tid = threadIdx.x;
+  const int c = tid % c4n, rg = tid / c4n;
+  if (rg < RG) {
+    float4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    int i = rg;
+    for (; i + RG < rows; i += 2 * RG) {
+      const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)i * cols + 4 * c);
+      const float4 w1 = *reinterpret_cast<const float4*>(W + (size_t)(i + RG) * cols + 4 * c);
+      const float v0 = v[i], v1 = v[i + RG];
+      a0.x = fmaf(w0.x, v0, a0.x); a0.y = fmaf(w0.y, v0, a0.y); a0.z = fmaf(w0.z, v0, a0.z); a0.w = fmaf(w0.w, v0, a0.w);
+      a1.x = fmaf(w1.x, v1, a1.x); a1.y = fmaf(w1.y, v1, a1.y); a1.z = fmaf(w1.z, v1, a1.z); a1.w = fmaf(w1.w, v1, a1.w);
+    }
+    if (i < rows) {
+      const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)i * cols + 4 * c);
+      const float v0 = v[i];
+      a0.x = fmaf(w0.x, v0, a0.x); a0.y = fmaf(w0.y, v0, a0.y); a0.z = fmaf(w0.z, v0, a0.z); a0.w = fmaf(w0.w, v0, a0.w);
+    }
+    float4 s = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
+    *reinterpret_cast<float4*>(part + rg * cols + 4 * c) = s;
+  }
+  __syncthreads();
+  for (int j = tid; j < cols; j += POI_BLOCK) {
+    float s = 0.f;
+    for (int g = 0; g < RG; ++g) s += part[g * cols + j];
+    if (ACCUM) out[j] += s; else out[j] = s;
+  }
+  __syncthreads();
+}
+
+}  // namespace poi

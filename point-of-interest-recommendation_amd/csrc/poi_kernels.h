@@ -1,0 +1,89 @@
+// Internal (non-ABI) declarations shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace poi {
+
+// Arguments of the per-sequence engine kernels (passed by value).
+struct SeqArgs {
+  // parameters (device)
+  float *lt, *di, *ui, *wh, *bi, *vs, *bs, *wd, *lw;
+  int n_item, n_dist, dim;
+  // CSR index tables (device)
+  const int *off, *p, *q, *dp, *dq;
+  int len_max;       // padded row length of the reference tables (analytic padding-row decay)
+  int cap;           // capacity in steps of the per-workgroup scratch (>= longest sequence)
+  // launch
+  const int* uidx;
+  int n_seq;
+  float* out;        // spatial: 5 per sequence; plain: 1 per sequence
+  // scratch (owned by poi_ctx)
+  float* ws; size_t ws_stride;      // per-workgroup activations
+  float* slab;                      // per-workgroup dense-gradient slabs
+  float *g_lt, *g_di;               // zero-initialised gradient tables
+  int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
+  // predict outputs
+  float *hts, *sts;
+};
+
+// Layout of one dense-gradient slab (offsets in floats).
+struct DenseLayout { int ui, wh, bi, vs, bs, wd, sur, upq, total; };
+__host__ __device__ inline DenseLayout dense_layout(int D, int XW, int NB) {
+  DenseLayout l;
+  l.ui = 0;
+  l.wh = l.ui + 3 * D * XW;
+  l.bi = l.wh + 3 * D * D;
+  l.vs = l.bi + 3 * D;
+  l.bs = l.vs + NB * D;
+  l.wd = l.bs + NB;
+  l.sur = l.wd + 1;
+  l.upq = l.sur + 1;
+  l.total = (l.upq + 1 + 3) & ~3;
+  return l;
+}
+
+size_t seq_ws_floats(int D, int NB, int cap);
+hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st);
+hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st);
+
+// BPR-MF
+struct BprArgs {
+  float *ux, *lt;
+  int n_user, n_item, dim;
+  const int *uidx, *p, *q;
+  int n;
+  float alpha, lambda;
+  float* loss;
+  float *g_ux, *g_lt;
+  int *cnt_ux, *cnt_lt;   // touches per row in this launch (== multiplicity == distinct triples)
+};
+hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st);
+
+// scoring / top-K
+struct ScoreArgs {
+  const float *users, *items;
+  int n, n_item, dim;
+  const float *wd, *prob;
+  float* scores;            // (n, n_item) or null
+  int k;                    // 0 = no top-K
+  int n_split;              // item splits for the fused top-K
+  float* cand_score; int* cand_idx;   // (n_split, n_pad, k) partial top-K lists
+  int* idx_out; float* score_out;
+};
+hipError_t launch_score(const ScoreArgs& A, hipStream_t st);
+hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, hipStream_t st);
+hipError_t launch_topk_rows(const float* scores, int n, int n_item, int k, int* idx_out, float* score_out, hipStream_t st);
+
+// misc
+hipError_t launch_auc(const float* users, const float* items, int n, int dim, const int* tp, const int* tq,
+                      const int* tm, int len, uint8_t* out, hipStream_t st);
+hipError_t launch_sumsq(const float* x, int64_t n, double* out, hipStream_t st);
+hipError_t launch_dist_prob(const double* coords, const int* last_poi, const float* sts, int n, int n_item,
+                            int n_dist, double dd, float* prob, hipStream_t st);
+hipError_t launch_delta_make(const float* cur, const float* base, float* delta, int64_t n, hipStream_t st);
+hipError_t launch_delta_apply(float* cur, const float* base, const float* dsum, int64_t n, hipStream_t st);
+hipError_t launch_selftest(float* buf, int* fail, hipStream_t st);
+
+}  // namespace poi

@@ -1,0 +1,219 @@
+"""Host-side input contract of the hot path (the reference's public/Load_Data_by_length.py), vectorised
+with numpy, plus the synthetic Foursquare/Gowalla-shaped generator used by bench.py and the tests.
+
+Layouts follow the reference exactly where the model sees them:
+  * padding id = n_item for POIs and dist_num for distance bins (Load_Data_by_length.py:115-124);
+  * dist[0] = dist_num for every sequence (:77); bin = min(int(km*1000/dd), dist_num) (:38-39);
+  * negatives uniform over [0, n_item) rejecting the user's own train POIs (:127-143);
+  * negative distance bin t = bin(neg_t, pos_{t-1}) (:165-180).
+On the device nothing is padded: sequences are CSR-packed (off / flat arrays); `to_padded()` rebuilds
+the reference's nested-list tables for API compatibility.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+EARTH_D = 12742                      # Load_Data_by_length.py:30
+DEG = 0.017453292519943295           # :31
+
+
+def cal_dis_vec(lat1, lon1, lat2, lon2, dd, dist_num):
+    """Vectorised public/Load_Data_by_length.py:24-42 (same float64 expression order)."""
+    lat1, lon1, lat2, lon2 = (np.asarray(v, np.float64) for v in (lat1, lon1, lat2, lon2))
+    a = (lat1 - lat2) * DEG
+    b = (lon1 - lon2) * DEG
+    c = (1.0 - np.cos(a)) / 2 + np.cos(lat1 * DEG) * np.cos(lat2 * DEG) * (1.0 - np.cos(b)) / 2
+    dist = EARTH_D * np.arcsin(np.sqrt(c))
+    interval = (dist * 1000 / dd).astype(np.int64)
+    return np.minimum(interval, dist_num)
+
+
+def padded_to_csr(rows, lens):
+    """Nested (U, LM) table + valid lengths -> (off int32 (U+1), flat int32)."""
+    rows = np.asarray(rows)
+    lens = np.asarray(lens, np.int64)
+    off = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    mask = np.arange(rows.shape[1])[None, :] < lens[:, None]
+    return off.astype(np.int32), np.ascontiguousarray(rows[mask], dtype=np.int32)
+
+
+def csr_to_padded(off, flat, pad, len_max=None):
+    off = np.asarray(off, np.int64)
+    lens = np.diff(off)
+    lm = int(lens.max()) if len_max is None else int(len_max)
+    out = np.full((len(lens), lm), pad, np.int32)
+    mask = np.arange(lm)[None, :] < lens[:, None]
+    out[mask] = flat
+    return out
+
+
+def sample_negatives(rng, n_item, off, pos_flat, exclude_off=None, exclude_flat=None):
+    """One uniform negative per position, rejecting the user's own items
+    (fun_random_neg_masks_tra :127-143; with exclude_* also the test items, _tes :146-162)."""
+    off = np.asarray(off, np.int64)
+    lens = np.diff(off)
+    user_of = np.repeat(np.arange(len(lens)), lens)
+    stride = np.int64(n_item) + 1
+    own = user_of * stride + np.asarray(pos_flat, np.int64)
+    if exclude_flat is not None:
+        eoff = np.asarray(exclude_off, np.int64)
+        euser = np.repeat(np.arange(len(eoff) - 1), np.diff(eoff))
+        own = np.concatenate((own, euser * stride + np.asarray(exclude_flat, np.int64)))
+    own = np.unique(own)
+    return own, user_of, stride
+
+
+def random_neg_tra(rng, n_item, off, p_flat):
+    own, user_of, stride = sample_negatives(rng, n_item, off, p_flat)
+    neg = rng.integers(0, n_item, size=len(p_flat), dtype=np.int64)
+    bad = np.isin(user_of * stride + neg, own, assume_unique=False)
+    while bad.any():
+        neg[bad] = rng.integers(0, n_item, size=int(bad.sum()), dtype=np.int64)
+        bad[bad] = np.isin(user_of[bad] * stride + neg[bad], own)
+    return neg.astype(np.int32)
+
+
+def random_neg_tes(rng, n_item, tra_off, tra_flat, tes_off, tes_flat):
+    own, _, stride = sample_negatives(rng, n_item, tra_off, tra_flat, tes_off, tes_flat)
+    tes_off = np.asarray(tes_off, np.int64)
+    user_of = np.repeat(np.arange(len(tes_off) - 1), np.diff(tes_off))
+    neg = rng.integers(0, n_item, size=len(tes_flat), dtype=np.int64)
+    bad = np.isin(user_of * stride + neg, own)
+    while bad.any():
+        neg[bad] = rng.integers(0, n_item, size=int(bad.sum()), dtype=np.int64)
+        bad[bad] = np.isin(user_of[bad] * stride + neg[bad], own)
+    return neg.astype(np.int32)
+
+
+def dist_neg_bins(off, p_flat, q_flat, coords, dd, dist_num):
+    """fun_compute_dist_neg (:165-180): bin(neg_t, pos_{t-1}) for t >= 1, dist_num at t = 0."""
+    off = np.asarray(off, np.int64)
+    out = np.full(len(p_flat), dist_num, np.int32)
+    first = np.zeros(len(p_flat), bool)
+    first[off[:-1][np.diff(off) > 0]] = True
+    idx = np.nonzero(~first)[0]
+    prev = coords[np.asarray(p_flat)[idx - 1]]
+    cur = coords[np.asarray(q_flat)[idx]]
+    out[idx] = cal_dis_vec(cur[:, 0], cur[:, 1], prev[:, 0], prev[:, 1], dd, dist_num)
+    return out
+
+
+def dist_pos_bins(off, p_flat, coords, dd, dist_num):
+    """load_data's train distance sequence (:70-78): bin(pos_t, pos_{t-1}), dist_num at t = 0."""
+    off = np.asarray(off, np.int64)
+    out = np.full(len(p_flat), dist_num, np.int32)
+    first = np.zeros(len(p_flat), bool)
+    first[off[:-1][np.diff(off) > 0]] = True
+    idx = np.nonzero(~first)[0]
+    prev = coords[np.asarray(p_flat)[idx - 1]]
+    cur = coords[np.asarray(p_flat)[idx]]
+    out[idx] = cal_dis_vec(cur[:, 0], cur[:, 1], prev[:, 0], prev[:, 1], dd, dist_num)
+    return out
+
+
+@dataclasses.dataclass
+class PoiDataset:
+    """CSR-packed check-in data in the shape Params.__init__ (prog_bpr_gru_spatial.py:49-100) builds."""
+    n_user: int
+    n_item: int
+    dist_num: int
+    dd: float
+    coords: np.ndarray          # (n_item, 2) float64 lat, lon  (pois_cordis)
+    off: np.ndarray             # (n_user+1,) int32
+    tra_p: np.ndarray           # flat train POIs
+    tra_dp: np.ndarray          # flat train distance bins
+    tes_p: np.ndarray           # (n_user,) held-out POI (split = -1)
+    tes_dp: np.ndarray          # (n_user,) its distance bin
+    tra_q: np.ndarray = None    # flat negatives (resampled per epoch)
+    tra_dq: np.ndarray = None   # flat negative distance bins
+    tes_q: np.ndarray = None    # (n_user,) test negatives
+
+    @property
+    def lens(self):
+        return np.diff(np.asarray(self.off, np.int64))
+
+    @property
+    def len_max(self):
+        return int(self.lens.max())
+
+    def resample_negatives(self, rng):
+        """Per-epoch refresh, prog_bpr_gru_spatial.py:221-228."""
+        self.tra_q = random_neg_tra(rng, self.n_item, self.off, self.tra_p)
+        tes_off = np.arange(self.n_user + 1, dtype=np.int32)
+        self.tes_q = random_neg_tes(rng, self.n_item, self.off, self.tra_p, tes_off, self.tes_p)
+        self.tra_dq = dist_neg_bins(self.off, self.tra_p, self.tra_q, self.coords, self.dd, self.dist_num)
+
+    def last_pois(self):
+        return np.asarray(self.tra_p)[np.asarray(self.off, np.int64)[1:] - 1]
+
+    def to_padded(self):
+        """The reference's nested tables: (train, test, dist) argument triples of the model ctors."""
+        lm = self.len_max
+        tra_buys = csr_to_padded(self.off, self.tra_p, self.n_item, lm)
+        tra_neg = csr_to_padded(self.off, self.tra_q, self.n_item, lm)
+        tra_dist = csr_to_padded(self.off, self.tra_dp, self.dist_num, lm)
+        tra_dneg = csr_to_padded(self.off, self.tra_dq, self.dist_num, lm)
+        tra_mask = (np.arange(lm)[None, :] < self.lens[:, None]).astype(np.int32)
+        tes_buys = self.tes_p.reshape(-1, 1).astype(np.int32)
+        tes_neg = self.tes_q.reshape(-1, 1).astype(np.int32)
+        tes_dist = self.tes_dp.reshape(-1, 1).astype(np.int32)
+        tes_mask = np.ones((self.n_user, 1), np.int32)
+        return dict(train=[tra_buys, tra_mask, tra_neg], test=[tes_buys, tes_mask, tes_neg],
+                    dist=[tra_dist, tes_dist, tra_dneg])
+
+
+SHAPES = {
+    # name: (n_item, n_user, max_len, dim)   BASELINE.json configs / BASELINE.md section 3
+    "tiny": (300, 64, 12, 16),
+    "foursquare": (10_000, 5_000, 20, 64),
+    "gowalla": (100_000, 50_000, 50, 128),
+}
+
+
+def make_synthetic(n_user, n_item, max_len, seed, dd=200, ud_km=40, min_len=4, box_km=40.0, zipf=1.0):
+    """Synthetic Foursquare/Gowalla-shaped data: lognormal sequence lengths clipped to
+    [min_len, max_len] (+1 held-out check-in), Zipf POI popularity, POIs uniform in a ~box_km square."""
+    rng = np.random.default_rng(seed)
+    dist_num = int(ud_km * 1000 / dd)                    # prog_bpr_gru_spatial.py:81
+    mu, sigma = np.log(max(max_len / 3.0, min_len)), 0.6
+    lens = np.clip(np.rint(rng.lognormal(mu, sigma, n_user)), min_len, max_len).astype(np.int64)
+    raw = lens + 1                                        # + the held-out last check-in (split = -1)
+    w = 1.0 / np.power(np.arange(1, n_item + 1, dtype=np.float64), zipf)
+    cdf = np.cumsum(w / w.sum())
+    perm = rng.permutation(n_item)
+    ranks = np.minimum(np.searchsorted(cdf, rng.random(int(raw.sum()))), n_item - 1)
+    pois = perm[ranks].astype(np.int32)
+    lat = 40.0 + rng.random(n_item) * (box_km / 111.19)
+    lon = -74.0 + rng.random(n_item) * (box_km / (111.19 * np.cos(40.0 * DEG)))
+    coords = np.stack([lat, lon], 1)
+    roff = np.zeros(n_user + 1, np.int64)
+    np.cumsum(raw, out=roff[1:])
+    rdist = dist_pos_bins(roff, pois, coords, dd, dist_num)
+    is_last = np.zeros(len(pois), bool)
+    is_last[roff[1:] - 1] = True
+    off = np.zeros(n_user + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    ds = PoiDataset(n_user=n_user, n_item=n_item, dist_num=dist_num, dd=float(dd), coords=coords,
+                    off=off.astype(np.int32), tra_p=pois[~is_last], tra_dp=rdist[~is_last],
+                    tes_p=pois[is_last], tes_dp=rdist[is_last])
+    ds.resample_negatives(rng)
+    return ds
+
+
+def shard_users(n_user, world_size, rank, lens=None):
+    """Contiguous user shard [lo, hi) of rank `rank`; with `lens`, boundaries balance the number of
+    check-ins (GRU steps) rather than the number of users."""
+    if lens is None:
+        per = (n_user + world_size - 1) // world_size
+        lo = min(rank * per, n_user)
+        return lo, min(lo + per, n_user)
+    c = np.concatenate(([0], np.cumsum(np.asarray(lens, np.int64))))
+    tot = c[-1]
+    bounds = [int(np.searchsorted(c, tot * r / world_size, side="left")) for r in range(world_size)] + [n_user]
+    bounds[0] = 0
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds[rank], bounds[rank + 1]

@@ -1,0 +1,430 @@
+"""Host-side mirror of the reference's model-object protocol on top of libpoi_hip.so.
+
+Class / method names, argument meaning and return shapes follow the Theano classes the drivers call:
+    OboSpatialGru  public/GRU_Spatial.py:42-292      OboGru  public/GRU.py:301-389 (+ GruBasic :32-205)
+    OboBpr         public/BPR.py:191-241 (+ MfBasic :28-134)
+so that prog_bpr_gru_spatial.py's epoch loop and public/Valuate.py's evaluator run against them
+unchanged in shape.  State lives in torch ROCm tensors (device-memory containers only); every piece of
+arithmetic is a HIP kernel reached through ctypes.  There is no CPU path: without the library or a GPU
+the constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data import padded_to_csr
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Shared:
+    """Stand-in for a Theano shared variable: .get_value() / .set_value() on a device tensor."""
+
+    def __init__(self, tensor, scalar=False):
+        self.t = tensor
+        self.scalar = scalar
+
+    def get_value(self, borrow=False):
+        a = self.t.detach().cpu().numpy()
+        return a.reshape(()).copy() if self.scalar else a
+
+    def set_value(self, value, borrow=False):
+        v = torch.as_tensor(np.asarray(value, dtype=np.float64), dtype=self.t.dtype).reshape(self.t.shape)
+        self.t.copy_(v.to(self.t.device))
+
+
+class _L2:
+    """model.l2 - an object with .eval() (public/GRU_Spatial.py:83-88)."""
+
+    def __init__(self, model, names):
+        self.model, self.names = model, names
+
+    def eval(self):
+        m = self.model
+        acc = torch.zeros(1, dtype=torch.float64, device=m.device)
+        for n in self.names:
+            t = getattr(m, n).t
+            m.ctx.check(m.lib.poi_sumsq(m.ctx.handle, _ptr(t), t.numel(), _ptr(acc), m._stream()))
+        return 0.5 * m.alpha_lambda[1] * float(acc.item())
+
+
+class _Base:
+    def _setup(self, device, alpha_lambda):
+        if not torch.cuda.is_available():
+            raise _lib.PoiError("no ROCm device visible: the next-POI hot path has no CPU implementation")
+        self.device = torch.device(device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.ctx = _lib.context(idx)
+        self.lib = self.ctx.lib
+        self.alpha_lambda = [float(alpha_lambda[0]), float(alpha_lambda[1])]
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype=torch.float32):
+        return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(self.device).contiguous()
+
+    def _ids(self, idxs):
+        """(int32 device tensor of user ids, lo) - lo is the first id when the ids are a contiguous
+        ascending range (then the tensor is a zero-copy view of a resident arange), else None."""
+        if isinstance(idxs, torch.Tensor):
+            return idxs.to(device=self.device, dtype=torch.int32).contiguous(), None
+        a = np.atleast_1d(np.asarray(idxs)).astype(np.int64)
+        if len(a) and np.all(np.diff(a) == 1):
+            lo = int(a[0])
+            return self._arange[lo:lo + len(a)], lo
+        return torch.as_tensor(a.astype(np.int32)).to(self.device), None
+
+    def _rows(self, table, ids, lo):
+        n = ids.numel()
+        return table[lo:lo + n] if lo is not None else table.index_select(0, ids.long()).contiguous()
+
+    # ---- tables -------------------------------------------------------------------------------
+    def _load_tables(self, train, test):
+        tra_buys_masks, tra_masks, tra_buys_neg_masks = train
+        tes_buys_masks, tes_masks, tes_buys_neg_masks = test
+        tra_masks = np.asarray(tra_masks)
+        self._lens = tra_masks.sum(axis=1).astype(np.int64)
+        self.len_max = int(tra_masks.shape[1])                 # padded length LM of the reference tables
+        self.max_len = int(self._lens.max())
+        off, p = padded_to_csr(tra_buys_masks, self._lens)
+        _, q = padded_to_csr(tra_buys_neg_masks, self._lens)
+        self._off_host = off
+        self.off, self.p, self.q = (torch.as_tensor(v).to(self.device) for v in (off, p, q))
+        self.tes_buys_masks = self._dev(tes_buys_masks, torch.int32)
+        self.tes_masks = self._dev(tes_masks, torch.int32)
+        self.tes_buys_neg_masks = self._dev(tes_buys_neg_masks, torch.int32)
+        self._arange = torch.arange(self.n_user, dtype=torch.int32, device=self.device)
+
+    def update_neg_masks(self, tra_buys_neg_masks, tes_buys_neg_masks):
+        """public/GRU.py:79-82 / public/BPR.py:61-64 - new negatives every epoch."""
+        _, q = padded_to_csr(tra_buys_neg_masks, self._lens)
+        self.q = torch.as_tensor(q).to(self.device)
+        self.tes_buys_neg_masks = self._dev(tes_buys_neg_masks, torch.int32)
+
+    def set_negatives_csr(self, q_flat, tes_q=None, dq_flat=None):
+        """CSR form of update_neg_masks / s_update_neg_masks (no padded tables built)."""
+        self.q = torch.as_tensor(np.ascontiguousarray(q_flat, dtype=np.int32)).to(self.device)
+        if tes_q is not None:
+            self.tes_buys_neg_masks = self._dev(np.asarray(tes_q).reshape(self.n_user, -1), torch.int32)
+        if dq_flat is not None:
+            self.dq = torch.as_tensor(np.ascontiguousarray(dq_flat, dtype=np.int32)).to(self.device)
+
+    # ---- snapshots ----------------------------------------------------------------------------
+    def update_trained_items(self):
+        """public/GRU.py:84-87: eval sees a snapshot of lt, not the live table."""
+        self.trained_items.t.copy_(self.lt.t)
+
+    def compute_sub_auc_preference(self, start_end):
+        """public/GRU.py:98-110 -> bool ndarray (n, len_tes)."""
+        ids, lo = self._ids(start_end)
+        n = ids.numel()
+        ln = self.tes_masks.shape[1]
+        users = self._rows(self.trained_users.t, ids, lo)
+        tp, tq, tm = (self._rows(t, ids, lo) for t in (self.tes_buys_masks, self.tes_buys_neg_masks, self.tes_masks))
+        out = torch.empty((n, ln), dtype=torch.uint8, device=self.device)
+        self.ctx.check(self.lib.poi_auc_preference(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.dim,
+                                                   _ptr(tp), _ptr(tq), _ptr(tm), ln, _ptr(out), self._stream()))
+        return out.cpu().numpy().astype(bool)
+
+    def _users_rows(self, start_end):
+        ids, lo = self._ids(start_end)
+        return ids, self._rows(self.trained_users.t, ids, lo), lo
+
+    def _prob_rows(self, ids, lo):
+        return None, None
+
+    def compute_sub_all_scores(self, start_end):
+        """public/GRU.py:93-96 (spatial: public/GRU_Spatial.py:117-125) -> ndarray (n, n_item)."""
+        return self.compute_sub_all_scores_device(start_end).cpu().numpy()
+
+    def compute_sub_all_scores_device(self, start_end):
+        ids, users, lo = self._users_rows(start_end)
+        n = ids.numel()
+        wd, prob = self._prob_rows(ids, lo)
+        out = torch.empty((n, self.n_item), dtype=torch.float32, device=self.device)
+        self.ctx.check(self.lib.poi_score_all(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim,
+                                              _ptr(wd), _ptr(prob), _ptr(out), self._stream()))
+        return out
+
+    def compute_sub_topk(self, start_end, k, return_scores=False):
+        """Fused a8+a9: (n, k) int32 indices sorted by descending score (public/Valuate.py:132-146)
+        without materialising the (n, n_item) score matrix."""
+        ids, users, lo = self._users_rows(start_end)
+        n = ids.numel()
+        wd, prob = self._prob_rows(ids, lo)
+        idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
+        self.ctx.check(self.lib.poi_score_topk(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim,
+                                               _ptr(wd), _ptr(prob), int(k), _ptr(idx), _ptr(sc), self._stream()))
+        return (idx, sc) if return_scores else idx
+
+
+# =================================================================================================
+class GruBasic(_Base):
+    """public/GRU.py:32-205."""
+
+    spatial = False
+
+    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None):
+        if n_in != n_hidden:
+            raise ValueError("the reference drivers always pass n_in == n_hidden (prog_bpr_gru_spatial.py:138-139)")
+        self._setup(device, alpha_lambda)
+        self.n_user, self.n_item, self.dim = int(n_user), int(n_item), int(n_in)
+        self._load_tables(train, test)
+        rng = np.random.default_rng(seed) if seed is not None else np.random
+        u = lambda *s: rng.uniform(-0.5, 0.5, s)
+        D = self.dim
+        init = init or {}
+        g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
+        self.lt = Shared(self._dev(g("lt", lambda: u(n_item + 1, D))))                     # GRU.py:60
+        self.ui = Shared(self._dev(g("ui", lambda: u(3, D, self._xw()))))                  # :61 / GRU_Spatial.py:51
+        self.wh = Shared(self._dev(g("wh", lambda: u(3, D, D))))                           # :62
+        self.bi = Shared(self._dev(g("bi", lambda: np.zeros((3, D)))))                     # :64
+        self.h0 = Shared(torch.zeros(D, device=self.device))                               # :63 never trained
+        self.trained_items = Shared(self._dev(u(n_item + 1, D)))                           # :71
+        self.trained_users = Shared(self._dev(u(n_user, D)))                               # :72
+
+    def _xw(self):
+        return self.dim
+
+    def update_trained_users(self, all_hus):
+        """public/GRU.py:89-91."""
+        if isinstance(all_hus, torch.Tensor):
+            self.trained_users.t.copy_(all_hus.to(self.device, torch.float32).reshape(self.n_user, self.dim))
+        else:
+            self.trained_users.t.copy_(self._dev(np.asarray(all_hus, np.float64)).reshape(self.n_user, self.dim))
+
+    # ---- ctypes views ---------------------------------------------------------------------------
+    def _params(self, snapshot=False):
+        P = _lib.GruParams()
+        P.lt = (self.trained_items if snapshot else self.lt).t.data_ptr()
+        P.ui, P.wh, P.bi = self.ui.t.data_ptr(), self.wh.t.data_ptr(), self.bi.t.data_ptr()
+        P.di = P.vs = P.bs = P.wd = P.lw = None
+        P.n_item, P.n_dist, P.dim = self.n_item, 0, self.dim
+        return P
+
+    def _tables(self):
+        T = _lib.SeqTables()
+        T.off, T.p, T.q = self.off.data_ptr(), self.p.data_ptr(), self.q.data_ptr()
+        T.dp = T.dq = None
+        T.n_user, T.len_max, T.max_len = self.n_user, self.len_max, self.max_len
+        return T
+
+    def predict(self, idxs):
+        """public/GRU.py:204-205 -> hts ndarray (n, D)."""
+        return self.predict_device(idxs).cpu().numpy()
+
+    def predict_device(self, idxs):
+        ids, _ = self._ids(idxs)
+        n = ids.numel()
+        hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        P, T = self._params(snapshot=True), self._tables()
+        self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n, _ptr(hts), None,
+                                                self._stream()))
+        return hts
+
+
+class OboGru(GruBasic):
+    """public/GRU.py:301-389 - plain GRU + BPR, one SGD step per user sequence."""
+
+    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, **kw):
+        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, **kw)
+        self.params = [self.ui, self.wh, self.bi]
+        self.l2 = _L2(self, ["lt", "ui", "wh", "bi"])                                      # :304-308
+
+    def train(self, idx):
+        """seq_train(uidx) -> float (public/GRU.py:387-389)."""
+        return float(self.train_batch(np.atleast_1d(idx))[0])
+
+    def train_batch(self, idxs, sync=True):
+        """Throughput mode: n sequences per launch, batch semantics of include/poi_hip.h."""
+        ids, _ = self._ids(idxs)
+        n = ids.numel()
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        P, T = self._params(), self._tables()
+        self.ctx.check(self.lib.poi_gru_step(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n,
+                                             self.alpha_lambda[0], self.alpha_lambda[1], _ptr(out), self._stream()))
+        return out.cpu().numpy() if sync else out
+
+
+class OboSpatialGru(GruBasic):
+    """public/GRU_Spatial.py:42-292 - Distance2Pre."""
+
+    spatial = True
+
+    def __init__(self, train, test, dist, alpha_lambda, n_user, n_item, n_dists, n_in, n_hidden,
+                 device="cuda:0", init=None, seed=None, coords=None):
+        n_dist, dd = n_dists
+        self.n_dist, self.dd = int(n_dist), float(dd)                                      # dd in km (ref passes dd/1000)
+        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device=device, init=init, seed=seed)
+        tra_dist_masks, tes_dist_masks, tra_dist_neg_masks = dist
+        _, dp = padded_to_csr(tra_dist_masks, self._lens)
+        _, dq = padded_to_csr(tra_dist_neg_masks, self._lens)
+        self.dp, self.dq = torch.as_tensor(dp).to(self.device), torch.as_tensor(dq).to(self.device)
+        self.tes_dist_masks = self._dev(tes_dist_masks, torch.int32)
+        rng = np.random.default_rng(None if seed is None else seed + 1) if seed is not None else np.random
+        u = lambda *s: rng.uniform(-0.5, 0.5, s)
+        D, NB = self.dim, self.n_dist + 1
+        init = init or {}
+        g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
+        self.di = Shared(self._dev(g("di", lambda: u(NB, D))))                             # :57
+        self.vs = Shared(self._dev(g("vs", lambda: u(NB, D))))                             # :60
+        self.bs = Shared(self._dev(g("bs", lambda: np.zeros(NB))))                         # :61
+        self.wd = Shared(self._dev(np.reshape(g("wd", lambda: rng.uniform(0, 0.5)), (1,))), scalar=True)   # :66
+        self.loss_weight = Shared(self._dev(g("loss_weight", lambda: u(2))))               # :70
+        self.trained_dists = Shared(self._dev(u(NB, D)))                                   # :74
+        self.prob = None                       # dense (n_user, n_item) only on request (update_prob)
+        self.trained_sus = None                # (n_user, NB) - fused alternative to `prob`
+        self.coords = None if coords is None else self._dev(np.asarray(coords, np.float64), torch.float64)
+        self.params = [self.ui, self.wh, self.bi, self.vs, self.bs, self.wd, self.loss_weight]
+        self.l2 = _L2(self, ["lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight"])   # :83-88
+
+    def _xw(self):
+        return 2 * self.dim
+
+    def load_params(self, loaded_objects):
+        """public/GRU_Spatial.py:92-101: [loss_weight, wd, lt, di, ui, wh, bi, vs, bs]."""
+        for sh, v in zip((self.loss_weight, self.wd, self.lt, self.di, self.ui, self.wh, self.bi, self.vs, self.bs), loaded_objects):
+            sh.set_value(v)
+
+    def s_update_neg_masks(self, tra_buys_neg_masks, tes_buys_neg_masks, tra_dist_neg_masks):
+        """public/GRU_Spatial.py:103-107."""
+        self.update_neg_masks(tra_buys_neg_masks, tes_buys_neg_masks)
+        _, dq = padded_to_csr(tra_dist_neg_masks, self._lens)
+        self.dq = torch.as_tensor(dq).to(self.device)
+
+    def update_trained_dists(self):
+        """public/GRU_Spatial.py:109-112."""
+        self.trained_dists.t.copy_(self.di.t)
+
+    def update_prob(self, prob):
+        """public/GRU_Spatial.py:114-115 - dense (n_user, n_item) matrix (compatibility path)."""
+        self.prob = self._dev(np.asarray(prob, np.float64)).reshape(self.n_user, self.n_item)
+
+    def update_trained_sus(self, all_sus):
+        """Fused replacement of fun_acquire_prob + update_prob (Load_Data_by_length.py:218-235): keep the
+        (n_user, n_dist+1) distance-bin probabilities; prob rows are rebuilt on the device per batch
+        from the POI coordinates (needs coords= at construction)."""
+        t = all_sus if isinstance(all_sus, torch.Tensor) else self._dev(np.asarray(all_sus, np.float64))
+        self.trained_sus = t.to(self.device, torch.float32).reshape(self.n_user, self.n_dist + 1).contiguous()
+        self.prob = None
+        lens = torch.as_tensor(self._off_host[1:].astype(np.int64) - 1).to(self.device)
+        self._last_poi = self.p.index_select(0, lens).contiguous()
+
+    def _prob_rows(self, ids, lo):
+        if self.prob is not None:
+            return self.wd.t, self._rows(self.prob, ids, lo)
+        if self.trained_sus is not None:
+            if self.coords is None:
+                raise _lib.PoiError("update_trained_sus needs coords= at construction")
+            n = ids.numel()
+            lp, st = self._rows(self._last_poi, ids, lo), self._rows(self.trained_sus, ids, lo)
+            prob = torch.empty((n, self.n_item), dtype=torch.float32, device=self.device)
+            self.ctx.check(self.lib.poi_dist_prob(self.ctx.handle, _ptr(self.coords), _ptr(lp), _ptr(st), n,
+                                                  self.n_item, self.n_dist, self.dd * 1000.0, _ptr(prob), self._stream()))
+            return self.wd.t, prob
+        return None, None
+
+    def _params(self, snapshot=False):
+        P = super()._params(snapshot)
+        P.di = (self.trained_dists if snapshot else self.di).t.data_ptr()
+        P.vs, P.bs, P.wd, P.lw = self.vs.t.data_ptr(), self.bs.t.data_ptr(), self.wd.t.data_ptr(), self.loss_weight.t.data_ptr()
+        P.n_dist = self.n_dist
+        return P
+
+    def _tables(self):
+        T = super()._tables()
+        T.dp, T.dq = self.dp.data_ptr(), self.dq.data_ptr()
+        return T
+
+    def train(self, idx):
+        """seq_train(uidx) -> [los, sur, upq, ls] (public/GRU_Spatial.py:222,290-292)."""
+        o = self.train_batch(np.atleast_1d(idx))[0]
+        return [float(o[0]), float(o[1]), float(o[2]), np.array([o[3], o[4]])]
+
+    def train_batch(self, idxs, sync=True):
+        """Throughput mode: (n, 5) rows [los, sur, upq, ls0, ls1]."""
+        ids, _ = self._ids(idxs)
+        n = ids.numel()
+        out = torch.empty((n, 5), dtype=torch.float32, device=self.device)
+        P, T = self._params(), self._tables()
+        self.ctx.check(self.lib.poi_spatial_step(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n,
+                                                 self.alpha_lambda[0], self.alpha_lambda[1], _ptr(out), self._stream()))
+        return out.cpu().numpy() if sync else out
+
+    def predict(self, idxs):
+        """public/GRU_Spatial.py:282-288 -> [hts (n, D), sts (n, n_dist+1)]."""
+        h, s = self.predict_device(idxs)
+        return [h.cpu().numpy(), s.cpu().numpy()]
+
+    def predict_device(self, idxs):
+        ids, _ = self._ids(idxs)
+        n = ids.numel()
+        hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        sts = torch.empty((n, self.n_dist + 1), dtype=torch.float32, device=self.device)
+        P, T = self._params(snapshot=True), self._tables()
+        self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n, _ptr(hts), _ptr(sts),
+                                                self._stream()))
+        return hts, sts
+
+
+# =================================================================================================
+class MfBasic(_Base):
+    """public/BPR.py:28-134."""
+
+    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None):
+        self._setup(device, alpha_lambda)
+        self.n_user, self.n_item, self.dim = int(n_user), int(n_item), int(n_in)
+        self._load_tables(train, test)
+        rng = np.random.default_rng(seed) if seed is not None else np.random
+        u = lambda *s: rng.uniform(-0.5, 0.5, s)
+        init = init or {}
+        g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
+        self.ux = Shared(self._dev(g("ux", lambda: u(n_user, self.dim))))                  # BPR.py:51
+        self.lt = Shared(self._dev(g("lt", lambda: u(n_item + 1, self.dim))))              # :52
+        self.trained_items = Shared(self._dev(u(n_item + 1, self.dim)))
+        self.trained_users = Shared(self._dev(u(n_user, self.dim)))
+
+    def update_trained_users(self):
+        """public/BPR.py:71-74 (no argument: copies ux)."""
+        self.trained_users.t.copy_(self.ux.t)
+
+
+class OboBpr(MfBasic):
+    """public/BPR.py:191-241."""
+
+    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, **kw):
+        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, **kw)
+        self.params = [self.ux, self.lt]
+        self.l2 = _L2(self, ["ux", "lt"])                                                  # :194-197
+
+    def train(self, u_idx, pq_idx):
+        """bpr_train(uidx, [p, q]) -> -log sigmoid(u)  (public/BPR.py:234-241)."""
+        return float(self.train_batch([u_idx], [pq_idx[0]], [pq_idx[1]])[0])
+
+    def train_batch(self, uidx, p, q, mode="snapshot", sync=True):
+        conv = lambda v: v.to(self.device, torch.int32).contiguous() if isinstance(v, torch.Tensor) else \
+            torch.as_tensor(np.asarray(v, np.int32)).to(self.device)
+        u, pp, qq = conv(uidx), conv(p), conv(q)
+        n = u.numel()
+        loss = torch.empty(n, dtype=torch.float32, device=self.device)
+        m = _lib.BPR_HOGWILD if mode == "hogwild" else _lib.BPR_SNAPSHOT
+        self.ctx.check(self.lib.poi_bpr_step(self.ctx.handle, _ptr(self.ux.t), _ptr(self.lt.t), self.n_user, self.n_item, self.dim,
+                                             _ptr(u), _ptr(pp), _ptr(qq), n, self.alpha_lambda[0], self.alpha_lambda[1],
+                                             _ptr(loss), m, self._stream()))
+        return loss.cpu().numpy() if sync else loss
+
+    def epoch_triples(self):
+        """All (user, pos_t, neg_t) triples of the train tables, in the reference's order
+        (prog_bpr_gru_spatial.py:240-244) - device int32 tensors."""
+        lens = torch.as_tensor(np.diff(self._off_host.astype(np.int64))).to(self.device)
+        u = torch.repeat_interleave(self._arange, lens)
+        return u, self.p, self.q

@@ -1,0 +1,108 @@
+"""CPU-only tests: the C-ABI library loads and exports exactly what include/poi_hip.h declares, and the
+host-side input-contract code (data.py) agrees with the reference's golden vectors.  No GPU compute."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import poi_amd
+from poi_amd import data as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    poi_amd.build.build_lib()
+    return poi_amd._lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "poi_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(poi_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(poi_amd._lib.SIGNATURES), declared ^ set(poi_amd._lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.poi_abi_version() == poi_amd._lib.ABI_VERSION
+
+
+def test_argument_counts_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "poi_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for name, (_, args) in poi_amd._lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^)]*)\)" % name, hdr)
+        assert m, name
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(args), (name, params, len(args))
+
+
+def test_models_refuse_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    T = dict(train=[[[0, 1]], [[1, 1]], [[1, 0]]], test=[[[1]], [[1]], [[0]]])
+    with pytest.raises(poi_amd.PoiError):
+        poi_amd.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=1, n_item=2, n_in=4, n_hidden=4)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "point-of-interest-recommendation_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_cal_dis_vec_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cal_dis.npz"))
+    assert np.array_equal(D.cal_dis_vec(g["lat1"], g["lon1"], g["lat2"], g["lon2"], 200, 200), g["bins_dd200_B200"])
+    assert np.array_equal(D.cal_dis_vec(g["lat1"], g["lon1"], g["lat2"], g["lon2"], 25, 1520), g["bins_dd25_B1520"])
+
+
+def test_csr_roundtrip_and_bins_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "masks.npz"))
+    N, B, dd = int(g["n_item"]), int(g["n_dist"]), float(g["dd"])
+    lens = g["lens"]
+    off, p = D.padded_to_csr(g["pois_m"], lens)
+    assert np.array_equal(p, g["ragged_pois"])
+    assert np.array_equal(D.csr_to_padded(off, p, N), g["pois_m"])
+    _, q = D.padded_to_csr(g["negs"], lens)
+    assert np.array_equal(D.dist_pos_bins(off, p, g["coords"], dd, B), g["ragged_dist"])
+    dq = D.dist_neg_bins(off, p, q, g["coords"], dd, B)
+    assert np.array_equal(D.csr_to_padded(off, dq, B), g["dist_neg"])
+
+
+def test_negative_sampler_contract():
+    ds = D.make_synthetic(200, 500, 15, seed=3)
+    off = ds.off.astype(np.int64)
+    assert ds.lens.min() >= 4 and ds.lens.max() <= 15
+    assert np.all(ds.tra_dp[off[:-1]] == ds.dist_num) and np.all(ds.tra_dq[off[:-1]] == ds.dist_num)
+    for u in range(ds.n_user):
+        own = set(ds.tra_p[off[u]:off[u + 1]])
+        assert not own & set(ds.tra_q[off[u]:off[u + 1]])
+        assert ds.tes_q[u] not in own and ds.tes_q[u] != ds.tes_p[u]
+    assert ds.tra_q.min() >= 0 and ds.tra_q.max() < ds.n_item
+    pad = ds.to_padded()
+    assert pad["train"][0].shape == (200, ds.len_max) and pad["train"][0].max() == ds.n_item
+    assert pad["dist"][0].max() == ds.dist_num
+    before = ds.tra_q.copy()
+    ds.resample_negatives(np.random.default_rng(9))
+    assert not np.array_equal(before, ds.tra_q)
+
+
+def test_shard_users_partitions_everything():
+    lens = np.random.default_rng(0).integers(4, 50, 1000)
+    for ws in (1, 2, 3, 8):
+        cover = []
+        for r in range(ws):
+            lo, hi = D.shard_users(1000, ws, r, lens)
+            cover.extend(range(lo, hi))
+        assert cover == list(range(1000))
+        los = [D.shard_users(1000, ws, r)[0] for r in range(ws)]
+        assert los == sorted(los)
+    # balanced by check-ins within 5 %
+    work = [lens[slice(*D.shard_users(1000, 8, r, lens))].sum() for r in range(8)]
+    assert max(work) / (sum(work) / 8) < 1.05
