@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path on MI355X: Distance2Pre training epochs (check-in sequences / s) and
+all-POI top-20 evaluation (users / s) on synthetic Gowalla-shaped data (BASELINE.json configs[2]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one training epoch over the rank's user shard: ceil(users/B) launches of the batched
+training step (B users per launch, batch semantics of include/poi_hip.h) plus, for N > 1, the
+per-epoch replica reconciliation (one RCCL all-reduce of the parameter deltas).  Users are sharded
+across ranks (total work fixed: strong scaling); every rank holds the full parameter replica.
+Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla"])
+    ap.add_argument("--batch-users", type=int, default=8192)
+    ap.add_argument("--eval-steps", type=int, default=2)
+    ap.add_argument("--eval-chunk", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def step_flops(D, NB):
+    """Algorithmic flops of one GRU step of one sequence, forward + backward:
+    54 D^2 for the cell (2D-wide input) + 6 (B+1) D for the distance-softmax head."""
+    return 54.0 * D * D + 6.0 * NB * D
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import poi_amd
+    from poi_amd import data as pdata
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
+    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2)
+    lo, hi = pdata.shard_users(n_user, world, rank, ds.lens)
+    tab = ds.shard(lo, hi)
+    n_local = hi - lo
+    NB = ds.dist_num + 1
+    model = poi_amd.models.OboSpatialGru(train=tab, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=n_local,
+                                         n_item=n_item, n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=D, n_hidden=D,
+                                         device=dev, seed=7, coords=ds.coords)
+    ctx = model.ctx
+    sync = poi_amd.dist.ReplicaSync([getattr(model, k).t for k in ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")], ctx=ctx)
+
+    # shuffled user order (prog_bpr_gru_spatial.py:236-238), resident on the device
+    order = torch.as_tensor(np.random.default_rng(123).permutation(n_local).astype(np.int32)).to(dev)
+    B = min(a.batch_users, n_local)
+    lens_local = np.diff(tab.off.astype(np.int64))
+    steps_per_epoch = float(np.maximum(lens_local - 1, 0).sum())
+
+    def train_epoch():
+        for b0 in range(0, n_local, B):
+            model.train_batch(order[b0:b0 + B], sync=False)
+        sync.end_epoch()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def rank_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for _ in range(a.warmup):
+        train_epoch()
+    ctx.timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        train_epoch()
+    barrier()
+    dt = rank_max(time.perf_counter() - t0)
+    ms_train, n_train = ctx.timing_get("seq_train")
+    ms_rows, n_rows = ctx.timing_get("rows_apply")
+    ms_dense, _ = ctx.timing_get("dense_apply")
+    ctx.timing(False)
+    seq_per_s = n_user * a.steps / dt
+
+    # ---- evaluation: snapshot -> user vectors -> fused distance term + all-POI score + top-20 -------
+    eval_users_per_s = None
+    eval_detail = {}
+    if not a.no_eval:
+        all_ids = np.arange(n_local, dtype=np.int32)
+        tes = torch.as_tensor(tab.tes_p.reshape(-1).astype(np.int32)).to(dev)
+
+        def eval_epoch():
+            model.update_trained_items(); model.update_trained_dists()
+            hts, sts = model.predict_device(all_ids)
+            model.update_trained_users(hts); model.update_trained_sus(sts)
+            hits = torch.zeros((), dtype=torch.int64, device=dev)
+            for c0 in range(0, n_local, a.eval_chunk):
+                ids = all_ids[c0:min(c0 + a.eval_chunk, n_local)]
+                idx = model.compute_sub_topk(ids, 20)
+                hits += (idx == tes[c0:c0 + len(ids), None]).any(dim=1).sum()
+            return hits
+
+        eval_epoch()
+        ctx.timing(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.eval_steps):
+            hits = eval_epoch()
+        barrier()
+        dte = rank_max(time.perf_counter() - t0)
+        ms_score, n_score = ctx.timing_get("score_topk")
+        ms_pred, _ = ctx.timing_get("seq_predict")
+        ctx.timing(False)
+        eval_users_per_s = n_user * a.eval_steps / dte
+        fl = 2.0 * n_local * n_item * D * a.eval_steps
+        eval_detail = {"ms_per_eval": 1e3 * dte / a.eval_steps, "recall_at_20": float(hits.item()) / n_local,
+                       "score_topk_tflops": fl / (ms_score * 1e-3) / 1e12 if ms_score > 0 else None,
+                       "score_topk_frac_of_f32_mfma_peak": fl / (ms_score * 1e-3) / 1e12 / PEAK_F32_TFLOPS if ms_score > 0 else None,
+                       "ms_predict_per_eval": ms_pred / a.eval_steps, "ms_score_topk_per_eval": ms_score / a.eval_steps}
+
+    # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region) -----------
+    flops_total = steps_per_epoch * step_flops(D, NB) * a.steps
+    ach = flops_total / (ms_train * 1e-3) / 1e12 if ms_train > 0 else 0.0
+    roofline = {"kernel": "seq_train_kernel<spatial>", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "traffic": None,
+                "launches": n_train, "avg_ms": ms_train / max(n_train, 1),
+                "note": "f32 arithmetic; f32 vector peak == f32-input MFMA peak on gfx950"}
+    # sparse write-back kernel: algorithmic bytes = unique rows per sequence x D x 4
+    off64 = tab.off.astype(np.int64)
+    uniq = 0
+    for u in range(0, n_local, max(1, n_local // 2000)):          # sampled estimate, scaled
+        s, e = off64[u], off64[u + 1]
+        uniq += len(np.unique(np.concatenate((tab.p[s:e], tab.q[s:e])))) + len(np.unique(tab.dp[s:e]))
+    uniq = uniq * (n_local / len(range(0, n_local, max(1, n_local // 2000))))
+    sc_bytes = uniq * D * 4.0 * a.steps
+    hbm = {"kernel": "rows_apply_kernel", "bound": "hbm", "achieved": sc_bytes / (ms_rows * 1e-3) / 1e9 if ms_rows > 0 else 0.0,
+           "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
+    hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
+
+    # ---- CPU baseline: plain-C float64 port of the same per-sequence algorithm, 1 thread -------------
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import c_oracle as C
+        from oracle import poi_oracle as O
+        rng = np.random.default_rng(7)
+        P = O.init_spatial_params(rng, n_item, ds.dist_num, D)
+        ordr = np.random.default_rng(123).permutation(n_local).astype(np.int32)
+        t0 = time.perf_counter()
+        C.spatial_epoch(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, ordr[:8], tab.len_max, 0.01, 0.001)
+        per = (time.perf_counter() - t0) / 8
+        S = int(min(max(a.cpu_seconds / max(per, 1e-6), 16), 4000, n_local))
+        t0 = time.perf_counter()
+        C.spatial_epoch(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, ordr[:S], tab.len_max, 0.01, 0.001)
+        tc = time.perf_counter() - t0
+        ne = 16
+        t0 = time.perf_counter()
+        C.score_topk(rng.uniform(-0.5, 0.5, (ne, D)), P["lt"][:-1], 20)
+        te = time.perf_counter() - t0
+        cpu = {"value": S / tc, "unit": "sequences/s", "cores": 1, "kind": "port",
+               "sample": "%d sequences of the same shuffled order, sequential per-user SGD (reference semantics), "
+                         "plain-C float64 port of public/GRU_Spatial.py:127-229 (Theano cannot be built or shipped)" % S,
+               "eval_users_per_s": ne / te, "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        out = {
+            "metric": "check-in sequences/sec training (Distance2Pre) + all-POI top-K eval users/sec",
+            "value": seq_per_s, "unit": "sequences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic %s-shape: %d POIs, %d users, seq<=%d, dim=%d, %d distance bins; one step = one "
+                                   "Distance2Pre training epoch over all users" % (a.shape, n_item, n_user, max_len, D, ds.dist_num),
+                       "batch_users_per_launch": B, "parallelism": "user-shard x%d, per-epoch delta all-reduce" % world,
+                       "alpha": 0.01, "lambda": 0.001, "engine": "per-sequence (seq_train_kernel)"},
+            "eval_users_per_s": eval_users_per_s, "eval": eval_detail,
+            "roofline": roofline, "roofline_scatter": hbm,
+            "kernel_ms_per_step": {"seq_train": ms_train / a.steps, "rows_apply": ms_rows / a.steps, "dense_apply": ms_dense / a.steps},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

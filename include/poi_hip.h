@@ -145,6 +145,13 @@ int poi_dist_prob(poi_ctx* ctx, const double* coords, const int32_t* last_poi, c
 int poi_delta_make(poi_ctx* ctx, const float* cur, const float* base, float* delta, int64_t n, void* stream);
 int poi_delta_apply(poi_ctx* ctx, float* cur, const float* base, const float* delta_sum, int64_t n, void* stream);
 
+/* ---- per-kernel timing with HIP events on the launch stream (bench.py's live roofline figures).
+ * Kernel names: "seq_train", "rows_apply", "dense_apply", "seq_predict", "bpr_hogwild", "bpr_grad",
+ * "bpr_apply", "score_topk", "score_all".  poi_timing_get synchronises the device. */
+int poi_timing_enable(poi_ctx* ctx, int on);
+int poi_timing_reset(poi_ctx* ctx);
+int poi_timing_get(poi_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);
+
 /* ---- primitive self-test (wave reductions, atomics) used by tests/ and smoke() --------------- */
 int poi_selftest(poi_ctx* ctx, void* stream);
 

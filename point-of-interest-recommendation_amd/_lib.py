@@ -52,6 +52,9 @@ SIGNATURES = {
                               c_void_p]),
     "poi_delta_make": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "poi_delta_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "poi_timing_enable": (c_int, [c_void_p, c_int]),
+    "poi_timing_reset": (c_int, [c_void_p]),
+    "poi_timing_get": (c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64)]),
     "poi_selftest": (c_int, [c_void_p, c_void_p]),
 }
 
@@ -96,6 +99,16 @@ class Context:
     @property
     def num_cu(self):
         return self.lib.poi_ctx_num_cu(self.handle)
+
+    def timing(self, on=True):
+        self.check(self.lib.poi_timing_reset(self.handle))
+        self.check(self.lib.poi_timing_enable(self.handle, 1 if on else 0))
+
+    def timing_get(self, kernel):
+        """(total milliseconds, launches) recorded for `kernel` since the last timing() call."""
+        ms, n = c_double(0), c_int64(0)
+        self.check(self.lib.poi_timing_get(self.handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def close(self):
         if getattr(self, "handle", None):

@@ -21,7 +21,7 @@ struct DevBuf {
 struct poi_ctx {
   int device = 0;
   int num_cu = 0;
-  int wg_per_cu = 4;
+  int wg_per_cu = 2;
   std::string err;
   // per-sequence engine
   DevBuf ws, slab;
@@ -32,6 +32,7 @@ struct poi_ctx {
   DevBuf cand_s, cand_i;
   // selftest
   DevBuf st;
+  poi::Timing tm;
 };
 
 static int fail(poi_ctx* c, int code, const char* fmt, ...) {
@@ -94,6 +95,7 @@ int poi_ctx_destroy(poi_ctx* c) {
   DevBuf* all[] = {&c->ws, &c->slab, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di,
                    &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->st};
   (void)hipDeviceSynchronize();
+  c->tm.clear();
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c;
   return POI_OK;
@@ -153,7 +155,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   A.slab = (float*)c->slab.p;
   A.g_lt = (float*)c->g_lt.p; A.mult_lt = (int*)c->mult_lt.p; A.nseq_lt = (int*)c->nseq_lt.p;
   A.g_di = (float*)c->g_di.p; A.mult_di = (int*)c->mult_di.p; A.nseq_di = (int*)c->nseq_di.p;
-  HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st));
+  HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st, &c->tm));
   return POI_OK;
 }
 
@@ -180,7 +182,7 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   A.hts = hts; A.sts = sts;
   int grid = c->num_cu * c->wg_per_cu;
   if (grid > n) grid = n;
-  HIPCHK(c, poi::launch_seq_predict(A, spatial, grid, (hipStream_t)stream));
+  HIPCHK(c, poi::launch_seq_predict(A, spatial, grid, (hipStream_t)stream, &c->tm));
   return POI_OK;
 }
 
@@ -207,7 +209,7 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
     if ((rc = ensure(c, c->cnt_blt, sizeof(int) * (size_t)(n_item + 1), st))) return rc;
     A.g_ux = (float*)c->g_ux.p; A.cnt_ux = (int*)c->cnt_ux.p; A.g_lt = (float*)c->g_blt.p; A.cnt_lt = (int*)c->cnt_blt.p;
   }
-  HIPCHK(c, poi::launch_bpr(A, mode, st));
+  HIPCHK(c, poi::launch_bpr(A, mode, st, &c->tm));
   return POI_OK;
 }
 
@@ -240,7 +242,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     if ((rc = ensure(c, c->cand_i, sizeof(int) * cand, st))) return rc;
     A.cand_score = (float*)c->cand_s.p; A.cand_idx = (int*)c->cand_i.p;
   }
-  HIPCHK(c, poi::launch_score(A, st));
+  HIPCHK(c, poi::launch_score(A, st, &c->tm));
   if (k > 0) HIPCHK(c, poi::launch_topk_merge(A, n_split, st));
   return POI_OK;
 }
@@ -310,6 +312,32 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
   if (!c || !cur || !base || !delta_sum || n < 0) return fail(c, POI_EINVAL, "poi_delta_apply: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, poi::launch_delta_apply(cur, base, delta_sum, n, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_timing_enable(poi_ctx* c, int on) {
+  if (!c) return fail(c, POI_EINVAL, "NULL ctx");
+  c->tm.on = on != 0;
+  return POI_OK;
+}
+
+int poi_timing_reset(poi_ctx* c) {
+  if (!c) return fail(c, POI_EINVAL, "NULL ctx");
+  HIPCHK(c, hipDeviceSynchronize());
+  c->tm.clear();
+  return POI_OK;
+}
+
+int poi_timing_get(poi_ctx* c, const char* kernel, double* total_ms, int64_t* launches) {
+  if (!c || !kernel || !total_ms || !launches) return fail(c, POI_EINVAL, "poi_timing_get: NULL argument");
+  HIPCHK(c, hipDeviceSynchronize());
+  double tot = 0; int64_t n = 0;
+  for (auto& r : c->tm.recs) {
+    if (r.name != kernel) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; ++n; }
+  }
+  *total_ms = tot; *launches = n;
   return POI_OK;
 }
 

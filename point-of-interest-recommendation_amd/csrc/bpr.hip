@@ -126,24 +126,30 @@ __global__ __launch_bounds__(POI_BLOCK) void bpr_apply_kernel(BprArgs A) {
 }
 
 template <int LPT>
-static hipError_t launch_bpr_t(const BprArgs& A, int mode, hipStream_t st) {
+static hipError_t launch_bpr_t(const BprArgs& A, int mode, hipStream_t st, Timing* tm) {
   const int gpb = POI_BLOCK / LPT;
   int grid = (A.n + gpb - 1) / gpb;
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
   if (mode == 1) {
+    tm->begin("bpr_hogwild", st);
     hipLaunchKernelGGL(bpr_hogwild_kernel<LPT>, dim3(grid), dim3(POI_BLOCK), 0, st, A);
+    tm->end(st);
   } else {
+    tm->begin("bpr_grad", st);
     hipLaunchKernelGGL(bpr_grad_kernel<LPT>, dim3(grid), dim3(POI_BLOCK), 0, st, A);
+    tm->end(st);
+    tm->begin("bpr_apply", st);
     hipLaunchKernelGGL(bpr_apply_kernel<LPT>, dim3(grid), dim3(POI_BLOCK), 0, st, A);
+    tm->end(st);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st) {
-  if (A.dim <= 64) return launch_bpr_t<16>(A, mode, st);
-  if (A.dim <= 128) return launch_bpr_t<32>(A, mode, st);
-  return launch_bpr_t<64>(A, mode, st);
+hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st, Timing* tm) {
+  if (A.dim <= 64) return launch_bpr_t<16>(A, mode, st, tm);
+  if (A.dim <= 128) return launch_bpr_t<32>(A, mode, st, tm);
+  return launch_bpr_t<64>(A, mode, st, tm);
 }
 
 }  // namespace poi

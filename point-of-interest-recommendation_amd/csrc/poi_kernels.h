@@ -4,7 +4,30 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+#include <vector>
+
 namespace poi {
+
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's live
+// roofline measurement).  Disabled by default: begin()/end() are then no-ops.
+struct Timing {
+  struct Rec { std::string name; hipEvent_t a, b; };
+  bool on = false;
+  std::vector<Rec> recs;
+  size_t limit = 8192;
+  void begin(const char* name, hipStream_t st) {
+    if (!on || recs.size() >= limit) { open_ = false; return; }
+    Rec r; r.name = name;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { open_ = false; return; }
+    (void)hipEventRecord(r.a, st);
+    recs.push_back(r); open_ = true;
+  }
+  void end(hipStream_t st) { if (open_) { (void)hipEventRecord(recs.back().b, st); open_ = false; } }
+  void clear() { for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } recs.clear(); }
+ private:
+  bool open_ = false;
+};
 
 // Arguments of the per-sequence engine kernels (passed by value).
 struct SeqArgs {
@@ -45,8 +68,8 @@ __host__ __device__ inline DenseLayout dense_layout(int D, int XW, int NB) {
 }
 
 size_t seq_ws_floats(int D, int NB, int cap);
-hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st);
-hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st);
+hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
+hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st, Timing* tm);
 
 // BPR-MF
 struct BprArgs {
@@ -59,7 +82,7 @@ struct BprArgs {
   float *g_ux, *g_lt;
   int *cnt_ux, *cnt_lt;   // touches per row in this launch (== multiplicity == distinct triples)
 };
-hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st);
+hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st, Timing* tm);
 
 // scoring / top-K
 struct ScoreArgs {
@@ -72,7 +95,7 @@ struct ScoreArgs {
   float* cand_score; int* cand_idx;   // (n_split, n_pad, k) partial top-K lists
   int* idx_out; float* score_out;
 };
-hipError_t launch_score(const ScoreArgs& A, hipStream_t st);
+hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm);
 hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, hipStream_t st);
 hipError_t launch_topk_rows(const float* scores, int n, int n_item, int k, int* idx_out, float* score_out, hipStream_t st);
 

@@ -255,17 +255,19 @@ __global__ __launch_bounds__(POI_BLOCK) void topk_rows_kernel(const float* __res
 }
 
 template <int D8, bool DB>
-static hipError_t launch_score_t(const ScoreArgs& A, hipStream_t st) {
+static hipError_t launch_score_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   dim3 grid((A.n + 31) / 32, A.n_split / POI_NWAVE);
+  tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
   hipLaunchKernelGGL((score_kernel<D8, DB>), grid, dim3(POI_BLOCK), 0, st, A);
+  tm->end(st);
   return hipGetLastError();
 }
 
-hipError_t launch_score(const ScoreArgs& A, hipStream_t st) {
-  if (A.dim <= 32) return launch_score_t<4, true>(A, st);
-  if (A.dim <= 64) return launch_score_t<8, true>(A, st);
-  if (A.dim <= 128) return launch_score_t<16, true>(A, st);
-  if (A.dim <= 256) return launch_score_t<32, false>(A, st);
+hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm) {
+  if (A.dim <= 32) return launch_score_t<4, true>(A, st, tm);
+  if (A.dim <= 64) return launch_score_t<8, true>(A, st, tm);
+  if (A.dim <= 128) return launch_score_t<16, true>(A, st, tm);
+  if (A.dim <= 256) return launch_score_t<32, false>(A, st, tm);
   return hipErrorInvalidValue;
 }
 

@@ -506,28 +506,33 @@ size_t seq_ws_floats(int D, int NB, int cap) {
   return (size_t)(cap + 1) * D + (size_t)3 * cap * D + (size_t)cap * 3 * D + (size_t)cap * NBpad + (size_t)cap + 16;
 }
 
-hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st) {
+hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm) {
   const int D = A.dim, XW = spatial ? 2 * D : D, NB = spatial ? A.n_dist + 1 : 0;
   const size_t lds = sizeof(float) * seq_lds_floats(D, XW, (NB + 3) & ~3);
   const DenseLayout dl = dense_layout(D, XW, NB);
   const int dgrid = (dl.total + POI_BLOCK - 1) / POI_BLOCK;
-  if (spatial) {
-    hipLaunchKernelGGL(seq_train_kernel<true>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
-    hipLaunchKernelGGL(rows_apply_kernel<true>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
-    hipLaunchKernelGGL(dense_apply_kernel<true>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, grid, alpha, lambda);
-  } else {
-    hipLaunchKernelGGL(seq_train_kernel<false>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
-    hipLaunchKernelGGL(rows_apply_kernel<false>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
-    hipLaunchKernelGGL(dense_apply_kernel<false>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, grid, alpha, lambda);
-  }
+  tm->begin("seq_train", st);
+  if (spatial) hipLaunchKernelGGL(seq_train_kernel<true>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
+  else hipLaunchKernelGGL(seq_train_kernel<false>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
+  tm->end(st);
+  tm->begin("rows_apply", st);
+  if (spatial) hipLaunchKernelGGL(rows_apply_kernel<true>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
+  else hipLaunchKernelGGL(rows_apply_kernel<false>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
+  tm->end(st);
+  tm->begin("dense_apply", st);
+  if (spatial) hipLaunchKernelGGL(dense_apply_kernel<true>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, grid, alpha, lambda);
+  else hipLaunchKernelGGL(dense_apply_kernel<false>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, grid, alpha, lambda);
+  tm->end(st);
   return hipGetLastError();
 }
 
-hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st) {
+hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st, Timing* tm) {
   const int D = A.dim, XW = spatial ? 2 * D : D, NB = spatial ? A.n_dist + 1 : 0;
   const size_t lds = sizeof(float) * seq_lds_floats(D, XW, (NB + 3) & ~3);
+  tm->begin("seq_predict", st);
   if (spatial) hipLaunchKernelGGL(seq_predict_kernel<true>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
   else hipLaunchKernelGGL(seq_predict_kernel<false>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
+  tm->end(st);
   return hipGetLastError();
 }
 

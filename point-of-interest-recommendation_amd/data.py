@@ -115,6 +115,25 @@ def dist_pos_bins(off, p_flat, coords, dd, dist_num):
 
 
 @dataclasses.dataclass
+class CsrTables:
+    """Unpadded form of the (train, test, dist) ctor arguments for a user range: what the device holds."""
+    off: np.ndarray
+    p: np.ndarray
+    q: np.ndarray
+    dp: np.ndarray
+    dq: np.ndarray
+    len_max: int               # padded row length the reference would have used (dataset-wide maximum)
+    tes_p: np.ndarray          # (n, len_tes)
+    tes_q: np.ndarray
+    tes_mask: np.ndarray
+    tes_dp: np.ndarray
+
+    @property
+    def n_user(self):
+        return len(self.off) - 1
+
+
+@dataclasses.dataclass
 class PoiDataset:
     """CSR-packed check-in data in the shape Params.__init__ (prog_bpr_gru_spatial.py:49-100) builds."""
     n_user: int
@@ -145,6 +164,17 @@ class PoiDataset:
         tes_off = np.arange(self.n_user + 1, dtype=np.int32)
         self.tes_q = random_neg_tes(rng, self.n_item, self.off, self.tra_p, tes_off, self.tes_p)
         self.tra_dq = dist_neg_bins(self.off, self.tra_p, self.tra_q, self.coords, self.dd, self.dist_num)
+
+    def shard(self, lo=0, hi=None):
+        """CsrTables of users [lo, hi) (offsets re-based); len_max stays the dataset-wide maximum, as
+        in the reference where every user is padded to the longest sequence of the whole file."""
+        hi = self.n_user if hi is None else hi
+        off = np.asarray(self.off, np.int64)
+        a, b = off[lo], off[hi]
+        return CsrTables(off=(off[lo:hi + 1] - a).astype(np.int32), p=self.tra_p[a:b], q=self.tra_q[a:b],
+                         dp=self.tra_dp[a:b], dq=self.tra_dq[a:b], len_max=self.len_max,
+                         tes_p=self.tes_p[lo:hi].reshape(-1, 1), tes_q=self.tes_q[lo:hi].reshape(-1, 1),
+                         tes_mask=np.ones((hi - lo, 1), np.int32), tes_dp=self.tes_dp[lo:hi].reshape(-1, 1))
 
     def last_pois(self):
         return np.asarray(self.tra_p)[np.asarray(self.off, np.int64)[1:] - 1]

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .data import padded_to_csr
+from .data import CsrTables, padded_to_csr
 
 
 def _ptr(t):
@@ -88,6 +88,18 @@ class _Base:
 
     # ---- tables -------------------------------------------------------------------------------
     def _load_tables(self, train, test):
+        self._csr = train if isinstance(train, CsrTables) else None
+        if self._csr is not None:
+            c = self._csr
+            off = np.ascontiguousarray(c.off, np.int32)
+            self._lens = np.diff(off.astype(np.int64))
+            self.len_max, self.max_len = int(c.len_max), int(self._lens.max())
+            self._off_host = off
+            i32 = lambda v: torch.as_tensor(np.ascontiguousarray(v, dtype=np.int32)).to(self.device)
+            self.off, self.p, self.q = i32(off), i32(c.p), i32(c.q)
+            self.tes_buys_masks, self.tes_masks, self.tes_buys_neg_masks = i32(c.tes_p), i32(c.tes_mask), i32(c.tes_q)
+            self._arange = torch.arange(self.n_user, dtype=torch.int32, device=self.device)
+            return
         tra_buys_masks, tra_masks, tra_buys_neg_masks = train
         tes_buys_masks, tes_masks, tes_buys_neg_masks = test
         tra_masks = np.asarray(tra_masks)
@@ -265,9 +277,12 @@ class OboSpatialGru(GruBasic):
         n_dist, dd = n_dists
         self.n_dist, self.dd = int(n_dist), float(dd)                                      # dd in km (ref passes dd/1000)
         super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device=device, init=init, seed=seed)
-        tra_dist_masks, tes_dist_masks, tra_dist_neg_masks = dist
-        _, dp = padded_to_csr(tra_dist_masks, self._lens)
-        _, dq = padded_to_csr(tra_dist_neg_masks, self._lens)
+        if self._csr is not None:
+            dp, dq, tes_dist_masks = (np.ascontiguousarray(v, np.int32) for v in (self._csr.dp, self._csr.dq, self._csr.tes_dp))
+        else:
+            tra_dist_masks, tes_dist_masks, tra_dist_neg_masks = dist
+            _, dp = padded_to_csr(tra_dist_masks, self._lens)
+            _, dq = padded_to_csr(tra_dist_neg_masks, self._lens)
         self.dp, self.dq = torch.as_tensor(dp).to(self.device), torch.as_tensor(dq).to(self.device)
         self.tes_dist_masks = self._dev(tes_dist_masks, torch.int32)
         rng = np.random.default_rng(None if seed is None else seed + 1) if seed is not None else np.random
