@@ -76,10 +76,16 @@ def main():
     ctx = model.ctx
     sync = poi_amd.dist.ReplicaSync([getattr(model, k).t for k in ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")], ctx=ctx)
 
-    # shuffled user order (prog_bpr_gru_spatial.py:236-238), resident on the device
-    order = torch.as_tensor(np.random.default_rng(123).permutation(n_local).astype(np.int32)).to(dev)
-    B = min(a.batch_users, n_local)
+    # shuffled user order (prog_bpr_gru_spatial.py:236-238), cut into launches of B users; inside a launch
+    # the ids are sorted by descending length so that 32-sequence tiles are homogeneous.  Resident on device.
     lens_local = np.diff(tab.off.astype(np.int64))
+    perm = np.random.default_rng(123).permutation(n_local)
+    B = min(a.batch_users, n_local)
+    batches = []
+    for b0 in range(0, n_local, B):
+        ids = perm[b0:b0 + B]
+        batches.append(ids[np.argsort(-lens_local[ids], kind="stable")])
+    order = torch.as_tensor(np.concatenate(batches).astype(np.int32)).to(dev)
     steps_per_epoch = float(np.maximum(lens_local - 1, 0).sum())
 
     def train_epoch():
@@ -109,9 +115,9 @@ def main():
         train_epoch()
     barrier()
     dt = rank_max(time.perf_counter() - t0)
-    ms_train, n_train = ctx.timing_get("seq_train")
-    ms_rows, n_rows = ctx.timing_get("rows_apply")
-    ms_dense, _ = ctx.timing_get("dense_apply")
+    KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx",
+          "te_finalize", "rows_apply", "dense_apply"]
+    kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
     seq_per_s = n_user * a.steps / dt
 
@@ -142,7 +148,7 @@ def main():
         barrier()
         dte = rank_max(time.perf_counter() - t0)
         ms_score, n_score = ctx.timing_get("score_topk")
-        ms_pred, _ = ctx.timing_get("seq_predict")
+        ms_pred = ctx.timing_get("seq_predict")[0] + ctx.timing_get("te_predict")[0]
         ctx.timing(False)
         eval_users_per_s = n_user * a.eval_steps / dte
         fl = 2.0 * n_local * n_item * D * a.eval_steps
@@ -152,23 +158,43 @@ def main():
                        "ms_predict_per_eval": ms_pred / a.eval_steps, "ms_score_topk_per_eval": ms_score / a.eval_steps}
 
     # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region) -----------
-    flops_total = steps_per_epoch * step_flops(D, NB) * a.steps
-    ach = flops_total / (ms_train * 1e-3) / 1e12 if ms_train > 0 else 0.0
-    roofline = {"kernel": "seq_train_kernel<spatial>", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "traffic": None,
-                "launches": n_train, "avg_ms": ms_train / max(n_train, 1),
-                "note": "f32 arithmetic; f32 vector peak == f32-input MFMA peak on gfx950"}
-    # sparse write-back kernel: algorithmic bytes = unique rows per sequence x D x 4
+    # algorithmic work per GRU step of one sequence: flops for the contractions, bytes
+    # for the gather (3 rows + 4 indices) and the sparse write-back (unique rows per sequence).
     off64 = tab.off.astype(np.int64)
-    uniq = 0
-    for u in range(0, n_local, max(1, n_local // 2000)):          # sampled estimate, scaled
-        s, e = off64[u], off64[u + 1]
-        uniq += len(np.unique(np.concatenate((tab.p[s:e], tab.q[s:e])))) + len(np.unique(tab.dp[s:e]))
-    uniq = uniq * (n_local / len(range(0, n_local, max(1, n_local // 2000))))
-    sc_bytes = uniq * D * 4.0 * a.steps
-    hbm = {"kernel": "rows_apply_kernel", "bound": "hbm", "achieved": sc_bytes / (ms_rows * 1e-3) / 1e9 if ms_rows > 0 else 0.0,
-           "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
+    samp = range(0, n_local, max(1, n_local // 2000))
+    uniq = sum(len(np.unique(np.concatenate((tab.p[off64[u]:off64[u + 1]], tab.q[off64[u]:off64[u + 1]])))) +
+               len(np.unique(tab.dp[off64[u]:off64[u + 1]])) for u in samp) * (n_local / len(samp))
+    D2 = float(D * D)
+    work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
+            "te_gemm_ax": ("flop", 12 * D2 * steps_per_epoch), "te_rec_fwd": ("flop", 6 * D2 * steps_per_epoch),
+            "te_head": ("flop", 6.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
+            "te_wgrad": ("flop", 18 * D2 * steps_per_epoch), "te_gemm_dx": ("flop", 12 * D2 * steps_per_epoch),
+            "te_gather": ("byte", (3.0 * D * 4 + 16) * float(lens_local.sum())),
+            "rows_apply": ("byte", uniq * D * 4.0)}
+    kernels = {}
+    for k in KN:
+        ms, nl = kt[k]
+        if nl == 0:
+            continue
+        ent = {"ms_per_step": ms / a.steps, "launches": nl, "avg_ms": ms / nl}
+        if k in work:
+            kind, w = work[k]
+            rate = w * a.steps / (ms * 1e-3)
+            if kind == "flop":
+                ent.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=rate / 1e12 / PEAK_F32_TFLOPS)
+            else:
+                ent.update(bound="hbm", achieved=rate / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=rate / 1e9 / PEAK_HBM_GBS)
+        kernels[k] = ent
+    dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
+    roofline = dict(kernel=dom, traffic=None, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
+    roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
+    gs_ms = sum(kernels[k]["ms_per_step"] for k in ("te_gather", "rows_apply") if k in kernels)
+    gs_bytes = sum(work[k][1] for k in ("te_gather", "rows_apply") if k in kernels)
+    hbm = {"kernels": [k for k in ("te_gather", "rows_apply") if k in kernels], "bound": "hbm",
+           "achieved": gs_bytes / (gs_ms * 1e-3) / 1e9 if gs_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
     hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
+    total_flops = step_flops(D, NB) * steps_per_epoch
+    train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels)
 
     # ---- CPU baseline: plain-C float64 port of the same per-sequence algorithm, 1 thread -------------
     cpu = None
@@ -177,7 +203,7 @@ def main():
         from oracle import poi_oracle as O
         rng = np.random.default_rng(7)
         P = O.init_spatial_params(rng, n_item, ds.dist_num, D)
-        ordr = np.random.default_rng(123).permutation(n_local).astype(np.int32)
+        ordr = perm.astype(np.int32)
         t0 = time.perf_counter()
         C.spatial_epoch(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, ordr[:8], tab.len_max, 0.01, 0.001)
         per = (time.perf_counter() - t0) / 8
@@ -203,10 +229,10 @@ def main():
             "config": {"workload": "synthetic %s-shape: %d POIs, %d users, seq<=%d, dim=%d, %d distance bins; one step = one "
                                    "Distance2Pre training epoch over all users" % (a.shape, n_item, n_user, max_len, D, ds.dist_num),
                        "batch_users_per_launch": B, "parallelism": "user-shard x%d, per-epoch delta all-reduce" % world,
-                       "alpha": 0.01, "lambda": 0.001, "engine": "per-sequence (seq_train_kernel)"},
+                       "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence"},
             "eval_users_per_s": eval_users_per_s, "eval": eval_detail,
-            "roofline": roofline, "roofline_scatter": hbm,
-            "kernel_ms_per_step": {"seq_train": ms_train / a.steps, "rows_apply": ms_rows / a.steps, "dense_apply": ms_dense / a.steps},
+            "roofline": roofline, "roofline_gather_scatter": hbm, "kernels": kernels,
+            "train_step_tflops": total_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

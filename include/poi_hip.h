@@ -74,6 +74,12 @@ const char* poi_last_error(const poi_ctx* ctx);   /* also valid with ctx == NULL
 /* number of CUs / name of the device the ctx is bound to (host-side queries) */
 int poi_ctx_num_cu(const poi_ctx* ctx);
 
+/* Engine used by poi_spatial_step / poi_gru_predict (spatial): 0 = auto (tile engine for launches of
+ * >= 64 sequences when dim is 64 or 128 and n_dist+1 <= 256, per-sequence engine otherwise),
+ * 1 = per-sequence engine, 2 = tile engine whenever supported.  Both implement the same arithmetic
+ * (only the f32 summation order differs).  Also settable with POI_ENGINE=seq|tile. */
+int poi_ctx_set_engine(poi_ctx* ctx, int engine);
+
 /* ---- a5: BPR-MF step - OboBpr.bpr_train(uidx, [p, q]), public/BPR.py:201-241 ----------------
  * n independent (user, positive, negative) triples.  ux (n_user, D), lt (n_item+1, D).
  * loss_out[n] = -log sigmoid(u).  mode: POI_BPR_SNAPSHOT = batch semantics above;
@@ -147,7 +153,8 @@ int poi_delta_apply(poi_ctx* ctx, float* cur, const float* base, const float* de
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's live roofline figures).
  * Kernel names: "seq_train", "rows_apply", "dense_apply", "seq_predict", "bpr_hogwild", "bpr_grad",
- * "bpr_apply", "score_topk", "score_all".  poi_timing_get synchronises the device. */
+ * "bpr_apply", "score_topk", "score_all", and for the tile engine "te_prep", "te_gather", "te_gemm_ax",
+ * "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx", "te_finalize", "te_predict".  poi_timing_get synchronises the device. */
 int poi_timing_enable(poi_ctx* ctx, int on);
 int poi_timing_reset(poi_ctx* ctx);
 int poi_timing_get(poi_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "poi_ctx_destroy": (c_int, [c_void_p]),
     "poi_last_error": (c_char_p, [c_void_p]),
     "poi_ctx_num_cu": (c_int, [c_void_p]),
+    "poi_ctx_set_engine": (c_int, [c_void_p, c_int]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                              c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
     "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
@@ -99,6 +100,10 @@ class Context:
     @property
     def num_cu(self):
         return self.lib.poi_ctx_num_cu(self.handle)
+
+    def set_engine(self, name):
+        """'auto' | 'seq' | 'tile' (see poi_ctx_set_engine)."""
+        self.check(self.lib.poi_ctx_set_engine(self.handle, {"auto": 0, "seq": 1, "tile": 2}[name]))
 
     def timing(self, on=True):
         self.check(self.lib.poi_timing_reset(self.handle))

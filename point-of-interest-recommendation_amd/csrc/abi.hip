@@ -24,7 +24,8 @@ struct poi_ctx {
   int wg_per_cu = 2;
   std::string err;
   // per-sequence engine
-  DevBuf ws, slab;
+  DevBuf ws, slab, te_ws;
+  int engine = 0;   // 0 auto, 1 per-sequence, 2 tile
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
@@ -85,6 +86,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipGetDeviceProperties failed"); }
   c->num_cu = prop.multiProcessorCount;
   if (const char* e = getenv("POI_SEQ_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
+  if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   *out = c;
   return POI_OK;
@@ -92,7 +94,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di,
+  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di,
                    &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
@@ -125,6 +127,39 @@ static void fill_args(poi::SeqArgs& A, const poi_gru_params* P, const poi_seq_ta
   A.uidx = uidx; A.n_seq = n;
 }
 
+// Carve the tile engine's packed-row workspace out of one grow-only buffer.
+static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int n,
+                    bool predict, hipStream_t st) {
+  memset(&A, 0, sizeof A);
+  const int D = P->dim, NBP = poi::te_nbp(P->n_dist);
+  A.lt = P->lt; A.di = P->di; A.ui = P->ui; A.wh = P->wh; A.bi = P->bi; A.vs = P->vs; A.bs = P->bs; A.wd = P->wd; A.lw = P->lw;
+  A.n_item = P->n_item; A.n_dist = P->n_dist; A.dim = D;
+  A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
+  A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
+  A.dl = poi::dense_layout(D, 2 * D, P->n_dist + 1);
+  const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 64;
+  const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D;
+  const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64;
+  const size_t nin = Tcap * 3 + (size_t)n + 16;
+  int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
+  if (rc) return rc;
+  float* f = (float*)c->te_ws.p;
+  auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
+  A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
+  A.RH = take(Tcap * D); A.DH = take(Tcap * D); A.rowloss = take(Tcap * 2);
+  A.pUiT = (float4*)take((size_t)6 * D * D); A.pUi = (float4*)take((size_t)6 * D * D);
+  A.pWhT = (float4*)take((size_t)3 * D * D); A.pWhc = (float4*)take((size_t)D * D); A.pWhzr = (float4*)take((size_t)2 * D * D);
+  A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
+  int* ip = (int*)f;
+  A.soff = ip; ip += (n + 4) & ~3; A.row_src = ip; ip += Tcap; A.row_t = ip; ip += Tcap; A.row_seq = ip;
+  return POI_OK;
+}
+
+static bool use_tile(const poi_ctx* c, const poi_gru_params* P, bool spatial, int n) {
+  if (!spatial || c->engine == 1 || !poi::te_supported(P->dim, P->n_dist)) return false;
+  return c->engine == 2 || n >= 64;
+}
+
 static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
                     float alpha, float lambda, float* out, void* stream, bool spatial) {
   int rc = check_gru(c, P, T, spatial, true);
@@ -138,8 +173,13 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (grid > n) grid = n;
   const poi::DenseLayout dl = poi::dense_layout(D, XW, NB);
   const size_t wsf = poi::seq_ws_floats(D, NB, T->max_len);
-  if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
-  if ((rc = ensure(c, c->slab, sizeof(float) * (size_t)dl.total * grid, st))) return rc;
+  const bool tile = use_tile(c, P, spatial, n);
+  int n_head = 0, n_kc = 0, n_slab = grid;
+  if (tile) {
+    n_head = c->num_cu; n_kc = 16;
+    n_slab = n_head > n_kc ? n_head : n_kc;
+  } else if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
+  if ((rc = ensure(c, c->slab, sizeof(float) * (size_t)dl.total * n_slab, st))) return rc;
   if ((rc = ensure(c, c->g_lt, sizeof(float) * (size_t)(P->n_item + 1) * D, st))) return rc;
   if ((rc = ensure(c, c->mult_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
   if ((rc = ensure(c, c->nseq_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
@@ -155,6 +195,17 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   A.slab = (float*)c->slab.p;
   A.g_lt = (float*)c->g_lt.p; A.mult_lt = (int*)c->mult_lt.p; A.nseq_lt = (int*)c->nseq_lt.p;
   A.g_di = (float*)c->g_di.p; A.mult_di = (int*)c->mult_di.p; A.nseq_di = (int*)c->nseq_di.p;
+  if (tile) {
+    poi::TeArgs E;
+    if ((rc = te_setup(c, E, P, T, uidx, n, false, st))) return rc;
+    E.out = out; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
+    E.g_lt = A.g_lt; E.g_di = A.g_di; E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
+    HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
+    int agrid = c->num_cu * 4; if (agrid > n) agrid = n;
+    HIPCHK(c, poi::launch_rows_apply(A, true, agrid, alpha, lambda, st, &c->tm));
+    HIPCHK(c, poi::launch_dense_apply(A, true, n_slab, alpha, lambda, st, &c->tm));
+    return POI_OK;
+  }
   HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st, &c->tm));
   return POI_OK;
 }
@@ -177,6 +228,13 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (!uidx || !hts || n < 0) return fail(c, POI_EINVAL, "uidx/hts NULL or n < 0");
   if (n == 0) return POI_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  if (use_tile(c, P, spatial, n)) {
+    poi::TeArgs E;
+    if ((rc = te_setup(c, E, P, T, uidx, n, true, (hipStream_t)stream))) return rc;
+    E.hts = hts; E.sts = sts;
+    HIPCHK(c, poi::launch_te_predict(E, c->num_cu, (hipStream_t)stream, &c->tm));
+    return POI_OK;
+  }
   poi::SeqArgs A;
   fill_args(A, P, T, uidx, n);
   A.hts = hts; A.sts = sts;
@@ -312,6 +370,12 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
   if (!c || !cur || !base || !delta_sum || n < 0) return fail(c, POI_EINVAL, "poi_delta_apply: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, poi::launch_delta_apply(cur, base, delta_sum, n, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_ctx_set_engine(poi_ctx* c, int engine) {
+  if (!c || engine < 0 || engine > 2) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence) or 2 (tile)");
+  c->engine = engine;
   return POI_OK;
 }
 

@@ -67,6 +67,34 @@ __host__ __device__ inline DenseLayout dense_layout(int D, int XW, int NB) {
   return l;
 }
 
+// Arguments of the tile engine (tile_engine.hip).
+struct TeArgs {
+  float *lt, *di, *ui, *wh, *bi, *vs, *bs, *wd, *lw;
+  int n_item, n_dist, dim;
+  const int *off, *p, *q, *dp, *dq;
+  int len_max;
+  const int* uidx;
+  int n_seq;
+  float* out;
+  int predict;                        // 1: forward over all L positions, no bookkeeping
+  // packed-row workspace
+  int *soff, *row_src, *row_t, *row_seq;
+  float *X, *E, *G, *H, *RH, *DH, *rowloss;
+  float4 *pUiT, *pUi, *pWhT, *pWhc, *pWhzr, *pVsT, *pVs;
+  float* slab;
+  int n_slab, n_head, n_kc;
+  DenseLayout dl;
+  float *g_lt, *g_di;
+  int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
+  float *hts, *sts;
+};
+bool te_supported(int D, int n_dist);
+int te_nbp(int n_dist);
+hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
+hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
+hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
+hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, float alpha, float lambda, hipStream_t st, Timing* tm);
+
 size_t seq_ws_floats(int D, int NB, int cap);
 hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
 hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st, Timing* tm);

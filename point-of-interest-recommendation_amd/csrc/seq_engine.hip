@@ -509,19 +509,30 @@ size_t seq_ws_floats(int D, int NB, int cap) {
 hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm) {
   const int D = A.dim, XW = spatial ? 2 * D : D, NB = spatial ? A.n_dist + 1 : 0;
   const size_t lds = sizeof(float) * seq_lds_floats(D, XW, (NB + 3) & ~3);
-  const DenseLayout dl = dense_layout(D, XW, NB);
-  const int dgrid = (dl.total + POI_BLOCK - 1) / POI_BLOCK;
   tm->begin("seq_train", st);
   if (spatial) hipLaunchKernelGGL(seq_train_kernel<true>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
   else hipLaunchKernelGGL(seq_train_kernel<false>, dim3(grid), dim3(POI_BLOCK), lds, st, A);
   tm->end(st);
+  hipError_t e = launch_rows_apply(A, spatial, grid, alpha, lambda, st, tm);
+  if (e != hipSuccess) return e;
+  return launch_dense_apply(A, spatial, grid, alpha, lambda, st, tm);
+}
+
+hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm) {
   tm->begin("rows_apply", st);
   if (spatial) hipLaunchKernelGGL(rows_apply_kernel<true>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
   else hipLaunchKernelGGL(rows_apply_kernel<false>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
   tm->end(st);
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, float alpha, float lambda, hipStream_t st, Timing* tm) {
+  const int D = A.dim, XW = spatial ? 2 * D : D, NB = spatial ? A.n_dist + 1 : 0;
+  const DenseLayout dl = dense_layout(D, XW, NB);
+  const int dgrid = (dl.total + POI_BLOCK - 1) / POI_BLOCK;
   tm->begin("dense_apply", st);
-  if (spatial) hipLaunchKernelGGL(dense_apply_kernel<true>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, grid, alpha, lambda);
-  else hipLaunchKernelGGL(dense_apply_kernel<false>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, grid, alpha, lambda);
+  if (spatial) hipLaunchKernelGGL(dense_apply_kernel<true>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, n_slab, alpha, lambda);
+  else hipLaunchKernelGGL(dense_apply_kernel<false>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, n_slab, alpha, lambda);
   tm->end(st);
   return hipGetLastError();
 }

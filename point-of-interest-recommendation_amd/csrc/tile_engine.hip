@@ -1,0 +1,799 @@
+// Tile engine ("throughput mode"): the Distance2Pre training step for a BATCH of sequences, decomposed
+// so that every heavy contraction is a tile GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32,
+// exact f32 products / accumulation), with the recurrence confined to two small per-tile kernels:
+//
+//   te_scan      exclusive scan of the per-sequence step counts -> packed row offsets
+//   te_rowmap    packed row -> CSR position; table-touch bookkeeping (multiplicity / distinct sequences)
+//   te_pack      weights -> MFMA B-fragment order (every weight load is then a coalesced 1-KiB stream)
+//   te_gather    X[r] = [lt[p_t] | di[dp_t]],  E[r] = lt[p_{t+1}] - lt[q_{t+1}]          (HBM-bound)
+//   te_gemm_ax   G[r] = X[r] . ui^T + bi                      (all steps at once, K = 2D)
+//   te_rec_fwd   per 32-sequence tile, t ascending: gates from G + h_{t-1} . wh^T  -> G := z|r|c, H, RH
+//   te_head      per 32-row tile: logits = H . vs^T + bs, softmax, BPR + survival losses, d logits,
+//                DH = dlogits . vs + g * E, d vs partials, +-g*h scattered to the gradient table
+//   te_rec_bwd   per 32-sequence tile, t descending (BPTT): G := da_z|da_r|da_c, d bi partials
+//   te_wgrad     split-K  d ui = DA^T . X,  d wh = DA^T . [Hprev | RH]   -> per-chunk slabs
+//   te_gemm_dx   dx = DA . ui, scattered (float atomics) into the gradient tables
+//   te_finalize  per-sequence losses, loss-weight statistics
+// followed by the shared rows_apply / dense_apply write-back (seq_engine.hip).
+//
+// Math and semantics are identical to the per-sequence engine (public/GRU_Spatial.py:127-229, batch
+// rule of include/poi_hip.h); only the summation order differs.
+#include "poi_common.h"
+#include "poi_kernels.h"
+
+namespace poi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TE_BLOCK 256
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// C/D layout of the 32x32 tile: element (row, col) of register r in lane l
+__device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// -------------------------------------------------------------------------------------------------
+// Packed B operand: logical B[k][n], k < K (padded to K8*8), n < N (padded to NT*32):
+//   P[(nt * K8 + m) * 64 + lane] = float4{ B[8m + 4h + c][32 nt + j], c = 0..3 },  lane = h*32 + j.
+// MFMA step 4m+c consumes component c of both operands, so A (read as float4 at k = 8m+4h from a
+// row-major LDS tile) and B agree on a permuted k order and every loaded byte is used.
+// -------------------------------------------------------------------------------------------------
+struct PackJob { const float* src; int sk, sn, K, N, K8, NT; float4* dst; };
+struct PackJobs { PackJob j[8]; int n; };
+
+__global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
+  const PackJob& j = J.j[blockIdx.y];
+  const int total = j.NT * j.K8 * 64;
+  for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < total; e += gridDim.x * TE_BLOCK) {
+    const int lane = e & 63, m = (e >> 6) % j.K8, nt = (e >> 6) / j.K8;
+    const int n = nt * 32 + (lane & 31), k0 = 8 * m + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c;
+      v[c] = (k < j.K && n < j.N) ? j.src[(size_t)k * j.sk + (size_t)n * j.sn] : 0.f;
+    }
+    j.dst[e] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// acc[i][j] += A_i (32 x 8*K8, LDS row-major, leading dim lda) . B_j (packed n-tile j of `bp`)
+template <int MT, int NTW, int K8>
+__device__ __forceinline__ void mma_lds_packed(f32x16 (&acc)[MT][NTW], const float* __restrict__ ldsA, int lda,
+                                               const float4* __restrict__ bp, const int (&nt)[NTW]) {
+  const int lane = lane_id(), li = lane & 31, h = lane >> 5;
+  const float* arow = ldsA + li * lda + 4 * h;
+  float4 bq[2][NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) bq[0][j] = bp[((size_t)nt[j] * K8 + 0) * 64 + lane];
+#pragma unroll
+  for (int m = 0; m < K8; ++m) {
+    if (m + 1 < K8) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) bq[(m + 1) & 1][j] = bp[((size_t)nt[j] * K8 + (m + 1)) * 64 + lane];
+    }
+    float4 a[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda + 8 * m);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const float4 b = bq[m & 1][j];
+        acc[i][j] = mfma32(a[i].x, b.x, acc[i][j]);
+        acc[i][j] = mfma32(a[i].y, b.y, acc[i][j]);
+        acc[i][j] = mfma32(a[i].z, b.z, acc[i][j]);
+        acc[i][j] = mfma32(a[i].w, b.w, acc[i][j]);
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// bookkeeping kernels
+// -------------------------------------------------------------------------------------------------
+// soff[k] = sum_{k' < k} (L_k' - 1); soff[n] = total packed rows.  One 1024-thread block.
+__global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, n = A.n_seq;
+  const int per = (n + 1023) / 1024;
+  const int b = tid * per, e = min(n, b + per);
+  int s = 0;
+  for (int k = b; k < e; ++k) { const int u = A.uidx[k]; const int L = A.off[u + 1] - A.off[u]; s += A.predict ? L : (L > 0 ? L - 1 : 0); }
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) { int v = tid >= o ? part[tid - o] : 0; __syncthreads(); part[tid] += v; __syncthreads(); }
+  int run = tid > 0 ? part[tid - 1] : 0;
+  for (int k = b; k < e; ++k) { A.soff[k] = run; const int u = A.uidx[k]; const int L = A.off[u + 1] - A.off[u]; run += A.predict ? L : (L > 0 ? L - 1 : 0); }
+  if (tid == 1023) A.soff[n] = part[1023];
+}
+
+// one wavefront per sequence: row maps + table-touch counts (same rules as seq_engine count_rows)
+__device__ __forceinline__ void te_count(const int* a, const int* b, int L, bool two, int pad_row, int pad_mult,
+                                         int* mult, int* nseq) {
+  const int n = two ? 2 * L : L, lane = lane_id();
+  int seen = 0;
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const int e = e0 + lane;
+    int row = -1;
+    if (e < n) {
+      row = (two && e >= L) ? b[e - L] : a[e];
+      atomicAdd(&mult[row], 1);
+      int dup = 0;
+      for (int j = 0; j < e; ++j) dup |= (((two && j >= L) ? b[j - L] : a[j]) == row) ? 1 : 0;
+      if (!dup) atomicAdd(&nseq[row], 1);
+    }
+    seen |= __any(row == pad_row) ? 1 : 0;
+  }
+  if (pad_mult > 0 && lane == 0) {
+    atomicAdd(&mult[pad_row], pad_mult);
+    if (!seen) atomicAdd(&nseq[pad_row], 1);
+  }
+}
+
+__global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
+  const int k = blockIdx.x * POI_NWAVE + wave_id();
+  if (k >= A.n_seq) return;
+  const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = A.soff[k];
+  for (int t = lane_id(); t < ns; t += 64) { A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t; A.row_seq[r0 + t] = k; }
+  if (A.predict) return;
+  te_count(A.p + base, A.q + base, L, true, A.n_item, 2 * (A.len_max - L), A.mult_lt, A.nseq_lt);
+  te_count(A.dp + base, A.dp + base, L, false, A.n_dist, A.len_max - L, A.mult_di, A.nseq_di);
+}
+
+// X[r] = [lt[p_t] | di[dp_t]], E[r] = lt[p_{t+1}] - lt[q_{t+1}].  LPR lanes per row, float4 per lane.
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A, int predict) {
+  constexpr int LPR = D / 4;                    // lanes per table row
+  constexpr int RPB = TE_BLOCK / LPR;           // rows per block pass
+  const int T = A.soff[A.n_seq];
+  const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
+  for (int r = blockIdx.x * RPB + sub; r < T; r += gridDim.x * RPB) {
+    const int s = A.row_src[r];
+    const float4 xp = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s] * D + c);
+    const float4 xd = *reinterpret_cast<const float4*>(A.di + (size_t)A.dp[s] * D + c);
+    *reinterpret_cast<float4*>(A.X + (size_t)r * 2 * D + c) = xp;
+    *reinterpret_cast<float4*>(A.X + (size_t)r * 2 * D + D + c) = xd;
+    if (!predict) {
+      const float4 a = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s + 1] * D + c);
+      const float4 b = *reinterpret_cast<const float4*>(A.lt + (size_t)A.q[s + 1] * D + c);
+      *reinterpret_cast<float4*>(A.E + (size_t)r * D + c) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    }
+  }
+}
+
+// stage `rows` x `cols` floats (row r of the tile = global row r0 + r, zero beyond T) into LDS
+__device__ __forceinline__ void stage_rows(float* lds, int lda, const float* __restrict__ src, int ld_src, int cols,
+                                           int r0, int rows, int T) {
+  const int c4n = cols >> 2;
+  for (int e = threadIdx.x; e < rows * c4n; e += blockDim.x) {
+    const int r = e / c4n, c = (e % c4n) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < T) v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * ld_src + c);
+    *reinterpret_cast<float4*>(lds + (size_t)r * lda + c) = v;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_gemm_ax: G[r][0:3D] = X[r] . ui^T + bi      (64 rows per iteration, 4 waves split the 3D columns)
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_gemm_ax_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int XW = 2 * D, K8 = XW / 8, NT = 3 * D / 32, NTW = (NT + 3) / 4, LDA = XW + 4;
+  const int T = A.soff[A.n_seq];
+  const int lane = lane_id(), w = wave_id(), li = lane & 31;
+  int nt[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
+  for (int r0 = blockIdx.x * 64; r0 < T; r0 += gridDim.x * 64) {
+    __syncthreads();
+    stage_rows(lds, LDA, A.X, XW, XW, r0, 64, T);
+    __syncthreads();
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    mma_lds_packed<2, NTW, K8>(acc, lds, LDA, A.pUiT, nt);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if (w + 4 * j >= NT) continue;
+      const int col = nt[j] * 32 + li;
+      const float b = A.bi[col];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + 32 * i + c_row(r, lane);
+          if (row < T) A.G[(size_t)row * 3 * D + col] = acc[i][j][r] + b;
+        }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_rec_fwd: one workgroup (D/32 waves) per tile of 32 sequences; wave w owns hidden columns
+// [32w, 32w+32) of z, r, c and h, so the state update is lane-local; h_{t-1} and r*h_{t-1} are
+// exchanged through LDS (two barriers per step).
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int K8 = D / 8, LDA = D + 4, NTD = D / 32;
+  float* Hb0 = lds;                      // h_{t-1}
+  float* Hb1 = Hb0 + 32 * LDA;           // h_t
+  float* RHb = Hb1 + 32 * LDA;           // r * h_{t-1}
+  __shared__ int s_r0[32], s_ns[32];
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  const int col = 32 * w + li;
+  const int tile = blockIdx.x;
+  if (tid < 32) {
+    const int k = tile * 32 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) {
+      r0 = A.soff[k];
+      ns = A.soff[k + 1] - r0;
+    }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  for (int e = tid; e < 32 * LDA; e += blockDim.x) { Hb0[e] = 0.f; Hb1[e] = 0.f; }
+  __syncthreads();
+  int ns_max = 0;
+  for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
+  int rowb[16], nsr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
+  const int ntz[1] = {w}, ntr[1] = {NTD + w}, ntc[1] = {2 * NTD + w};
+  float* Hp = Hb0; float* Hn = Hb1;
+  for (int t = 0; t < ns_max; ++t) {
+    f32x16 az[1][1], ar[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool on = t < nsr[r];
+      const float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
+      az[0][0][r] = on ? g[col] : 0.f;
+      ar[0][0][r] = on ? g[D + col] : 0.f;
+    }
+    mma_lds_packed<1, 1, K8>(az, Hp, LDA, A.pWhT, ntz);
+    mma_lds_packed<1, 1, K8>(ar, Hp, LDA, A.pWhT, ntr);
+    float zv[16], hp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = c_row(r, lane);
+      const bool on = t < nsr[r];
+      zv[r] = sigmoidf_(az[0][0][r]);
+      const float rv = sigmoidf_(ar[0][0][r]);
+      hp[r] = Hp[i * LDA + col];
+      const float rh = rv * hp[r];
+      RHb[i * LDA + col] = rh;
+      if (on) {
+        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
+        g[D + col] = rv;
+        if (!predict) A.RH[(size_t)(rowb[r] + t) * D + col] = rh;
+      }
+    }
+    __syncthreads();
+    f32x16 ac[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ac[0][0][r] = (t < nsr[r]) ? A.G[(size_t)(rowb[r] + t) * 3 * D + 2 * D + col] : 0.f;
+    mma_lds_packed<1, 1, K8>(ac, RHb, LDA, A.pWhT, ntc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = c_row(r, lane);
+      const bool on = t < nsr[r];
+      const float c = tanhf(ac[0][0][r]);
+      const float hn = on ? (1.0f - zv[r]) * hp[r] + zv[r] * c : hp[r];
+      Hn[i * LDA + col] = hn;
+      if (on && !predict) {
+        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
+        g[col] = zv[r]; g[2 * D + col] = c;
+        A.H[(size_t)(rowb[r] + t) * D + col] = hn;
+      }
+    }
+    __syncthreads();
+    float* tmp = Hp; Hp = Hn; Hn = tmp;
+  }
+  if (predict) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = c_row(r, lane), k = tile * 32 + i;
+      if (k < A.n_seq) A.hts[(size_t)k * D + col] = Hp[i * LDA + col];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_head: 32 packed rows per iteration (persistent grid).  NBT = number of 32-bin tiles (bins padded).
+// mode 0: training (losses, d logits, DH, d vs partials, +-g*h scatter); mode 1: predict (sts only,
+// rows = sequences, H = hts).
+// -------------------------------------------------------------------------------------------------
+template <int D, int NBT>
+__global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int K8 = D / 8, LDH = D + 4, NBP = NBT * 32, LDO = NBP + 4, NTW = (NBT + 3) / 4, NTD = D / 32;
+  constexpr int KB8 = NBP / 8, DTW = (NTD + 3) / 4, VT = (NBT * NTD + 3) / 4;   // d vs tiles per wave
+  float* Ht = lds;                  // 32 x LDH
+  float* Ot = Ht + 32 * LDH;        // 32 x LDO : logits -> softmax -> d logits
+  __shared__ float s_g[32], s_red[8];
+  const int NB = A.n_dist + 1;
+  const int T = mode ? A.n_seq : A.soff[A.n_seq];
+  const float* Hsrc = mode ? A.hts : A.H;
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  float ls0 = 0.f, ls1 = 1.f, wd = 0.f;
+  {
+    const float a = A.lw[0], b = A.lw[1], m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    ls0 = ea / (ea + eb); ls1 = eb / (ea + eb); wd = A.wd[0];
+  }
+  int nto[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) nto[j] = min(w + 4 * j, NBT - 1);
+  // d vs accumulators: output tile v = w + 4*jj covers bins tile (v / NTD), hidden tile (v % NTD)
+  f32x16 dvs[VT];
+#pragma unroll
+  for (int v = 0; v < VT; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dvs[v][r] = 0.f;
+  float dbs_acc = 0.f;      // thread tid < NBP accumulates d bs[tid]
+  float dwd_acc = 0.f;      // meaningful in the row-owner lanes, reduced at the end
+
+  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    __syncthreads();
+    stage_rows(Ht, LDH, Hsrc, D, D, r0, 32, T);
+    __syncthreads();
+    {   // logits
+      f32x16 acc[1][NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+      mma_lds_packed<1, NTW, K8>(acc, Ht, LDH, A.pVsT, nto);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        if (w + 4 * j >= NBT) continue;
+        const int bin = nto[j] * 32 + li;
+        const float b = bin < NB ? A.bs[bin] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + bin] = bin < NB ? acc[0][j][r] + b : -INFINITY;
+      }
+    }
+    __syncthreads();
+    {   // row-wise softmax + losses: 8 lanes per row
+      const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
+      float* o = Ot + row * LDO;
+      float mx = -INFINITY;
+      for (int k = sub; k < NBP; k += 8) mx = fmaxf(mx, o[k]);
+      mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx));
+      float sum = 0.f;
+      for (int k = sub; k < NBP; k += 8) { const float e = expf(o[k] - mx); o[k] = e; sum += e; }
+      sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
+      const float inv = 1.0f / sum;
+      if (mode) {
+        if (gr < T) for (int k = sub; k < NB; k += 8) A.sts[(size_t)gr * NB + k] = o[k] * inv;
+      } else {
+        int a = 0, b = 0;
+        if (gr < T) { const int s = A.row_src[gr]; a = A.dp[s + 1]; b = A.dq[s + 1]; }
+        float cum = 0.f, he = 0.f;
+        for (int k = sub; k < NBP; k += 8) { const float s = o[k] * inv; o[k] = s; if (k <= a) cum += s; }
+        if (gr < T) for (int j = sub; j < D; j += 8) he += Ht[row * LDH + j] * A.E[(size_t)gr * D + j];
+        cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
+        he += dpp_f<0xB1>(he); he += dpp_f<0x4E>(he); he += dpp_f<0x141>(he);
+        // (the 8 lanes of a row now hold identical cum / he; they all wrote disjoint o[k])
+        __builtin_amdgcn_wave_barrier();
+        const float sa = o[a], sb = o[b];
+        float g = 0.f, dot = 0.f;
+        if (gr < T) {
+          const float u = he + wd * (sa - sb);
+          g = -ls1 * sigmoidf_(-u);
+          dot = ls0 * cum - ls0 + g * wd * (sa - sb);
+          if (sub == 0) {
+            A.rowloss[2 * (size_t)gr] = cum - logf(sa);
+            A.rowloss[2 * (size_t)gr + 1] = log_sigmoidf_(u);
+            dwd_acc += g * (sa - sb);
+          }
+        }
+        if (sub == 0) s_g[row] = g;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = sub; k < NBP; k += 8) {
+          float dl = 0.f;
+          if (gr < T && k < NB) {
+            float ds = (k <= a ? ls0 : 0.f);
+            if (k == a) ds += g * wd - ls0 / sa;
+            if (k == b) ds -= g * wd;
+            dl = o[k] * (ds - dot);
+          }
+          o[k] = dl;
+        }
+      }
+    }
+    __syncthreads();
+    if (!mode) {
+      if (tid < NBP) { float s = 0.f; for (int r = 0; r < 32; ++r) s += Ot[r * LDO + tid]; dbs_acc += s; }
+      // DH = d logits . vs + g * E ; +-g*h scatter
+      int ntd[DTW];
+#pragma unroll
+      for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
+      f32x16 acc[1][DTW];
+#pragma unroll
+      for (int j = 0; j < DTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+      mma_lds_packed<1, DTW, KB8>(acc, Ot, LDO, A.pVs, ntd);
+#pragma unroll
+      for (int j = 0; j < DTW; ++j) {
+        if (w + 4 * j >= NTD) continue;
+        const int col = ntd[j] * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = c_row(r, lane), gr = r0 + i;
+          if (gr < T) {
+            const float g = s_g[i];
+            A.DH[(size_t)gr * D + col] = acc[0][j][r] + g * A.E[(size_t)gr * D + col];
+            const int s = A.row_src[gr];
+            const float gh = g * Ht[i * LDH + col];
+            atomicAdd(A.g_lt + (size_t)A.p[s + 1] * D + col, gh);
+            atomicAdd(A.g_lt + (size_t)A.q[s + 1] * D + col, -gh);
+          }
+        }
+      }
+      // d vs += d logits^T . H   (A[i = bin][k = row] from Ot, B[k = row][j = hidden col] from Ht)
+#pragma unroll
+      for (int v = 0; v < VT; ++v) {
+        const int vt = w + 4 * v;
+        if (vt >= NBT * NTD) continue;
+        const int bt = vt / NTD, ht = vt % NTD;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const int row = 2 * kk + (lane >> 5);
+          dvs[v] = mfma32(Ot[row * LDO + bt * 32 + li], Ht[row * LDH + ht * 32 + li], dvs[v]);
+        }
+      }
+    }
+  }
+  if (!mode) {
+    float* slab = A.slab + (size_t)blockIdx.x * A.dl.total;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      const int vt = w + 4 * v;
+      if (vt >= NBT * NTD) continue;
+      const int bt = vt / NTD, ht = vt % NTD;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int bin = bt * 32 + c_row(r, lane);
+        if (bin < NB) slab[A.dl.vs + (size_t)bin * D + ht * 32 + li] += dvs[v][r];
+      }
+    }
+    if (tid < NB) slab[A.dl.bs + tid] += dbs_acc;
+    const float dw = block_sum(dwd_acc, s_red);
+    if (tid == 0) slab[A.dl.wd] += dw;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_rec_bwd: BPTT per 32-sequence tile, t descending; wave w owns hidden columns [32w, 32w+32).
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int K8 = D / 8, LDA = D + 4, LDB = 2 * D + 4, NTD = D / 32;
+  float* Ac = lds;                       // da_c           32 x LDA
+  float* Azr = Ac + 32 * LDA;            // da_z | da_r    32 x LDB
+  __shared__ int s_r0[32], s_ns[32];
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  const int col = 32 * w + li;
+  const int tile = blockIdx.x;
+  if (tid < 32) {
+    const int k = tile * 32 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  __syncthreads();
+  int ns_max = 0;
+  for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
+  int rowb[16], nsr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
+  const int ntc[1] = {w};                 // wh[2] as B[k = i][n = j]: packed pWhc, NTD n-tiles
+  const int ntzr[1] = {w};                // wh[0:2] rows as K = 2D: packed pWhzr
+  float dhn[16], sbz = 0.f, sbr = 0.f, sbc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dhn[r] = 0.f;
+  for (int t = ns_max - 1; t >= 0; --t) {
+    float zv[16], rv[16], hp[16], dz[16], dhp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = c_row(r, lane);
+      const bool on = t < nsr[r];
+      const size_t row = (size_t)(rowb[r] + t);
+      float z = 0.f, rr = 0.f, c = 0.f, h = 0.f, dh = 0.f;
+      if (on) {
+        const float* g = A.G + row * 3 * D;
+        z = g[col]; rr = g[D + col]; c = g[2 * D + col];
+        h = t > 0 ? A.H[(row - 1) * D + col] : 0.f;
+        dh = dhn[r] + A.DH[row * D + col];
+      }
+      zv[r] = z; rv[r] = rr; hp[r] = h;
+      dz[r] = dh * (c - h);
+      dhp[r] = dh * (1.0f - z);
+      Ac[i * LDA + col] = dh * z * (1.0f - c * c);
+    }
+    __syncthreads();
+    f32x16 m[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[0][0][r] = 0.f;
+    mma_lds_packed<1, 1, K8>(m, Ac, LDA, A.pWhc, ntc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = c_row(r, lane);
+      const float mv = m[0][0][r];
+      const float dr = mv * hp[r];
+      dhp[r] += mv * rv[r];
+      const float daz = dz[r] * zv[r] * (1.0f - zv[r]);
+      const float dar = dr * rv[r] * (1.0f - rv[r]);
+      Azr[i * LDB + col] = daz;
+      Azr[i * LDB + D + col] = dar;
+      const bool on = t < nsr[r];
+      if (on) {
+        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
+        const float dac = Ac[i * LDA + col];
+        g[col] = daz; g[D + col] = dar; g[2 * D + col] = dac;
+        sbz += daz; sbr += dar; sbc += dac;
+      }
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    mma_lds_packed<1, 1, 2 * K8>(acc, Azr, LDB, A.pWhzr, ntzr);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][0][r] : 0.f;
+    // (the next iteration's writes to Ac happen before its barrier; reads of Azr are complete because
+    //  every wave passes the next barrier only after finishing this MFMA block)
+    __syncthreads();
+  }
+  // d bi partial sums of this tile (columns owned by this lane in both half-waves)
+  float* slab = A.slab + (size_t)(tile % A.n_slab) * A.dl.total;
+  sbz += __shfl_xor(sbz, 32, 64); sbr += __shfl_xor(sbr, 32, 64); sbc += __shfl_xor(sbc, 32, 64);
+  if (lane < 32 && ns_max > 0) {
+    atomicAdd(slab + A.dl.bi + col, sbz);
+    atomicAdd(slab + A.dl.bi + D + col, sbr);
+    atomicAdd(slab + A.dl.bi + 2 * D + col, sbc);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_wgrad: split-K transposed GEMMs  out[m][n] = sum_r DA[r][m0+m] * Bsrc[r][n0+n]  on 64x64 output
+// blocks; K-chunk c covers packed rows [c*chunk, (c+1)*chunk).  job -> (A column block, B source).
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
+  __shared__ __align__(16) float At[32][64 + 4];
+  __shared__ __align__(16) float Bt[32][64 + 4];
+  constexpr int XW = 2 * D;
+  constexpr int NB_UI = (3 * D / 64) * (XW / 64), NB_ZR = (2 * D / 64) * (D / 64), NB_C = (D / 64) * (D / 64);
+  const int T = A.soff[A.n_seq];
+  const int job = blockIdx.x, kc = blockIdx.y;
+  int m0, n0, ldo, bsel; size_t oo;
+  if (job < NB_UI) { const int bn = XW / 64; m0 = (job / bn) * 64; n0 = (job % bn) * 64; ldo = XW; oo = A.dl.ui; bsel = 0; }
+  else if (job < NB_UI + NB_ZR) { const int j = job - NB_UI, bn = D / 64; m0 = (j / bn) * 64; n0 = (j % bn) * 64; ldo = D; oo = A.dl.wh; bsel = 1; }
+  else { const int j = job - NB_UI - NB_ZR, bn = D / 64; m0 = 2 * D + (j / bn) * 64; n0 = (j % bn) * 64; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
+  const int chunk = (((T + nkc - 1) / nkc) + 31) & ~31;
+  const int rb = kc * chunk, re = min(T, rb + chunk);
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
+  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r0 = rb; r0 < re; r0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < 32 * 16; e += TE_BLOCK) {
+      const int r = e >> 4, c = (e & 15) * 4, gr = r0 + r;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (gr < re) {
+        a = *reinterpret_cast<const float4*>(A.G + (size_t)gr * 3 * D + m0 + c);
+        if (bsel == 0) b = *reinterpret_cast<const float4*>(A.X + (size_t)gr * XW + n0 + c);
+        else if (bsel == 1) { if (A.row_t[gr] > 0) b = *reinterpret_cast<const float4*>(A.H + (size_t)(gr - 1) * D + n0 + c); }
+        else b = *reinterpret_cast<const float4*>(A.RH + (size_t)gr * D + n0 + c);
+      }
+      *reinterpret_cast<float4*>(&At[r][c]) = a;
+      *reinterpret_cast<float4*>(&Bt[r][c]) = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = mfma32(At[2 * kk + h][wm + li], Bt[2 * kk + h][wn + li], acc);
+  }
+  // m index of the output = DA column: for bsel 2 the slab row is (m0 - 2D + ...) inside wh[2]
+  float* out = A.slab + (size_t)kc * A.dl.total + oo;
+  const int mbase = (bsel == 2 ? m0 - 2 * D : m0) + wm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[(size_t)(mbase + c_row(r, lane)) * ldo + n0 + wn + li] += acc[r];
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_gemm_dx: dx[r] = DA[r] . ui (K = 3D, N = 2D); columns [0, D) -> g_lt[p_t], [D, 2D) -> g_di[dp_t]
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_gemm_dx_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int K = 3 * D, K8 = K / 8, NT = 2 * D / 32, NTW = (NT + 3) / 4, LDA = K + 4;
+  const int T = A.soff[A.n_seq];
+  const int lane = lane_id(), w = wave_id(), li = lane & 31;
+  int nt[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
+  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    __syncthreads();
+    stage_rows(lds, LDA, A.G, K, K, r0, 32, T);
+    __syncthreads();
+    f32x16 acc[1][NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    mma_lds_packed<1, NTW, K8>(acc, lds, LDA, A.pUi, nt);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if (w + 4 * j >= NT) continue;
+      const int col = nt[j] * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + c_row(r, lane);
+        if (gr < T) {
+          const int s = A.row_src[gr];
+          float* dst = col < D ? A.g_lt + (size_t)A.p[s] * D + col : A.g_di + (size_t)A.dp[s] * D + (col - D);
+          atomicAdd(dst, acc[0][j][r]);
+        }
+      }
+    }
+  }
+}
+
+// per-sequence losses (deterministic row order) + loss-weight statistics
+__global__ __launch_bounds__(TE_BLOCK) void te_finalize_kernel(TeArgs A) {
+  __shared__ float red[8];
+  const int k = blockIdx.x * TE_BLOCK + threadIdx.x;
+  float sur = 0.f, bpr = 0.f;
+  float ls0, ls1;
+  {
+    const float a = A.lw[0], b = A.lw[1], m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    ls0 = ea / (ea + eb); ls1 = eb / (ea + eb);
+  }
+  if (k < A.n_seq) {
+    for (int r = A.soff[k]; r < A.soff[k + 1]; ++r) { sur += A.rowloss[2 * (size_t)r]; bpr += A.rowloss[2 * (size_t)r + 1]; }
+    float* o = A.out + (size_t)k * 5;
+    o[0] = ls0 * sur - ls1 * bpr; o[1] = sur; o[2] = -bpr; o[3] = ls0; o[4] = ls1;
+  }
+  const float s1 = block_sum(sur, red);
+  const float s2 = block_sum(-bpr, red);
+  if (threadIdx.x == 0) {
+    float* slab = A.slab + (size_t)(blockIdx.x % A.n_slab) * A.dl.total;
+    atomicAdd(slab + A.dl.sur, s1);
+    atomicAdd(slab + A.dl.upq, s2);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+bool te_supported(int D, int n_dist) { return (D == 64 || D == 128) && n_dist + 1 <= 256; }
+
+int te_nbp(int n_dist);
+static int nbt_for(int nb) { const int t = (nb + 31) / 32; return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8; }
+
+int te_nbp(int n_dist) { return nbt_for(n_dist + 1) * 32; }
+
+template <int D, int NBT>
+static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_t st) {
+  const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (NBT * 32 + 4));
+  hipLaunchKernelGGL((te_head_kernel<D, NBT>), dim3(grid), dim3(TE_BLOCK), lds, st, A, mode);
+  return hipGetLastError();
+}
+
+template <int D>
+static hipError_t te_head_dispatch(const TeArgs& A, int mode, int grid, hipStream_t st) {
+  switch (nbt_for(A.n_dist + 1)) {
+    case 1: return te_launch_head<D, 1>(A, mode, grid, st);
+    case 2: return te_launch_head<D, 2>(A, mode, grid, st);
+    case 4: return te_launch_head<D, 4>(A, mode, grid, st);
+    case 7: return te_launch_head<D, 7>(A, mode, grid, st);
+    default: return te_launch_head<D, 8>(A, mode, grid, st);
+  }
+}
+
+static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
+  const int D = A.dim, XW = 2 * D, NBP = nbt_for(A.n_dist + 1) * 32, NB = A.n_dist + 1;
+  int n = 0;
+  // B[k][n] = ui[n][k]   (K = 2D, N = 3D)
+  J.j[n++] = PackJob{A.ui, 1, XW, XW, 3 * D, XW / 8, 3 * D / 32, A.pUiT};
+  // B[k][n] = wh_flat[n][k]   (K = D, N = 3D)
+  J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT};
+  // B[k][n] = vs[n][k]   (K = D, N = NB -> NBP)
+  J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 8, NBP / 32, A.pVsT};
+  if (train) {
+    // B[k][n] = vs[k][n]   (K = NB -> NBP, N = D)
+    J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
+    // B[k][n] = wh[2][k][n]   (K = D, N = D)
+    J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 8, D / 32, A.pWhc};
+    // B[k][n] = wh_flat[k][n], k < 2D   (K = 2D, N = D)
+    J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 8, D / 32, A.pWhzr};
+    // B[k][n] = ui_flat[k][n]   (K = 3D, N = 2D)
+    J.j[n++] = PackJob{A.ui, XW, 1, 3 * D, XW, 3 * D / 8, XW / 32, A.pUi};
+  }
+  J.n = n;
+}
+
+template <int D>
+static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
+  const int n = A.n_seq, tiles = (n + 31) / 32;
+  PackJobs J; te_pack_jobs(A, J, true);
+  tm->begin("te_prep", st);
+  hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
+  hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
+  hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+  tm->end(st);
+  tm->begin("te_gather", st);
+  hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 0);
+  tm->end(st);
+  tm->begin("te_gemm_ax", st);
+  hipLaunchKernelGGL(te_gemm_ax_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 64 * (2 * D + 4), st, A);
+  tm->end(st);
+  tm->begin("te_rec_fwd", st);
+  hipLaunchKernelGGL(te_rec_fwd_kernel<D>, dim3(tiles), dim3(D * 2), sizeof(float) * 3 * 32 * (D + 4), st, A, 0);
+  tm->end(st);
+  tm->begin("te_head", st);
+  hipError_t e = te_head_dispatch<D>(A, 0, A.n_head, st);
+  if (e != hipSuccess) return e;
+  tm->end(st);
+  tm->begin("te_rec_bwd", st);
+  hipLaunchKernelGGL(te_rec_bwd_kernel<D>, dim3(tiles), dim3(D * 2), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
+  tm->end(st);
+  tm->begin("te_wgrad", st);
+  {
+    const int jobs = (3 * D / 64) * (2 * D / 64) + (2 * D / 64) * (D / 64) + (D / 64) * (D / 64);
+    hipLaunchKernelGGL(te_wgrad_kernel<D>, dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
+  }
+  tm->end(st);
+  tm->begin("te_gemm_dx", st);
+  hipLaunchKernelGGL(te_gemm_dx_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 32 * (3 * D + 4), st, A);
+  tm->end(st);
+  tm->begin("te_finalize", st);
+  hipLaunchKernelGGL(te_finalize_kernel, dim3((n + TE_BLOCK - 1) / TE_BLOCK), dim3(TE_BLOCK), 0, st, A);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
+  if (A.dim == 64) return te_train_t<64>(A, num_cu, st, tm);
+  if (A.dim == 128) return te_train_t<128>(A, num_cu, st, tm);
+  return hipErrorInvalidValue;
+}
+
+template <int D>
+static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
+  const int n = A.n_seq, tiles = (n + 31) / 32;
+  PackJobs J; te_pack_jobs(A, J, false);
+  tm->begin("te_predict", st);
+  hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
+  hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
+  hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+  hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 1);
+  hipLaunchKernelGGL(te_gemm_ax_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 64 * (2 * D + 4), st, A);
+  hipLaunchKernelGGL(te_rec_fwd_kernel<D>, dim3(tiles), dim3(D * 2), sizeof(float) * 3 * 32 * (D + 4), st, A, 1);
+  hipError_t e = hipSuccess;
+  if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
+  tm->end(st);
+  return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
+  if (A.dim == 64) return te_predict_t<64>(A, num_cu, st, tm);
+  if (A.dim == 128) return te_predict_t<128>(A, num_cu, st, tm);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace poi

@@ -1,0 +1,104 @@
+"""-m gpu parity tests of the tile engine (batched f32-MFMA decomposition of the Distance2Pre step):
+forced through poi_ctx_set_engine(tile) and compared with the float64 oracle (single sequence ==
+the reference step; batches == mean-of-touching-sequences rule) and with the per-sequence engine."""
+import numpy as np
+import pytest
+
+from oracle import poi_oracle as O
+from tests.gpu_util import assert_close, batch_mean_update, round_f32, spatial_params, toy_problem
+
+pytestmark = pytest.mark.gpu
+
+SP_NAMES = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import torch
+    assert torch.cuda.is_available()
+    import poi_amd
+    poi_amd._lib.load()
+    yield poi_amd
+    poi_amd._lib.context(0).set_engine("auto")
+
+
+def _model(pa, T, P):
+    return pa.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001],
+                                   n_user=T["n_user"], n_item=T["n_item"], n_dists=[T["n_dist"], 0.2],
+                                   n_in=T["dim"], n_hidden=T["dim"], init=P)
+
+
+def _get(model):
+    out = {}
+    for k in SP_NAMES:
+        v = getattr(model, k).get_value()
+        out[k] = float(v) if k == "wd" else v
+    return out
+
+
+def _oracle_batch(P, T, users):
+    Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
+    news, touched, outs = [], [], []
+    for u in users:
+        Pn, out = O.spatial_step(P, Pm[u], Qm[u], DPm[u], DQm[u], Mm[u], 0.01, 0.001)
+        news.append(Pn); outs.append(out)
+        touched.append(dict(lt=np.unique(np.concatenate((Pm[u], Qm[u]))), di=np.unique(DPm[u])))
+    exp = batch_mean_update(P, news, touched, ("lt", "di"), ("ui", "wh", "bi", "vs", "bs", "wd", "loss_weight"))
+    return exp, outs
+
+
+@pytest.mark.parametrize("dim,n_dist", [(64, 11), (64, 200), (128, 40), (128, 200)])
+def test_tile_single_sequence_is_the_reference_step(pa, dim, n_dist):
+    T = toy_problem(60 + dim + n_dist, n_user=4, n_item=90, n_dist=n_dist, dim=dim, len_max=9)
+    P = spatial_params(60 + dim, T)
+    model = _model(pa, T, P)
+    model.ctx.set_engine("tile")
+    Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
+    for u in [2, 0, 2]:
+        P, out = O.spatial_step(P, Pm[u], Qm[u], DPm[u], DQm[u], Mm[u], 0.01, 0.001)
+        los, sur, upq, ls = model.train(np.int32(u))
+        assert_close([los, sur, upq], out[:3], "losses")
+        got = _get(model)
+        for k in SP_NAMES:
+            assert_close(got[k], P[k], "%s after user %d" % (k, u))
+        P = round_f32({**P, **got})
+    model.ctx.set_engine("auto")
+
+
+@pytest.mark.parametrize("dim,n_dist,n_user", [(64, 11, 45), (64, 200, 70), (128, 200, 37)])
+def test_tile_batch_matches_mean_rule_and_seq_engine(pa, dim, n_dist, n_user):
+    T = toy_problem(70 + dim, n_user=n_user, n_item=120, n_dist=n_dist, dim=dim, len_max=11, hot=30)
+    P = spatial_params(70 + dim, T)
+    users = np.random.default_rng(0).permutation(n_user)[: n_user - 3].astype(np.int32)   # unsorted lengths, ragged last tile
+    exp, outs = _oracle_batch(P, T, users)
+    res = {}
+    for eng in ("tile", "seq"):
+        model = _model(pa, T, P)
+        model.ctx.set_engine(eng)
+        got_out = model.train_batch(users)
+        for k, out in enumerate(outs):
+            assert_close(got_out[k][:3], out[:3], "%s losses[%d]" % (eng, k), rtol=2e-5)
+        got = _get(model)
+        for k in SP_NAMES:
+            assert_close(got[k], exp[k], "%s %s" % (eng, k))
+        res[eng] = got
+        # a second launch on the updated state exercises the re-zeroed gradient tables / slabs
+        model.train_batch(users[:40])
+        res[eng + "2"] = _get(model)
+    for k in SP_NAMES:
+        assert_close(res["tile2"][k], res["seq2"][k], "tile vs seq second launch " + k, rtol=2e-5)
+    pa._lib.context(0).set_engine("auto")
+
+
+@pytest.mark.parametrize("dim,n_dist", [(64, 23), (128, 200)])
+def test_tile_predict_matches_oracle(pa, dim, n_dist):
+    T = toy_problem(80 + dim, n_user=75, n_item=200, n_dist=n_dist, dim=dim, len_max=13)
+    P = spatial_params(80 + dim, T)
+    model = _model(pa, T, P)
+    model.ctx.set_engine("tile")
+    model.update_trained_items(); model.update_trained_dists()
+    ids = np.arange(2, 73, dtype=np.int32)
+    hts, sts = model.predict(ids)
+    eh, es = O.spatial_predict(P, P["lt"], P["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
+    assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
+    model.ctx.set_engine("auto")
