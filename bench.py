@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla"])
     ap.add_argument("--batch-users", type=int, default=8192)
     ap.add_argument("--eval-steps", type=int, default=2)
-    ap.add_argument("--eval-chunk", type=int, default=1024)
+    ap.add_argument("--eval-chunk", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -149,13 +149,15 @@ def main():
         dte = rank_max(time.perf_counter() - t0)
         ms_score, n_score = ctx.timing_get("score_topk")
         ms_pred = ctx.timing_get("seq_predict")[0] + ctx.timing_get("te_predict")[0]
+        ms_dist = ctx.timing_get("dist_prob")[0]
         ctx.timing(False)
         eval_users_per_s = n_user * a.eval_steps / dte
         fl = 2.0 * n_local * n_item * D * a.eval_steps
         eval_detail = {"ms_per_eval": 1e3 * dte / a.eval_steps, "recall_at_20": float(hits.item()) / n_local,
                        "score_topk_tflops": fl / (ms_score * 1e-3) / 1e12 if ms_score > 0 else None,
                        "score_topk_frac_of_f32_mfma_peak": fl / (ms_score * 1e-3) / 1e12 / PEAK_F32_TFLOPS if ms_score > 0 else None,
-                       "ms_predict_per_eval": ms_pred / a.eval_steps, "ms_score_topk_per_eval": ms_score / a.eval_steps}
+                       "ms_predict_per_eval": ms_pred / a.eval_steps, "ms_score_topk_per_eval": ms_score / a.eval_steps,
+                       "ms_dist_prob_per_eval": ms_dist / a.eval_steps, "eval_chunk_users": a.eval_chunk}
 
     # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region) -----------
     # algorithmic work per GRU step of one sequence: flops for the contractions, bytes

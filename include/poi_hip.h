@@ -143,9 +143,13 @@ int poi_sumsq(poi_ctx* ctx, const float* x, int64_t n, double* out, void* stream
 /* ---- last-train-POI -> all-POI distance-bin probability rows (8f rank 2) ---------------------
  * public/Load_Data_by_length.py:183-235 (fun_compute_distance + fun_acquire_prob) for a user batch:
  * prob_out[k][j] = sts[k][bin] * (bin < n_dist), bin = cal_dis(coord[last_poi[k]], coord[j]).
- * coords (n_item, 2) float64 lat,lon; sts (n, n_dist+1) float32; dd in metres. */
-int poi_dist_prob(poi_ctx* ctx, const double* coords, const int32_t* last_poi, const float* sts,
-                  int32_t n, int32_t n_item, int32_t n_dist, double dd, float* prob_out, void* stream);
+ * coords (n_item, 2) float64 lat,lon; sts (n, n_dist+1) float32; dd in metres.
+ * Fast exact path: cphi (n_item) float64 = cos(lat*pi/180) and thr (n_dist) float64 = the smallest
+ * Haversine `c` at which each bin starts, both precomputed on the host with the reference's libm
+ * (data.py cos_lat / bin_thresholds); then no asin/sqrt runs on the device and the bins equal
+ * cal_dis for every c.  With cphi == thr == NULL the kernel evaluates cal_dis literally. */
+int poi_dist_prob(poi_ctx* ctx, const double* coords, const double* cphi, const double* thr, const int32_t* last_poi,
+                  const float* sts, int32_t n, int32_t n_item, int32_t n_dist, double dd, float* prob_out, void* stream);
 
 /* ---- multi-GPU reconciliation helpers (8e): delta = cur - base ; cur = base + sum_delta ------ */
 int poi_delta_make(poi_ctx* ctx, const float* cur, const float* base, float* delta, int64_t n, void* stream);

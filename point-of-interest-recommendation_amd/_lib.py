@@ -49,8 +49,8 @@ SIGNATURES = {
     "poi_auc_preference": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                    c_void_p, c_void_p]),
     "poi_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "poi_dist_prob": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double, c_void_p,
-                              c_void_p]),
+    "poi_dist_prob": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_double,
+                              c_void_p, c_void_p]),
     "poi_delta_make": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "poi_delta_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "poi_timing_enable": (c_int, [c_void_p, c_int]),

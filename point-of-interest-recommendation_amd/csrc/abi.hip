@@ -26,11 +26,12 @@ struct poi_ctx {
   // per-sequence engine
   DevBuf ws, slab, te_ws;
   int engine = 0;   // 0 auto, 1 per-sequence, 2 tile
+  int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1|2 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
-  DevBuf cand_s, cand_i;
+  DevBuf cand_s, cand_i, items_pk, gbound;
   // selftest
   DevBuf st;
   poi::Timing tm;
@@ -86,6 +87,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipGetDeviceProperties failed"); }
   c->num_cu = prop.multiProcessorCount;
   if (const char* e = getenv("POI_SEQ_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
+  if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->score_variant = v; }
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   *out = c;
@@ -95,7 +97,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
   DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di,
-                   &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->st};
+                   &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
@@ -287,21 +289,44 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   memset(&A, 0, sizeof A);
   A.users = users; A.items = items; A.n = n; A.n_item = n_item; A.dim = dim; A.wd = wd; A.prob = prob;
   A.scores = scores; A.k = k; A.idx_out = idx_out; A.score_out = score_out;
-  const int n_utile = (n + 31) / 32, ntile = (n_item + 31) / 32;
-  int want = (c->num_cu * 8 + n_utile - 1) / n_utile;     // aim for >= 8 wavefronts per CU
-  if (want > ntile) want = ntile;
-  int n_split = ((want + 3) / 4) * 4;
-  if (n_split < 4) n_split = 4;
+  if (const char* e = getenv("POI_SCORE_DBG")) A.dbg = atoi(e);
+  const int ntile = (n_item + 31) / 32;
+  // variant: 0 = one item stream per wave (row-per-lane loads; small n), 1 = packed item stream per
+  // wave, 2 = 4 user tiles per workgroup sharing each item tile through LDS (default for n >= 128)
+  int variant = (n >= 128 && dim <= 128) ? 1 : 0;
+  if (c->score_variant >= 0 && dim <= 128) variant = c->score_variant;
+  const int n_utile = variant == 2 ? ((n + 127) / 128) * 4 : (n + 31) / 32;
+  const int units = variant == 2 ? n_utile / 4 : n_utile;
+  // long item streams keep per-user thresholds high (few top-K compactions)
+  int want = variant == 2 ? (c->num_cu + units - 1) / units : (c->num_cu * 8 + units - 1) / units;   // 8 waves per CU
+  if (want > ntile / 8) want = ntile / 8;      // >= 8 tiles per stream: amortise the per-wave top-K epilogue
+  if (want < 1) want = 1;
+  int n_split = variant == 2 ? want : ((want + 3) / 4) * 4;
   A.n_split = n_split;
+  const int n_pad = n_utile * 32;
+  int rc;
   if (k > 0) {
-    const size_t cand = (size_t)n_split * n_utile * 32 * k;
-    int rc;
+    const size_t cand = (size_t)n_split * n_pad * k;
     if ((rc = ensure(c, c->cand_s, sizeof(float) * cand, st))) return rc;
     if ((rc = ensure(c, c->cand_i, sizeof(int) * cand, st))) return rc;
     A.cand_score = (float*)c->cand_s.p; A.cand_idx = (int*)c->cand_i.p;
+    if (n_split > 1) {
+      if ((rc = ensure(c, c->gbound, sizeof(unsigned) * (size_t)n_pad, st))) return rc;
+      HIPCHK(c, hipMemsetAsync(c->gbound.p, 0, sizeof(unsigned) * (size_t)n_pad, st));
+      A.gbound = (unsigned*)c->gbound.p;
+    }
   }
-  HIPCHK(c, poi::launch_score(A, st, &c->tm));
-  if (k > 0) HIPCHK(c, poi::launch_topk_merge(A, n_split, st));
+  if (variant == 1) {
+    const int d8 = dim <= 32 ? 4 : dim <= 64 ? 8 : 16;
+    if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
+    A.items_packed = (float4*)c->items_pk.p;
+    HIPCHK(c, poi::launch_score_packed(A, st, &c->tm));
+  } else if (variant == 2) {
+    HIPCHK(c, poi::launch_score_shared(A, st, &c->tm));
+  } else {
+    HIPCHK(c, poi::launch_score(A, st, &c->tm));
+  }
+  if (k > 0) HIPCHK(c, poi::launch_topk_merge(A, n_split, n_pad, st));
   return POI_OK;
 }
 
@@ -346,15 +371,18 @@ int poi_sumsq(poi_ctx* c, const float* x, int64_t n, double* out, void* stream) 
   return POI_OK;
 }
 
-int poi_dist_prob(poi_ctx* c, const double* coords, const int32_t* last_poi, const float* sts, int32_t n, int32_t n_item,
-                  int32_t n_dist, double dd, float* prob_out, void* stream) {
+int poi_dist_prob(poi_ctx* c, const double* coords, const double* cphi, const double* thr, const int32_t* last_poi,
+                  const float* sts, int32_t n, int32_t n_item, int32_t n_dist, double dd, float* prob_out, void* stream) {
   if (!c || !coords || !last_poi || !sts || !prob_out) return fail(c, POI_EINVAL, "poi_dist_prob: NULL argument");
+  if ((cphi == nullptr) != (thr == nullptr)) return fail(c, POI_EINVAL, "poi_dist_prob: cphi and thr go together");
   if (n < 0 || n_item <= 0 || n_dist <= 0 || !(dd > 0)) return fail(c, POI_EINVAL, "bad sizes");
   HIPCHK(c, hipSetDevice(c->device));
   for (int32_t o = 0; o < n; o += 32768) {
     const int32_t m = n - o < 32768 ? n - o : 32768;
-    HIPCHK(c, poi::launch_dist_prob(coords, last_poi + o, sts + (size_t)o * (n_dist + 1), m, n_item, n_dist, dd,
+    c->tm.begin("dist_prob", (hipStream_t)stream);
+    HIPCHK(c, poi::launch_dist_prob(coords, cphi, thr, last_poi + o, sts + (size_t)o * (n_dist + 1), m, n_item, n_dist, dd,
                                     prob_out + (size_t)o * n_item, (hipStream_t)stream));
+    c->tm.end((hipStream_t)stream);
   }
   return POI_OK;
 }

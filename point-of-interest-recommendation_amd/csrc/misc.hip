@@ -54,17 +54,62 @@ __device__ __forceinline__ int cal_dis_bin(double lat1, double lon1, double lat2
   return interval < dist_num ? interval : dist_num;
 }
 
+// cos(x) for the small angle differences of nearby POIs: a 6-term Taylor/Horner polynomial (error
+// < 1e-27 for |x| < 1/32, evaluation rounding <= 1 ulp); larger arguments take the library cos.
+__device__ __forceinline__ double cos_small(double x) {
+  if (fabs(x) < 0.03125) {
+    const double z = x * x;
+    double p = -1.0 / 479001600.0;
+    p = fma(p, z, 1.0 / 3628800.0);
+    p = fma(p, z, -1.0 / 40320.0);
+    p = fma(p, z, 1.0 / 720.0);
+    p = fma(p, z, -1.0 / 24.0);
+    p = fma(p, z, 0.5);
+    return fma(-z, p, 1.0);
+  }
+  return cos(x);
+}
+
 // fun_compute_distance + fun_acquire_prob (public/Load_Data_by_length.py:183-235) for a user batch.
-__global__ __launch_bounds__(POI_BLOCK) void dist_prob_kernel(const double* __restrict__ coords, const int* __restrict__ last_poi,
+// With `cphi` (host cos(lat*pi/180) per POI) and `thr` (bin_thresholds of data.py: the smallest c at
+// which each bin starts, found with the reference's own libm) the per-pair work is two small-angle
+// cosines, the Haversine `c` in the reference's operation order, and a binary search - exactly
+// equivalent to cal_dis for every c.  Without them the kernel evaluates cal_dis literally.
+__global__ __launch_bounds__(POI_BLOCK) void dist_prob_kernel(const double* __restrict__ coords, const double* __restrict__ cphi,
+                                                               const double* __restrict__ thr, const int* __restrict__ last_poi,
                                                                const float* __restrict__ sts, int n, int N, int n_dist,
                                                                double dd, float* __restrict__ prob) {
+  extern __shared__ __align__(16) double s_thr[];       // n_dist thresholds, then n_dist+1 probabilities (float)
   const int k = blockIdx.y;
   const int lp = last_poi[k];
   const double lat1 = coords[2 * lp], lon1 = coords[2 * lp + 1];
   const float* s = sts + (size_t)k * (n_dist + 1);
+  if (!thr) {
+    for (int j = blockIdx.x * POI_BLOCK + threadIdx.x; j < N; j += gridDim.x * POI_BLOCK) {
+      const int bin = cal_dis_bin(lat1, lon1, coords[2 * j], coords[2 * j + 1], dd, n_dist);
+      prob[(size_t)k * N + j] = bin < n_dist ? s[bin] : 0.f;
+    }
+    return;
+  }
+  float* s_p = reinterpret_cast<float*>(s_thr + n_dist);
+  for (int i = threadIdx.x; i < n_dist; i += POI_BLOCK) s_thr[i] = thr[i];
+  for (int i = threadIdx.x; i <= n_dist; i += POI_BLOCK) s_p[i] = i < n_dist ? s[i] : 0.f;
+  __syncthreads();
+  const double pr = 0.017453292519943295;
+  const double c1 = cphi[lp];
   for (int j = blockIdx.x * POI_BLOCK + threadIdx.x; j < N; j += gridDim.x * POI_BLOCK) {
-    const int bin = cal_dis_bin(lat1, lon1, coords[2 * j], coords[2 * j + 1], dd, n_dist);
-    prob[(size_t)k * N + j] = bin < n_dist ? s[bin] : 0.f;
+    int bin;
+    {
+#pragma clang fp contract(off)
+      const double a = (lat1 - coords[2 * j]) * pr;
+      const double b = (lon1 - coords[2 * j + 1]) * pr;
+      const double c = (1.0 - cos_small(a)) / 2 + c1 * cphi[j] * (1.0 - cos_small(b)) / 2;
+      // bin = #{ t : c >= thr[t] }  (upper bound by binary search; thr ascending)
+      int lo = 0, hi = n_dist;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (c >= s_thr[mid]) lo = mid + 1; else hi = mid; }
+      bin = lo;
+    }
+    prob[(size_t)k * N + j] = s_p[bin];
   }
 }
 
@@ -107,11 +152,13 @@ hipError_t launch_sumsq(const float* x, int64_t n, double* out, hipStream_t st) 
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)g), dim3(POI_BLOCK), 0, st, x, n, out);
   return hipGetLastError();
 }
-hipError_t launch_dist_prob(const double* coords, const int* last_poi, const float* sts, int n, int n_item,
-                            int n_dist, double dd, float* prob, hipStream_t st) {
-  int gx = (n_item + POI_BLOCK - 1) / POI_BLOCK;
-  if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(dist_prob_kernel, dim3(gx, n), dim3(POI_BLOCK), 0, st, coords, last_poi, sts, n, n_item, n_dist, dd, prob);
+hipError_t launch_dist_prob(const double* coords, const double* cphi, const double* thr, const int* last_poi, const float* sts,
+                            int n, int n_item, int n_dist, double dd, float* prob, hipStream_t st) {
+  int gx = (n_item + POI_BLOCK * 4 - 1) / (POI_BLOCK * 4);
+  if (gx > 32) gx = 32;
+  if (gx < 1) gx = 1;
+  const size_t lds = thr ? sizeof(double) * n_dist + sizeof(float) * (n_dist + 1) : 0;
+  hipLaunchKernelGGL(dist_prob_kernel, dim3(gx, n), dim3(POI_BLOCK), lds, st, coords, cphi, thr, last_poi, sts, n, n_item, n_dist, dd, prob);
   return hipGetLastError();
 }
 hipError_t launch_delta_make(const float* cur, const float* base, float* delta, int64_t n, hipStream_t st) {

@@ -115,24 +115,29 @@ hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st, Timing* tm);
 // scoring / top-K
 struct ScoreArgs {
   const float *users, *items;
+  float4* items_packed;     // MFMA B-fragment order (large-n kernel), ctx scratch
   int n, n_item, dim;
   const float *wd, *prob;
   float* scores;            // (n, n_item) or null
   int k;                    // 0 = no top-K
   int n_split;              // item splits for the fused top-K
   float* cand_score; int* cand_idx;   // (n_split, n_pad, k) partial top-K lists
+  int dbg;                  // tuning switch (POI_SCORE_DBG), 0 in production
+  unsigned* gbound;         // (n_pad) per-user lower bound of the K-th best score shared by all item ranges
   int* idx_out; float* score_out;
 };
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm);
-hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, hipStream_t st);
+hipError_t launch_score_packed(const ScoreArgs& A, hipStream_t st, Timing* tm);
+hipError_t launch_score_shared(const ScoreArgs& A, hipStream_t st, Timing* tm);
+hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, int n_pad, hipStream_t st);
 hipError_t launch_topk_rows(const float* scores, int n, int n_item, int k, int* idx_out, float* score_out, hipStream_t st);
 
 // misc
 hipError_t launch_auc(const float* users, const float* items, int n, int dim, const int* tp, const int* tq,
                       const int* tm, int len, uint8_t* out, hipStream_t st);
 hipError_t launch_sumsq(const float* x, int64_t n, double* out, hipStream_t st);
-hipError_t launch_dist_prob(const double* coords, const int* last_poi, const float* sts, int n, int n_item,
-                            int n_dist, double dd, float* prob, hipStream_t st);
+hipError_t launch_dist_prob(const double* coords, const double* cphi, const double* thr, const int* last_poi, const float* sts,
+                            int n, int n_item, int n_dist, double dd, float* prob, hipStream_t st);
 hipError_t launch_delta_make(const float* cur, const float* base, float* delta, int64_t n, hipStream_t st);
 hipError_t launch_delta_apply(float* cur, const float* base, const float* dsum, int64_t n, hipStream_t st);
 hipError_t launch_selftest(float* buf, int* fail, hipStream_t st);

@@ -20,7 +20,8 @@ namespace poi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define TK_CAP 64   // candidate slots per user per wave (>= K + 32)
+#define TK_CAP 72   // candidate slots per user per wave (>= K + 32; compaction when cnt > TK_CAP - 32).
+                    // 4 waves x 32 users x 72 x 8 B = 74 KB per workgroup -> two workgroups per CU
 
 __device__ __forceinline__ bool better(float s, int i, float ps, int pi) {
   return (s > ps) || (s == ps && i < pi);
@@ -49,25 +50,129 @@ struct WaveTopk {   // LDS state of one wavefront
   int ci[32][TK_CAP];
   int cnt[32];
   float thr[32];
+  unsigned gseen[32];   // last global bound seen / published per user (order-mapped)
 };
 
+// Orders this wavefront's LDS traffic only (LDS is in-order per wave; the waitcnt makes returned data
+// available, the clobber stops compiler reordering).  Deliberately NOT a memory fence: a wavefront-
+// scope __builtin_amdgcn_fence also drains vmcnt, i.e. waits for every outstanding global load /
+// atomic (the published bounds below), which costs microseconds per compaction.
 __device__ __forceinline__ void wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
-// Keep the best K of user i's candidate list; update its threshold.
-__device__ __forceinline__ void compact_user(WaveTopk& T, int i, int K) {
+// Order-preserving map float -> uint (larger float <=> larger uint).
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+__device__ __forceinline__ int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+
+// Keep the best K of user i's (unsorted, <= 128 entries) candidate list and raise its threshold to the
+// K-th best score.  Selection by rank counting on the vector ALUs: every candidate (two per lane)
+// counts how many candidates beat it (higher score, or equal score and lower index) while the list
+// is broadcast from LDS; rank < K survives, rank == K-1 is the new threshold.  No sort, no scalar-unit
+// dependency chain (a ballot-based radix select measured ~400 cycles per bit with 8 waves per CU
+// sharing the one scalar ALU).
+__device__ __forceinline__ void compact_user(WaveTopk& T, int i, int K, unsigned* gbound = nullptr, int dbg = 0) {
   const int lane = lane_id();
-  const int n = T.cnt[i];
-  float s = lane < n ? T.cs[i][lane] : -INFINITY;
-  int idx = lane < n ? T.ci[i][lane] : INT_MAX;
-  wave_sort_desc(s, idx);
+  const int n = __builtin_amdgcn_readfirstlane(T.cnt[i]);
+  if (n <= K) { if (lane == 0) T.thr[i] = -INFINITY; return; }
+  const bool v0 = lane < n, v1 = lane + 64 < n;
+  const float s0 = v0 ? T.cs[i][lane] : -INFINITY, s1 = v1 ? T.cs[i][lane + 64] : -INFINITY;
+  const int i0 = v0 ? T.ci[i][lane] : INT_MAX, i1 = v1 ? T.ci[i][lane + 64] : INT_MAX;
+  int r0 = 0, r1 = 0;
+  for (int j = 0; j < n; ++j) {
+    const float sj = T.cs[i][j];          // same address in every lane: LDS broadcast
+    const int ij = T.ci[i][j];
+    r0 += (sj > s0 || (sj == s0 && ij < i0)) ? 1 : 0;
+    r1 += (sj > s1 || (sj == s1 && ij < i1)) ? 1 : 0;
+  }
+  const bool keep0 = v0 && r0 < K, keep1 = v1 && r1 < K;
+  // the K-th best (rank K-1) sits in exactly one slot
+  const unsigned long long kb0 = __ballot(v0 && r0 == K - 1), kb1 = __ballot(v1 && r1 == K - 1);
+  const float kth = kb0 ? readlane_f(s0, __builtin_ctzll(kb0)) : readlane_f(s1, __builtin_ctzll(kb1 | (1ull << 63)));
   wave_fence();
-  if (lane < K) { T.cs[i][lane] = s; T.ci[i][lane] = idx; }
-  const float kth = __shfl(s, K - 1, 64);
-  if (lane == 0) { T.cnt[i] = n < K ? n : K; T.thr[i] = n >= K ? kth : -INFINITY; }
+  if (keep0) { T.cs[i][r0] = s0; T.ci[i][r0] = i0; }     // ranks 0..K-1 are distinct: sorted, gap-free
+  if (keep1) { T.cs[i][r1] = s1; T.ci[i][r1] = i1; }
+  if (lane == 0) {
+    T.cnt[i] = K;
+    T.thr[i] = kth;
+    // Any subset's K-th best score bounds the global K-th best from below: publish (kth - 1 ulp, so
+    // that `score > bound` keeps ties) for the waves that scan other item ranges of the same user,
+    // but only when it improves on the bound last seen (keeps atomic traffic on hot words low).
+    if (gbound && dbg != 4) {
+      const unsigned o = f2ord(kth);
+      if (o > 1u && o - 1u > T.gseen[i]) { atomicMax(gbound, o - 1u); T.gseen[i] = o - 1u; }
+    }
+  }
   wave_fence();
+}
+
+// Per-tile epilogue shared by the scoring kernels.  The 32x32 result tile is in `acc` (C layout:
+// item = lane&31, user row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  The per-user thresholds of this lane's
+// 16 rows live in registers (`thr`, reloaded only after a compaction); the pass flags are computed
+// branch-free and ONE wave-uniform branch skips the whole insertion block when no lane passes - the
+// common case once the thresholds have risen - so the fast path has no LDS round trips at all.
+__device__ __forceinline__ void tile_epilogue(const ScoreArgs& A, WaveTopk& T, const f32x16& acc, const float (&pv)[16],
+                                              float (&thr)[16], float wd, int ut, int j, bool jvalid, int K, int tile_no) {
+  const int lane = lane_id(), h = lane >> 5, N = A.n_item;
+  float sc[16];
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    sc[r] = acc[r] + wd * pv[r];
+    any |= sc[r] > thr[r];
+  }
+  if (A.scores) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (jvalid && urow < A.n) A.scores[(size_t)urow * N + j] = sc[r];
+    }
+  }
+  if (K <= 0 || !jvalid) any = false;
+  if (A.dbg == 1) { if (__any(any) && lane == 0) T.cnt[0] = 1; return; }     // tuning: filter check only
+  if (K > 0 && A.gbound && (tile_no & 7) == 7 && A.dbg != 2) {
+    // fold the bounds published by the other item ranges into the register thresholds (stale values
+    // are merely weaker bounds, so relaxed device-scope loads suffice)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const unsigned g = __hip_atomic_load(A.gbound + ut * 32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g) { thr[r] = fmaxf(thr[r], ord2f(g)); if ((lane & 31) == 0 && g > T.gseen[i]) T.gseen[i] = g; }
+    }
+  }
+  if (!__any(any)) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (any && sc[r] > thr[r] && ut * 32 + i < A.n) {
+      const int pos = atomicAdd(&T.cnt[i], 1);
+      T.cs[i][pos] = sc[r]; T.ci[i][pos] = j;
+    }
+  }
+  wave_fence();
+  const int c = lane < 32 ? T.cnt[lane] : 0;
+  unsigned long long need = __ballot(c > TK_CAP - 32);
+  if (A.dbg == 3 && need) {            // tuning: inserts, but compaction replaced by a reset
+    if (lane < 32 && c > TK_CAP - 32) T.cnt[lane] = K;
+    wave_fence();
+    return;
+  }
+  if (need) {
+    while (need) {
+      const int i = __builtin_ctzll(need);
+      need &= need - 1;
+      compact_user(T, i, K, A.gbound ? A.gbound + ut * 32 + i : nullptr, A.dbg);
+    }
+    if (A.dbg != 6) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) thr[r] = fmaxf(thr[r], T.thr[(r & 3) + 8 * (r >> 2) + 4 * h]);
+    }
+  }
 }
 
 template <int D8, bool DB>
@@ -84,9 +189,12 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
   const int t_end = min(ntile, t_begin + tps);
   WaveTopk& T = tk[w];
   if (K > 0) {
-    if (lane < 32) { T.cnt[lane] = 0; T.thr[lane] = -INFINITY; }
+    if (lane < 32) { T.cnt[lane] = 0; T.thr[lane] = -INFINITY; T.gseen[lane] = 0; }
     wave_fence();
   }
+  float thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
 
   // A fragment: user row (clamped), k-slices 8m+4h
   float4 af[D8];
@@ -126,34 +234,16 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, b0[m].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, b0[m].w, acc, 0, 0, 0);
     }
-    // epilogue: C layout col = lane&31 (item), row = (r&3) + 8*(r>>2) + 4*h (user)
-    const int j = tile * 32 + li;
-    const bool jvalid = j < N;
+    {
+      const int j = tile * 32 + li;
+      const bool jvalid = j < N;
+      float pv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int urow = ut * 32 + i;
-      float sc = acc[r];
-      const bool valid = jvalid && urow < A.n;
-      if (valid) {
-        if (A.prob) sc = sc + wd * A.prob[(size_t)urow * N + j];
-        if (A.scores) A.scores[(size_t)urow * N + j] = sc;
-        if (K > 0 && sc > T.thr[i]) {
-          const int pos = atomicAdd(&T.cnt[i], 1);
-          T.cs[i][pos] = sc; T.ci[i][pos] = j;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
       }
-    }
-    if (K > 0) {
-      wave_fence();
-      // lists that could overflow on the next tile (cnt > CAP - 32) are compacted now
-      const int c = lane < 32 ? T.cnt[lane] : 0;
-      unsigned long long need = __ballot(c > TK_CAP - 32);
-      while (need) {
-        const int i = __builtin_ctzll(need);
-        need &= need - 1;
-        compact_user(T, i, K);
-      }
+      tile_epilogue(A, T, acc, pv, thr, wd, ut, j, jvalid, K, tile - t_begin);
     }
     if constexpr (DB) {
 #pragma unroll
@@ -165,6 +255,203 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
 
   if (K > 0) {   // final per-split lists -> global candidates (split, user, K)
     const int n_pad = gridDim.x * 32;
+    for (int i = 0; i < 32; ++i) {
+      compact_user(T, i, K);
+      const int n = T.cnt[i];
+      if (lane < K) {
+        const size_t o = ((size_t)split * n_pad + ut * 32 + i) * K + lane;
+        A.cand_score[o] = lane < n ? T.cs[i][lane] : -INFINITY;
+        A.cand_idx[o] = lane < n ? T.ci[i][lane] : INT_MAX;
+      }
+    }
+  }
+}
+
+// Pack the item table into MFMA B-fragment order (see tile_engine.hip):
+//   P[(tile * D8 + m) * 64 + lane] = float4{ items[32 tile + j][8m + 4h + c], c = 0..3 }, lane = 32h + j
+// so that a wave's B loads are contiguous 1-KiB streams.  Rows >= n_item and k >= D are zero.
+__global__ __launch_bounds__(POI_BLOCK) void pack_items_kernel(const float* __restrict__ items, int n_item, int D, int D8,
+                                                               float4* __restrict__ out, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * POI_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * POI_BLOCK) {
+    const int lane = (int)(e & 63);
+    const size_t tm = e >> 6;
+    const int m = (int)(tm % D8);
+    const size_t tile = tm / D8;
+    const size_t row = tile * 32 + (lane & 31);
+    const int k0 = 8 * m + 4 * (lane >> 5);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < (size_t)n_item && k0 < D) v = *reinterpret_cast<const float4*>(items + row * D + k0);
+    out[e] = v;
+  }
+}
+
+// Large-n variant on the packed item table: every wavefront is independent (own 32-user tile, own
+// item range, B fragments double-buffered in registers straight from the packed stream); no LDS
+// staging and no workgroup barrier, so a wave that stops to compact a candidate list only delays
+// itself while its SIMD partner keeps the matrix core busy.
+template <int D8>
+__global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A) {
+  extern __shared__ __align__(16) float dyn[];
+  WaveTopk* tk = reinterpret_cast<WaveTopk*>(dyn);
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
+  const int D = A.dim, N = A.n_item, K = A.k;
+  const int ut = blockIdx.x;
+  const int split = blockIdx.y * POI_NWAVE + w;
+  const int ntile = (N + 31) / 32;
+  const int tps = (ntile + A.n_split - 1) / A.n_split;
+  const int t_begin = split * tps;
+  const int t_end = min(ntile, t_begin + tps);
+  WaveTopk& T = tk[w];
+  if (K > 0) {
+    if (lane < 32) { T.cnt[lane] = 0; T.thr[lane] = -INFINITY; T.gseen[lane] = 0; }
+    wave_fence();
+  }
+  float thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
+  float4 af[D8];
+  {
+    const int urow = min(ut * 32 + li, A.n - 1);
+    const float* up = A.users + (size_t)urow * D;
+#pragma unroll
+    for (int m = 0; m < D8; ++m) {
+      const int k0 = 8 * m + 4 * h;
+      af[m] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float wd = (A.prob && A.wd) ? A.wd[0] : 0.f;
+  const float4* bp = A.items_packed + lane;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    // two wavefronts share each SIMD (launch bounds): while this one waits for its B stream or runs
+    // the top-K filter, its partner issues MFMAs - no software pipelining needed
+    float4 b0[D8];
+#pragma unroll
+    for (int m = 0; m < D8; ++m) b0[m] = bp[((size_t)tile * D8 + m) * 64];
+    const int j = tile * 32 + li;
+    const bool jvalid = j < N;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < D8; ++m) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, b0[m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, b0[m].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, b0[m].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, b0[m].w, acc, 0, 0, 0);
+    }
+    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, jvalid, K, tile - t_begin);
+  }
+  if (K > 0) {
+    const int n_pad = gridDim.x * 32;
+    for (int i = 0; i < 32; ++i) {
+      compact_user(T, i, K);
+      const int n = T.cnt[i];
+      if (lane < K) {
+        const size_t o = ((size_t)split * n_pad + ut * 32 + i) * K + lane;
+        A.cand_score[o] = lane < n ? T.cs[i][lane] : -INFINITY;
+        A.cand_idx[o] = lane < n ? T.ci[i][lane] : INT_MAX;
+      }
+    }
+  }
+}
+
+// Shared-tile variant: a workgroup = 4 wavefronts = 4 user tiles (128 users) sharing every 32-item
+// tile through LDS (4x less L2/MALL traffic than one stream per wave).  The item tile is loaded once
+// per workgroup with coalesced float4 loads, double-buffered, one barrier per tile; the global loads
+// of the next tile and of this tile's `prob` values are issued BEFORE the MFMA block and the LDS
+// write happens after it (async-stage split), so their latency hides under the matrix work.
+template <int D8>
+__global__ __launch_bounds__(POI_BLOCK) void score_kernel_shared(ScoreArgs A) {
+  extern __shared__ __align__(16) float dyn[];
+  constexpr int DP = D8 * 8, LDB = DP + 4;
+  constexpr int C4N = DP / 4;
+  constexpr int SPT = (32 * C4N + POI_BLOCK - 1) / POI_BLOCK;
+  float* Bt0 = dyn;
+  float* Bt1 = dyn + 32 * LDB;
+  WaveTopk* tk = reinterpret_cast<WaveTopk*>(dyn + 2 * 32 * LDB);
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
+  const int D = A.dim, N = A.n_item, K = A.k;
+  const int ut = blockIdx.x * POI_NWAVE + w;
+  const int split = blockIdx.y;
+  const int ntile = (N + 31) / 32;
+  const int tps = (ntile + A.n_split - 1) / A.n_split;
+  const int t_begin = split * tps;
+  const int t_end = min(ntile, t_begin + tps);
+  WaveTopk& T = tk[w];
+  if (K > 0) {
+    if (lane < 32) { T.cnt[lane] = 0; T.thr[lane] = -INFINITY; T.gseen[lane] = 0; }
+    wave_fence();
+  }
+  float thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
+  float4 af[D8];
+  {
+    const int urow = min(ut * 32 + li, A.n - 1);
+    const float* up = A.users + (size_t)urow * D;
+#pragma unroll
+    for (int m = 0; m < D8; ++m) {
+      const int k0 = 8 * m + 4 * h;
+      af[m] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float wd = (A.prob && A.wd) ? A.wd[0] : 0.f;
+  auto stage_load = [&](float4 (&sv)[SPT], int tile) {
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+      const int e = tid + s * POI_BLOCK;
+      const int r = e / C4N, c = (e % C4N) * 4;
+      const int irow = min(tile * 32 + r, N - 1);
+      sv[s] = (e < 32 * C4N && c < D) ? *reinterpret_cast<const float4*>(A.items + (size_t)irow * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage_store = [&](const float4 (&sv)[SPT], float* Bt) {
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+      const int e = tid + s * POI_BLOCK;
+      if (e < 32 * C4N) *reinterpret_cast<float4*>(Bt + (e / C4N) * LDB + (e % C4N) * 4) = sv[s];
+    }
+  };
+  float4 sv[SPT];
+  if (t_begin < t_end) { stage_load(sv, t_begin); stage_store(sv, Bt0); }
+  __syncthreads();
+  float* Bc = Bt0; float* Bn = Bt1;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const bool more = tile + 1 < t_end;
+    if (more) stage_load(sv, tile + 1);
+    const int j = tile * 32 + li;
+    const bool jvalid = j < N;
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* brow = Bc + li * LDB + 4 * h;
+#pragma unroll
+    for (int m = 0; m < D8; ++m) {
+      const float4 b = *reinterpret_cast<const float4*>(brow + 8 * m);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, b.w, acc, 0, 0, 0);
+    }
+    if (more) stage_store(sv, Bn);
+    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, jvalid, K, tile - t_begin);
+    __syncthreads();
+    float* t = Bc; Bc = Bn; Bn = t;
+  }
+  if (K > 0) {
+    const int n_pad = gridDim.x * POI_NWAVE * 32;
     for (int i = 0; i < 32; ++i) {
       compact_user(T, i, K);
       const int n = T.cnt[i];
@@ -263,6 +550,43 @@ static hipError_t launch_score_t(const ScoreArgs& A, hipStream_t st, Timing* tm)
   return hipGetLastError();
 }
 
+template <int D8>
+static hipError_t launch_score_packed_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
+  const size_t total = (size_t)((A.n_item + 31) / 32) * D8 * 64;
+  tm->begin("pack_items", st);
+  hipLaunchKernelGGL(pack_items_kernel, dim3(2048), dim3(POI_BLOCK), 0, st, A.items, A.n_item, A.dim, D8, A.items_packed, total);
+  tm->end(st);
+  dim3 grid((A.n + 31) / 32, A.n_split / POI_NWAVE);
+  tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
+  hipLaunchKernelGGL((score_kernel_packed<D8>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+hipError_t launch_score_packed(const ScoreArgs& A, hipStream_t st, Timing* tm) {
+  if (A.dim <= 32) return launch_score_packed_t<4>(A, st, tm);
+  if (A.dim <= 64) return launch_score_packed_t<8>(A, st, tm);
+  if (A.dim <= 128) return launch_score_packed_t<16>(A, st, tm);
+  return hipErrorInvalidValue;
+}
+
+template <int D8>
+static hipError_t launch_score_shared_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
+  dim3 grid((A.n + 127) / 128, A.n_split);
+  const size_t lds = sizeof(float) * 2 * 32 * (D8 * 8 + 4) + sizeof(WaveTopk) * POI_NWAVE;
+  tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
+  hipLaunchKernelGGL((score_kernel_shared<D8>), grid, dim3(POI_BLOCK), lds, st, A);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+hipError_t launch_score_shared(const ScoreArgs& A, hipStream_t st, Timing* tm) {
+  if (A.dim <= 32) return launch_score_shared_t<4>(A, st, tm);
+  if (A.dim <= 64) return launch_score_shared_t<8>(A, st, tm);
+  if (A.dim <= 128) return launch_score_shared_t<16>(A, st, tm);
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   if (A.dim <= 32) return launch_score_t<4, true>(A, st, tm);
   if (A.dim <= 64) return launch_score_t<8, true>(A, st, tm);
@@ -271,8 +595,7 @@ hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, hipStream_t st) {
-  const int n_pad = ((A.n + 31) / 32) * 32;
+hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, int n_pad, hipStream_t st) {
   hipLaunchKernelGGL(topk_merge_kernel, dim3((A.n + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, A, n_lists, n_pad);
   return hipGetLastError();
 }

@@ -30,6 +30,51 @@ def cal_dis_vec(lat1, lon1, lat2, lon2, dd, dist_num):
     return np.minimum(interval, dist_num)
 
 
+def bin_thresholds(dd, dist_num):
+    """thr[k-1] = the smallest float64 c with int(12742*asin(sqrt(c))*1000/dd) >= k, k = 1..dist_num,
+    found by bisection on the float64 bit pattern with the SAME libm calls as cal_dis
+    (Load_Data_by_length.py:36-38).  Then  bin(c) = #{k : c >= thr[k-1]}  reproduces the reference's
+    asin/sqrt/int chain exactly for every c, and the device needs no asin/sqrt at all."""
+    import math
+    import struct
+
+    def f(c):
+        return int(EARTH_D * math.asin(math.sqrt(c)) * 1000 / dd)
+
+    def bits(x):
+        return struct.unpack("<q", struct.pack("<d", x))[0]
+
+    def val(b):
+        return struct.unpack("<d", struct.pack("<q", b))[0]
+
+    out = np.empty(dist_num, np.float64)
+    lo_b = 0
+    for k in range(1, dist_num + 1):
+        hi = math.sin(min(k * dd / 1000.0 / EARTH_D, math.pi / 2)) ** 2
+        hi = min(hi * (1 + 1e-6) + 1e-300, 1.0)
+        while f(hi) < k and hi < 1.0:
+            hi = min(hi * 1.001, 1.0)
+        lo, hb = lo_b, bits(hi)            # f(val(lo)) < k <= f(val(hb))  (lo = previous threshold - works since f is monotone)
+        if f(val(lo)) >= k:
+            out[k - 1] = val(lo)
+            continue
+        while hb - lo > 1:
+            mid = (lo + hb) // 2
+            if f(val(mid)) >= k:
+                hb = mid
+            else:
+                lo = mid
+        out[k - 1] = val(hb)
+        lo_b = lo
+    return out
+
+
+def cos_lat(coords):
+    """cos(lat * pi/180) per POI with the scalar libm cos the reference calls (cal_dis :35)."""
+    import math
+    return np.array([math.cos(float(v) * DEG) for v in np.asarray(coords)[:, 0]], np.float64)
+
+
 def padded_to_csr(rows, lens):
     """Nested (U, LM) table + valid lengths -> (off int32 (U+1), flat int32)."""
     rows = np.asarray(rows)

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .data import CsrTables, padded_to_csr
+from .data import CsrTables, bin_thresholds, cos_lat, padded_to_csr
 
 
 def _ptr(t):
@@ -299,6 +299,8 @@ class OboSpatialGru(GruBasic):
         self.prob = None                       # dense (n_user, n_item) only on request (update_prob)
         self.trained_sus = None                # (n_user, NB) - fused alternative to `prob`
         self.coords = None if coords is None else self._dev(np.asarray(coords, np.float64), torch.float64)
+        self._cphi = None if coords is None else self._dev(cos_lat(coords), torch.float64)
+        self._binthr = None if coords is None else self._dev(bin_thresholds(self.dd * 1000.0, self.n_dist), torch.float64)
         self.params = [self.ui, self.wh, self.bi, self.vs, self.bs, self.wd, self.loss_weight]
         self.l2 = _L2(self, ["lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight"])   # :83-88
 
@@ -343,7 +345,7 @@ class OboSpatialGru(GruBasic):
             n = ids.numel()
             lp, st = self._rows(self._last_poi, ids, lo), self._rows(self.trained_sus, ids, lo)
             prob = torch.empty((n, self.n_item), dtype=torch.float32, device=self.device)
-            self.ctx.check(self.lib.poi_dist_prob(self.ctx.handle, _ptr(self.coords), _ptr(lp), _ptr(st), n,
+            self.ctx.check(self.lib.poi_dist_prob(self.ctx.handle, _ptr(self.coords), _ptr(self._cphi), _ptr(self._binthr), _ptr(lp), _ptr(st), n,
                                                   self.n_item, self.n_dist, self.dd * 1000.0, _ptr(prob), self._stream()))
             return self.wd.t, prob
         return None, None

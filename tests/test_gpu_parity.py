@@ -215,7 +215,8 @@ def test_topk_golden_bit_exact(pa, golden_dir):
     assert np.array_equal(O.topk_desc(g["scores"], 20), g["ranks"])
 
 
-@pytest.mark.parametrize("n,n_item,dim,k", [(5, 100, 16, 5), (70, 1777, 64, 20), (33, 5000, 128, 20), (32, 640, 256, 10), (3, 50, 20, 20)])
+@pytest.mark.parametrize("n,n_item,dim,k", [(5, 100, 16, 5), (70, 1777, 64, 20), (33, 5000, 128, 20), (32, 640, 256, 10), (3, 50, 20, 20),
+                                            (128, 3001, 128, 20), (300, 2500, 64, 20), (129, 700, 256, 7), (200, 999, 20, 20)])
 def test_score_topk_fused_bit_exact_ranks(pa, n, n_item, dim, k):
     """Fused MFMA scoring + top-K: ranks bit-exact vs the oracle's ordering of the float64 scores on
     fixtures with a checked minimum score gap ("bit-exact ranks vs precision")."""
@@ -276,10 +277,43 @@ def test_dist_prob_matches_reference_bins(pa, golden_dir):
     ctx = pa._lib.context(0)
     dc = torch.as_tensor(g["coords"].astype(np.float64)).cuda()
     dl, ds = torch.as_tensor(last).cuda(), torch.as_tensor(sts).cuda()
-    out = torch.empty((U, N), dtype=torch.float32, device="cuda")
-    ctx.check(ctx.lib.poi_dist_prob(ctx.handle, dc.data_ptr(), dl.data_ptr(), ds.data_ptr(), U, N, B, dd, out.data_ptr(), None))
     exp = O.acquire_prob(sts.astype(np.float64), ul, B)
-    assert np.array_equal(out.cpu().numpy(), exp.astype(np.float32))
+    out = torch.empty((U, N), dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.poi_dist_prob(ctx.handle, dc.data_ptr(), None, None, dl.data_ptr(), ds.data_ptr(), U, N, B, dd, out.data_ptr(), None))
+    assert np.array_equal(out.cpu().numpy(), exp.astype(np.float32))          # literal cal_dis path
+    from poi_amd.data import bin_thresholds, cos_lat
+    cphi = torch.as_tensor(cos_lat(g["coords"])).cuda()
+    thr = torch.as_tensor(bin_thresholds(dd, B)).cuda()
+    out2 = torch.empty((U, N), dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.poi_dist_prob(ctx.handle, dc.data_ptr(), cphi.data_ptr(), thr.data_ptr(), dl.data_ptr(), ds.data_ptr(), U, N, B, dd,
+                                    out2.data_ptr(), None))
+    assert np.array_equal(out2.cpu().numpy(), exp.astype(np.float32))         # threshold path
+
+
+def test_dist_prob_threshold_path_matches_oracle_at_scale(pa):
+    """3000 POIs x 40 users (120k pairs) of synthetic Gowalla-like coordinates: bins from the
+    threshold path == oracle cal_dis (python libm) for every pair."""
+    import torch
+    from poi_amd.data import bin_thresholds, cos_lat, make_synthetic
+    ds = make_synthetic(40, 3000, 12, seed=5)
+    B, dd = ds.dist_num, ds.dd
+    last = ds.last_pois().astype(np.int32)
+    # probabilities = bin index itself, so that the output reveals the bin
+    sts = np.tile(np.arange(B + 1, dtype=np.float32), (40, 1))
+    ctx = pa._lib.context(0)
+    dc = torch.as_tensor(ds.coords).cuda(); dl = torch.as_tensor(last).cuda(); dst = torch.as_tensor(sts).cuda()
+    cphi = torch.as_tensor(cos_lat(ds.coords)).cuda(); thr = torch.as_tensor(bin_thresholds(dd, B)).cuda()
+    out = torch.empty((40, 3000), dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.poi_dist_prob(ctx.handle, dc.data_ptr(), cphi.data_ptr(), thr.data_ptr(), dl.data_ptr(), dst.data_ptr(), 40, 3000, B, dd,
+                                    out.data_ptr(), None))
+    got = out.cpu().numpy()
+    exp = np.empty((40, 3000), np.float32)
+    for u in range(40):
+        lc = ds.coords[last[u]]
+        for j in range(3000):
+            b = O.cal_dis(lc[0], lc[1], ds.coords[j][0], ds.coords[j][1], dd, B)
+            exp[u, j] = b if b < B else 0
+    assert np.array_equal(got, exp)
 
 
 def test_l2_eval(pa):

@@ -106,3 +106,24 @@ def test_shard_users_partitions_everything():
     # balanced by check-ins within 5 %
     work = [lens[slice(*D.shard_users(1000, 8, r, lens))].sum() for r in range(8)]
     assert max(work) / (sum(work) / 8) < 1.05
+
+
+def test_bin_thresholds_reproduce_cal_dis(golden_dir):
+    """bin(c) = #{k: c >= thr[k-1]} must equal int(d*asin(sqrt(c))*1000/dd) for every c, in particular
+    right at and next to each threshold, and on the reference's golden pairs."""
+    import math
+    thr = D.bin_thresholds(200, 200)
+    assert np.all(np.diff(thr) > 0)
+
+    def f(c):
+        return min(int(12742 * math.asin(math.sqrt(c)) * 1000 / 200), 200)
+    rng = np.random.default_rng(0)
+    cs = np.concatenate((thr, np.nextafter(thr, 0), np.nextafter(thr, 1), rng.uniform(0, thr[-1] * 1.2, 20000)))
+    got = np.searchsorted(thr, cs, side="right")
+    assert np.array_equal(got, [f(c) for c in cs])
+    g = np.load(os.path.join(golden_dir, "cal_dis.npz"))
+    p = D.DEG
+    a = (g["lat1"] - g["lat2"]) * p; b = (g["lon1"] - g["lon2"]) * p
+    c = (1.0 - np.cos(a)) / 2 + np.cos(g["lat1"] * p) * np.cos(g["lat2"] * p) * (1.0 - np.cos(b)) / 2
+    assert np.array_equal(np.searchsorted(thr, c, side="right"), g["bins_dd200_B200"])
+    assert np.array_equal(D.cos_lat(np.stack([g["lat1"], g["lon1"]], 1)), np.cos(g["lat1"] * p))
