@@ -344,7 +344,10 @@ class OboSpatialGru(GruBasic):
                 raise _lib.PoiError("update_trained_sus needs coords= at construction")
             n = ids.numel()
             lp, st = self._rows(self._last_poi, ids, lo), self._rows(self.trained_sus, ids, lo)
-            prob = torch.empty((n, self.n_item), dtype=torch.float32, device=self.device)
+            need = n * self.n_item                      # persistent grow-only buffer: no allocator churn per batch
+            if getattr(self, "_prob_buf", None) is None or self._prob_buf.numel() < need:
+                self._prob_buf = torch.empty(need, dtype=torch.float32, device=self.device)
+            prob = self._prob_buf[:need].view(n, self.n_item)
             self.ctx.check(self.lib.poi_dist_prob(self.ctx.handle, _ptr(self.coords), _ptr(self._cphi), _ptr(self._binthr), _ptr(lp), _ptr(st), n,
                                                   self.n_item, self.n_dist, self.dd * 1000.0, _ptr(prob), self._stream()))
             return self.wd.t, prob
