@@ -1,0 +1,98 @@
+"""Epoch loop in the shape of prog_bpr_gru_spatial.py:182-334 (train_valid_or_test) on a PoiDataset:
+per-epoch negative refresh -> shuffled user order -> train (one user per step like the reference, or
+`batch_users` per launch) -> snapshots -> predict -> evaluate.  The reference's three-way timing split
+(train / user vectors / test, :232,264,299,305-310) is kept."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import models
+from .evaluate import GlobalBest, fun_predict_auc_recall_map_ndcg
+
+
+def compute_start_end(user_num, size):
+    """Params.compute_start_end (prog_bpr_gru_spatial.py:156-179): contiguous np.arange batches."""
+    return [np.arange(s, min(s + size, user_num), dtype=np.int32) for s in range(0, user_num, size)]
+
+
+def default_params():
+    """The in-source config of prog_bpr_gru_spatial.py:54-78 (flag 2 = Distance2Pre)."""
+    return dict(at_nums=[5, 10, 15, 20], epochs=3, latent_size=20, alpha=0.01, **{"lambda": 0.001}, gru=2,
+                batch_size_test=32, batch_users=1, seed=123)
+
+
+def build_model(ds, p, device="cuda:0", seed=None):
+    tab = ds.shard()
+    size = p["latent_size"]
+    al = [p["alpha"], p["lambda"]]
+    if p["gru"] == 0:
+        return models.OboBpr(train=tab, test=None, alpha_lambda=al, n_user=ds.n_user, n_item=ds.n_item, n_in=size, n_hidden=size,
+                             device=device, seed=seed)
+    if p["gru"] == 1:
+        return models.OboGru(train=tab, test=None, alpha_lambda=al, n_user=ds.n_user, n_item=ds.n_item, n_in=size, n_hidden=size,
+                             device=device, seed=seed)
+    return models.OboSpatialGru(train=tab, test=None, dist=None, alpha_lambda=al, n_user=ds.n_user, n_item=ds.n_item,
+                                n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=size, n_hidden=size, device=device, seed=seed,
+                                coords=ds.coords)
+
+
+def train_valid_or_test(ds, p, device="cuda:0", log=print):
+    model = build_model(ds, p, device, seed=p.get("seed"))
+    best = GlobalBest(p["at_nums"])
+    U = ds.n_user
+    ses_tes = compute_start_end(U, p["batch_size_test"])
+    ses_auc = compute_start_end(U, p["batch_size_test"] * 10)
+    tes_p, tes_m = ds.tes_p.reshape(-1, 1), np.ones((U, 1), np.int32)
+    lens = ds.lens
+    history = []
+    rng_neg = np.random.default_rng(p.get("seed", 0) + 1000)
+    B = int(p.get("batch_users", 1))
+    for epoch in range(p["epochs"]):
+        if epoch > 0:                                               # :221-228
+            ds.resample_negatives(rng_neg)
+            model.set_negatives_csr(ds.tra_q, ds.tes_q, ds.tra_dq if p["gru"] == 2 else None)
+        t0 = time.time()
+        order = np.random.default_rng(123 + epoch).permutation(U).astype(np.int32)      # :236-238
+        loss = 0.0
+        if p["gru"] == 0:                                           # :240-244 - one triple per valid position
+            u, pp, qq = model.epoch_triples()
+            if B <= 1:
+                off = ds.off.astype(np.int64)
+                for uidx in order:
+                    for i in range(off[uidx], off[uidx + 1]):
+                        loss += model.train(int(uidx), [int(ds.tra_p[i]), int(ds.tra_q[i])])
+            else:
+                loss = float(model.train_batch(u, pp, qq, mode="snapshot").sum())
+        elif B <= 1:                                                # :246-254
+            for uidx in order:
+                r = model.train(np.int32(uidx))
+                loss += r[0] if p["gru"] == 2 else r
+        else:
+            for b0 in range(0, U, B):
+                ids = order[b0:b0 + B]
+                ids = ids[np.argsort(-lens[ids], kind="stable")]
+                out = model.train_batch(ids)
+                loss += float(out[:, 0].sum()) if p["gru"] == 2 else float(out.sum())
+        l2 = model.l2.eval()                                        # :255
+        t1 = time.time()
+        model.update_trained_items()                                # :266-298
+        if p["gru"] == 0:
+            model.update_trained_users()
+        elif p["gru"] == 1:
+            model.update_trained_users(torch.cat([model.predict_device(se) for se in ses_tes]))
+        else:
+            model.update_trained_dists()
+            hs, ss = zip(*[model.predict_device(se) for se in ses_tes])
+            model.update_trained_users(torch.cat(hs))
+            model.update_trained_sus(torch.cat(ss))
+        t2 = time.time()
+        m = fun_predict_auc_recall_map_ndcg(p, model, best, epoch, ses_auc, ses_tes, tes_p, tes_m)
+        t3 = time.time()
+        history.append(dict(epoch=epoch, loss=loss, l2=l2, auc=m["auc"], recall=[m["at"][k]["recall"] for k in p["at_nums"]],
+                            times=(t1 - t0, t2 - t1, t3 - t2)))
+        log("epoch %d  sum_loss = %.3f = %.3f + %.3f  auc %.4f  recall@%d %.4f  time (train, user, test) %.2fs %.2fs %.2fs"
+            % (epoch, loss + l2, loss, l2, m["auc"], p["at_nums"][-1], m["at"][p["at_nums"][-1]]["recall"], t1 - t0, t2 - t1, t3 - t2))
+    return model, best, history

@@ -127,3 +127,13 @@ def test_bin_thresholds_reproduce_cal_dis(golden_dir):
     c = (1.0 - np.cos(a)) / 2 + np.cos(g["lat1"] * p) * np.cos(g["lat2"] * p) * (1.0 - np.cos(b)) / 2
     assert np.array_equal(np.searchsorted(thr, c, side="right"), g["bins_dd200_B200"])
     assert np.array_equal(D.cos_lat(np.stack([g["lat1"], g["lon1"]], 1)), np.cos(g["lat1"] * p))
+
+
+def test_rank_metrics_match_reference_golden(golden_dir):
+    """evaluate.rank_metrics (vectorised Valuate.py:149-172) vs the reference's per-row helpers."""
+    from poi_amd.evaluate import rank_metrics
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    m = rank_metrics(g["recom"], g["test_lst"], g["test_mask"], [20])[20]
+    assert m["hits"] == g["zero_one"].sum()
+    assert np.isclose(m["map"], g["map"].mean(), rtol=1e-12) and np.isclose(m["ndcg"], g["ndcg"].mean(), rtol=1e-12)
+    assert np.isclose(m["recall"], g["zero_one"].sum() / g["test_mask"].sum())
