@@ -26,6 +26,8 @@ struct poi_ctx {
   // per-sequence engine
   DevBuf ws, slab, te_ws;
   int engine = 0;   // 0 auto, 1 per-sequence, 2 tile
+  int wgrad_rounds = 2;
+  int head_rounds = 1;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
   int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1|2 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   // BPR
@@ -87,6 +89,8 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipGetDeviceProperties failed"); }
   c->num_cu = prop.multiProcessorCount;
   if (const char* e = getenv("POI_SEQ_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
+  if (const char* e = getenv("POI_HEAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->head_rounds = v; }
+  if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->score_variant = v; }
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
@@ -138,6 +142,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.n_item = P->n_item; A.n_dist = P->n_dist; A.dim = D;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
+  if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
   A.dl = poi::dense_layout(D, 2 * D, P->n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 64;
   const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D;
@@ -178,7 +183,9 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   const bool tile = use_tile(c, P, spatial, n);
   int n_head = 0, n_kc = 0, n_slab = grid;
   if (tile) {
-    n_head = c->num_cu; n_kc = 16;
+    n_head = c->num_cu * c->head_rounds;
+    // te_wgrad launches 9 output-tile jobs x n_kc K-chunks: fill the CUs exactly (no ragged second round)
+    n_kc = (c->num_cu * c->wgrad_rounds) / 9; if (n_kc < 1) n_kc = 1;
     n_slab = n_head > n_kc ? n_head : n_kc;
   } else if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
   if ((rc = ensure(c, c->slab, sizeof(float) * (size_t)dl.total * n_slab, st))) return rc;
@@ -205,7 +212,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
     int agrid = c->num_cu * 4; if (agrid > n) agrid = n;
     HIPCHK(c, poi::launch_rows_apply(A, true, agrid, alpha, lambda, st, &c->tm));
-    HIPCHK(c, poi::launch_dense_apply(A, true, n_slab, alpha, lambda, st, &c->tm));
+    HIPCHK(c, poi::launch_dense_apply(A, true, n_kc, n_head, alpha, lambda, st, &c->tm));
     return POI_OK;
   }
   HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st, &c->tm));

@@ -77,6 +77,7 @@ struct TeArgs {
   int n_seq;
   float* out;
   int predict;                        // 1: forward over all L positions, no bookkeeping
+  int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_seq;
   float *X, *E, *G, *H, *RH, *DH, *rowloss;
@@ -93,7 +94,7 @@ int te_nbp(int n_dist);
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
-hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, float alpha, float lambda, hipStream_t st, Timing* tm);
+hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, int n_slab_head, float alpha, float lambda, hipStream_t st, Timing* tm);
 
 size_t seq_ws_floats(int D, int NB, int cap);
 hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);

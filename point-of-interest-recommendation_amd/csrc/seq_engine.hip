@@ -411,15 +411,15 @@ __global__ __launch_bounds__(POI_BLOCK) void seq_predict_kernel(SeqArgs A) {
 // and re-zeroes G / mult.  With n_seq == 1 this is the reference's unique(p U q) write-back
 // (public/GRU_Spatial.py:149-153,212-215) including the padding rows.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void claim_apply(float* __restrict__ T, float* __restrict__ G, int* __restrict__ mult,
-                                            int* __restrict__ nseq, int row, int D, float alpha, float lambda) {
-  int got = 0;
-  if (lane_id() == 0) got = atomicExch(&nseq[row], 0);
-  got = __builtin_amdgcn_readfirstlane(got);
+// One wavefront per table row: rows whose distinct-sequence counter is non-zero were touched by this
+// launch and get   row <- row - alpha * (G[row] + lambda * mult[row] * row) / nseq[row]   ; G / mult /
+// nseq are re-zeroed.  No atomics (each row has exactly one owner), deterministic, and the scan of
+// the counters costs 4 bytes per table row.
+__device__ __forceinline__ void apply_row(float* __restrict__ T, float* __restrict__ G, int* __restrict__ mult,
+                                          int* __restrict__ nseq, int row, int D, float alpha, float lambda) {
+  const int got = nseq[row];
   if (got <= 0) return;
-  int m = 0;
-  if (lane_id() == 0) m = atomicExch(&mult[row], 0);
-  m = __builtin_amdgcn_readfirstlane(m);
+  const int m = mult[row];
   const float sc = alpha / (float)got, lm = lambda * (float)m;
   float* t = T + (size_t)row * D;
   float* g = G + (size_t)row * D;
@@ -431,27 +431,16 @@ __device__ __forceinline__ void claim_apply(float* __restrict__ T, float* __rest
     *reinterpret_cast<float4*>(t + j) = tv;
     *reinterpret_cast<float4*>(g + j) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  if (lane_id() == 0) { nseq[row] = 0; mult[row] = 0; }
 }
 
 template <bool SPATIAL>
 __global__ __launch_bounds__(POI_BLOCK) void rows_apply_kernel(SeqArgs A, float alpha, float lambda) {
   const int D = A.dim;
-  const int w = wave_id();
-  for (int k = blockIdx.x; k < A.n_seq; k += gridDim.x) {
-    const int u = A.uidx[k];
-    const int base = A.off[u];
-    const int L = A.off[u + 1] - base;
-    const int n_lt = 2 * L + 1;                    // p, q, padding row
-    for (int e = w; e < n_lt; e += POI_NWAVE) {
-      const int row = e < L ? A.p[base + e] : (e < 2 * L ? A.q[base + e - L] : A.n_item);
-      claim_apply(A.lt, A.g_lt, A.mult_lt, A.nseq_lt, row, D, alpha, lambda);
-    }
-    if (SPATIAL) {
-      for (int e = w; e < L + 1; e += POI_NWAVE) {
-        const int row = e < L ? A.dp[base + e] : A.n_dist;
-        claim_apply(A.di, A.g_di, A.mult_di, A.nseq_di, row, D, alpha, lambda);
-      }
-    }
+  const int n_lt = A.n_item + 1, n_di = SPATIAL ? A.n_dist + 1 : 0;
+  for (int r = blockIdx.x * POI_NWAVE + wave_id(); r < n_lt + n_di; r += gridDim.x * POI_NWAVE) {
+    if (r < n_lt) apply_row(A.lt, A.g_lt, A.mult_lt, A.nseq_lt, r, D, alpha, lambda);
+    else apply_row(A.di, A.g_di, A.mult_di, A.nseq_di, r - n_lt, D, alpha, lambda);
   }
 }
 
@@ -460,18 +449,27 @@ __global__ __launch_bounds__(POI_BLOCK) void rows_apply_kernel(SeqArgs A, float 
 // public/GRU_Spatial.py:210-211 (n_seq == 1: identical).
 // ---------------------------------------------------------------------------------------------
 template <bool SPATIAL>
-__global__ __launch_bounds__(POI_BLOCK) void dense_apply_kernel(SeqArgs A, int n_slab, float alpha, float lambda) {
+__global__ __launch_bounds__(POI_BLOCK) void dense_apply_kernel(SeqArgs A, int n_slab, int n_slab_head, float alpha, float lambda) {
   const int D = A.dim, XW = SPATIAL ? 2 * D : D, NB = SPATIAL ? A.n_dist + 1 : 0;
   const DenseLayout dl = dense_layout(D, XW, NB);
   const float inv_n = 1.0f / (float)A.n_seq;
   const int i = blockIdx.x * POI_BLOCK + threadIdx.x;
   if (i >= dl.total) return;
   if (SPATIAL && i == dl.upq) return;   // consumed together with dl.sur by one thread (below)
+  // regions vs | bs | wd are written by up to n_slab_head workgroups, everything else by n_slab
+  const int ns = (i >= dl.vs && i <= dl.wd) ? n_slab_head : n_slab;
   float g = 0.f;
-  for (int s = 0; s < n_slab; ++s) {
-    float* ptr = A.slab + (size_t)s * dl.total + i;
-    g += *ptr;
-    *ptr = 0.f;
+  {
+    float* base = A.slab + i;
+    const size_t st = dl.total;
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {           // four independent loads in flight
+      float* p0 = base + (size_t)s * st;
+      const float v0 = p0[0], v1 = p0[st], v2 = p0[2 * st], v3 = p0[3 * st];
+      p0[0] = 0.f; p0[st] = 0.f; p0[2 * st] = 0.f; p0[3 * st] = 0.f;
+      g += (v0 + v1) + (v2 + v3);
+    }
+    for (; s < ns; ++s) { float* p0 = base + (size_t)s * st; g += *p0; *p0 = 0.f; }
   }
   g *= inv_n;
   float* theta = nullptr;
@@ -515,10 +513,13 @@ hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alph
   tm->end(st);
   hipError_t e = launch_rows_apply(A, spatial, grid, alpha, lambda, st, tm);
   if (e != hipSuccess) return e;
-  return launch_dense_apply(A, spatial, grid, alpha, lambda, st, tm);
+  return launch_dense_apply(A, spatial, grid, grid, alpha, lambda, st, tm);
 }
 
 hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm) {
+  const int rows = A.n_item + 1 + (spatial ? A.n_dist + 1 : 0);
+  grid = (rows + POI_NWAVE - 1) / POI_NWAVE;
+  if (grid > 8192) grid = 8192;
   tm->begin("rows_apply", st);
   if (spatial) hipLaunchKernelGGL(rows_apply_kernel<true>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
   else hipLaunchKernelGGL(rows_apply_kernel<false>, dim3(grid), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
@@ -526,13 +527,13 @@ hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alp
   return hipGetLastError();
 }
 
-hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, float alpha, float lambda, hipStream_t st, Timing* tm) {
+hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, int n_slab_head, float alpha, float lambda, hipStream_t st, Timing* tm) {
   const int D = A.dim, XW = spatial ? 2 * D : D, NB = spatial ? A.n_dist + 1 : 0;
   const DenseLayout dl = dense_layout(D, XW, NB);
   const int dgrid = (dl.total + POI_BLOCK - 1) / POI_BLOCK;
   tm->begin("dense_apply", st);
-  if (spatial) hipLaunchKernelGGL(dense_apply_kernel<true>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, n_slab, alpha, lambda);
-  else hipLaunchKernelGGL(dense_apply_kernel<false>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, n_slab, alpha, lambda);
+  if (spatial) hipLaunchKernelGGL(dense_apply_kernel<true>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, n_slab, n_slab_head, alpha, lambda);
+  else hipLaunchKernelGGL(dense_apply_kernel<false>, dim3(dgrid), dim3(POI_BLOCK), 0, st, A, n_slab, n_slab_head, alpha, lambda);
   tm->end(st);
   return hipGetLastError();
 }

@@ -59,19 +59,25 @@ __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
 }
 
 // acc[i][j] += A_i (32 x 8*K8, LDS row-major, leading dim lda) . B_j (packed n-tile j of `bp`)
-template <int MT, int NTW, int K8>
+// The packed B stream is prefetched PF k-groups ahead through a register ring: one k-group is only
+// 4*MT*NTW MFMAs (0.1 - 0.6 us), shorter than the L2 latency, so a depth-1 prefetch starves the
+// matrix pipe.  All ring indices are compile-time after unrolling (no scratch).
+template <int MT, int NTW, int K8, int PF = 4>
 __device__ __forceinline__ void mma_lds_packed(f32x16 (&acc)[MT][NTW], const float* __restrict__ ldsA, int lda,
                                                const float4* __restrict__ bp, const int (&nt)[NTW]) {
   const int lane = lane_id(), li = lane & 31, h = lane >> 5;
   const float* arow = ldsA + li * lda + 4 * h;
-  float4 bq[2][NTW];
+  constexpr int R = PF + 1;
+  float4 bq[R][NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) bq[0][j] = bp[((size_t)nt[j] * K8 + 0) * 64 + lane];
+  for (int m = 0; m < PF && m < K8; ++m)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bq[m % R][j] = bp[((size_t)nt[j] * K8 + m) * 64 + lane];
 #pragma unroll
   for (int m = 0; m < K8; ++m) {
-    if (m + 1 < K8) {
+    if (m + PF < K8) {
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[(m + 1) & 1][j] = bp[((size_t)nt[j] * K8 + (m + 1)) * 64 + lane];
+      for (int j = 0; j < NTW; ++j) bq[(m + PF) % R][j] = bp[((size_t)nt[j] * K8 + (m + PF)) * 64 + lane];
     }
     float4 a[MT];
 #pragma unroll
@@ -80,7 +86,7 @@ __device__ __forceinline__ void mma_lds_packed(f32x16 (&acc)[MT][NTW], const flo
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        const float4 b = bq[m & 1][j];
+        const float4 b = bq[m % R][j];
         acc[i][j] = mfma32(a[i].x, b.x, acc[i][j]);
         acc[i][j] = mfma32(a[i].y, b.y, acc[i][j]);
         acc[i][j] = mfma32(a[i].z, b.z, acc[i][j]);
@@ -108,37 +114,68 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   if (tid == 1023) A.soff[n] = part[1023];
 }
 
-// one wavefront per sequence: row maps + table-touch counts (same rules as seq_engine count_rows)
-__device__ __forceinline__ void te_count(const int* a, const int* b, int L, bool two, int pad_row, int pad_mult,
-                                         int* mult, int* nseq) {
+// one wavefront per sequence: row maps + table-touch counts (same rules as seq_engine count_rows).
+// The sequence's ids are staged in the wave's LDS slice so that the O(L^2) first-occurrence test
+// reads LDS (all lanes read the same j: broadcast) instead of global memory.
+#define TE_CNT_MAX 256     // ids per sequence handled through LDS (2 * L <= 256); longer falls back to global reads
+// Returns (in every lane) the number of literal occurrences of `pad_row` among the ids; those and
+// the analytic padding multiplicity are accumulated per workgroup by the caller, because EVERY
+// sequence touches the padding rows and ~6 same-address device atomics per sequence serialise
+// (13 ns each).
+__device__ __forceinline__ int te_count(const int* a, const int* b, int L, bool two, int pad_row,
+                                        int* mult, int* nseq, int* ids) {
   const int n = two ? 2 * L : L, lane = lane_id();
-  int seen = 0;
+  const bool in_lds = n <= TE_CNT_MAX;
+  if (in_lds) {
+    for (int e = lane; e < n; e += 64) ids[e] = (two && e >= L) ? b[e - L] : a[e];
+    __builtin_amdgcn_wave_barrier();
+  }
+  int pads = 0;
   for (int e0 = 0; e0 < n; e0 += 64) {
     const int e = e0 + lane;
-    int row = -1;
+    bool is_pad = false;
     if (e < n) {
-      row = (two && e >= L) ? b[e - L] : a[e];
-      atomicAdd(&mult[row], 1);
-      int dup = 0;
-      for (int j = 0; j < e; ++j) dup |= (((two && j >= L) ? b[j - L] : a[j]) == row) ? 1 : 0;
-      if (!dup) atomicAdd(&nseq[row], 1);
+      const int row = in_lds ? ids[e] : ((two && e >= L) ? b[e - L] : a[e]);
+      is_pad = row == pad_row;
+      if (!is_pad) {
+        atomicAdd(&mult[row], 1);
+        int dup = 0;
+        if (in_lds) { for (int j = 0; j < e; ++j) dup |= (ids[j] == row) ? 1 : 0; }
+        else { for (int j = 0; j < e; ++j) dup |= (((two && j >= L) ? b[j - L] : a[j]) == row) ? 1 : 0; }
+        if (!dup) atomicAdd(&nseq[row], 1);
+      }
     }
-    seen |= __any(row == pad_row) ? 1 : 0;
+    pads += __builtin_popcountll(__ballot(is_pad));
   }
-  if (pad_mult > 0 && lane == 0) {
-    atomicAdd(&mult[pad_row], pad_mult);
-    if (!seen) atomicAdd(&nseq[pad_row], 1);
-  }
+  __builtin_amdgcn_wave_barrier();
+  return pads;
 }
 
+#define TE_SEQ_PER_WAVE 4
 __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
-  const int k = blockIdx.x * POI_NWAVE + wave_id();
-  if (k >= A.n_seq) return;
-  const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = A.soff[k];
-  for (int t = lane_id(); t < ns; t += 64) { A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t; A.row_seq[r0 + t] = k; }
+  __shared__ int s_ids[POI_NWAVE][TE_CNT_MAX];
+  __shared__ int s_pad[POI_NWAVE][4];
+  const int w = wave_id(), lane = lane_id();
+  int m_lt = 0, n_lt = 0, m_di = 0, n_di = 0;
+  for (int i = 0; i < TE_SEQ_PER_WAVE; ++i) {
+    const int k = (blockIdx.x * POI_NWAVE + w) * TE_SEQ_PER_WAVE + i;
+    if (k >= A.n_seq) break;
+    const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = A.soff[k];
+    for (int t = lane; t < ns; t += 64) { A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t; A.row_seq[r0 + t] = k; }
+    if (A.predict) continue;
+    const int c_lt = 2 * (A.len_max - L) + te_count(A.p + base, A.q + base, L, true, A.n_item, A.mult_lt, A.nseq_lt, s_ids[w]);
+    const int c_di = (A.len_max - L) + te_count(A.dp + base, A.dp + base, L, false, A.n_dist, A.mult_di, A.nseq_di, s_ids[w]);
+    m_lt += c_lt; n_lt += c_lt > 0; m_di += c_di; n_di += c_di > 0;
+  }
   if (A.predict) return;
-  te_count(A.p + base, A.q + base, L, true, A.n_item, 2 * (A.len_max - L), A.mult_lt, A.nseq_lt);
-  te_count(A.dp + base, A.dp + base, L, false, A.n_dist, A.len_max - L, A.mult_di, A.nseq_di);
+  if (lane == 0) { s_pad[w][0] = m_lt; s_pad[w][1] = n_lt; s_pad[w][2] = m_di; s_pad[w][3] = n_di; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int t = s_pad[0][threadIdx.x] + s_pad[1][threadIdx.x] + s_pad[2][threadIdx.x] + s_pad[3][threadIdx.x];
+    int* dst = threadIdx.x == 0 ? A.mult_lt + A.n_item : threadIdx.x == 1 ? A.nseq_lt + A.n_item
+             : threadIdx.x == 2 ? A.mult_di + A.n_dist : A.nseq_di + A.n_dist;
+    if (t) atomicAdd(dst, t);
+  }
 }
 
 // X[r] = [lt[p_t] | di[dp_t]], E[r] = lt[p_{t+1}] - lt[q_{t+1}].  LPR lanes per row, float4 per lane.
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gemm_ax_kernel(TeArgs A) {
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    mma_lds_packed<2, NTW, K8>(acc, lds, LDA, A.pUiT, nt);
+    mma_lds_packed<2, NTW, K8, 2>(acc, lds, LDA, A.pUiT, nt);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       if (w + 4 * j >= NT) continue;
@@ -257,8 +294,8 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
       az[0][0][r] = on ? g[col] : 0.f;
       ar[0][0][r] = on ? g[D + col] : 0.f;
     }
-    mma_lds_packed<1, 1, K8>(az, Hp, LDA, A.pWhT, ntz);
-    mma_lds_packed<1, 1, K8>(ar, Hp, LDA, A.pWhT, ntr);
+    mma_lds_packed<1, 1, K8, 8>(az, Hp, LDA, A.pWhT, ntz);
+    mma_lds_packed<1, 1, K8, 8>(ar, Hp, LDA, A.pWhT, ntr);
     float zv[16], hp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
     f32x16 ac[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ac[0][0][r] = (t < nsr[r]) ? A.G[(size_t)(rowb[r] + t) * 3 * D + 2 * D + col] : 0.f;
-    mma_lds_packed<1, 1, K8>(ac, RHb, LDA, A.pWhT, ntc);
+    mma_lds_packed<1, 1, K8, 8>(ac, RHb, LDA, A.pWhT, ntc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
@@ -317,7 +354,9 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
   constexpr int KB8 = NBP / 8, DTW = (NTD + 3) / 4, VT = (NBT * NTD + 3) / 4;   // d vs tiles per wave
   float* Ht = lds;                  // 32 x LDH
   float* Ot = Ht + 32 * LDH;        // 32 x LDO : logits -> softmax -> d logits
+  float* Et = Ot + 32 * LDO;        // 32 x LDH : E tile (training only)
   __shared__ float s_g[32], s_red[8];
+  __shared__ int s_p1[32], s_q1[32], s_a[32], s_b[32];   // destination rows / target bins of the tile's rows
   const int NB = A.n_dist + 1;
   const int T = mode ? A.n_seq : A.soff[A.n_seq];
   const float* Hsrc = mode ? A.hts : A.H;
@@ -343,6 +382,15 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
     __syncthreads();
     stage_rows(Ht, LDH, Hsrc, D, D, r0, 32, T);
+    if (!mode) {
+      stage_rows(Et, LDH, A.E, D, D, r0, 32, T);
+      if (tid < 32) {
+        const int gr = r0 + tid;
+        int p1 = 0, q1 = 0, a = 0, b = 0;
+        if (gr < T) { const int s = A.row_src[gr]; p1 = A.p[s + 1]; q1 = A.q[s + 1]; a = A.dp[s + 1]; b = A.dq[s + 1]; }
+        s_p1[tid] = p1; s_q1[tid] = q1; s_a[tid] = a; s_b[tid] = b;
+      }
+    }
     __syncthreads();
     {   // logits
       f32x16 acc[1][NTW];
@@ -374,11 +422,10 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
       if (mode) {
         if (gr < T) for (int k = sub; k < NB; k += 8) A.sts[(size_t)gr * NB + k] = o[k] * inv;
       } else {
-        int a = 0, b = 0;
-        if (gr < T) { const int s = A.row_src[gr]; a = A.dp[s + 1]; b = A.dq[s + 1]; }
+        const int a = s_a[row], b = s_b[row];
         float cum = 0.f, he = 0.f;
         for (int k = sub; k < NBP; k += 8) { const float s = o[k] * inv; o[k] = s; if (k <= a) cum += s; }
-        if (gr < T) for (int j = sub; j < D; j += 8) he += Ht[row * LDH + j] * A.E[(size_t)gr * D + j];
+        for (int j = sub; j < D; j += 8) he += Ht[row * LDH + j] * Et[row * LDH + j];
         cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
         he += dpp_f<0xB1>(he); he += dpp_f<0x4E>(he); he += dpp_f<0x141>(he);
         // (the 8 lanes of a row now hold identical cum / he; they all wrote disjoint o[k])
@@ -431,11 +478,12 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
           const int i = c_row(r, lane), gr = r0 + i;
           if (gr < T) {
             const float g = s_g[i];
-            A.DH[(size_t)gr * D + col] = acc[0][j][r] + g * A.E[(size_t)gr * D + col];
-            const int s = A.row_src[gr];
+            A.DH[(size_t)gr * D + col] = acc[0][j][r] + g * Et[i * LDH + col];
             const float gh = g * Ht[i * LDH + col];
-            atomicAdd(A.g_lt + (size_t)A.p[s + 1] * D + col, gh);
-            atomicAdd(A.g_lt + (size_t)A.q[s + 1] * D + col, -gh);
+            if (A.dbg != 1) {
+              atomicAdd(A.g_lt + (size_t)s_p1[i] * D + col, gh);
+              atomicAdd(A.g_lt + (size_t)s_q1[i] * D + col, -gh);
+            }
           }
         }
       }
@@ -525,7 +573,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
     f32x16 m[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) m[0][0][r] = 0.f;
-    mma_lds_packed<1, 1, K8>(m, Ac, LDA, A.pWhc, ntc);
+    mma_lds_packed<1, 1, K8, 8>(m, Ac, LDA, A.pWhc, ntc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
@@ -548,7 +596,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    mma_lds_packed<1, 1, 2 * K8>(acc, Azr, LDB, A.pWhzr, ntzr);
+    mma_lds_packed<1, 1, 2 * K8, 8>(acc, Azr, LDB, A.pWhzr, ntzr);
 #pragma unroll
     for (int r = 0; r < 16; ++r) dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][0][r] : 0.f;
     // (the next iteration's writes to Ac happen before its barrier; reads of Azr are complete because
@@ -556,7 +604,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
     __syncthreads();
   }
   // d bi partial sums of this tile (columns owned by this lane in both half-waves)
-  float* slab = A.slab + (size_t)(tile % A.n_slab) * A.dl.total;
+  float* slab = A.slab + (size_t)(tile % A.n_kc) * A.dl.total;
   sbz += __shfl_xor(sbz, 32, 64); sbr += __shfl_xor(sbr, 32, 64); sbc += __shfl_xor(sbc, 32, 64);
   if (lane < 32 && ns_max > 0) {
     atomicAdd(slab + A.dl.bi + col, sbz);
@@ -566,32 +614,42 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// te_wgrad: split-K transposed GEMMs  out[m][n] = sum_r DA[r][m0+m] * Bsrc[r][n0+n]  on 64x64 output
-// blocks; K-chunk c covers packed rows [c*chunk, (c+1)*chunk).  job -> (A column block, B source).
+// te_wgrad: split-K transposed GEMMs  out[m][n] = sum_r DA[r][m0+m] * Bsrc[r][n0+n]  on TxT output
+// blocks (T = 128 when D % 128 == 0, else 64); K-chunk c covers packed rows [c*chunk, (c+1)*chunk).
+// job -> (A column block, B source).  Waves form a 2x2 grid, each owning (T/2)x(T/2) = Q x Q 32x32
+// accumulators; each 32-row stage is loaded from HBM/L2 into registers BEFORE the MFMA block of the
+// previous stage and written to the other LDS buffer after it (async-stage split, one barrier/stage).
 // -------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int T>
 __global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
-  __shared__ __align__(16) float At[32][64 + 4];
-  __shared__ __align__(16) float Bt[32][64 + 4];
-  constexpr int XW = 2 * D;
-  constexpr int NB_UI = (3 * D / 64) * (XW / 64), NB_ZR = (2 * D / 64) * (D / 64), NB_C = (D / 64) * (D / 64);
-  const int T = A.soff[A.n_seq];
+  constexpr int XW = 2 * D, LDT = T + 4, Q = T / 64;         // Q x Q accumulators per wave
+  constexpr int F4 = 32 * (T / 4) / TE_BLOCK;                // float4 per thread per operand per stage
+  __shared__ __align__(16) float At[2][32][LDT];
+  __shared__ __align__(16) float Bt[2][32][LDT];
+  constexpr int NB_UI = (3 * D / T) * (XW / T), NB_ZR = (2 * D / T) * (D / T);
+  const int Trows = A.soff[A.n_seq];
   const int job = blockIdx.x, kc = blockIdx.y;
   int m0, n0, ldo, bsel; size_t oo;
-  if (job < NB_UI) { const int bn = XW / 64; m0 = (job / bn) * 64; n0 = (job % bn) * 64; ldo = XW; oo = A.dl.ui; bsel = 0; }
-  else if (job < NB_UI + NB_ZR) { const int j = job - NB_UI, bn = D / 64; m0 = (j / bn) * 64; n0 = (j % bn) * 64; ldo = D; oo = A.dl.wh; bsel = 1; }
-  else { const int j = job - NB_UI - NB_ZR, bn = D / 64; m0 = 2 * D + (j / bn) * 64; n0 = (j % bn) * 64; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
-  const int chunk = (((T + nkc - 1) / nkc) + 31) & ~31;
-  const int rb = kc * chunk, re = min(T, rb + chunk);
+  if (job < NB_UI) { const int bn = XW / T; m0 = (job / bn) * T; n0 = (job % bn) * T; ldo = XW; oo = A.dl.ui; bsel = 0; }
+  else if (job < NB_UI + NB_ZR) { const int j = job - NB_UI, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.wh; bsel = 1; }
+  else { const int j = job - NB_UI - NB_ZR, bn = D / T; m0 = 2 * D + (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
+  const int chunk = (((Trows + nkc - 1) / nkc) + 31) & ~31;
+  const int rb = kc * chunk, re = min(Trows, rb + chunk);
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
-  const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
-  f32x16 acc;
+  const int wm = (w >> 1) * (T / 2), wn = (w & 1) * (T / 2);
+  f32x16 acc[Q][Q];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int r0 = rb; r0 < re; r0 += 32) {
-    __syncthreads();
-    for (int e = tid; e < 32 * 16; e += TE_BLOCK) {
-      const int r = e >> 4, c = (e & 15) * 4, gr = r0 + r;
+  for (int i = 0; i < Q; ++i)
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 ra[F4], rbv[F4];
+  auto gload = [&](int r0) {
+#pragma unroll
+    for (int s = 0; s < F4; ++s) {
+      const int e = tid + s * TE_BLOCK;
+      const int r = e / (T / 4), c = (e % (T / 4)) * 4, gr = r0 + r;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
       if (gr < re) {
         a = *reinterpret_cast<const float4*>(A.G + (size_t)gr * 3 * D + m0 + c);
@@ -599,25 +657,56 @@ __global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
         else if (bsel == 1) { if (A.row_t[gr] > 0) b = *reinterpret_cast<const float4*>(A.H + (size_t)(gr - 1) * D + n0 + c); }
         else b = *reinterpret_cast<const float4*>(A.RH + (size_t)gr * D + n0 + c);
       }
-      *reinterpret_cast<float4*>(&At[r][c]) = a;
-      *reinterpret_cast<float4*>(&Bt[r][c]) = b;
+      ra[s] = a; rbv[s] = b;
     }
-    __syncthreads();
+  };
+  auto lstore = [&](int buf) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc = mfma32(At[2 * kk + h][wm + li], Bt[2 * kk + h][wn + li], acc);
+    for (int s = 0; s < F4; ++s) {
+      const int e = tid + s * TE_BLOCK;
+      const int r = e / (T / 4), c = (e % (T / 4)) * 4;
+      *reinterpret_cast<float4*>(&At[buf][r][c]) = ra[s];
+      *reinterpret_cast<float4*>(&Bt[buf][r][c]) = rbv[s];
+    }
+  };
+  if (rb < re) { gload(rb); lstore(0); }
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rb; r0 < re; r0 += 32) {
+    const bool more = r0 + 32 < re;
+    if (more) gload(r0 + 32);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[Q], bv[Q];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) av[i] = At[buf][2 * kk + h][wm + 32 * i + li];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) bv[j] = Bt[buf][2 * kk + h][wn + 32 * j + li];
+#pragma unroll
+      for (int i = 0; i < Q; ++i)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
-  // m index of the output = DA column: for bsel 2 the slab row is (m0 - 2D + ...) inside wh[2]
   float* out = A.slab + (size_t)kc * A.dl.total + oo;
   const int mbase = (bsel == 2 ? m0 - 2 * D : m0) + wm;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) out[(size_t)(mbase + c_row(r, lane)) * ldo + n0 + wn + li] += acc[r];
+  for (int i = 0; i < Q; ++i)
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        out[(size_t)(mbase + 32 * i + c_row(r, lane)) * ldo + n0 + wn + 32 * j + li] += acc[i][j][r];
 }
 
 // -------------------------------------------------------------------------------------------------
 // te_gemm_dx: dx[r] = DA[r] . ui (K = 3D, N = 2D); columns [0, D) -> g_lt[p_t], [D, 2D) -> g_di[dp_t]
 // -------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(TE_BLOCK) void te_gemm_dx_kernel(TeArgs A) {
+__global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int K = 3 * D, K8 = K / 8, NT = 2 * D / 32, NTW = (NT + 3) / 4, LDA = K + 4;
   const int T = A.soff[A.n_seq];
@@ -625,9 +714,16 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gemm_dx_kernel(TeArgs A) {
   int nt[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
+  __shared__ int s_pt[32], s_dpt[32];
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
     __syncthreads();
     stage_rows(lds, LDA, A.G, K, K, r0, 32, T);
+    if (threadIdx.x < 32) {
+      const int gr = r0 + threadIdx.x;
+      int pt = 0, dpt = 0;
+      if (gr < T) { const int s = A.row_src[gr]; pt = A.p[s]; dpt = A.dp[s]; }
+      s_pt[threadIdx.x] = pt; s_dpt[threadIdx.x] = dpt;
+    }
     __syncthreads();
     f32x16 acc[1][NTW];
 #pragma unroll
@@ -641,11 +737,10 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gemm_dx_kernel(TeArgs A) {
       const int col = nt[j] * 32 + li;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int gr = r0 + c_row(r, lane);
+        const int i = c_row(r, lane), gr = r0 + i;
         if (gr < T) {
-          const int s = A.row_src[gr];
-          float* dst = col < D ? A.g_lt + (size_t)A.p[s] * D + col : A.g_di + (size_t)A.dp[s] * D + (col - D);
-          atomicAdd(dst, acc[0][j][r]);
+          float* dst = col < D ? A.g_lt + (size_t)s_pt[i] * D + col : A.g_di + (size_t)s_dpt[i] * D + (col - D);
+          if (A.dbg != 1) atomicAdd(dst, acc[0][j][r]);
         }
       }
     }
@@ -671,7 +766,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_finalize_kernel(TeArgs A) {
   const float s1 = block_sum(sur, red);
   const float s2 = block_sum(-bpr, red);
   if (threadIdx.x == 0) {
-    float* slab = A.slab + (size_t)(blockIdx.x % A.n_slab) * A.dl.total;
+    float* slab = A.slab + (size_t)(blockIdx.x % A.n_kc) * A.dl.total;
     atomicAdd(slab + A.dl.sur, s1);
     atomicAdd(slab + A.dl.upq, s2);
   }
@@ -689,7 +784,7 @@ int te_nbp(int n_dist) { return nbt_for(n_dist + 1) * 32; }
 
 template <int D, int NBT>
 static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_t st) {
-  const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (NBT * 32 + 4));
+  const size_t lds = sizeof(float) * (2 * 32 * (D + 4) + 32 * (NBT * 32 + 4));
   hipLaunchKernelGGL((te_head_kernel<D, NBT>), dim3(grid), dim3(TE_BLOCK), lds, st, A, mode);
   return hipGetLastError();
 }
@@ -733,7 +828,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   PackJobs J; te_pack_jobs(A, J, true);
   tm->begin("te_prep", st);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
-  hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
+  hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   tm->end(st);
   tm->begin("te_gather", st);
@@ -754,12 +849,13 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_wgrad", st);
   {
-    const int jobs = (3 * D / 64) * (2 * D / 64) + (2 * D / 64) * (D / 64) + (D / 64) * (D / 64);
-    hipLaunchKernelGGL(te_wgrad_kernel<D>, dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
+    constexpr int T = (D % 128 == 0) ? 128 : 64;
+    const int jobs = (3 * D / T) * (2 * D / T) + (2 * D / T) * (D / T) + (D / T) * (D / T);
+    hipLaunchKernelGGL((te_wgrad_kernel<D, T>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
   tm->begin("te_gemm_dx", st);
-  hipLaunchKernelGGL(te_gemm_dx_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 32 * (3 * D + 4), st, A);
+  hipLaunchKernelGGL(te_gemm_dx_kernel<D>, dim3(num_cu * 3), dim3(TE_BLOCK), sizeof(float) * 32 * (3 * D + 4), st, A);
   tm->end(st);
   tm->begin("te_finalize", st);
   hipLaunchKernelGGL(te_finalize_kernel, dim3((n + TE_BLOCK - 1) / TE_BLOCK), dim3(TE_BLOCK), 0, st, A);
@@ -779,7 +875,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   PackJobs J; te_pack_jobs(A, J, false);
   tm->begin("te_predict", st);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
-  hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
+  hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 1);
   hipLaunchKernelGGL(te_gemm_ax_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 64 * (2 * D + 4), st, A);
