@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla"])
-    ap.add_argument("--batch-users", type=int, default=8192)
+    ap.add_argument("--batch-users", type=int, default=12500)
     ap.add_argument("--eval-steps", type=int, default=2)
     ap.add_argument("--eval-chunk", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -162,17 +162,21 @@ def main():
     # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region) -----------
     # algorithmic work per GRU step of one sequence: flops for the contractions, bytes
     # for the gather (3 rows + 4 indices) and the sparse write-back (unique rows per sequence).
+    # rows actually written by the sparse write-back: unique table rows per LAUNCH (batch rule: one write per row)
     off64 = tab.off.astype(np.int64)
-    samp = range(0, n_local, max(1, n_local // 2000))
-    uniq = sum(len(np.unique(np.concatenate((tab.p[off64[u]:off64[u + 1]], tab.q[off64[u]:off64[u + 1]])))) +
-               len(np.unique(tab.dp[off64[u]:off64[u + 1]])) for u in samp) * (n_local / len(samp))
+    order_host = order.cpu().numpy()
+    uniq = 0
+    for b0 in range(0, n_local, B):
+        ids = order_host[b0:b0 + B]
+        sel = np.concatenate([np.arange(off64[u], off64[u + 1]) for u in ids])
+        uniq += len(np.unique(np.concatenate((tab.p[sel], tab.q[sel])))) + 1 + len(np.unique(np.append(tab.dp[sel], ds.dist_num)))
     D2 = float(D * D)
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
             "te_gemm_ax": ("flop", 12 * D2 * steps_per_epoch), "te_rec_fwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_head": ("flop", 6.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_wgrad": ("flop", 18 * D2 * steps_per_epoch), "te_gemm_dx": ("flop", 12 * D2 * steps_per_epoch),
             "te_gather": ("byte", (3.0 * D * 4 + 16) * float(lens_local.sum())),
-            "rows_apply": ("byte", uniq * D * 4.0)}
+            "rows_apply": ("byte", 2.0 * uniq * D * 4.0)}      # read + write of every touched row
     kernels = {}
     for k in KN:
         ms, nl = kt[k]
@@ -188,12 +192,25 @@ def main():
                 ent.update(bound="hbm", achieved=rate / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=rate / 1e9 / PEAK_HBM_GBS)
         kernels[k] = ent
     dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
-    roofline = dict(kernel=dom, traffic=None, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    # runs, gfx950 correction applied - profiles/r01_pmc_traffic.json); only valid for the profiled workload
+    traffic = {}
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if a.shape == "gowalla" and B == 12500 and world == 1:
+            traffic = {k: v["hbm_bytes_per_launch"] for k, v in pj["kernels"].items()}
+    except Exception:
+        pass
+    for k in kernels:
+        if k in traffic:
+            kernels[k]["traffic_bytes_per_launch"] = traffic[k]
+    roofline = dict(kernel=dom, traffic=traffic.get(dom), **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
     roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
     gs_ms = sum(kernels[k]["ms_per_step"] for k in ("te_gather", "rows_apply") if k in kernels)
     gs_bytes = sum(work[k][1] for k in ("te_gather", "rows_apply") if k in kernels)
     hbm = {"kernels": [k for k in ("te_gather", "rows_apply") if k in kernels], "bound": "hbm",
-           "achieved": gs_bytes / (gs_ms * 1e-3) / 1e9 if gs_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
+           "achieved": gs_bytes * a.steps / (gs_ms * a.steps * 1e-3) / 1e9 if gs_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "traffic": sum(traffic.get(k, 0) for k in ("te_gather", "rows_apply")) or None}
     hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
     total_flops = step_flops(D, NB) * steps_per_epoch
     train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels)

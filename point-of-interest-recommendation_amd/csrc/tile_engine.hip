@@ -30,6 +30,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a release fence that
+// waits for every outstanding GLOBAL store / atomic of the wave (vmcnt(0)) - microseconds per barrier
+// in these loops, where global results are consumed only by later kernels and just LDS tiles cross
+// waves.  (Loads feeding ds_write are still waited for by the data dependence.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// tanh on the hardware exp: 1 - 2 / (1 + e^{2x}); saturates correctly (e^{2x} -> inf gives 1, -> 0 gives -1);
+// absolute error ~1e-7, far inside the 1e-5 parity bar.  The library tanhf is a long branchy routine.
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
 // C/D layout of the 32x32 tile: element (row, col) of register r in lane l
 __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -224,9 +236,9 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gemm_ax_kernel(TeArgs A) {
 #pragma unroll
   for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
   for (int r0 = blockIdx.x * 64; r0 < T; r0 += gridDim.x * 64) {
-    __syncthreads();
+    lds_barrier();
     stage_rows(lds, LDA, A.X, XW, XW, r0, 64, T);
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[2][NTW];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
     s_r0[tid] = r0; s_ns[tid] = ns;
   }
   for (int e = tid; e < 32 * LDA; e += blockDim.x) { Hb0[e] = 0.f; Hb1[e] = 0.f; }
-  __syncthreads();
+  lds_barrier();
   int ns_max = 0;
   for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
   int rowb[16], nsr[16];
@@ -285,15 +297,23 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
   for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
   const int ntz[1] = {w}, ntr[1] = {NTD + w}, ntc[1] = {2 * NTD + w};
   float* Hp = Hb0; float* Hn = Hb1;
+  // pre-activations of the NEXT step are fetched while the current step's MFMAs run: they do not
+  // depend on the recurrence (G still holds X.ui^T + bi for rows not yet visited)
+  float cz[16], cr[16], cc[16], nz[16], nr[16], nc[16];
+  auto fetch = [&](int t, float (&z)[16], float (&r)[16], float (&c)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool on = t < nsr[q];
+      const float* g = A.G + (size_t)(rowb[q] + t) * 3 * D;
+      z[q] = on ? g[col] : 0.f; r[q] = on ? g[D + col] : 0.f; c[q] = on ? g[2 * D + col] : 0.f;
+    }
+  };
+  if (ns_max > 0) fetch(0, cz, cr, cc);
   for (int t = 0; t < ns_max; ++t) {
+    if (t + 1 < ns_max) fetch(t + 1, nz, nr, nc);
     f32x16 az[1][1], ar[1][1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool on = t < nsr[r];
-      const float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
-      az[0][0][r] = on ? g[col] : 0.f;
-      ar[0][0][r] = on ? g[D + col] : 0.f;
-    }
+    for (int r = 0; r < 16; ++r) { az[0][0][r] = cz[r]; ar[0][0][r] = cr[r]; }
     mma_lds_packed<1, 1, K8, 8>(az, Hp, LDA, A.pWhT, ntz);
     mma_lds_packed<1, 1, K8, 8>(ar, Hp, LDA, A.pWhT, ntr);
     float zv[16], hp[16];
@@ -312,16 +332,16 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
         if (!predict) A.RH[(size_t)(rowb[r] + t) * D + col] = rh;
       }
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 ac[1][1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ac[0][0][r] = (t < nsr[r]) ? A.G[(size_t)(rowb[r] + t) * 3 * D + 2 * D + col] : 0.f;
+    for (int r = 0; r < 16; ++r) ac[0][0][r] = cc[r];
     mma_lds_packed<1, 1, K8, 8>(ac, RHb, LDA, A.pWhT, ntc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
       const bool on = t < nsr[r];
-      const float c = tanhf(ac[0][0][r]);
+      const float c = fast_tanh(ac[0][0][r]);
       const float hn = on ? (1.0f - zv[r]) * hp[r] + zv[r] * c : hp[r];
       Hn[i * LDA + col] = hn;
       if (on && !predict) {
@@ -330,8 +350,10 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
         A.H[(size_t)(rowb[r] + t) * D + col] = hn;
       }
     }
-    __syncthreads();
+    lds_barrier();
     float* tmp = Hp; Hp = Hn; Hn = tmp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cz[r] = nz[r]; cr[r] = nr[r]; cc[r] = nc[r]; }
   }
   if (predict) {
 #pragma unroll
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
   float dwd_acc = 0.f;      // meaningful in the row-owner lanes, reduced at the end
 
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
-    __syncthreads();
+    lds_barrier();
     stage_rows(Ht, LDH, Hsrc, D, D, r0, 32, T);
     if (!mode) {
       stage_rows(Et, LDH, A.E, D, D, r0, 32, T);
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
         s_p1[tid] = p1; s_q1[tid] = q1; s_a[tid] = a; s_b[tid] = b;
       }
     }
-    __syncthreads();
+    lds_barrier();
     {   // logits
       f32x16 acc[1][NTW];
 #pragma unroll
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
         for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + bin] = bin < NB ? acc[0][j][r] + b : -INFINITY;
       }
     }
-    __syncthreads();
+    lds_barrier();
     {   // row-wise softmax + losses: 8 lanes per row
       const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
       float* o = Ot + row * LDO;
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (!mode) {
       if (tid < NBP) { float s = 0.f; for (int r = 0; r < 32; ++r) s += Ot[r * LDO + tid]; dbs_acc += s; }
       // DH = d logits . vs + g * E ; +-g*h scatter
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
     if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
   }
-  __syncthreads();
+  lds_barrier();
   int ns_max = 0;
   for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
   int rowb[16], nsr[16];
@@ -550,26 +572,35 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
   float dhn[16], sbz = 0.f, sbr = 0.f, sbc = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dhn[r] = 0.f;
+  // operands of step t-1 (z, r, c, h_{t-2}, DH) are fetched while step t computes
+  float fz[16], fr[16], fc[16], fh[16], fd[16], gz[16], gr_[16], gc[16], gh[16], gd[16];
+  auto fetch = [&](int t, float (&z)[16], float (&r)[16], float (&c)[16], float (&h)[16], float (&d)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool on = t >= 0 && t < nsr[q];
+      const size_t row = (size_t)(rowb[q] + t);
+      const float* g = A.G + row * 3 * D;
+      z[q] = on ? g[col] : 0.f; r[q] = on ? g[D + col] : 0.f; c[q] = on ? g[2 * D + col] : 0.f;
+      h[q] = (on && t > 0) ? A.H[(row - 1) * D + col] : 0.f;
+      d[q] = on ? A.DH[row * D + col] : 0.f;
+    }
+  };
+  if (ns_max > 0) fetch(ns_max - 1, fz, fr, fc, fh, fd);
   for (int t = ns_max - 1; t >= 0; --t) {
+    if (t > 0) fetch(t - 1, gz, gr_, gc, gh, gd);
     float zv[16], rv[16], hp[16], dz[16], dhp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
       const bool on = t < nsr[r];
-      const size_t row = (size_t)(rowb[r] + t);
-      float z = 0.f, rr = 0.f, c = 0.f, h = 0.f, dh = 0.f;
-      if (on) {
-        const float* g = A.G + row * 3 * D;
-        z = g[col]; rr = g[D + col]; c = g[2 * D + col];
-        h = t > 0 ? A.H[(row - 1) * D + col] : 0.f;
-        dh = dhn[r] + A.DH[row * D + col];
-      }
+      const float z = fz[r], rr = fr[r], c = fc[r], h = fh[r];
+      const float dh = on ? dhn[r] + fd[r] : 0.f;
       zv[r] = z; rv[r] = rr; hp[r] = h;
       dz[r] = dh * (c - h);
       dhp[r] = dh * (1.0f - z);
       Ac[i * LDA + col] = dh * z * (1.0f - c * c);
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 m[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) m[0][0][r] = 0.f;
@@ -592,16 +623,19 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
         sbz += daz; sbr += dar; sbc += dac;
       }
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
     mma_lds_packed<1, 1, 2 * K8, 8>(acc, Azr, LDB, A.pWhzr, ntzr);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][0][r] : 0.f;
-    // (the next iteration's writes to Ac happen before its barrier; reads of Azr are complete because
-    //  every wave passes the next barrier only after finishing this MFMA block)
-    __syncthreads();
+    for (int r = 0; r < 16; ++r) {
+      dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][0][r] : 0.f;
+      fz[r] = gz[r]; fr[r] = gr_[r]; fc[r] = gc[r]; fh[r] = gh[r]; fd[r] = gd[r];
+    }
+    // No barrier here: Ac is free once every wave passed the second barrier (its readers ran before
+    // it), and the next step's Azr writes come after the next first barrier, which every wave reaches
+    // only after finishing this step's MFMA block on Azr.
   }
   // d bi partial sums of this tile (columns owned by this lane in both half-waves)
   float* slab = A.slab + (size_t)(tile % A.n_kc) * A.dl.total;
@@ -716,7 +750,7 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
   for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
   __shared__ int s_pt[32], s_dpt[32];
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
-    __syncthreads();
+    lds_barrier();
     stage_rows(lds, LDA, A.G, K, K, r0, 32, T);
     if (threadIdx.x < 32) {
       const int gr = r0 + threadIdx.x;
@@ -724,7 +758,7 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
       if (gr < T) { const int s = A.row_src[gr]; pt = A.p[s]; dpt = A.dp[s]; }
       s_pt[threadIdx.x] = pt; s_dpt[threadIdx.x] = dpt;
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 acc[1][NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j)

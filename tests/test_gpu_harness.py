@@ -68,3 +68,28 @@ def test_harness_runs_all_model_flags(pa, gru, batch):
     assert len(hist) == 2 and all(np.isfinite(h["loss"]) and np.isfinite(h["l2"]) for h in hist)
     assert 0.0 <= hist[-1]["auc"] <= 1.0 and best.best_auc >= hist[-1]["auc"] - 1e-12
     assert hist[1]["loss"] != hist[0]["loss"]
+
+
+def test_replica_sync_hip_delta_kernels(pa):
+    """The product's delta arithmetic (poi_delta_make / poi_delta_apply) on device tensors: with a
+    simulated second replica the reconciliation must give theta_start + sum of deltas."""
+    import torch
+    ctx = pa._lib.context(0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.rand(100003, device="cuda", generator=g)
+    cur = base + torch.rand(100003, device="cuda", generator=g) * 0.1
+    other_delta = torch.rand(100003, device="cuda", generator=g) * 0.1
+    delta = torch.empty_like(base)
+    ctx.check(ctx.lib.poi_delta_make(ctx.handle, cur.data_ptr(), base.data_ptr(), delta.data_ptr(), cur.numel(), None))
+    assert torch.equal(delta, cur - base)
+    summed = delta + other_delta                       # what the all-reduce would deliver
+    out = cur.clone()
+    ctx.check(ctx.lib.poi_delta_apply(ctx.handle, out.data_ptr(), base.data_ptr(), summed.data_ptr(), out.numel(), None))
+    assert torch.equal(out, base + summed)
+    # ReplicaSync at world size 1 is the identity and re-snapshots
+    t = [torch.rand(50, 8, device="cuda"), torch.rand(7, device="cuda")]
+    sync = pa.dist.ReplicaSync(t, ctx=ctx)
+    t[0] += 1.0
+    want = t[0].clone()
+    sync.end_epoch()
+    assert torch.equal(t[0], want) and torch.equal(sync.base[:400].view(50, 8), want)
