@@ -29,6 +29,8 @@ class ReplicaSync:
 
     def __init__(self, tensors, group=None, delta_ops=None, ctx=None):
         self.tensors = list(tensors)
+        if delta_ops is None and any(t.dtype != torch.float32 for t in self.tensors):
+            raise TypeError("ReplicaSync with the HIP delta kernels needs float32 tensors")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if delta_ops is None:

@@ -200,7 +200,7 @@ class GruBasic(_Base):
         self.ui = Shared(self._dev(g("ui", lambda: u(3, D, self._xw()))))                  # :61 / GRU_Spatial.py:51
         self.wh = Shared(self._dev(g("wh", lambda: u(3, D, D))))                           # :62
         self.bi = Shared(self._dev(g("bi", lambda: np.zeros((3, D)))))                     # :64
-        self.h0 = Shared(torch.zeros(D, device=self.device))                               # :63 never trained
+        self.h0 = Shared(torch.zeros(D, dtype=torch.float32, device=self.device))                               # :63 never trained
         self.trained_items = Shared(self._dev(u(n_item + 1, D)))                           # :71
         self.trained_users = Shared(self._dev(u(n_user, D)))                               # :72
 

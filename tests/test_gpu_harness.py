@@ -76,9 +76,9 @@ def test_replica_sync_hip_delta_kernels(pa):
     import torch
     ctx = pa._lib.context(0)
     g = torch.Generator(device="cuda").manual_seed(3)
-    base = torch.rand(100003, device="cuda", generator=g)
-    cur = base + torch.rand(100003, device="cuda", generator=g) * 0.1
-    other_delta = torch.rand(100003, device="cuda", generator=g) * 0.1
+    base = torch.rand(100003, device="cuda", generator=g, dtype=torch.float32)
+    cur = base + torch.rand(100003, device="cuda", generator=g, dtype=torch.float32) * 0.1
+    other_delta = torch.rand(100003, device="cuda", generator=g, dtype=torch.float32) * 0.1
     delta = torch.empty_like(base)
     ctx.check(ctx.lib.poi_delta_make(ctx.handle, cur.data_ptr(), base.data_ptr(), delta.data_ptr(), cur.numel(), None))
     assert torch.equal(delta, cur - base)
@@ -87,7 +87,7 @@ def test_replica_sync_hip_delta_kernels(pa):
     ctx.check(ctx.lib.poi_delta_apply(ctx.handle, out.data_ptr(), base.data_ptr(), summed.data_ptr(), out.numel(), None))
     assert torch.equal(out, base + summed)
     # ReplicaSync at world size 1 is the identity and re-snapshots
-    t = [torch.rand(50, 8, device="cuda"), torch.rand(7, device="cuda")]
+    t = [torch.rand(50, 8, device="cuda", dtype=torch.float32), torch.rand(7, device="cuda", dtype=torch.float32)]
     sync = pa.dist.ReplicaSync(t, ctx=ctx)
     t[0] += 1.0
     want = t[0].clone()

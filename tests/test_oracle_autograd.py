@@ -12,7 +12,7 @@ import torch
 
 from oracle import poi_oracle as O
 
-torch.set_default_dtype(torch.float64)
+F64 = torch.float64      # explicit dtype everywhere: a global set_default_dtype would leak into other test modules
 
 
 def _toy_spatial(seed, N=23, B=7, D=5, LM=9, L=6):
@@ -33,7 +33,7 @@ def _torch_spatial_cost(T, p, q, dp, dq, L, lam):
     xps, xqs, xds = lt[p], lt[q], di[dp]
     xs = torch.cat((xps, xds), 1)
     ls = torch.softmax(lw, 0)
-    h = torch.zeros(lt.shape[1])
+    h = torch.zeros(lt.shape[1], dtype=F64)
     sur = 0.0; bpr = 0.0
     for t in range(L - 1):
         zr = torch.sigmoid(torch.einsum('gij,j->gi', ui[:2], xs[t]) + torch.einsum('gij,j->gi', wh[:2], h) + bi[:2])
@@ -54,7 +54,7 @@ def _torch_spatial_cost(T, p, q, dp, dq, L, lam):
 def test_spatial_step_matches_autograd(seed, L):
     alpha, lam = 0.01, 0.001
     P, p, q, dp, dq, mask = _toy_spatial(seed, L=L)
-    T = {k: torch.tensor(np.asarray(v, float), requires_grad=True) for k, v in P.items() if k != 'h0'}
+    T = {k: torch.tensor(np.asarray(v, float), dtype=F64, requires_grad=True) for k, v in P.items() if k != 'h0'}
     cost, los, sur, upq, ls = _torch_spatial_cost(T, p, q, dp, dq, L, lam)
     cost.backward()
     Pn, out = O.spatial_step(P, p, q, dp, dq, mask, alpha, lam)
@@ -94,7 +94,7 @@ def test_spatial_forward_cost_consistent_and_fd():
 def _torch_gru_cost(T, p, q, L, lam):
     lt, ui, wh, bi = T['lt'], T['ui'], T['wh'], T['bi']
     xps, xqs = lt[p], lt[q]
-    h = torch.zeros(lt.shape[1]); tot = 0.0
+    h = torch.zeros(lt.shape[1], dtype=F64); tot = 0.0
     for t in range(L):
         tot = tot + torch.log(torch.sigmoid(h @ (xps[t] - xqs[t])))
         z = torch.sigmoid(ui[0] @ xps[t] + wh[0] @ h + bi[0])
@@ -113,7 +113,7 @@ def test_gru_step_matches_autograd(seed, L):
     p = np.full(LM, N); q = np.full(LM, N)
     p[:L] = rng.integers(0, 5, L); q[:L] = rng.integers(3, N, L)
     mask = np.array([1] * L + [0] * (LM - L))
-    T = {k: torch.tensor(v, requires_grad=True) for k, v in P.items() if k != 'h0'}
+    T = {k: torch.tensor(v, dtype=F64, requires_grad=True) for k, v in P.items() if k != 'h0'}
     cost, loss = _torch_gru_cost(T, p, q, L, lam)
     cost.backward()
     Pn, out = O.gru_step(P, p, q, mask, alpha, lam)
@@ -130,7 +130,7 @@ def test_bpr_step_matches_autograd():
     rng = np.random.default_rng(7)
     P = O.init_bpr_params(rng, 11, 13, 8)
     u, pi, qi = 4, 2, 9
-    T = {k: torch.tensor(v, requires_grad=True) for k, v in P.items()}
+    T = {k: torch.tensor(v, dtype=F64, requires_grad=True) for k, v in P.items()}
     usr, xpq = T['ux'][u], T['lt'][[pi, qi]]
     upq = torch.log(torch.sigmoid(usr @ (xpq[0] - xpq[1])))
     cost = -upq + 0.5 * lam * ((usr ** 2).sum() + (xpq ** 2).sum())
