@@ -61,7 +61,8 @@ def main():
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or under_launcher:
         dist.init_process_group("nccl", device_id=dev)
 
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
@@ -74,7 +75,8 @@ def main():
                                          n_item=n_item, n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=D, n_hidden=D,
                                          device=dev, seed=7, coords=ds.coords)
     ctx = model.ctx
-    sync = poi_amd.dist.ReplicaSync([getattr(model, k).t for k in ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")], ctx=ctx)
+    sync = poi_amd.dist.ReplicaSync([getattr(model, k).t for k in ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")], ctx=ctx,
+                                    force=os.environ.get("POI_BENCH_FORCE_SYNC") == "1")
 
     # shuffled user order (prog_bpr_gru_spatial.py:236-238), cut into launches of B users; inside a launch
     # the ids are sorted by descending length so that 32-sequence tiles are homogeneous.  Resident on device.
@@ -255,7 +257,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(POI_BLOCK) void dist_prob_kernel(const double* __re
   __syncthreads();
   const double pr = 0.017453292519943295;
   const double c1 = cphi[lp];
+  const float scale = (float)(12742.0 * 1000.0 / dd);
   for (int j = blockIdx.x * POI_BLOCK + threadIdx.x; j < N; j += gridDim.x * POI_BLOCK) {
     int bin;
     {
@@ -104,10 +105,13 @@ __global__ __launch_bounds__(POI_BLOCK) void dist_prob_kernel(const double* __re
       const double a = (lat1 - coords[2 * j]) * pr;
       const double b = (lon1 - coords[2 * j + 1]) * pr;
       const double c = (1.0 - cos_small(a)) / 2 + c1 * cphi[j] * (1.0 - cos_small(b)) / 2;
-      // bin = #{ t : c >= thr[t] }  (upper bound by binary search; thr ascending)
-      int lo = 0, hi = n_dist;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (c >= s_thr[mid]) lo = mid + 1; else hi = mid; }
-      bin = lo;
+      // bin = #{ t : c >= thr[t] } (thr ascending).  asin(x) ~ x for these distances, so
+      // int(sqrt(c) * 12742e3/dd) is within one bin of the answer; the exact thresholds then decide.
+      int g = (int)(sqrtf((float)c) * scale);
+      g = g < 0 ? 0 : (g > n_dist ? n_dist : g);
+      while (g > 0 && c < s_thr[g - 1]) --g;
+      while (g < n_dist && c >= s_thr[g]) ++g;
+      bin = g;
     }
     prob[(size_t)k * N + j] = s_p[bin];
   }

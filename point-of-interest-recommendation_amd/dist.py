@@ -27,12 +27,13 @@ def _hip_delta_ops(ctx, stream_fn):
 class ReplicaSync:
     """Keeps the epoch-start snapshot of a list of parameter tensors and reconciles replicas."""
 
-    def __init__(self, tensors, group=None, delta_ops=None, ctx=None):
+    def __init__(self, tensors, group=None, delta_ops=None, ctx=None, force=False):
         self.tensors = list(tensors)
         if delta_ops is None and any(t.dtype != torch.float32 for t in self.tensors):
             raise TypeError("ReplicaSync with the HIP delta kernels needs float32 tensors")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(force) and dist.is_initialized()      # run the full delta/all-reduce path even at world size 1 (self-check)
         if delta_ops is None:
             if ctx is None:
                 raise ValueError("ReplicaSync needs a poi context (HIP delta kernels) or explicit delta_ops")
@@ -56,7 +57,7 @@ class ReplicaSync:
 
     def end_epoch(self):
         """All-reduce the deltas and rebuild every replica; then start the next epoch's snapshot."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for t, (o, n) in zip(self.tensors, self._views):
                 self.make(t.reshape(-1), self.base[o:o + n], self.delta[o:o + n])
             dist.all_reduce(self.delta, op=dist.ReduceOp.SUM, group=self.group)
