@@ -227,7 +227,7 @@ __device__ __forceinline__ void stage_rows(float* lds, int lda, const float* __r
 // te_gemm_ax: G[r][0:3D] = X[r] . ui^T + bi      (64 rows per iteration, 4 waves split the 3D columns)
 // -------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(TE_BLOCK) void te_gemm_ax_kernel(TeArgs A) {
+__global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ax_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int XW = 2 * D, K8 = XW / 8, NT = 3 * D / 32, NTW = (NT + 3) / 4, LDA = XW + 4;
   const int T = A.soff[A.n_seq];
@@ -401,19 +401,40 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
   float dbs_acc = 0.f;      // thread tid < NBP accumulates d bs[tid]
   float dwd_acc = 0.f;      // meaningful in the row-owner lanes, reduced at the end
 
+  // async-stage split: the NEXT tile's H / E rows and row metadata are fetched into registers while
+  // the current tile computes, and written to LDS at the top of the next iteration
+  constexpr int SF4 = 32 * (D / 4) / TE_BLOCK;          // float4 per thread per staged tile
+  float4 ph[SF4], pe[SF4];
+  int pm[4] = {0, 0, 0, 0};
+  auto prefetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / (D / 4), c = (e % (D / 4)) * 4;
+      float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), ve = vh;
+      if (r0 + r < T) {
+        vh = *reinterpret_cast<const float4*>(Hsrc + (size_t)(r0 + r) * D + c);
+        if (!mode) ve = *reinterpret_cast<const float4*>(A.E + (size_t)(r0 + r) * D + c);
+      }
+      ph[q] = vh; pe[q] = ve;
+    }
+    if (!mode && tid < 32) {
+      const int gr = r0 + tid;
+      pm[0] = pm[1] = pm[2] = pm[3] = 0;
+      if (gr < T) { const int s = A.row_src[gr]; pm[0] = A.p[s + 1]; pm[1] = A.q[s + 1]; pm[2] = A.dp[s + 1]; pm[3] = A.dq[s + 1]; }
+    }
+  };
+  if ((int)blockIdx.x * 32 < T) prefetch(blockIdx.x * 32);
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
     lds_barrier();
-    stage_rows(Ht, LDH, Hsrc, D, D, r0, 32, T);
-    if (!mode) {
-      stage_rows(Et, LDH, A.E, D, D, r0, 32, T);
-      if (tid < 32) {
-        const int gr = r0 + tid;
-        int p1 = 0, q1 = 0, a = 0, b = 0;
-        if (gr < T) { const int s = A.row_src[gr]; p1 = A.p[s + 1]; q1 = A.q[s + 1]; a = A.dp[s + 1]; b = A.dq[s + 1]; }
-        s_p1[tid] = p1; s_q1[tid] = q1; s_a[tid] = a; s_b[tid] = b;
-      }
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / (D / 4), c = (e % (D / 4)) * 4;
+      *reinterpret_cast<float4*>(Ht + r * LDH + c) = ph[q];
+      if (!mode) *reinterpret_cast<float4*>(Et + r * LDH + c) = pe[q];
     }
+    if (!mode && tid < 32) { s_p1[tid] = pm[0]; s_q1[tid] = pm[1]; s_a[tid] = pm[2]; s_b[tid] = pm[3]; }
     lds_barrier();
+    if (r0 + (int)gridDim.x * 32 < T) prefetch(r0 + gridDim.x * 32);
     {   // logits
       f32x16 acc[1][NTW];
 #pragma unroll
