@@ -151,13 +151,34 @@ int poi_sumsq(poi_ctx* ctx, const float* x, int64_t n, double* out, void* stream
 int poi_dist_prob(poi_ctx* ctx, const double* coords, const double* cphi, const double* thr, const int32_t* last_poi,
                   const float* sts, int32_t n, int32_t n_item, int32_t n_dist, double dd, float* prob_out, void* stream);
 
+/* ---- rank metrics on the device (8f rank 3) - public/Valuate.py:23-88,149-172 --------------------
+ * ranks (n, k) int32 (descending score); tes_p / tes_mask (n, len_tes); at_nums (n_at <= 8, ascending,
+ * <= k, device int32).  acc (n_at, 3) float64, caller-zeroed, receives SUMS over the n users of
+ * [hits, average precision, NDCG] at each cut-off (recall = hits / sum(mask), precision = hits/(k n),
+ * MAP / NDCG = sums / n_user, as Valuate.py:155-172). */
+int poi_rank_metrics(poi_ctx* ctx, const int32_t* ranks, int32_t n, int32_t k, const int32_t* tes_p, const int32_t* tes_mask,
+                     int32_t len_tes, const int32_t* at_nums, int32_t n_at, double* acc, void* stream);
+
+/* ---- per-epoch negative refresh on the device (8f rank 1) --------------------------------------
+ * poi_sample_negatives: fun_random_neg_masks_tra / _tes, public/Load_Data_by_length.py:127-162, called
+ * every epoch by prog_bpr_gru_spatial.py:221-222.  q_out (flat, CSR) gets one uniform draw over
+ * [0, n_item) per train position, redrawn while it equals one of the user's train items;
+ * tes_q_out (n_user, len_tes) or NULL likewise, also avoiding the user's test items (padded test
+ * positions keep n_item).  Counter-based RNG: same (seed, data) -> same output.
+ * poi_neg_dist_bins: fun_compute_dist_neg, :165-180 - dq[t] = cal_dis(neg_t, pos_{t-1}), dq[0] = n_dist,
+ * with the exact host thresholds of poi_dist_prob (cphi, thr). */
+int poi_sample_negatives(poi_ctx* ctx, const int32_t* off, const int32_t* p, int32_t n_user, int32_t n_item, const int32_t* tes_p,
+                         const int32_t* tes_mask, int32_t len_tes, uint64_t seed, int32_t* q_out, int32_t* tes_q_out, void* stream);
+int poi_neg_dist_bins(poi_ctx* ctx, const int32_t* off, const int32_t* p, const int32_t* q, int32_t n_user, const double* coords,
+                      const double* cphi, const double* thr, int32_t n_dist, double dd, int32_t* dq_out, void* stream);
+
 /* ---- multi-GPU reconciliation helpers (8e): delta = cur - base ; cur = base + sum_delta ------ */
 int poi_delta_make(poi_ctx* ctx, const float* cur, const float* base, float* delta, int64_t n, void* stream);
 int poi_delta_apply(poi_ctx* ctx, float* cur, const float* base, const float* delta_sum, int64_t n, void* stream);
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's live roofline figures).
  * Kernel names: "seq_train", "rows_apply", "dense_apply", "seq_predict", "bpr_hogwild", "bpr_grad",
- * "bpr_apply", "score_topk", "score_all", and for the tile engine "te_prep", "te_gather", "te_gemm_ax",
+ * "bpr_apply", "score_topk", "score_all", "dist_prob", "sample_neg", "neg_dist", and for the tile engine "te_prep", "te_gather", "te_gemm_ax",
  * "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx", "te_finalize", "te_predict".  poi_timing_get synchronises the device. */
 int poi_timing_enable(poi_ctx* ctx, int on);
 int poi_timing_reset(poi_ctx* ctx);

@@ -394,6 +394,41 @@ int poi_dist_prob(poi_ctx* c, const double* coords, const double* cphi, const do
   return POI_OK;
 }
 
+int poi_rank_metrics(poi_ctx* c, const int32_t* ranks, int32_t n, int32_t k, const int32_t* tes_p, const int32_t* tes_mask,
+                     int32_t len_tes, const int32_t* at_nums, int32_t n_at, double* acc, void* stream) {
+  if (!c || !ranks || !tes_p || !tes_mask || !at_nums || !acc) return fail(c, POI_EINVAL, "poi_rank_metrics: NULL argument");
+  if (n < 0 || k <= 0 || len_tes <= 0 || n_at <= 0 || n_at > 8) return fail(c, POI_EINVAL, "poi_rank_metrics: bad sizes (n_at <= 8)");
+  if (n == 0) return POI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, poi::launch_rank_metrics(ranks, n, k, tes_p, tes_mask, len_tes, at_nums, n_at, acc, (hipStream_t)stream));
+  return POI_OK;
+}
+
+int poi_sample_negatives(poi_ctx* c, const int32_t* off, const int32_t* p, int32_t n_user, int32_t n_item, const int32_t* tes_p,
+                         const int32_t* tes_mask, int32_t len_tes, uint64_t seed, int32_t* q_out, int32_t* tes_q_out, void* stream) {
+  if (!c || !off || !p || !q_out) return fail(c, POI_EINVAL, "poi_sample_negatives: NULL argument");
+  if (tes_q_out && (!tes_p || !tes_mask || len_tes <= 0)) return fail(c, POI_EINVAL, "poi_sample_negatives: test tables missing");
+  if (n_user < 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
+  if (n_user == 0) return POI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->tm.begin("sample_neg", (hipStream_t)stream);
+  HIPCHK(c, poi::launch_sample_neg(off, p, n_user, n_item, tes_p, tes_mask, len_tes, seed, q_out, tes_q_out, (hipStream_t)stream));
+  c->tm.end((hipStream_t)stream);
+  return POI_OK;
+}
+
+int poi_neg_dist_bins(poi_ctx* c, const int32_t* off, const int32_t* p, const int32_t* q, int32_t n_user, const double* coords,
+                      const double* cphi, const double* thr, int32_t n_dist, double dd, int32_t* dq_out, void* stream) {
+  if (!c || !off || !p || !q || !coords || !cphi || !thr || !dq_out) return fail(c, POI_EINVAL, "poi_neg_dist_bins: NULL argument");
+  if (n_user < 0 || n_dist <= 0 || !(dd > 0)) return fail(c, POI_EINVAL, "bad sizes");
+  if (n_user == 0) return POI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->tm.begin("neg_dist", (hipStream_t)stream);
+  HIPCHK(c, poi::launch_neg_dist(off, p, q, n_user, coords, cphi, thr, n_dist, dd, dq_out, (hipStream_t)stream));
+  c->tm.end((hipStream_t)stream);
+  return POI_OK;
+}
+
 int poi_delta_make(poi_ctx* c, const float* cur, const float* base, float* delta, int64_t n, void* stream) {
   if (!c || !cur || !base || !delta || n < 0) return fail(c, POI_EINVAL, "poi_delta_make: bad argument");
   HIPCHK(c, hipSetDevice(c->device));

@@ -117,6 +117,145 @@ __global__ __launch_bounds__(POI_BLOCK) void dist_prob_kernel(const double* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-epoch negative refresh on the device (prog_bpr_gru_spatial.py:221-228):
+//   fun_random_neg_masks_tra / _tes (public/Load_Data_by_length.py:127-162): one uniform draw over
+//   [0, n_item) per valid position, redrawn while it hits one of the user's own train (and, for the
+//   test negative, test) items;
+//   fun_compute_dist_neg (:165-180): dq[t] = cal_dis(neg_t, pos_{t-1}), dq[0] = n_dist.
+// Counter-based RNG (splitmix64 of seed, position, attempt): reproducible for a seed, independent of
+// launch geometry.  The reference draws from Python's Mersenne Twister, whose stream cannot be
+// matched; the CONTRACT (support, exclusions, bins) is what the tests pin.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ int draw_item(unsigned long long seed, unsigned long long pos, unsigned attempt, int n_item) {
+  const unsigned long long r = splitmix64(splitmix64(seed ^ (pos * 0xD1342543DE82EF95ull)) + attempt);
+  return (int)__umul64hi(r, (unsigned long long)n_item);      // floor(r / 2^64 * n_item): bias < 2^-47
+}
+
+#define NEG_MAX_L 256      // items per user staged in LDS; longer sequences fall back to global reads
+__global__ __launch_bounds__(POI_BLOCK) void sample_neg_kernel(const int* __restrict__ off, const int* __restrict__ p, int n_user,
+                                                                int n_item, const int* __restrict__ tes_p, const int* __restrict__ tes_mask,
+                                                                int len_tes, unsigned long long seed, int* __restrict__ q_out,
+                                                                int* __restrict__ tes_q_out) {
+  __shared__ int s_items[POI_NWAVE][NEG_MAX_L];
+  const int w = wave_id(), lane = lane_id();
+  const int u = blockIdx.x * POI_NWAVE + w;
+  if (u >= n_user) return;
+  const int base = off[u], L = off[u + 1] - base;
+  const bool in_lds = L <= NEG_MAX_L;
+  if (in_lds) {
+    for (int i = lane; i < L; i += 64) s_items[w][i] = p[base + i];
+    __builtin_amdgcn_wave_barrier();
+  }
+  auto owns = [&](int j) {
+    bool hit = false;
+    if (in_lds) { for (int i = 0; i < L; ++i) hit |= s_items[w][i] == j; }
+    else { for (int i = 0; i < L; ++i) hit |= p[base + i] == j; }
+    return hit;
+  };
+  for (int t = lane; t < L; t += 64) {
+    unsigned attempt = 0;
+    int j = draw_item(seed, (unsigned long long)(base + t), attempt, n_item);
+    while (owns(j)) j = draw_item(seed, (unsigned long long)(base + t), ++attempt, n_item);
+    q_out[base + t] = j;
+  }
+  if (tes_q_out) {
+    for (int t = lane; t < len_tes; t += 64) {
+      const int e = u * len_tes + t;
+      if (!tes_mask[e]) { tes_q_out[e] = n_item; continue; }     // padded test position keeps the padding id
+      unsigned attempt = 0;
+      const unsigned long long pos = 0x8000000000000000ull | (unsigned long long)e;
+      auto in_test = [&](int j) { bool h = false; for (int i = 0; i < len_tes; ++i) h |= tes_mask[u * len_tes + i] && tes_p[u * len_tes + i] == j; return h; };
+      int j = draw_item(seed, pos, attempt, n_item);
+      while (owns(j) || in_test(j)) j = draw_item(seed, pos, ++attempt, n_item);
+      tes_q_out[e] = j;
+    }
+  }
+}
+
+// dq[t] = bin(coord[q_t], coord[p_{t-1}]) for t >= 1 inside a sequence, n_dist at t = 0 (one thread per position)
+__global__ __launch_bounds__(POI_BLOCK) void neg_dist_kernel(const int* __restrict__ off, const int* __restrict__ p, const int* __restrict__ q,
+                                                              int n_user, const double* __restrict__ coords, const double* __restrict__ cphi,
+                                                              const double* __restrict__ thr, int n_dist, double dd, int* __restrict__ dq) {
+  extern __shared__ __align__(16) double s_thr[];
+  for (int i = threadIdx.x; i < n_dist; i += POI_BLOCK) s_thr[i] = thr[i];
+  __syncthreads();
+  const int total = off[n_user];
+  const double pr = 0.017453292519943295;
+  const float scale = (float)(12742.0 * 1000.0 / dd);
+  for (int e = blockIdx.x * POI_BLOCK + threadIdx.x; e < total; e += gridDim.x * POI_BLOCK) {
+    // owning user by binary search over the offsets (first position of a sequence -> n_dist)
+    int lo = 0, hi = n_user;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= e) lo = mid; else hi = mid - 1; }
+    int bin = n_dist;
+    if (e > off[lo]) {
+#pragma clang fp contract(off)
+      const int a_ = q[e], b_ = p[e - 1];
+      const double a = (coords[2 * a_] - coords[2 * b_]) * pr;
+      const double b = (coords[2 * a_ + 1] - coords[2 * b_ + 1]) * pr;
+      const double c = (1.0 - cos_small(a)) / 2 + cphi[a_] * cphi[b_] * (1.0 - cos_small(b)) / 2;
+      int g = (int)(sqrtf((float)c) * scale);
+      g = g < 0 ? 0 : (g > n_dist ? n_dist : g);
+      while (g > 0 && c < s_thr[g - 1]) --g;
+      while (g < n_dist && c >= s_thr[g]) ++g;
+      bin = g;
+    }
+    dq[e] = bin;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rank metrics on the device (public/Valuate.py:23-88,149-172): one thread per user walks its K
+// recommendations once and, at every cut-off at_nums[m], adds its hit count, average precision and
+// NDCG to the accumulators acc[m*3 + {0,1,2}] (double; block reduction + one atomic per block).
+// ---------------------------------------------------------------------------------------------
+#define RM_MAX_AT 8
+__global__ __launch_bounds__(POI_BLOCK) void rank_metrics_kernel(const int* __restrict__ ranks, int n, int K, const int* __restrict__ tes_p,
+                                                                  const int* __restrict__ tes_mask, int len_tes, const int* __restrict__ at_nums,
+                                                                  int n_at, double* __restrict__ acc) {
+  __shared__ double red[POI_NWAVE];
+  const int u = blockIdx.x * POI_BLOCK + threadIdx.x;
+  double v[RM_MAX_AT][3];
+#pragma unroll
+  for (int m = 0; m < RM_MAX_AT; ++m) v[m][0] = v[m][1] = v[m][2] = 0.0;
+  if (u < n) {
+    int n_test = 0;
+    for (int i = 0; i < len_tes; ++i) n_test += tes_mask[u * len_tes + i] != 0;
+    int hits = 0, m = 0;
+    double ap = 0.0, dcg = 0.0;
+    for (int r = 0; r < K && m < n_at; ++r) {
+      const int item = ranks[(size_t)u * K + r];
+      bool hit = false;
+      for (int i = 0; i < len_tes; ++i) hit |= tes_mask[u * len_tes + i] && tes_p[u * len_tes + i] == item;
+      if (hit) { ++hits; ap += (double)hits / (double)(r + 1); dcg += 1.0 / log2((double)r + 2.0); }
+      while (m < n_at && at_nums[m] == r + 1) {
+        double ideal = 0.0;
+        const int lim = n_test < r + 1 ? n_test : r + 1;
+        for (int i = 0; i < lim; ++i) ideal += 1.0 / log2((double)i + 2.0);
+        v[m][0] = hits;
+        v[m][1] = n_test > 0 ? ap / (double)n_test : 0.0;
+        v[m][2] = (hits > 0 && ideal > 0.0) ? dcg / ideal : 0.0;
+        ++m;
+      }
+    }
+  }
+  for (int m = 0; m < n_at; ++m)
+    for (int j = 0; j < 3; ++j) {
+      double x = v[m][j];
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+      __syncthreads();
+      if (lane_id() == 0) red[wave_id()] = x;
+      __syncthreads();
+      if (threadIdx.x == 0) atomicAdd(&acc[m * 3 + j], (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
 __global__ void delta_make_kernel(const float* __restrict__ cur, const float* __restrict__ base, float* __restrict__ d, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = cur[i] - base[i];
 }
@@ -163,6 +302,23 @@ hipError_t launch_dist_prob(const double* coords, const double* cphi, const doub
   if (gx < 1) gx = 1;
   const size_t lds = thr ? sizeof(double) * n_dist + sizeof(float) * (n_dist + 1) : 0;
   hipLaunchKernelGGL(dist_prob_kernel, dim3(gx, n), dim3(POI_BLOCK), lds, st, coords, cphi, thr, last_poi, sts, n, n_item, n_dist, dd, prob);
+  return hipGetLastError();
+}
+hipError_t launch_rank_metrics(const int* ranks, int n, int K, const int* tes_p, const int* tes_mask, int len_tes, const int* at_nums,
+                               int n_at, double* acc, hipStream_t st) {
+  hipLaunchKernelGGL(rank_metrics_kernel, dim3((n + POI_BLOCK - 1) / POI_BLOCK), dim3(POI_BLOCK), 0, st, ranks, n, K, tes_p, tes_mask, len_tes,
+                     at_nums, n_at, acc);
+  return hipGetLastError();
+}
+hipError_t launch_sample_neg(const int* off, const int* p, int n_user, int n_item, const int* tes_p, const int* tes_mask, int len_tes,
+                             unsigned long long seed, int* q_out, int* tes_q_out, hipStream_t st) {
+  hipLaunchKernelGGL(sample_neg_kernel, dim3((n_user + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, off, p, n_user, n_item, tes_p,
+                     tes_mask, len_tes, seed, q_out, tes_q_out);
+  return hipGetLastError();
+}
+hipError_t launch_neg_dist(const int* off, const int* p, const int* q, int n_user, const double* coords, const double* cphi,
+                           const double* thr, int n_dist, double dd, int* dq, hipStream_t st) {
+  hipLaunchKernelGGL(neg_dist_kernel, dim3(2048), dim3(POI_BLOCK), sizeof(double) * n_dist, st, off, p, q, n_user, coords, cphi, thr, n_dist, dd, dq);
   return hipGetLastError();
 }
 hipError_t launch_delta_make(const float* cur, const float* base, float* delta, int64_t n, hipStream_t st) {

@@ -139,6 +139,12 @@ hipError_t launch_auc(const float* users, const float* items, int n, int dim, co
 hipError_t launch_sumsq(const float* x, int64_t n, double* out, hipStream_t st);
 hipError_t launch_dist_prob(const double* coords, const double* cphi, const double* thr, const int* last_poi, const float* sts,
                             int n, int n_item, int n_dist, double dd, float* prob, hipStream_t st);
+hipError_t launch_rank_metrics(const int* ranks, int n, int K, const int* tes_p, const int* tes_mask, int len_tes, const int* at_nums,
+                               int n_at, double* acc, hipStream_t st);
+hipError_t launch_sample_neg(const int* off, const int* p, int n_user, int n_item, const int* tes_p, const int* tes_mask, int len_tes,
+                             unsigned long long seed, int* q_out, int* tes_q_out, hipStream_t st);
+hipError_t launch_neg_dist(const int* off, const int* p, const int* q, int n_user, const double* coords, const double* cphi,
+                           const double* thr, int n_dist, double dd, int* dq, hipStream_t st);
 hipError_t launch_delta_make(const float* cur, const float* base, float* delta, int64_t n, hipStream_t st);
 hipError_t launch_delta_apply(float* cur, const float* base, const float* dsum, int64_t n, hipStream_t st);
 hipError_t launch_selftest(float* buf, int* fail, hipStream_t st);

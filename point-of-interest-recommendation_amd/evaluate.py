@@ -45,16 +45,46 @@ def rank_metrics(all_ranks, tes_buys_masks, tes_masks, at_nums):
     return out
 
 
-def fun_predict_auc_recall_map_ndcg(p, model, best, epoch, starts_ends_auc, starts_ends_tes, tes_buys_masks, tes_masks):
-    """Same signature and side effects on `best` as public/Valuate.py:103-191; returns the metrics too."""
+def device_rank_metrics(model, starts_ends_tes, at_nums):
+    """Fused top-K + metric accumulation on the device: only (len(at_nums), 3) doubles reach the host."""
+    import ctypes
+    import torch
+    kmax = at_nums[-1]
+    acc = torch.zeros((len(at_nums), 3), dtype=torch.float64, device=model.device)
+    at = torch.as_tensor(np.asarray(at_nums, np.int32)).to(model.device)
+    for se in starts_ends_tes:
+        ids, lo = model._ids(se)
+        idx = model.compute_sub_topk(se, kmax)
+        tp, tm = model._rows(model.tes_buys_masks, ids, lo), model._rows(model.tes_masks, ids, lo)
+        model.ctx.check(model.lib.poi_rank_metrics(model.ctx.handle, idx.data_ptr(), idx.shape[0], kmax, tp.data_ptr(), tm.data_ptr(),
+                                                   tm.shape[1], at.data_ptr(), len(at_nums), acc.data_ptr(), model._stream()))
+    a = acc.cpu().numpy()
+    n_user = model.n_user
+    denom = float(model.tes_masks.sum().item())
+    out = {}
+    for i, k in enumerate(at_nums):
+        hits = float(a[i, 0]); rec = hits / denom; pre = hits / (k * n_user)
+        out[k] = dict(hits=hits, recall=rec, precision=pre, f1=2.0 * rec * pre / (rec + pre) if rec + pre > 0 else 0.0,
+                      map=float(a[i, 1]) / n_user, ndcg=float(a[i, 2]) / n_user)
+    return out
+
+
+def fun_predict_auc_recall_map_ndcg(p, model, best, epoch, starts_ends_auc, starts_ends_tes, tes_buys_masks, tes_masks, on_device=True):
+    """Same signature and side effects on `best` as public/Valuate.py:103-191; returns the metrics too.
+    With on_device (default) the ranks never leave the GPU; on_device=False downloads them and uses the
+    vectorised numpy restatement (rank_metrics) - both are tested against the reference's helpers."""
     at_nums = p["at_nums"]
     upqs = np.concatenate([model.compute_sub_auc_preference(se) for se in starts_ends_auc])
     auc = float(upqs.sum()) / float(np.sum(tes_masks))             # Valuate.py:113-118
     if auc > best.best_auc:
         best.best_auc, best.best_epoch_auc = auc, epoch
     kmax = at_nums[-1]
-    all_ranks = np.concatenate([model.compute_sub_topk(se, kmax).cpu().numpy() for se in starts_ends_tes])
-    m = rank_metrics(all_ranks, tes_buys_masks, tes_masks, at_nums)
+    if on_device:
+        all_ranks = None
+        m = device_rank_metrics(model, starts_ends_tes, at_nums)
+    else:
+        all_ranks = np.concatenate([model.compute_sub_topk(se, kmax).cpu().numpy() for se in starts_ends_tes])
+        m = rank_metrics(all_ranks, tes_buys_masks, tes_masks, at_nums)
     for i, k in enumerate(at_nums):
         for name, key in (("recall", "recall"), ("precis", "precision"), ("f1scor", "f1"), ("map", "map"), ("ndcg", "ndcg")):
             cur = getattr(best, "best_" + name)

@@ -52,8 +52,11 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
     B = int(p.get("batch_users", 1))
     for epoch in range(p["epochs"]):
         if epoch > 0:                                               # :221-228
-            ds.resample_negatives(rng_neg)
-            model.set_negatives_csr(ds.tra_q, ds.tes_q, ds.tra_dq if p["gru"] == 2 else None)
+            if p.get("device_negatives", True):                     # on the GPU: ~0.1 ms instead of ~0.4 s of numpy
+                model.resample_negatives_device(p.get("seed", 0) * 1000003 + epoch)
+            else:
+                ds.resample_negatives(rng_neg)
+                model.set_negatives_csr(ds.tra_q, ds.tes_q, ds.tra_dq if p["gru"] == 2 else None)
         t0 = time.time()
         order = np.random.default_rng(123 + epoch).permutation(U).astype(np.int32)      # :236-238
         loss = 0.0
@@ -61,9 +64,10 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
             u, pp, qq = model.epoch_triples()
             if B <= 1:
                 off = ds.off.astype(np.int64)
+                hp, hq = model.p.cpu().numpy(), model.q.cpu().numpy()      # current (possibly device-refreshed) tables
                 for uidx in order:
                     for i in range(off[uidx], off[uidx + 1]):
-                        loss += model.train(int(uidx), [int(ds.tra_p[i]), int(ds.tra_q[i])])
+                        loss += model.train(int(uidx), [int(hp[i]), int(hq[i])])
             else:
                 loss = float(model.train_batch(u, pp, qq, mode="snapshot").sum())
         elif B <= 1:                                                # :246-254

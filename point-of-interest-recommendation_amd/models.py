@@ -129,6 +129,25 @@ class _Base:
         if dq_flat is not None:
             self.dq = torch.as_tensor(np.ascontiguousarray(dq_flat, dtype=np.int32)).to(self.device)
 
+    def resample_negatives_device(self, seed):
+        """Per-epoch negative refresh entirely on the device (prog_bpr_gru_spatial.py:221-228): new train /
+        test negatives (Load_Data_by_length.py:127-162) and, for the spatial model, their distance bins
+        (:165-180).  No host work, no upload; reproducible for a given seed."""
+        q = torch.empty_like(self.p)
+        tq = torch.empty_like(self.tes_buys_masks)
+        self.ctx.check(self.lib.poi_sample_negatives(self.ctx.handle, _ptr(self.off), _ptr(self.p), self.n_user, self.n_item,
+                                                     _ptr(self.tes_buys_masks), _ptr(self.tes_masks), self.tes_masks.shape[1],
+                                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(q), _ptr(tq), self._stream()))
+        self.q, self.tes_buys_neg_masks = q, tq
+        if getattr(self, "spatial", False):
+            if self.coords is None:
+                raise _lib.PoiError("resample_negatives_device on the spatial model needs coords= at construction")
+            dq = torch.empty_like(self.p)
+            self.ctx.check(self.lib.poi_neg_dist_bins(self.ctx.handle, _ptr(self.off), _ptr(self.p), _ptr(self.q), self.n_user,
+                                                      _ptr(self.coords), _ptr(self._cphi), _ptr(self._binthr), self.n_dist,
+                                                      self.dd * 1000.0, _ptr(dq), self._stream()))
+            self.dq = dq
+
     # ---- snapshots ----------------------------------------------------------------------------
     def update_trained_items(self):
         """public/GRU.py:84-87: eval sees a snapshot of lt, not the live table."""

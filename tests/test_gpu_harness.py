@@ -43,12 +43,15 @@ def test_one_by_one_epoch_equals_reference_sequential_epoch(pa):
     sc = model.compute_sub_all_scores(ids)
     ranks = model.compute_sub_topk(ids, 20).cpu().numpy()
     assert np.array_equal(ranks, O.topk_desc(sc, 20))
+    from poi_amd.evaluate import device_rank_metrics
+    dev_m = device_rank_metrics(model, [ids], [5, 10, 15, 20])
     exp_m = O.evaluate_ranks(ranks, ds.tes_p.reshape(-1, 1), np.ones((ds.n_user, 1), int), [5, 10, 15, 20])
     from poi_amd.evaluate import rank_metrics
     got_m = rank_metrics(ranks, ds.tes_p.reshape(-1, 1), np.ones((ds.n_user, 1), int), [5, 10, 15, 20])
     for k in (5, 10, 15, 20):
         for key in ("hits", "recall", "precision", "f1", "map", "ndcg"):
             assert np.isclose(got_m[k][key], exp_m[k][key], rtol=1e-12, atol=1e-15), (k, key)
+            assert np.isclose(dev_m[k][key], exp_m[k][key], rtol=1e-12, atol=1e-15), ("device", k, key)
     # the spatial score includes wd * prob rebuilt on the device: check one row against the oracle path
     hts, sts = model.predict(ids)
     ul = O.compute_distance(ds.to_padded()["train"][0], ds.to_padded()["train"][1], [list(c) for c in ds.coords], ds.dd, ds.dist_num)

@@ -330,3 +330,61 @@ def test_errors_are_loud(pa):
     assert rc < 0 and b"NULL" in ctx.lib.poi_last_error(ctx.handle)
     with pytest.raises(pa.PoiError):
         ctx.check(ctx.lib.poi_score_topk(ctx.handle, 1, 1, 1, 10, 6, None, None, 5, 1, None, None))   # dim % 4 != 0
+
+
+def test_device_negative_sampling_contract_and_bins(pa):
+    """On-device per-epoch negative refresh: the sampler's contract (Load_Data_by_length.py:127-162:
+    support [0, n_item), never one of the user's train items, test negative also avoids the test item)
+    and the negative distance bins bit-exact vs the oracle's fun_compute_dist_neg restatement on the
+    sampled negatives; reproducible per seed, different across seeds, roughly uniform."""
+    from poi_amd import harness
+    from poi_amd.data import make_synthetic
+    ds = make_synthetic(300, 400, 14, seed=21)
+    p = harness.default_params(); p.update(latent_size=16, gru=2)
+    model = harness.build_model(ds, p, seed=1)
+    model.resample_negatives_device(1234)
+    q1, dq1, tq1 = model.q.cpu().numpy(), model.dq.cpu().numpy(), model.tes_buys_neg_masks.cpu().numpy()
+    model.resample_negatives_device(1234)
+    assert np.array_equal(q1, model.q.cpu().numpy()) and np.array_equal(dq1, model.dq.cpu().numpy())
+    model.resample_negatives_device(99)
+    assert not np.array_equal(q1, model.q.cpu().numpy())
+    off = ds.off.astype(np.int64)
+    assert q1.min() >= 0 and q1.max() < ds.n_item
+    for u in range(ds.n_user):
+        own = set(ds.tra_p[off[u]:off[u + 1]])
+        assert not own & set(q1[off[u]:off[u + 1]])
+        assert tq1[u, 0] not in own and tq1[u, 0] != ds.tes_p[u] and 0 <= tq1[u, 0] < ds.n_item
+    pad = ds.to_padded()
+    from poi_amd.data import csr_to_padded
+    exp = O.compute_dist_neg(pad["train"][0], pad["train"][1], csr_to_padded(ds.off, q1, ds.n_item, ds.len_max),
+                             [list(c) for c in ds.coords], ds.dd, ds.dist_num)
+    assert np.array_equal(csr_to_padded(ds.off, dq1, ds.dist_num, ds.len_max), np.array(exp))
+    # uniformity: 400 items, ~2700 draws -> no item should be wildly over-represented
+    cnt = np.bincount(q1, minlength=ds.n_item)
+    assert cnt.max() < 8 * cnt.mean() + 10
+    # the refreshed tables feed training
+    out = model.train_batch(np.arange(64, dtype=np.int32))
+    assert np.all(np.isfinite(out))
+
+
+def test_device_rank_metrics_match_reference_golden(pa, golden_dir):
+    """poi_rank_metrics vs the reference's own fun_hit_zero_one / fun_evaluate_map / fun_evaluate_ndcg
+    outputs (tests/golden/metrics.npz) at several cut-offs, ragged test masks included."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    ranks, tes, msk = g["recom"].astype(np.int32), g["test_lst"].astype(np.int32), g["test_mask"].astype(np.int32)
+    at = [5, 10, 15, 20]
+    ctx = pa._lib.context(0)
+    dr, dt, dm = (torch.as_tensor(v).cuda() for v in (ranks, tes, msk))
+    da = torch.as_tensor(np.array(at, np.int32)).cuda()
+    acc = torch.zeros((4, 3), dtype=torch.float64, device="cuda")
+    ctx.check(ctx.lib.poi_rank_metrics(ctx.handle, dr.data_ptr(), ranks.shape[0], 20, dt.data_ptr(), dm.data_ptr(), tes.shape[1],
+                                       da.data_ptr(), 4, acc.data_ptr(), None))
+    got = acc.cpu().numpy()
+    exp = O.evaluate_ranks(ranks, tes, msk, at)
+    for i, k in enumerate(at):
+        assert got[i, 0] == exp[k]["hits"]
+        assert np.isclose(got[i, 1] / len(ranks), exp[k]["map"], rtol=1e-12) and np.isclose(got[i, 2] / len(ranks), exp[k]["ndcg"], rtol=1e-12)
+    # k = 20 equals the golden vectors produced by the reference helpers themselves
+    assert got[3, 0] == g["zero_one"].sum()
+    assert np.isclose(got[3, 1], g["map"].sum(), rtol=1e-12) and np.isclose(got[3, 2], g["ndcg"].sum(), rtol=1e-12)
