@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--emulate-world", type=int, default=0, help="tuning aid: train only rank 0's shard of an N-way split on one GPU")
     return ap.parse_args()
 
 
@@ -67,7 +68,7 @@ def main():
 
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
     ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2)
-    lo, hi = pdata.shard_users(n_user, world, rank, ds.lens)
+    lo, hi = pdata.shard_users(n_user, a.emulate_world or world, rank, ds.lens)
     tab = ds.shard(lo, hi)
     n_local = hi - lo
     NB = ds.dist_num + 1
@@ -121,7 +122,7 @@ def main():
           "te_finalize", "rows_apply", "dense_apply"]
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
-    seq_per_s = n_user * a.steps / dt
+    seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
 
     # ---- evaluation: snapshot -> user vectors -> fused distance term + all-POI score + top-20 -------
     eval_users_per_s = None

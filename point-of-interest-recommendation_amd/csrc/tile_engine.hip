@@ -107,6 +107,27 @@ __device__ __forceinline__ void mma_lds_packed(f32x16 (&acc)[MT][NTW], const flo
   }
 }
 
+// Same contraction with the B fragments already in registers (the recurrent kernels keep each wave's
+// own 32 weight columns of every gate resident for the whole sequence loop: D/8 float4 per gate).
+template <int K8>
+__device__ __forceinline__ void mma_lds_regb(f32x16& acc, const float* __restrict__ ldsA, int lda, const float4 (&b)[K8]) {
+  const int lane = lane_id(), li = lane & 31, h = lane >> 5;
+  const float* arow = ldsA + li * lda + 4 * h;
+#pragma unroll
+  for (int m = 0; m < K8; ++m) {
+    const float4 a = *reinterpret_cast<const float4*>(arow + 8 * m);
+    acc = mfma32(a.x, b[m].x, acc);
+    acc = mfma32(a.y, b[m].y, acc);
+    acc = mfma32(a.z, b[m].z, acc);
+    acc = mfma32(a.w, b[m].w, acc);
+  }
+}
+template <int K8>
+__device__ __forceinline__ void load_bfrag(float4 (&b)[K8], const float4* __restrict__ bp, int nt) {
+#pragma unroll
+  for (int m = 0; m < K8; ++m) b[m] = bp[((size_t)nt * K8 + m) * 64 + lane_id()];
+}
+
 // -------------------------------------------------------------------------------------------------
 // bookkeeping kernels
 // -------------------------------------------------------------------------------------------------
@@ -295,7 +316,11 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
   int rowb[16], nsr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
-  const int ntz[1] = {w}, ntr[1] = {NTD + w}, ntc[1] = {2 * NTD + w};
+  // this wave's recurrent weights (own 32 columns of z, r, c): resident in registers for every step
+  float4 wz[K8], wr[K8], wc[K8];
+  load_bfrag<K8>(wz, A.pWhT, w);
+  load_bfrag<K8>(wr, A.pWhT, NTD + w);
+  load_bfrag<K8>(wc, A.pWhT, 2 * NTD + w);
   float* Hp = Hb0; float* Hn = Hb1;
   // pre-activations of the NEXT step are fetched while the current step's MFMAs run: they do not
   // depend on the recurrence (G still holds X.ui^T + bi for rows not yet visited)
@@ -314,8 +339,8 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
     f32x16 az[1][1], ar[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { az[0][0][r] = cz[r]; ar[0][0][r] = cr[r]; }
-    mma_lds_packed<1, 1, K8, 8>(az, Hp, LDA, A.pWhT, ntz);
-    mma_lds_packed<1, 1, K8, 8>(ar, Hp, LDA, A.pWhT, ntr);
+    mma_lds_regb<K8>(az[0][0], Hp, LDA, wz);
+    mma_lds_regb<K8>(ar[0][0], Hp, LDA, wr);
     float zv[16], hp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
     f32x16 ac[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ac[0][0][r] = cc[r];
-    mma_lds_packed<1, 1, K8, 8>(ac, RHb, LDA, A.pWhT, ntc);
+    mma_lds_regb<K8>(ac[0][0], RHb, LDA, wc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
@@ -588,8 +613,10 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
   int rowb[16], nsr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
-  const int ntc[1] = {w};                 // wh[2] as B[k = i][n = j]: packed pWhc, NTD n-tiles
-  const int ntzr[1] = {w};                // wh[0:2] rows as K = 2D: packed pWhzr
+  // this wave's columns of wh[2] (K = D) and of wh[0:2] (K = 2D) as B fragments: resident in registers
+  float4 wcb[K8], wzrb[2 * K8];
+  load_bfrag<K8>(wcb, A.pWhc, w);
+  load_bfrag<2 * K8>(wzrb, A.pWhzr, w);
   float dhn[16], sbz = 0.f, sbr = 0.f, sbc = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dhn[r] = 0.f;
@@ -625,7 +652,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
     f32x16 m[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) m[0][0][r] = 0.f;
-    mma_lds_packed<1, 1, K8, 8>(m, Ac, LDA, A.pWhc, ntc);
+    mma_lds_regb<K8>(m[0][0], Ac, LDA, wcb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
@@ -648,7 +675,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    mma_lds_packed<1, 1, 2 * K8, 8>(acc, Azr, LDB, A.pWhzr, ntzr);
+    mma_lds_regb<2 * K8>(acc[0][0], Azr, LDB, wzrb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][0][r] : 0.f;
