@@ -119,7 +119,7 @@ def main():
     barrier()
     dt = rank_max(time.perf_counter() - t0)
     KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx",
-          "te_finalize", "rows_apply", "dense_apply"]
+          "te_finalize", "te_scatter", "rows_apply", "dense_apply"]
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
     seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
@@ -179,7 +179,9 @@ def main():
             "te_head": ("flop", 6.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_wgrad": ("flop", 18 * D2 * steps_per_epoch), "te_gemm_dx": ("flop", 12 * D2 * steps_per_epoch),
             "te_gather": ("byte", (3.0 * D * 4 + 16) * float(lens_local.sum())),
-            "rows_apply": ("byte", 2.0 * uniq * D * 4.0)}      # read + write of every touched row
+            "rows_apply": ("byte", 2.0 * uniq * D * 4.0),      # read + write of every touched row
+            # sorted scatter: per step dx (2D floats) + g*h (D floats) in, every touched row read + written
+            "te_scatter": ("byte", 3.0 * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0)}
     kernels = {}
     for k in KN:
         ms, nl = kt[k]
@@ -209,11 +211,11 @@ def main():
             kernels[k]["traffic_bytes_per_launch"] = traffic[k]
     roofline = dict(kernel=dom, traffic=traffic.get(dom), **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
     roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
-    gs_ms = sum(kernels[k]["ms_per_step"] for k in ("te_gather", "rows_apply") if k in kernels)
-    gs_bytes = sum(work[k][1] for k in ("te_gather", "rows_apply") if k in kernels)
-    hbm = {"kernels": [k for k in ("te_gather", "rows_apply") if k in kernels], "bound": "hbm",
+    gs_ms = sum(kernels[k]["ms_per_step"] for k in ("te_gather", "te_scatter", "rows_apply") if k in kernels)
+    gs_bytes = sum(work[k][1] for k in ("te_gather", "te_scatter", "rows_apply") if k in kernels)
+    hbm = {"kernels": [k for k in ("te_gather", "te_scatter", "rows_apply") if k in kernels], "bound": "hbm",
            "achieved": gs_bytes * a.steps / (gs_ms * a.steps * 1e-3) / 1e9 if gs_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "traffic": sum(traffic.get(k, 0) for k in ("te_gather", "rows_apply")) or None}
+           "traffic": sum(traffic.get(k, 0) for k in ("te_gather", "te_scatter", "rows_apply")) or None}
     hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
     total_flops = step_flops(D, NB) * steps_per_epoch
     train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels)

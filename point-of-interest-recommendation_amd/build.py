@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpoi_hip.so")
-SOURCES = ["abi.hip", "seq_engine.hip", "tile_engine.hip", "bpr.hip", "score_topk.hip", "misc.hip"]
+SOURCES = ["abi.hip", "seq_engine.hip", "tile_engine.hip", "te_scatter.hip", "bpr.hip", "score_topk.hip", "misc.hip"]
 HEADERS = ["poi_common.h", "poi_kernels.h", os.path.join("..", "..", "include", "poi_hip.h")]
 
 

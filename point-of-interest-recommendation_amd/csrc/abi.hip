@@ -30,6 +30,8 @@ struct poi_ctx {
   int head_rounds = 1;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
   int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1|2 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
+  DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
+  int te_sorted = 1;        // POI_TE_SORTED=0: float-atomic scatter into the gradient tables (tuning / A-B only)
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
@@ -92,6 +94,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_HEAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->head_rounds = v; }
   if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->score_variant = v; }
+  if (const char* e = getenv("POI_TE_SORTED")) c->te_sorted = atoi(e) != 0;
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   *out = c;
@@ -100,7 +103,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di,
+  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e,
                    &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
@@ -146,10 +149,18 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.dl = poi::dense_layout(D, 2 * D, P->n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 64;
   const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D;
-  const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64;
-  const size_t nin = Tcap * 3 + (size_t)n + 16;
+  // sorted scatter (training): 3 slots per sequence position
+  const bool sorted = !predict && c->te_sorted;
+  const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
+  const size_t n_hot = Ncap / (TE_COLD_MAX + 1) + 2, n_chunk = Ncap / TE_HOT_CHUNK + n_hot + 2;
+  const size_t sfl = sorted ? Tcap + n_chunk * D + 64 : 0;
+  const size_t sin = sorted ? 7 * Ncap + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
+  const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl;
+  const size_t nin = Tcap * 3 + (size_t)n + 16 + sin;
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
+  const int R = P->n_item + 1 + P->n_dist + 1;
+  if (sorted && ((rc = ensure(c, c->seg_s, sizeof(int) * (size_t)(R + 1), st)) || (rc = ensure(c, c->seg_e, sizeof(int) * (size_t)(R + 1), st)))) return rc;
   float* f = (float*)c->te_ws.p;
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
   A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
@@ -157,8 +168,21 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.pUiT = (float4*)take((size_t)6 * D * D); A.pUi = (float4*)take((size_t)6 * D * D);
   A.pWhT = (float4*)take((size_t)3 * D * D); A.pWhc = (float4*)take((size_t)D * D); A.pWhzr = (float4*)take((size_t)2 * D * D);
   A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
+  if (sorted) { A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); }
   int* ip = (int*)f;
-  A.soff = ip; ip += (n + 4) & ~3; A.row_src = ip; ip += Tcap; A.row_t = ip; ip += Tcap; A.row_seq = ip;
+  auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
+  A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_seq = itake(Tcap);
+  if (sorted) {
+    A.sorted = 1;
+    int bits = 1; while ((1 << bits) <= R) ++bits;      // keys 0..R (R = sentinel)
+    A.key_bits = bits;
+    A.keys0 = itake(Ncap); A.keys1 = itake(Ncap); A.vals0 = itake(Ncap); A.vals1 = itake(Ncap);
+    A.code = itake(Ncap); A.slot_seq = itake(Ncap); A.ent = itake(Ncap);
+    A.hist = itake(RS_HIST_INTS + RS_MAXBIN);   // + per-digit totals
+    A.cnt = itake(4);
+    A.hot_rows = (int4*)itake(4 * n_hot); A.hot_chunks = (int2*)itake(2 * n_chunk); A.hot_nf = itake(n_chunk);
+    A.seg_start = (int*)c->seg_s.p; A.seg_end = (int*)c->seg_e.p;
+  }
   return POI_OK;
 }
 
@@ -210,8 +234,11 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.out = out; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
     E.g_lt = A.g_lt; E.g_di = A.g_di; E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
-    int agrid = c->num_cu * 4; if (agrid > n) agrid = n;
-    HIPCHK(c, poi::launch_rows_apply(A, true, agrid, alpha, lambda, st, &c->tm));
+    if (E.sorted) HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));
+    else {
+      int agrid = c->num_cu * 4; if (agrid > n) agrid = n;
+      HIPCHK(c, poi::launch_rows_apply(A, true, agrid, alpha, lambda, st, &c->tm));
+    }
     HIPCHK(c, poi::launch_dense_apply(A, true, n_kc, n_head, alpha, lambda, st, &c->tm));
     return POI_OK;
   }

@@ -88,8 +88,36 @@ struct TeArgs {
   float *g_lt, *g_di;
   int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
   float *hts, *sts;
+  // sorted segmented scatter (te_scatter.hip): every table touch of the launch becomes one (row key,
+  // entry) pair; a stable radix sort groups them by row, and each row's update is a plain ordered sum
+  int sorted;                         // 1: sorted scatter (default), 0: float atomics into g_lt / g_di
+  int key_bits;                       // bits of the largest key (= sentinel = number of table rows)
+  int *keys0, *keys1, *vals0, *vals1; // sort ping-pong (key = unified row id, value = slot)
+  int *code, *slot_seq;               // per slot: entry code, sequence index in the launch
+  int *ent;                           // sorted entry codes (bit 31: first entry of its sequence in the row)
+  int *seg_start, *seg_end;           // per unified row: [start, end) in `ent`; end == 0 <=> untouched (persistent, re-zeroed)
+  int *hist;                          // radix histogram (bins x blocks)
+  int *cnt;                           // [0] number of slots, [1] hot rows, [2] hot chunks
+  int4* hot_rows;                     // {row, start, count, first chunk}
+  int2* hot_chunks;                   // {hot row index, chunk index}
+  float* hot_part;                    // (hot chunks, D) partial sums
+  int* hot_nf;                        // per hot chunk: distinct-sequence count
+  float* gcoef;                       // per packed row: d loss / d (h . e) (te_head)
 };
+// entry code: packed-row index of the position (28 bits) + what the position contributes
+#define TE_ENT_ROW 0x0FFFFFFF
+#define TE_ENT_DX 0x10000000      // + dx[row] (lt half for POI rows, di half for distance-bin rows)
+#define TE_ENT_GH 0x20000000      // + g[row-1] * h[row-1]
+#define TE_ENT_NEG 0x40000000     // the g*h term enters with a minus sign (negative sample)
+#define TE_ENT_FIRST 0x80000000u  // first entry of its sequence within the row segment
+#define TE_COLD_MAX 64            // rows with more entries are reduced in 256-entry chunks by whole workgroups
+#define TE_HOT_CHUNK 256
+#define RS_MAXBIN 512
+#define RS_GRID 256
+#define RS_HIST_INTS (RS_MAXBIN * RS_GRID)   // radix histogram: bins x blocks
 bool te_supported(int D, int n_dist);
+hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
+hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 int te_nbp(int n_dist);
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);

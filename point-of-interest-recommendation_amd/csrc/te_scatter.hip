@@ -1,0 +1,345 @@
+// Sorted segmented scatter for the tile engine: the sparse SGD write-back of
+// public/GRU_Spatial.py:149-153,212-215 (T.set_subtensor on the unique rows of p U q and of the
+// distance bins) for a whole launch, without float atomics and with a fixed summation order.
+//
+// Every table touch of the launch (POI ids of p and q, distance bins of dp, at every position of
+// every sequence) is one slot: key = unified row id (POI rows, then distance-bin rows), value = slot
+// index.  te_rowmap writes the slots; a stable LSD radix sort groups them by row; te_segment finds
+// each row's [start, end) range and marks the first entry of every sequence in it (= the distinct-
+// sequence count of the batch rule); te_reduce walks the rows: a row with <= 64 entries is summed
+// and updated by one wavefront, longer ("hot") rows - popular POIs, every distance bin - are cut into
+// 256-entry chunks summed by whole workgroups and combined in chunk order.  An entry names the packed
+// step row whose dx (te_gemm_dx) and/or g*h (te_head) it adds, so the gradient tables of the
+// per-sequence engine are not used at all and the result does not depend on scheduling.
+#include "poi_common.h"
+#include "poi_kernels.h"
+
+namespace poi {
+
+#define RS_BLOCK 256
+
+// -------------------------------------------------------------------------------------------------
+// stable LSD radix sort of (key, value) pairs, element count read from device memory
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rs_range(int N, int& b, int& e) {
+  const int G = gridDim.x;
+  const int per = ((((N + G - 1) / G) + RS_BLOCK - 1) / RS_BLOCK) * RS_BLOCK;
+  b = min(N, (int)blockIdx.x * per);
+  e = min(N, b + per);
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const int* __restrict__ keys, const int* __restrict__ n_ptr,
+                                                           int shift, int nbin, int* __restrict__ hist) {
+  __shared__ int cnt[RS_MAXBIN];
+  int b, e;
+  rs_range(*n_ptr, b, e);
+  for (int d = threadIdx.x; d < nbin; d += RS_BLOCK) cnt[d] = 0;
+  __syncthreads();
+  for (int i = b + threadIdx.x; i < e; i += RS_BLOCK) atomicAdd(&cnt[(keys[i] >> shift) & (nbin - 1)], 1);
+  __syncthreads();
+  for (int d = threadIdx.x; d < nbin; d += RS_BLOCK) hist[d * gridDim.x + blockIdx.x] = cnt[d];
+}
+
+// block d: exclusive scan over the blocks' counts of digit d (in place) + the digit total
+__global__ __launch_bounds__(RS_GRID) void rs_digit_scan_kernel(int* __restrict__ hist, int* __restrict__ total) {
+  __shared__ int wsum[RS_GRID / 64];
+  const int d = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int v = hist[d * RS_GRID + tid];
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int pre = 0;
+#pragma unroll
+  for (int i = 0; i < RS_GRID / 64; ++i) if (i < w) pre += wsum[i];
+  hist[d * RS_GRID + tid] = pre + inc - v;
+  if (tid == RS_GRID - 1) total[d] = pre + inc;
+}
+
+// vin == nullptr: values are the element indices (first pass)
+__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const int* __restrict__ kin, const int* __restrict__ vin,
+                                                              int* __restrict__ kout, int* __restrict__ vout,
+                                                              const int* __restrict__ n_ptr, int shift, int nbin,
+                                                              const int* __restrict__ hist, const int* __restrict__ total) {
+  __shared__ int base[RS_MAXBIN];
+  __shared__ int wcnt[RS_BLOCK / 64][RS_MAXBIN];
+  __shared__ int wsum[RS_BLOCK / 64];
+  int b, e;
+  rs_range(*n_ptr, b, e);
+  const int lane = lane_id(), w = wave_id();
+  // base[d] = (keys with a smaller digit) + (keys with digit d in earlier blocks): exclusive scan of
+  // the digit totals (two digits per thread) + this block's entry of the per-digit block scan
+  {
+    const int d0 = 2 * threadIdx.x, d1 = d0 + 1;
+    const int t0 = d0 < nbin ? total[d0] : 0, t1 = d1 < nbin ? total[d1] : 0;
+    int inc = t0 + t1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int pre = 0;
+#pragma unroll
+    for (int i = 0; i < RS_BLOCK / 64; ++i) if (i < w) pre += wsum[i];
+    const int ex = pre + inc - (t0 + t1);
+    if (d0 < nbin) base[d0] = ex + hist[d0 * gridDim.x + blockIdx.x];
+    if (d1 < nbin) base[d1] = ex + t0 + hist[d1 * gridDim.x + blockIdx.x];
+  }
+  for (int d = threadIdx.x; d < nbin; d += RS_BLOCK) {
+#pragma unroll
+    for (int ww = 0; ww < RS_BLOCK / 64; ++ww) wcnt[ww][d] = 0;
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int t0 = b; t0 < e; t0 += RS_BLOCK) {
+    const int i = t0 + threadIdx.x;
+    const bool valid = i < e;
+    const int key = valid ? kin[i] : 0;
+    const int val = valid ? (vin ? vin[i] : i) : 0;
+    const int d = (key >> shift) & (nbin - 1);
+    // lanes of this wave holding the same digit (stable rank = number of such lanes below this one)
+    unsigned long long m = __ballot(valid);
+    for (int bit = 1; bit < nbin; bit <<= 1) {
+      const unsigned long long bal = __ballot((d & bit) != 0);
+      m &= (d & bit) ? bal : ~bal;
+    }
+    const int rank = __builtin_popcountll(m & below), tot = __builtin_popcountll(m);
+    if (valid && rank == 0) wcnt[w][d] = tot;
+    __syncthreads();
+    if (valid) {
+      int o = base[d] + rank;
+      for (int w2 = 0; w2 < w; ++w2) o += wcnt[w2][d];
+      kout[o] = key; vout[o] = val;
+    }
+    __syncthreads();
+    if (valid && rank == 0) { atomicAdd(&base[d], tot); wcnt[w][d] = 0; }
+    __syncthreads();
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_segment: sorted (key, slot) -> entry codes + per-row ranges
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void te_segment_kernel(TeArgs A, const int* __restrict__ Ks, const int* __restrict__ Vs) {
+  const int N = A.cnt[0], R = A.n_item + 1 + A.n_dist + 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const int k = Ks[i];
+    if (k >= R) continue;                  // sentinel slots (sorted last)
+    const int v = Vs[i];
+    const bool same = i > 0 && Ks[i - 1] == k;
+    const bool first = !same || A.slot_seq[Vs[i - 1]] != A.slot_seq[v];
+    A.ent[i] = A.code[v] | (first ? (int)TE_ENT_FIRST : 0);
+    if (!same) A.seg_start[k] = i;
+    if (i == N - 1 || Ks[i + 1] != k) A.seg_end[k] = i + 1;
+  }
+}
+
+hipError_t launch_te_sort(TeArgs& A, hipStream_t st) {
+  const int bits = A.key_bits;
+  const int npass = bits <= 9 ? 1 : bits <= 18 ? 2 : bits <= 27 ? 3 : 4;
+  const int w = (bits + npass - 1) / npass, nbin = 1 << w;
+  const int *kin = A.keys0, *vin = nullptr;
+  int *kout = A.keys1, *vout = A.vals1;
+  for (int p = 0; p < npass; ++p) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(RS_GRID), dim3(RS_BLOCK), 0, st, kin, A.cnt, p * w, nbin, A.hist);
+    hipLaunchKernelGGL(rs_digit_scan_kernel, dim3(nbin), dim3(RS_GRID), 0, st, A.hist, A.hist + RS_HIST_INTS);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(RS_GRID), dim3(RS_BLOCK), 0, st, kin, vin, kout, vout, A.cnt, p * w, nbin, A.hist, A.hist + RS_HIST_INTS);
+    kin = kout; vin = vout;
+    if (kout == A.keys1) { kout = A.keys0; vout = A.vals0; } else { kout = A.keys1; vout = A.vals1; }
+  }
+  hipLaunchKernelGGL(te_segment_kernel, dim3(1024), dim3(256), 0, st, A, kin, vin);
+  return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// reduction of a row's entries
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int D>
+__device__ __forceinline__ float4 ent_contrib(const TeArgs& A, int e, int doff, int c) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t rr = (size_t)(e & TE_ENT_ROW);
+  if (e & TE_ENT_DX) v = *reinterpret_cast<const float4*>(A.X + rr * 2 * D + doff + c);
+  if (e & TE_ENT_GH) {
+    float g = A.gcoef[rr - 1];
+    if (e & TE_ENT_NEG) g = -g;
+    const float4 h = *reinterpret_cast<const float4*>(A.H + (rr - 1) * D + c);
+    v.x = fmaf(g, h.x, v.x); v.y = fmaf(g, h.y, v.y); v.z = fmaf(g, h.z, v.z); v.w = fmaf(g, h.w, v.w);
+  }
+  return v;
+}
+
+// One wavefront sums entries ent[s, s + cnt), cnt <= 64, in a fixed order: D/4 lanes per entry
+// (float4 each), 64/(D/4) entries per pass, four passes in flight.  The sum ends up in every lane
+// group (all groups hold the same total); *nfirst = number of TE_ENT_FIRST entries.
+template <int D>
+__device__ __forceinline__ float4 seg_sum(const TeArgs& A, int s, int cnt, int doff, int* nfirst) {
+  constexpr int LPR = D / 4, EPW = 64 / LPR;
+  const int lane = lane_id(), grp = lane / LPR, c = (lane % LPR) * 4;
+  const int mine = lane < cnt ? A.ent[s + lane] : 0;
+  *nfirst = __builtin_popcountll(__ballot(mine < 0));
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i0 = 0; i0 < cnt; i0 += 4 * EPW) {
+    int e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * EPW + grp;
+      const int got = __shfl(mine, idx & 63, 64);
+      e[u] = idx < cnt ? got : 0;
+    }
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ent_contrib<D>(A, e[u], doff, c);
+    acc = f4_add(acc, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  return acc;
+}
+
+// row <- row - alpha * (G + lambda * mult * row) / nseq      (batch rule, include/poi_hip.h)
+template <int D>
+__device__ __forceinline__ void apply_sum(float* __restrict__ trow, float4 g, int mult, int nseq, float alpha, float lambda) {
+  constexpr int LPR = D / 4;
+  const int lane = lane_id();
+  if (lane >= LPR) return;
+  const float sc = alpha / (float)nseq, lm = lambda * (float)mult;
+  float4 tv = *reinterpret_cast<float4*>(trow + lane * 4);
+  tv.x -= sc * (g.x + lm * tv.x); tv.y -= sc * (g.y + lm * tv.y);
+  tv.z -= sc * (g.z + lm * tv.z); tv.w -= sc * (g.w + lm * tv.w);
+  *reinterpret_cast<float4*>(trow + lane * 4) = tv;
+}
+
+struct RowInfo { float* trow; int* pm; int* pn; int doff; };
+__device__ __forceinline__ RowInfo row_info(const TeArgs& A, int row) {
+  RowInfo r;
+  const int D = A.dim;
+  if (row <= A.n_item) {
+    r.trow = A.lt + (size_t)row * D; r.doff = 0;
+    r.pm = row == A.n_item ? A.mult_lt + A.n_item : nullptr;
+    r.pn = row == A.n_item ? A.nseq_lt + A.n_item : nullptr;
+  } else {
+    const int b = row - A.n_item - 1;
+    r.trow = A.di + (size_t)b * D; r.doff = D;
+    r.pm = b == A.n_dist ? A.mult_di + A.n_dist : nullptr;
+    r.pn = b == A.n_dist ? A.nseq_di + A.n_dist : nullptr;
+  }
+  return r;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, float lambda) {
+  const int R = A.n_item + 1 + A.n_dist + 1;
+  const int lane = lane_id();
+  for (int row = blockIdx.x * 4 + wave_id(); row < R; row += gridDim.x * 4) {
+    const int end = A.seg_end[row];
+    const RowInfo ri = row_info(A, row);
+    // padding rows: analytic multiplicity / sequence count from te_rowmap
+    const int am = ri.pm ? *ri.pm : 0, an = ri.pn ? *ri.pn : 0;
+    if (end == 0 && an == 0) continue;
+    const int start = end ? A.seg_start[row] : 0, cnt = end - start;
+    if (cnt > TE_COLD_MAX) {
+      const int nch = (cnt + TE_HOT_CHUNK - 1) / TE_HOT_CHUNK;
+      int h = 0, c0 = 0;
+      if (lane == 0) {
+        h = atomicAdd(&A.cnt[1], 1);
+        c0 = atomicAdd(&A.cnt[2], nch);
+        A.hot_rows[h] = make_int4(row, start, cnt, c0);
+      }
+      h = __shfl(h, 0, 64); c0 = __shfl(c0, 0, 64);
+      for (int c = lane; c < nch; c += 64) A.hot_chunks[c0 + c] = make_int2(h, c);
+      continue;
+    }
+    int nf = 0;
+    const float4 g = seg_sum<D>(A, start, cnt, ri.doff, &nf);
+    apply_sum<D>(ri.trow, g, cnt + am, ri.pn ? an : nf, alpha, lambda);
+    if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void te_hot_reduce_kernel(TeArgs A) {
+  __shared__ __align__(16) float part[4][D];
+  __shared__ int s_nf[4];
+  constexpr int LPR = D / 4;
+  const int nchunk = A.cnt[2];
+  const int lane = lane_id(), w = wave_id();
+  for (int ci = blockIdx.x; ci < nchunk; ci += gridDim.x) {
+    const int2 item = A.hot_chunks[ci];
+    const int4 hr = A.hot_rows[item.x];
+    const int doff = hr.x <= A.n_item ? 0 : D;
+    const int s = hr.y + item.y * TE_HOT_CHUNK + 64 * w;
+    int wc = hr.z - item.y * TE_HOT_CHUNK - 64 * w;
+    wc = wc < 0 ? 0 : (wc > 64 ? 64 : wc);
+    int nf = 0;
+    const float4 g = seg_sum<D>(A, s, wc, doff, &nf);
+    if (lane < LPR) *reinterpret_cast<float4*>(&part[w][lane * 4]) = g;
+    if (lane == 0) s_nf[w] = nf;
+    __syncthreads();
+    if (threadIdx.x < D) {
+      const int j = threadIdx.x;
+      A.hot_part[(size_t)ci * D + j] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+    }
+    if (threadIdx.x == 0) A.hot_nf[ci] = s_nf[0] + s_nf[1] + s_nf[2] + s_nf[3];
+    __syncthreads();
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha, float lambda) {
+  constexpr int LPR = D / 4, EPW = 64 / LPR;
+  const int nhot = A.cnt[1];
+  const int lane = lane_id(), grp = lane / LPR, c = (lane % LPR) * 4;
+  for (int h = blockIdx.x * 4 + wave_id(); h < nhot; h += gridDim.x * 4) {
+    const int4 hr = A.hot_rows[h];
+    const int row = hr.x, cnt = hr.z, c0 = hr.w, nch = (cnt + TE_HOT_CHUNK - 1) / TE_HOT_CHUNK;
+    const RowInfo ri = row_info(A, row);
+    const int am = ri.pm ? *ri.pm : 0, an = ri.pn ? *ri.pn : 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0; i0 < nch; i0 += 4 * EPW) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * EPW + grp;
+        v[u] = idx < nch ? *reinterpret_cast<const float4*>(A.hot_part + (size_t)(c0 + idx) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      acc = f4_add(acc, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+      acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    int nf = 0;
+    for (int i = lane; i < nch; i += 64) nf += A.hot_nf[c0 + i];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) nf += __shfl_xor(nf, o, 64);
+    apply_sum<D>(ri.trow, acc, cnt + am, ri.pn ? an : nf, alpha, lambda);
+    if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
+  }
+}
+
+template <int D>
+static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm) {
+  const int R = A.n_item + 1 + A.n_dist + 1;
+  int grid = (R + 3) / 4;
+  if (grid > num_cu * 32) grid = num_cu * 32;
+  tm->begin("te_scatter", st);
+  hipLaunchKernelGGL(te_reduce_kernel<D>, dim3(grid), dim3(256), 0, st, A, alpha, lambda);
+  hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu), dim3(256), 0, st, A, alpha, lambda);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm) {
+  if (A.dim == 64) return te_scatter_t<64>(A, alpha, lambda, num_cu, st, tm);
+  if (A.dim == 128) return te_scatter_t<128>(A, alpha, lambda, num_cu, st, tm);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace poi

@@ -131,20 +131,32 @@ __device__ __forceinline__ void load_bfrag(float4 (&b)[K8], const float4* __rest
 // -------------------------------------------------------------------------------------------------
 // bookkeeping kernels
 // -------------------------------------------------------------------------------------------------
-// soff[k] = sum_{k' < k} (L_k' - 1); soff[n] = total packed rows.  One 1024-thread block.
+// soff[k] = sum_{k' < k} (L_k' - 1); soff[n] = total packed rows.  te_len writes the step counts
+// (one thread per sequence: the uidx -> off chain is two dependent loads), te_scan (one 1024-thread
+// block, contiguous runs per thread) turns them into offsets in place.
+__global__ __launch_bounds__(256) void te_len_kernel(TeArgs A) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= A.n_seq) return;
+  const int u = A.uidx[k];
+  const int L = A.off[u + 1] - A.off[u];
+  A.soff[k] = A.predict ? L : (L > 0 ? L - 1 : 0);
+}
 __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   __shared__ int part[1024];
   const int tid = threadIdx.x, n = A.n_seq;
   const int per = (n + 1023) / 1024;
-  const int b = tid * per, e = min(n, b + per);
+  const int b = min(n, tid * per), e = min(n, b + per);
   int s = 0;
-  for (int k = b; k < e; ++k) { const int u = A.uidx[k]; const int L = A.off[u + 1] - A.off[u]; s += A.predict ? L : (L > 0 ? L - 1 : 0); }
+  for (int k = b; k < e; ++k) s += A.soff[k];
   part[tid] = s;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) { int v = tid >= o ? part[tid - o] : 0; __syncthreads(); part[tid] += v; __syncthreads(); }
   int run = tid > 0 ? part[tid - 1] : 0;
-  for (int k = b; k < e; ++k) { A.soff[k] = run; const int u = A.uidx[k]; const int L = A.off[u + 1] - A.off[u]; run += A.predict ? L : (L > 0 ? L - 1 : 0); }
-  if (tid == 1023) A.soff[n] = part[1023];
+  for (int k = b; k < e; ++k) { const int v = A.soff[k]; A.soff[k] = run; run += v; }
+  if (tid == 1023) {
+    A.soff[n] = part[1023];
+    if (A.cnt) { A.cnt[0] = 3 * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; }   // slots, hot rows, hot chunks
+  }
 }
 
 // one wavefront per sequence: row maps + table-touch counts (same rules as seq_engine count_rows).
@@ -185,6 +197,31 @@ __device__ __forceinline__ int te_count(const int* a, const int* b, int L, bool 
 }
 
 #define TE_SEQ_PER_WAVE 4
+// Sorted-scatter slots of one sequence (te_scatter.hip): 3 * (ns + 1) slots at 3 * (r0 + k):
+// [0, L) POI ids of p, [L, 2L) negatives q, [2L, 3L) distance bins dp, rest sentinels.  Returns the
+// literal occurrences of the two padding rows (their analytic multiplicity is added by the caller).
+__device__ __forceinline__ void te_slots(const TeArgs& A, int k, int base, int L, int ns, int r0, int* pads_lt, int* pads_di) {
+  const int lane = lane_id();
+  const int S0 = 3 * (r0 + k), nslot = 3 * (ns + 1), sentinel = A.n_item + 1 + A.n_dist + 1;
+  int plt = 0, pdi = 0;
+  for (int e0 = 0; e0 < nslot; e0 += 64) {
+    const int e = e0 + lane;
+    int key = sentinel, code = 0;
+    bool is_plt = false, is_pdi = false;
+    if (e < nslot && e < 3 * L) {
+      const int sec = e / L, j = e - sec * L;
+      code = r0 + j;
+      if (sec == 0) { key = A.p[base + j]; code |= (j < ns ? TE_ENT_DX : 0) | (j >= 1 ? TE_ENT_GH : 0); is_plt = key == A.n_item; }
+      else if (sec == 1) { key = A.q[base + j]; code |= (j >= 1 ? (TE_ENT_GH | TE_ENT_NEG) : 0); is_plt = key == A.n_item; }
+      else { const int b = A.dp[base + j]; key = A.n_item + 1 + b; code |= (j < ns ? TE_ENT_DX : 0); is_pdi = b == A.n_dist; }
+    }
+    if (e < nslot) { A.keys0[S0 + e] = key; A.code[S0 + e] = code; A.slot_seq[S0 + e] = k; }
+    plt += __builtin_popcountll(__ballot(is_plt));
+    pdi += __builtin_popcountll(__ballot(is_pdi));
+  }
+  *pads_lt = plt; *pads_di = pdi;
+}
+
 __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
   __shared__ int s_ids[POI_NWAVE][TE_CNT_MAX];
   __shared__ int s_pad[POI_NWAVE][4];
@@ -196,6 +233,14 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
     const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = A.soff[k];
     for (int t = lane; t < ns; t += 64) { A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t; A.row_seq[r0 + t] = k; }
     if (A.predict) continue;
+    if (A.sorted) {
+      int plt, pdi;
+      te_slots(A, k, base, L, ns, r0, &plt, &pdi);
+      // the literal occurrences are counted by their row segment; only the analytic part goes here
+      m_lt += 2 * (A.len_max - L); n_lt += (2 * (A.len_max - L) + plt) > 0;
+      m_di += (A.len_max - L); n_di += ((A.len_max - L) + pdi) > 0;
+      continue;
+    }
     const int c_lt = 2 * (A.len_max - L) + te_count(A.p + base, A.q + base, L, true, A.n_item, A.mult_lt, A.nseq_lt, s_ids[w]);
     const int c_di = (A.len_max - L) + te_count(A.dp + base, A.dp + base, L, false, A.n_dist, A.mult_di, A.nseq_di, s_ids[w]);
     m_lt += c_lt; n_lt += c_lt > 0; m_di += c_di; n_di += c_di > 0;
@@ -510,7 +555,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
             dwd_acc += g * (sa - sb);
           }
         }
-        if (sub == 0) s_g[row] = g;
+        if (sub == 0) { s_g[row] = g; if (A.sorted && gr < T) A.gcoef[gr] = g; }
         __builtin_amdgcn_wave_barrier();
         for (int k = sub; k < NBP; k += 8) {
           float dl = 0.f;
@@ -548,7 +593,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
             const float g = s_g[i];
             A.DH[(size_t)gr * D + col] = acc[0][j][r] + g * Et[i * LDH + col];
             const float gh = g * Ht[i * LDH + col];
-            if (A.dbg != 1) {
+            if (!A.sorted && A.dbg != 1) {
               atomicAdd(A.g_lt + (size_t)s_p1[i] * D + col, gh);
               atomicAdd(A.g_lt + (size_t)s_q1[i] * D + col, -gh);
             }
@@ -821,8 +866,12 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
       for (int r = 0; r < 16; ++r) {
         const int i = c_row(r, lane), gr = r0 + i;
         if (gr < T) {
-          float* dst = col < D ? A.g_lt + (size_t)s_pt[i] * D + col : A.g_di + (size_t)s_dpt[i] * D + (col - D);
-          if (A.dbg != 1) atomicAdd(dst, acc[0][j][r]);
+          // sorted scatter: dx overwrites X (dead after te_wgrad) and te_reduce sums it per table row
+          if (A.sorted) A.X[(size_t)gr * 2 * D + col] = acc[0][j][r];
+          else {
+            float* dst = col < D ? A.g_lt + (size_t)s_pt[i] * D + col : A.g_di + (size_t)s_dpt[i] * D + (col - D);
+            if (A.dbg != 1) atomicAdd(dst, acc[0][j][r]);
+          }
         }
       }
     }
@@ -909,9 +958,11 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   const int n = A.n_seq, tiles = (n + 31) / 32;
   PackJobs J; te_pack_jobs(A, J, true);
   tm->begin("te_prep", st);
+  hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+  if (A.sorted) { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 0);
@@ -956,6 +1007,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   const int n = A.n_seq, tiles = (n + 31) / 32;
   PackJobs J; te_pack_jobs(A, J, false);
   tm->begin("te_predict", st);
+  hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);

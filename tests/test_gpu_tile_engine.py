@@ -102,3 +102,24 @@ def test_tile_predict_matches_oracle(pa, dim, n_dist):
     eh, es = O.spatial_predict(P, P["lt"], P["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
     assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
     model.ctx.set_engine("auto")
+
+
+def test_tile_sorted_scatter_hot_rows_are_exact_and_reproducible(pa):
+    """Few POIs / distance bins and many sequences: every table row collects hundreds of touches, so
+    the write-back goes through the chunked ("hot row") path of te_scatter.hip.  The result must match
+    the batch rule and - no float atomics, fixed summation order - be bitwise reproducible."""
+    T = toy_problem(91, n_user=300, n_item=26, n_dist=11, dim=64, len_max=12)
+    P = spatial_params(91, T)
+    users = np.random.default_rng(3).permutation(300).astype(np.int32)
+    exp, _ = _oracle_batch(P, T, users)
+    runs = []
+    for _ in range(2):
+        model = _model(pa, T, P)
+        model.ctx.set_engine("tile")
+        model.train_batch(users)
+        runs.append(_get(model))
+    for k in SP_NAMES:
+        assert_close(runs[0][k], exp[k], "hot rows " + k)
+    for k in ("lt", "di"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k + " differs between two identical launches"
+    pa._lib.context(0).set_engine("auto")
