@@ -176,8 +176,9 @@ def main():
     D2 = float(D * D)
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
             "te_gemm_ax": ("flop", 12 * D2 * steps_per_epoch), "te_rec_fwd": ("flop", 6 * D2 * steps_per_epoch),
-            "te_head": ("flop", 6.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
-            "te_wgrad": ("flop", 18 * D2 * steps_per_epoch), "te_gemm_dx": ("flop", 12 * D2 * steps_per_epoch),
+            "te_head": ("flop", 4.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
+            "te_wgrad": ("flop", (18 * D2 + 2.0 * NB * D) * steps_per_epoch),     # d ui, d wh and d vs (split-K)
+            "te_gemm_dx": ("flop", 12 * D2 * steps_per_epoch),
             "te_gather": ("byte", (3.0 * D * 4 + 16) * float(lens_local.sum())),
             "rows_apply": ("byte", 2.0 * uniq * D * 4.0),      # read + write of every touched row
             # sorted scatter: per step dx (2D floats) + g*h (D floats) in, every touched row read + written

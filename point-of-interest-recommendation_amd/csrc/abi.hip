@@ -24,14 +24,13 @@ struct poi_ctx {
   int wg_per_cu = 2;
   std::string err;
   // per-sequence engine
-  DevBuf ws, slab, te_ws;
+  DevBuf ws, slab, te_ws, hslab;
   int engine = 0;   // 0 auto, 1 per-sequence, 2 tile
   int wgrad_rounds = 2;
-  int head_rounds = 1;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
+  int head_rounds = 3;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
   int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1|2 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
-  int te_sorted = 1;        // POI_TE_SORTED=0: float-atomic scatter into the gradient tables (tuning / A-B only)
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
@@ -94,7 +93,6 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_HEAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->head_rounds = v; }
   if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->score_variant = v; }
-  if (const char* e = getenv("POI_TE_SORTED")) c->te_sorted = atoi(e) != 0;
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   *out = c;
@@ -103,7 +101,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e,
+  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e,
                    &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
@@ -150,10 +148,10 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 64;
   const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D;
   // sorted scatter (training): 3 slots per sequence position
-  const bool sorted = !predict && c->te_sorted;
+  const bool sorted = !predict;
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
   const size_t n_hot = Ncap / (TE_COLD_MAX + 1) + 2, n_chunk = Ncap / TE_HOT_CHUNK + n_hot + 2;
-  const size_t sfl = sorted ? Tcap + n_chunk * D + 64 : 0;
+  const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + 64 : 0;
   const size_t sin = sorted ? 7 * Ncap + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl;
   const size_t nin = Tcap * 3 + (size_t)n + 16 + sin;
@@ -168,12 +166,11 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.pUiT = (float4*)take((size_t)6 * D * D); A.pUi = (float4*)take((size_t)6 * D * D);
   A.pWhT = (float4*)take((size_t)3 * D * D); A.pWhc = (float4*)take((size_t)D * D); A.pWhzr = (float4*)take((size_t)2 * D * D);
   A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
-  if (sorted) { A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); }
+  if (sorted) { A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP); }
   int* ip = (int*)f;
   auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
   A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_seq = itake(Tcap);
   if (sorted) {
-    A.sorted = 1;
     int bits = 1; while ((1 << bits) <= R) ++bits;      // keys 0..R (R = sentinel)
     A.key_bits = bits;
     A.keys0 = itake(Ncap); A.keys1 = itake(Ncap); A.vals0 = itake(Ncap); A.vals1 = itake(Ncap);
@@ -208,9 +205,10 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   int n_head = 0, n_kc = 0, n_slab = grid;
   if (tile) {
     n_head = c->num_cu * c->head_rounds;
-    // te_wgrad launches 9 output-tile jobs x n_kc K-chunks: fill the CUs exactly (no ragged second round)
-    n_kc = (c->num_cu * c->wgrad_rounds) / 9; if (n_kc < 1) n_kc = 1;
-    n_slab = n_head > n_kc ? n_head : n_kc;
+    // te_wgrad launches (output-tile jobs) x n_kc K-chunks: fill the CUs exactly (no ragged second round)
+    n_kc = (c->num_cu * c->wgrad_rounds) / poi::te_wgrad_jobs(D, P->n_dist); if (n_kc < 1) n_kc = 1;
+    n_slab = n_kc;
+    if ((rc = ensure(c, c->hslab, sizeof(float) * (size_t)n_head * ((NB + 4) & ~3), st))) return rc;
   } else if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
   if ((rc = ensure(c, c->slab, sizeof(float) * (size_t)dl.total * n_slab, st))) return rc;
   if ((rc = ensure(c, c->g_lt, sizeof(float) * (size_t)(P->n_item + 1) * D, st))) return rc;
@@ -232,14 +230,11 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     poi::TeArgs E;
     if ((rc = te_setup(c, E, P, T, uidx, n, false, st))) return rc;
     E.out = out; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
-    E.g_lt = A.g_lt; E.g_di = A.g_di; E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
+    E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
+    E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
-    if (E.sorted) HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));
-    else {
-      int agrid = c->num_cu * 4; if (agrid > n) agrid = n;
-      HIPCHK(c, poi::launch_rows_apply(A, true, agrid, alpha, lambda, st, &c->tm));
-    }
-    HIPCHK(c, poi::launch_dense_apply(A, true, n_kc, n_head, alpha, lambda, st, &c->tm));
+    HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));
+    HIPCHK(c, poi::launch_dense_apply(A, true, n_kc, n_kc, alpha, lambda, st, &c->tm));
     return POI_OK;
   }
   HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st, &c->tm));

@@ -80,17 +80,16 @@ struct TeArgs {
   int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_seq;
-  float *X, *E, *G, *H, *RH, *DH, *rowloss;
+  float *X, *E, *G, *H, *RH, *DH, *DL, *rowloss;   // DL: d logits (T x padded bins)
   float4 *pUiT, *pUi, *pWhT, *pWhc, *pWhzr, *pVsT, *pVs;
   float* slab;
   int n_slab, n_head, n_kc;
+  float* hslab; int hstride;          // te_head's per-workgroup d bs | d wd partials (n_head x hstride)
   DenseLayout dl;
-  float *g_lt, *g_di;
-  int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
+  int *mult_lt, *nseq_lt, *mult_di, *nseq_di;    // only the padding rows' entries are used (analytic touches)
   float *hts, *sts;
   // sorted segmented scatter (te_scatter.hip): every table touch of the launch becomes one (row key,
   // entry) pair; a stable radix sort groups them by row, and each row's update is a plain ordered sum
-  int sorted;                         // 1: sorted scatter (default), 0: float atomics into g_lt / g_di
   int key_bits;                       // bits of the largest key (= sentinel = number of table rows)
   int *keys0, *keys1, *vals0, *vals1; // sort ping-pong (key = unified row id, value = slot)
   int *code, *slot_seq;               // per slot: entry code, sequence index in the launch
@@ -116,6 +115,7 @@ struct TeArgs {
 #define RS_GRID 256
 #define RS_HIST_INTS (RS_MAXBIN * RS_GRID)   // radix histogram: bins x blocks
 bool te_supported(int D, int n_dist);
+int te_wgrad_jobs(int D, int n_dist);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 int te_nbp(int n_dist);

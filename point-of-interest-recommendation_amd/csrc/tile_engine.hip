@@ -107,6 +107,38 @@ __device__ __forceinline__ void mma_lds_packed(f32x16 (&acc)[MT][NTW], const flo
   }
 }
 
+// Low-register variant for kernels that run several workgroups per CU (occupancy hides the L2 latency
+// of the packed B stream): depth-1 prefetch, loop unrolled by 2 only.
+template <int MT, int NTW, int K8>
+__device__ __forceinline__ void mma_lds_stream(f32x16 (&acc)[MT][NTW], const float* __restrict__ ldsA, int lda,
+                                               const float4* __restrict__ bp, const int (&nt)[NTW]) {
+  const int lane = lane_id(), li = lane & 31, h = lane >> 5;
+  const float* arow = ldsA + li * lda + 4 * h;
+  float4 bc[NTW], bn[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) bc[j] = bp[((size_t)nt[j] * K8) * 64 + lane];
+#pragma unroll 2
+  for (int m = 0; m < K8; ++m) {
+    const int mn = m + 1 < K8 ? m + 1 : m;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bn[j] = bp[((size_t)nt[j] * K8 + mn) * 64 + lane];
+    float4 a[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda + 8 * m);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        acc[i][j] = mfma32(a[i].x, bc[j].x, acc[i][j]);
+        acc[i][j] = mfma32(a[i].y, bc[j].y, acc[i][j]);
+        acc[i][j] = mfma32(a[i].z, bc[j].z, acc[i][j]);
+        acc[i][j] = mfma32(a[i].w, bc[j].w, acc[i][j]);
+      }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bc[j] = bn[j];
+  }
+}
+
 // Same contraction with the B fragments already in registers (the recurrent kernels keep each wave's
 // own 32 weight columns of every gate resident for the whole sequence loop: D/8 float4 per gate).
 template <int K8>
@@ -159,43 +191,6 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   }
 }
 
-// one wavefront per sequence: row maps + table-touch counts (same rules as seq_engine count_rows).
-// The sequence's ids are staged in the wave's LDS slice so that the O(L^2) first-occurrence test
-// reads LDS (all lanes read the same j: broadcast) instead of global memory.
-#define TE_CNT_MAX 256     // ids per sequence handled through LDS (2 * L <= 256); longer falls back to global reads
-// Returns (in every lane) the number of literal occurrences of `pad_row` among the ids; those and
-// the analytic padding multiplicity are accumulated per workgroup by the caller, because EVERY
-// sequence touches the padding rows and ~6 same-address device atomics per sequence serialise
-// (13 ns each).
-__device__ __forceinline__ int te_count(const int* a, const int* b, int L, bool two, int pad_row,
-                                        int* mult, int* nseq, int* ids) {
-  const int n = two ? 2 * L : L, lane = lane_id();
-  const bool in_lds = n <= TE_CNT_MAX;
-  if (in_lds) {
-    for (int e = lane; e < n; e += 64) ids[e] = (two && e >= L) ? b[e - L] : a[e];
-    __builtin_amdgcn_wave_barrier();
-  }
-  int pads = 0;
-  for (int e0 = 0; e0 < n; e0 += 64) {
-    const int e = e0 + lane;
-    bool is_pad = false;
-    if (e < n) {
-      const int row = in_lds ? ids[e] : ((two && e >= L) ? b[e - L] : a[e]);
-      is_pad = row == pad_row;
-      if (!is_pad) {
-        atomicAdd(&mult[row], 1);
-        int dup = 0;
-        if (in_lds) { for (int j = 0; j < e; ++j) dup |= (ids[j] == row) ? 1 : 0; }
-        else { for (int j = 0; j < e; ++j) dup |= (((two && j >= L) ? b[j - L] : a[j]) == row) ? 1 : 0; }
-        if (!dup) atomicAdd(&nseq[row], 1);
-      }
-    }
-    pads += __builtin_popcountll(__ballot(is_pad));
-  }
-  __builtin_amdgcn_wave_barrier();
-  return pads;
-}
-
 #define TE_SEQ_PER_WAVE 4
 // Sorted-scatter slots of one sequence (te_scatter.hip): 3 * (ns + 1) slots at 3 * (r0 + k):
 // [0, L) POI ids of p, [L, 2L) negatives q, [2L, 3L) distance bins dp, rest sentinels.  Returns the
@@ -222,8 +217,11 @@ __device__ __forceinline__ void te_slots(const TeArgs& A, int k, int base, int L
   *pads_lt = plt; *pads_di = pdi;
 }
 
+// one wavefront per sequence: packed row -> CSR position maps, sorted-scatter slots, and the analytic
+// part of the padding rows' bookkeeping (every sequence shorter than len_max touches the padding rows
+// 2*(len_max-L) / (len_max-L) times: public/GRU_Spatial.py:202-203), aggregated per workgroup because
+// same-address device atomics serialise.
 __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
-  __shared__ int s_ids[POI_NWAVE][TE_CNT_MAX];
   __shared__ int s_pad[POI_NWAVE][4];
   const int w = wave_id(), lane = lane_id();
   int m_lt = 0, n_lt = 0, m_di = 0, n_di = 0;
@@ -233,17 +231,11 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
     const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = A.soff[k];
     for (int t = lane; t < ns; t += 64) { A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t; A.row_seq[r0 + t] = k; }
     if (A.predict) continue;
-    if (A.sorted) {
-      int plt, pdi;
-      te_slots(A, k, base, L, ns, r0, &plt, &pdi);
-      // the literal occurrences are counted by their row segment; only the analytic part goes here
-      m_lt += 2 * (A.len_max - L); n_lt += (2 * (A.len_max - L) + plt) > 0;
-      m_di += (A.len_max - L); n_di += ((A.len_max - L) + pdi) > 0;
-      continue;
-    }
-    const int c_lt = 2 * (A.len_max - L) + te_count(A.p + base, A.q + base, L, true, A.n_item, A.mult_lt, A.nseq_lt, s_ids[w]);
-    const int c_di = (A.len_max - L) + te_count(A.dp + base, A.dp + base, L, false, A.n_dist, A.mult_di, A.nseq_di, s_ids[w]);
-    m_lt += c_lt; n_lt += c_lt > 0; m_di += c_di; n_di += c_di > 0;
+    int plt, pdi;
+    te_slots(A, k, base, L, ns, r0, &plt, &pdi);
+    // literal occurrences of a padding id are counted by its row segment; only the analytic part goes here
+    m_lt += 2 * (A.len_max - L); n_lt += (2 * (A.len_max - L) + plt) > 0;
+    m_di += (A.len_max - L); n_di += ((A.len_max - L) + pdi) > 0;
   }
   if (A.predict) return;
   if (lane == 0) { s_pad[w][0] = m_lt; s_pad[w][1] = n_lt; s_pad[w][2] = m_di; s_pad[w][3] = n_di; }
@@ -436,19 +428,20 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
 
 // -------------------------------------------------------------------------------------------------
 // te_head: 32 packed rows per iteration (persistent grid).  NBT = number of 32-bin tiles (bins padded).
-// mode 0: training (losses, d logits, DH, d vs partials, +-g*h scatter); mode 1: predict (sts only,
-// rows = sequences, H = hts).
+// mode 0: training - losses, d logits (stored to DL for the d vs job of te_wgrad), DH = d logits . vs
+// + g * E, g (for the sorted scatter), d bs / d wd partials; mode 1: predict (sts only, rows =
+// sequences, H = hts).  Small enough in registers (no d vs accumulators) and LDS (E never staged) for
+// three workgroups per CU, whose MFMA / softmax / staging phases overlap.
 // -------------------------------------------------------------------------------------------------
 template <int D, int NBT>
-__global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
+__global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode) {
   extern __shared__ __align__(16) float lds[];
   constexpr int K8 = D / 8, LDH = D + 4, NBP = NBT * 32, LDO = NBP + 4, NTW = (NBT + 3) / 4, NTD = D / 32;
-  constexpr int KB8 = NBP / 8, DTW = (NTD + 3) / 4, VT = (NBT * NTD + 3) / 4;   // d vs tiles per wave
+  constexpr int KB8 = NBP / 8, DTW = (NTD + 3) / 4, LPR = D / 4;
   float* Ht = lds;                  // 32 x LDH
   float* Ot = Ht + 32 * LDH;        // 32 x LDO : logits -> softmax -> d logits
-  float* Et = Ot + 32 * LDO;        // 32 x LDH : E tile (training only)
-  __shared__ float s_g[32], s_red[8];
-  __shared__ int s_p1[32], s_q1[32], s_a[32], s_b[32];   // destination rows / target bins of the tile's rows
+  __shared__ float s_g[32], s_he[32], s_red[8];
+  __shared__ int s_a[32], s_b[32];   // target bins of the tile's rows
   const int NB = A.n_dist + 1;
   const int T = mode ? A.n_seq : A.soff[A.n_seq];
   const float* Hsrc = mode ? A.hts : A.H;
@@ -462,35 +455,31 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
   int nto[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) nto[j] = min(w + 4 * j, NBT - 1);
-  // d vs accumulators: output tile v = w + 4*jj covers bins tile (v / NTD), hidden tile (v % NTD)
-  f32x16 dvs[VT];
-#pragma unroll
-  for (int v = 0; v < VT; ++v)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dvs[v][r] = 0.f;
   float dbs_acc = 0.f;      // thread tid < NBP accumulates d bs[tid]
   float dwd_acc = 0.f;      // meaningful in the row-owner lanes, reduced at the end
 
-  // async-stage split: the NEXT tile's H / E rows and row metadata are fetched into registers while
-  // the current tile computes, and written to LDS at the top of the next iteration
-  constexpr int SF4 = 32 * (D / 4) / TE_BLOCK;          // float4 per thread per staged tile
-  float4 ph[SF4], pe[SF4];
-  int pm[4] = {0, 0, 0, 0};
+  // async-stage split: the NEXT tile's H rows, h.e partial dot products and target bins are fetched
+  // into registers while the current tile computes, and written to LDS at the top of the next iteration
+  constexpr int SF4 = 32 * LPR / TE_BLOCK;          // float4 per thread per staged tile
+  float4 ph[SF4];
+  float phe[SF4];
+  int pm[2] = {0, 0};
   auto prefetch = [&](int r0) {
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
-      const int e = tid + q * TE_BLOCK, r = e / (D / 4), c = (e % (D / 4)) * 4;
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
       float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), ve = vh;
       if (r0 + r < T) {
         vh = *reinterpret_cast<const float4*>(Hsrc + (size_t)(r0 + r) * D + c);
         if (!mode) ve = *reinterpret_cast<const float4*>(A.E + (size_t)(r0 + r) * D + c);
       }
-      ph[q] = vh; pe[q] = ve;
+      ph[q] = vh;
+      phe[q] = (vh.x * ve.x + vh.y * ve.y) + (vh.z * ve.z + vh.w * ve.w);
     }
     if (!mode && tid < 32) {
       const int gr = r0 + tid;
-      pm[0] = pm[1] = pm[2] = pm[3] = 0;
-      if (gr < T) { const int s = A.row_src[gr]; pm[0] = A.p[s + 1]; pm[1] = A.q[s + 1]; pm[2] = A.dp[s + 1]; pm[3] = A.dq[s + 1]; }
+      pm[0] = pm[1] = 0;
+      if (gr < T) { const int s = A.row_src[gr]; pm[0] = A.dp[s + 1]; pm[1] = A.dq[s + 1]; }
     }
   };
   if ((int)blockIdx.x * 32 < T) prefetch(blockIdx.x * 32);
@@ -498,11 +487,16 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
-      const int e = tid + q * TE_BLOCK, r = e / (D / 4), c = (e % (D / 4)) * 4;
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
       *reinterpret_cast<float4*>(Ht + r * LDH + c) = ph[q];
-      if (!mode) *reinterpret_cast<float4*>(Et + r * LDH + c) = pe[q];
+      if (!mode) {     // h . e of row r: sum over the LPR lanes that hold the row
+        float d = phe[q];
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+        if ((tid % LPR) == 0) s_he[r] = d;
+      }
     }
-    if (!mode && tid < 32) { s_p1[tid] = pm[0]; s_q1[tid] = pm[1]; s_a[tid] = pm[2]; s_b[tid] = pm[3]; }
+    if (!mode && tid < 32) { s_a[tid] = pm[0]; s_b[tid] = pm[1]; }
     lds_barrier();
     if (r0 + (int)gridDim.x * 32 < T) prefetch(r0 + gridDim.x * 32);
     {   // logits
@@ -511,7 +505,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-      mma_lds_packed<1, NTW, K8>(acc, Ht, LDH, A.pVsT, nto);
+      mma_lds_stream<1, NTW, K8>(acc, Ht, LDH, A.pVsT, nto);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         if (w + 4 * j >= NBT) continue;
@@ -536,12 +530,11 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
         if (gr < T) for (int k = sub; k < NB; k += 8) A.sts[(size_t)gr * NB + k] = o[k] * inv;
       } else {
         const int a = s_a[row], b = s_b[row];
-        float cum = 0.f, he = 0.f;
+        const float he = s_he[row];
+        float cum = 0.f;
         for (int k = sub; k < NBP; k += 8) { const float s = o[k] * inv; o[k] = s; if (k <= a) cum += s; }
-        for (int j = sub; j < D; j += 8) he += Ht[row * LDH + j] * Et[row * LDH + j];
         cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
-        he += dpp_f<0xB1>(he); he += dpp_f<0x4E>(he); he += dpp_f<0x141>(he);
-        // (the 8 lanes of a row now hold identical cum / he; they all wrote disjoint o[k])
+        // (the 8 lanes of a row now hold identical cum; they all wrote disjoint o[k])
         __builtin_amdgcn_wave_barrier();
         const float sa = o[a], sb = o[b];
         float g = 0.f, dot = 0.f;
@@ -552,10 +545,11 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
           if (sub == 0) {
             A.rowloss[2 * (size_t)gr] = cum - logf(sa);
             A.rowloss[2 * (size_t)gr + 1] = log_sigmoidf_(u);
+            A.gcoef[gr] = g;
             dwd_acc += g * (sa - sb);
           }
         }
-        if (sub == 0) { s_g[row] = g; if (A.sorted && gr < T) A.gcoef[gr] = g; }
+        if (sub == 0) s_g[row] = g;
         __builtin_amdgcn_wave_barrier();
         for (int k = sub; k < NBP; k += 8) {
           float dl = 0.f;
@@ -571,17 +565,31 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
     }
     lds_barrier();
     if (!mode) {
-      if (tid < NBP) { float s = 0.f; for (int r = 0; r < 32; ++r) s += Ot[r * LDO + tid]; dbs_acc += s; }
-      // DH = d logits . vs + g * E ; +-g*h scatter
+      // g * E of this lane's DH elements: issued now, consumed after the MFMAs
       int ntd[DTW];
 #pragma unroll
       for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
+      float ge[DTW][16];
+#pragma unroll
+      for (int j = 0; j < DTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = c_row(r, lane), gr = r0 + i;
+          ge[j][r] = gr < T ? A.E[(size_t)gr * D + ntd[j] * 32 + li] : 0.f;
+        }
+      // d logits -> DL (A operand of the d vs job of te_wgrad), d bs partials
+      for (int e = tid; e < 32 * (NBP / 4); e += TE_BLOCK) {
+        const int r = e / (NBP / 4), c = (e % (NBP / 4)) * 4;
+        if (r0 + r < T) *reinterpret_cast<float4*>(A.DL + (size_t)(r0 + r) * NBP + c) = *reinterpret_cast<const float4*>(Ot + r * LDO + c);
+      }
+      if (tid < NBP) { float s = 0.f; for (int r = 0; r < 32; ++r) s += Ot[r * LDO + tid]; dbs_acc += s; }
+      // DH = d logits . vs + g * E
       f32x16 acc[1][DTW];
 #pragma unroll
       for (int j = 0; j < DTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-      mma_lds_packed<1, DTW, KB8>(acc, Ot, LDO, A.pVs, ntd);
+      mma_lds_stream<1, DTW, KB8>(acc, Ot, LDO, A.pVs, ntd);
 #pragma unroll
       for (int j = 0; j < DTW; ++j) {
         if (w + 4 * j >= NTD) continue;
@@ -589,47 +597,16 @@ __global__ __launch_bounds__(TE_BLOCK) void te_head_kernel(TeArgs A, int mode) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int i = c_row(r, lane), gr = r0 + i;
-          if (gr < T) {
-            const float g = s_g[i];
-            A.DH[(size_t)gr * D + col] = acc[0][j][r] + g * Et[i * LDH + col];
-            const float gh = g * Ht[i * LDH + col];
-            if (!A.sorted && A.dbg != 1) {
-              atomicAdd(A.g_lt + (size_t)s_p1[i] * D + col, gh);
-              atomicAdd(A.g_lt + (size_t)s_q1[i] * D + col, -gh);
-            }
-          }
-        }
-      }
-      // d vs += d logits^T . H   (A[i = bin][k = row] from Ot, B[k = row][j = hidden col] from Ht)
-#pragma unroll
-      for (int v = 0; v < VT; ++v) {
-        const int vt = w + 4 * v;
-        if (vt >= NBT * NTD) continue;
-        const int bt = vt / NTD, ht = vt % NTD;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const int row = 2 * kk + (lane >> 5);
-          dvs[v] = mfma32(Ot[row * LDO + bt * 32 + li], Ht[row * LDH + ht * 32 + li], dvs[v]);
+          if (gr < T) A.DH[(size_t)gr * D + col] = acc[0][j][r] + s_g[i] * ge[j][r];
         }
       }
     }
   }
   if (!mode) {
-    float* slab = A.slab + (size_t)blockIdx.x * A.dl.total;
-#pragma unroll
-    for (int v = 0; v < VT; ++v) {
-      const int vt = w + 4 * v;
-      if (vt >= NBT * NTD) continue;
-      const int bt = vt / NTD, ht = vt % NTD;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int bin = bt * 32 + c_row(r, lane);
-        if (bin < NB) slab[A.dl.vs + (size_t)bin * D + ht * 32 + li] += dvs[v][r];
-      }
-    }
-    if (tid < NB) slab[A.dl.bs + tid] += dbs_acc;
+    float* hs = A.hslab + (size_t)blockIdx.x * A.hstride;
+    if (tid < NB) hs[tid] += dbs_acc;
     const float dw = block_sum(dwd_acc, s_red);
-    if (tid == 0) slab[A.dl.wd] += dw;
+    if (tid == 0) hs[NB] += dw;
   }
 }
 
@@ -747,19 +724,23 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
 // accumulators; each 32-row stage is loaded from HBM/L2 into registers BEFORE the MFMA block of the
 // previous stage and written to the other LDS buffer after it (async-stage split, one barrier/stage).
 // -------------------------------------------------------------------------------------------------
+__host__ __device__ inline int te_nbp_dev(int n_dist) { const int t = (n_dist + 1 + 31) / 32; return 32 * (t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8); }
+
 template <int D, int T>
 __global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
   constexpr int XW = 2 * D, LDT = T + 4, Q = T / 64;         // Q x Q accumulators per wave
   constexpr int F4 = 32 * (T / 4) / TE_BLOCK;                // float4 per thread per operand per stage
   __shared__ __align__(16) float At[2][32][LDT];
   __shared__ __align__(16) float Bt[2][32][LDT];
-  constexpr int NB_UI = (3 * D / T) * (XW / T), NB_ZR = (2 * D / T) * (D / T);
+  constexpr int NB_UI = (3 * D / T) * (XW / T), NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
   const int Trows = A.soff[A.n_seq];
   const int job = blockIdx.x, kc = blockIdx.y;
   int m0, n0, ldo, bsel; size_t oo;
   if (job < NB_UI) { const int bn = XW / T; m0 = (job / bn) * T; n0 = (job % bn) * T; ldo = XW; oo = A.dl.ui; bsel = 0; }
   else if (job < NB_UI + NB_ZR) { const int j = job - NB_UI, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.wh; bsel = 1; }
-  else { const int j = job - NB_UI - NB_ZR, bn = D / T; m0 = 2 * D + (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
+  else if (job < NB_UI + NB_ZR + NB_C) { const int j = job - NB_UI - NB_ZR, bn = D / T; m0 = 2 * D + (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
+  else { const int j = job - NB_UI - NB_ZR - NB_C, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.vs; bsel = 3; }   // d vs = DL^T . H
+  const int NBP = te_nbp_dev(A.n_dist), NB = A.n_dist + 1;
   const int chunk = (((Trows + nkc - 1) / nkc) + 31) & ~31;
   const int rb = kc * chunk, re = min(Trows, rb + chunk);
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
@@ -779,8 +760,10 @@ __global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
       const int r = e / (T / 4), c = (e % (T / 4)) * 4, gr = r0 + r;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
       if (gr < re) {
-        a = *reinterpret_cast<const float4*>(A.G + (size_t)gr * 3 * D + m0 + c);
-        if (bsel == 0) b = *reinterpret_cast<const float4*>(A.X + (size_t)gr * XW + n0 + c);
+        if (bsel != 3) a = *reinterpret_cast<const float4*>(A.G + (size_t)gr * 3 * D + m0 + c);
+        else if (m0 + c < NBP) a = *reinterpret_cast<const float4*>(A.DL + (size_t)gr * NBP + m0 + c);
+        if (bsel == 3) b = *reinterpret_cast<const float4*>(A.H + (size_t)gr * D + n0 + c);
+        else if (bsel == 0) b = *reinterpret_cast<const float4*>(A.X + (size_t)gr * XW + n0 + c);
         else if (bsel == 1) { if (A.row_t[gr] > 0) b = *reinterpret_cast<const float4*>(A.H + (size_t)(gr - 1) * D + n0 + c); }
         else b = *reinterpret_cast<const float4*>(A.RH + (size_t)gr * D + n0 + c);
       }
@@ -825,12 +808,15 @@ __global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
 #pragma unroll
     for (int j = 0; j < Q; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        out[(size_t)(mbase + 32 * i + c_row(r, lane)) * ldo + n0 + wn + 32 * j + li] += acc[i][j][r];
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + 32 * i + c_row(r, lane);
+        if (bsel != 3 || m < NB) out[(size_t)m * ldo + n0 + wn + 32 * j + li] += acc[i][j][r];
+      }
 }
 
 // -------------------------------------------------------------------------------------------------
-// te_gemm_dx: dx[r] = DA[r] . ui (K = 3D, N = 2D); columns [0, D) -> g_lt[p_t], [D, 2D) -> g_di[dp_t]
+// te_gemm_dx: dx[r] = DA[r] . ui (K = 3D, N = 2D), stored over X[r]: columns [0, D) belong to table row
+// lt[p_t], [D, 2D) to di[dp_t] (summed per row by the sorted scatter, te_scatter.hip)
 // -------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
@@ -841,16 +827,9 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
   int nt[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
-  __shared__ int s_pt[32], s_dpt[32];
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
     lds_barrier();
     stage_rows(lds, LDA, A.G, K, K, r0, 32, T);
-    if (threadIdx.x < 32) {
-      const int gr = r0 + threadIdx.x;
-      int pt = 0, dpt = 0;
-      if (gr < T) { const int s = A.row_src[gr]; pt = A.p[s]; dpt = A.dp[s]; }
-      s_pt[threadIdx.x] = pt; s_dpt[threadIdx.x] = dpt;
-    }
     lds_barrier();
     f32x16 acc[1][NTW];
 #pragma unroll
@@ -866,12 +845,8 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
       for (int r = 0; r < 16; ++r) {
         const int i = c_row(r, lane), gr = r0 + i;
         if (gr < T) {
-          // sorted scatter: dx overwrites X (dead after te_wgrad) and te_reduce sums it per table row
-          if (A.sorted) A.X[(size_t)gr * 2 * D + col] = acc[0][j][r];
-          else {
-            float* dst = col < D ? A.g_lt + (size_t)s_pt[i] * D + col : A.g_di + (size_t)s_dpt[i] * D + (col - D);
-            if (A.dbg != 1) atomicAdd(dst, acc[0][j][r]);
-          }
+          // dx overwrites X (dead after te_wgrad); te_reduce sums it per table row
+          A.X[(size_t)gr * 2 * D + col] = acc[0][j][r];
         }
       }
     }
@@ -903,9 +878,25 @@ __global__ __launch_bounds__(TE_BLOCK) void te_finalize_kernel(TeArgs A) {
   }
 }
 
+// te_head's per-workgroup d bs | d wd partials -> slab 0 (fixed order: lane-strided sums + DPP tree);
+// one wavefront per element, partials re-zeroed
+__global__ __launch_bounds__(TE_BLOCK) void te_hslab_kernel(TeArgs A) {
+  const int j = blockIdx.x * POI_NWAVE + wave_id(), NB = A.n_dist + 1;
+  if (j > NB) return;
+  float s = 0.f;
+  for (int k = lane_id(); k < A.n_head; k += 64) { float* p = A.hslab + (size_t)k * A.hstride + j; s += *p; *p = 0.f; }
+  s = wave_sum(s);
+  if (lane_id() == 0) A.slab[A.dl.bs + j] += s;
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
+int te_wgrad_jobs(int D, int n_dist) {
+  const int T = (D % 128 == 0) ? 128 : 64;
+  return (3 * D / T) * (2 * D / T) + (2 * D / T) * (D / T) + (D / T) * (D / T) + ((te_nbp_dev(n_dist) + T - 1) / T) * (D / T);
+}
+
 bool te_supported(int D, int n_dist) { return (D == 64 || D == 128) && n_dist + 1 <= 256; }
 
 int te_nbp(int n_dist);
@@ -915,7 +906,7 @@ int te_nbp(int n_dist) { return nbt_for(n_dist + 1) * 32; }
 
 template <int D, int NBT>
 static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_t st) {
-  const size_t lds = sizeof(float) * (2 * 32 * (D + 4) + 32 * (NBT * 32 + 4));
+  const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (NBT * 32 + 4));
   hipLaunchKernelGGL((te_head_kernel<D, NBT>), dim3(grid), dim3(TE_BLOCK), lds, st, A, mode);
   return hipGetLastError();
 }
@@ -962,7 +953,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
-  if (A.sorted) { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
+  { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 0);
@@ -983,7 +974,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->begin("te_wgrad", st);
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
-    const int jobs = (3 * D / T) * (2 * D / T) + (2 * D / T) * (D / T) + (D / T) * (D / T);
+    const int jobs = te_wgrad_jobs(D, A.n_dist);
     hipLaunchKernelGGL((te_wgrad_kernel<D, T>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
@@ -992,6 +983,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_finalize", st);
   hipLaunchKernelGGL(te_finalize_kernel, dim3((n + TE_BLOCK - 1) / TE_BLOCK), dim3(TE_BLOCK), 0, st, A);
+  hipLaunchKernelGGL(te_hslab_kernel, dim3((A.n_dist + 2 + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
   tm->end(st);
   return hipGetLastError();
 }
