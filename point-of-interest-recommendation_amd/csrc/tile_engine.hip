@@ -727,7 +727,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
 __host__ __device__ inline int te_nbp_dev(int n_dist) { const int t = (n_dist + 1 + 31) / 32; return 32 * (t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8); }
 
 template <int D, int T>
-__global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
+__global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc) {
   constexpr int XW = 2 * D, LDT = T + 4, Q = T / 64;         // Q x Q accumulators per wave
   constexpr int F4 = 32 * (T / 4) / TE_BLOCK;                // float4 per thread per operand per stage
   __shared__ __align__(16) float At[2][32][LDT];
@@ -752,54 +752,81 @@ __global__ __launch_bounds__(TE_BLOCK) void te_wgrad_kernel(TeArgs A, int nkc) {
     for (int j = 0; j < Q; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float4 ra[F4], rbv[F4];
-  auto gload = [&](int r0) {
-#pragma unroll
-    for (int s = 0; s < F4; ++s) {
-      const int e = tid + s * TE_BLOCK;
-      const int r = e / (T / 4), c = (e % (T / 4)) * 4, gr = r0 + r;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (gr < re) {
-        if (bsel != 3) a = *reinterpret_cast<const float4*>(A.G + (size_t)gr * 3 * D + m0 + c);
-        else if (m0 + c < NBP) a = *reinterpret_cast<const float4*>(A.DL + (size_t)gr * NBP + m0 + c);
-        if (bsel == 3) b = *reinterpret_cast<const float4*>(A.H + (size_t)gr * D + n0 + c);
-        else if (bsel == 0) b = *reinterpret_cast<const float4*>(A.X + (size_t)gr * XW + n0 + c);
-        else if (bsel == 1) { if (A.row_t[gr] > 0) b = *reinterpret_cast<const float4*>(A.H + (size_t)(gr - 1) * D + n0 + c); }
-        else b = *reinterpret_cast<const float4*>(A.RH + (size_t)gr * D + n0 + c);
-      }
-      ra[s] = a; rbv[s] = b;
-    }
-  };
-  auto lstore = [&](int buf) {
+  // two register sets: the stage loaded during iteration i is written to LDS at the end of iteration
+  // i+1 and consumed in iteration i+2, so a global load has two MFMA blocks to land.  Loads are
+  // unconditional (clamped addresses) and masked when they are written to LDS: no branch, no wait.
+  const float* Ap = bsel != 3 ? A.G + m0 : A.DL + m0;
+  const int lda = bsel != 3 ? 3 * D : NBP;
+  const float* Bp = bsel == 0 ? A.X + n0 : bsel == 2 ? A.RH + n0 : A.H + n0;
+  const int ldb = bsel == 0 ? XW : D;
+  const int acols = bsel != 3 ? T : max(0, min(T, NBP - m0));     // valid columns of the A block
+  const int bshift = bsel == 1 ? 1 : 0;
+  float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
+  int rt0[F4], rt1[F4];
+  auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4]) {
 #pragma unroll
     for (int s = 0; s < F4; ++s) {
       const int e = tid + s * TE_BLOCK;
       const int r = e / (T / 4), c = (e % (T / 4)) * 4;
-      *reinterpret_cast<float4*>(&At[buf][r][c]) = ra[s];
-      *reinterpret_cast<float4*>(&Bt[buf][r][c]) = rbv[s];
+      const int gr = min(r0 + r, Trows - 1);
+      rt[s] = A.row_t[gr];                                      // h_{t-1} operand (bsel 1): none at the first step
+      ra[s] = *reinterpret_cast<const float4*>(Ap + (size_t)gr * lda + (c < acols ? c : 0));
+      rbv[s] = *reinterpret_cast<const float4*>(Bp + (size_t)max(gr - bshift, 0) * ldb + c);
     }
   };
-  if (rb < re) { gload(rb); lstore(0); }
-  __syncthreads();
-  int buf = 0;
-  for (int r0 = rb; r0 < re; r0 += 32) {
-    const bool more = r0 + 32 < re;
-    if (more) gload(r0 + 32);
+  auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4]) {
+#pragma unroll
+    for (int s = 0; s < F4; ++s) {
+      const int e = tid + s * TE_BLOCK;
+      const int r = e / (T / 4), c = (e % (T / 4)) * 4;
+      const bool in = r0 + r < re;
+      // (component-wise selects: a select between float4 aggregates sends the arrays to scratch)
+      const bool oa = in && c < acols, ob = in && rt[s] >= bshift;
+      *reinterpret_cast<float4*>(&At[buf][r][c]) = make_float4(oa ? ra[s].x : 0.f, oa ? ra[s].y : 0.f, oa ? ra[s].z : 0.f, oa ? ra[s].w : 0.f);
+      *reinterpret_cast<float4*>(&Bt[buf][r][c]) = make_float4(ob ? rbv[s].x : 0.f, ob ? rbv[s].y : 0.f, ob ? rbv[s].z : 0.f, ob ? rbv[s].w : 0.f);
+    }
+  };
+  // operands of MFMA step kk+1 are read from LDS before the MFMAs of step kk are issued (the compiler
+  // does not software-pipeline ds_read across the unrolled steps on its own)
+  auto mma = [&](int buf) {
+    float av[2][Q], bv[2][Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) av[0][i] = At[buf][h][wm + 32 * i + li];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) bv[0][j] = Bt[buf][h][wn + 32 * j + li];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      float av[Q], bv[Q];
+      if (kk + 1 < 16) {
 #pragma unroll
-      for (int i = 0; i < Q; ++i) av[i] = At[buf][2 * kk + h][wm + 32 * i + li];
+        for (int i = 0; i < Q; ++i) av[(kk + 1) & 1][i] = At[buf][2 * (kk + 1) + h][wm + 32 * i + li];
 #pragma unroll
-      for (int j = 0; j < Q; ++j) bv[j] = Bt[buf][2 * kk + h][wn + 32 * j + li];
+        for (int j = 0; j < Q; ++j) bv[(kk + 1) & 1][j] = Bt[buf][2 * (kk + 1) + h][wn + 32 * j + li];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the reads of step kk+1 above the MFMAs of step kk
 #pragma unroll
       for (int i = 0; i < Q; ++i)
 #pragma unroll
-        for (int j = 0; j < Q; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+        for (int j = 0; j < Q; ++j) acc[i][j] = mfma32(av[kk & 1][i], bv[kk & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) lstore(buf ^ 1);
+  };
+  if (rb < re) {
+    gload(rb, ra0, rb0, rt0); lstore(0, rb, ra0, rb0, rt0);
+    if (rb + 32 < re) gload(rb + 32, ra0, rb0, rt0);
+  }
+  __syncthreads();
+  for (int r0 = rb; r0 < re; r0 += 64) {
+    // even stage: LDS buffer 0; set 0 holds stage +1, set 1 receives stage +2
+    if (r0 + 64 < re) gload(r0 + 64, ra1, rb1, rt1);
+    mma(0);
+    if (r0 + 32 < re) lstore(1, r0 + 32, ra0, rb0, rt0);
     __syncthreads();
-    buf ^= 1;
+    if (r0 + 32 >= re) break;
+    // odd stage: LDS buffer 1; set 1 holds stage +1, set 0 receives stage +2
+    if (r0 + 96 < re) gload(r0 + 96, ra0, rb0, rt0);
+    mma(1);
+    if (r0 + 64 < re) lstore(0, r0 + 64, ra1, rb1, rt1);
+    __syncthreads();
   }
   float* out = A.slab + (size_t)kc * A.dl.total + oo;
   const int mbase = (bsel == 2 ? m0 - 2 * D : m0) + wm;
