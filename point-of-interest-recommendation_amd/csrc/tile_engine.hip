@@ -71,87 +71,71 @@ __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
 }
 
 // acc[i][j] += A_i (32 x 8*K8, LDS row-major, leading dim lda) . B_j (packed n-tile j of `bp`)
-// The packed B stream is prefetched PF k-groups ahead through a register ring: one k-group is only
-// 4*MT*NTW MFMAs (0.1 - 0.6 us), shorter than the L2 latency, so a depth-1 prefetch starves the
-// matrix pipe.  All ring indices are compile-time after unrolling (no scratch).
-template <int MT, int NTW, int K8, int PF = 4>
+// Explicit software pipeline, one k-group deep: the packed B fragments (L2) and the A fragments (LDS)
+// of k-group m+1 are requested before the MFMAs of k-group m are issued; sched_barriers pin that
+// order, because the compiler otherwise sinks every operand read next to its first MFMA (exposing the
+// LDS latency once per k-group) or, fully unrolled, hoists them all and spills.  The loop is unrolled
+// by two only (register renaming of the double buffers); the kernels using it run 2-3 waves per SIMD,
+// which covers the L2 latency of the B stream.
+template <int MT, int NTW, int K8>
 __device__ __forceinline__ void mma_lds_packed(f32x16 (&acc)[MT][NTW], const float* __restrict__ ldsA, int lda,
                                                const float4* __restrict__ bp, const int (&nt)[NTW]) {
   const int lane = lane_id(), li = lane & 31, h = lane >> 5;
   const float* arow = ldsA + li * lda + 4 * h;
-  constexpr int R = PF + 1;
-  float4 bq[R][NTW];
+  const float4* bj[NTW];
+  float4 bc[NTW], bn[NTW], ac[MT], an[MT];
 #pragma unroll
-  for (int m = 0; m < PF && m < K8; ++m)
+  for (int j = 0; j < NTW; ++j) { bj[j] = bp + ((size_t)nt[j] * K8) * 64 + lane; bc[j] = *bj[j]; }
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) bq[m % R][j] = bp[((size_t)nt[j] * K8 + m) * 64 + lane];
-#pragma unroll
-  for (int m = 0; m < K8; ++m) {
-    if (m + PF < K8) {
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) bq[(m + PF) % R][j] = bp[((size_t)nt[j] * K8 + (m + PF)) * 64 + lane];
-    }
-    float4 a[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda + 8 * m);
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const float4 b = bq[m % R][j];
-        acc[i][j] = mfma32(a[i].x, b.x, acc[i][j]);
-        acc[i][j] = mfma32(a[i].y, b.y, acc[i][j]);
-        acc[i][j] = mfma32(a[i].z, b.z, acc[i][j]);
-        acc[i][j] = mfma32(a[i].w, b.w, acc[i][j]);
-      }
-  }
-}
-
-// Low-register variant for kernels that run several workgroups per CU (occupancy hides the L2 latency
-// of the packed B stream): depth-1 prefetch, loop unrolled by 2 only.
-template <int MT, int NTW, int K8>
-__device__ __forceinline__ void mma_lds_stream(f32x16 (&acc)[MT][NTW], const float* __restrict__ ldsA, int lda,
-                                               const float4* __restrict__ bp, const int (&nt)[NTW]) {
-  const int lane = lane_id(), li = lane & 31, h = lane >> 5;
-  const float* arow = ldsA + li * lda + 4 * h;
-  float4 bc[NTW], bn[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) bc[j] = bp[((size_t)nt[j] * K8) * 64 + lane];
+  for (int i = 0; i < MT; ++i) ac[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda);
 #pragma unroll 2
   for (int m = 0; m < K8; ++m) {
     const int mn = m + 1 < K8 ? m + 1 : m;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) bn[j] = bp[((size_t)nt[j] * K8 + mn) * 64 + lane];
-    float4 a[MT];
+    for (int j = 0; j < NTW; ++j) bn[j] = bj[j][(size_t)mn * 64];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda + 8 * m);
+    for (int i = 0; i < MT; ++i) an[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda + 8 * mn);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        acc[i][j] = mfma32(a[i].x, bc[j].x, acc[i][j]);
-        acc[i][j] = mfma32(a[i].y, bc[j].y, acc[i][j]);
-        acc[i][j] = mfma32(a[i].z, bc[j].z, acc[i][j]);
-        acc[i][j] = mfma32(a[i].w, bc[j].w, acc[i][j]);
+        acc[i][j] = mfma32(ac[i].x, bc[j].x, acc[i][j]);
+        acc[i][j] = mfma32(ac[i].y, bc[j].y, acc[i][j]);
+        acc[i][j] = mfma32(ac[i].z, bc[j].z, acc[i][j]);
+        acc[i][j] = mfma32(ac[i].w, bc[j].w, acc[i][j]);
       }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) bc[j] = bn[j];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ac[i] = an[i];
   }
 }
 
 // Same contraction with the B fragments already in registers (the recurrent kernels keep each wave's
-// own 32 weight columns of every gate resident for the whole sequence loop: D/8 float4 per gate).
-template <int K8>
-__device__ __forceinline__ void mma_lds_regb(f32x16& acc, const float* __restrict__ ldsA, int lda, const float4 (&b)[K8]) {
+// own 32 weight columns of every gate resident for the whole sequence loop: D/8 float4 per gate);
+// NG gates share every A fragment.  A is read one k-group ahead (see mma_lds_packed).
+template <int K8, int NG>
+__device__ __forceinline__ void mma_lds_regb(f32x16 (&acc)[NG], const float* __restrict__ ldsA, int lda, const float4 (&b)[NG][K8]) {
   const int lane = lane_id(), li = lane & 31, h = lane >> 5;
   const float* arow = ldsA + li * lda + 4 * h;
+  float4 aq[2];
+  aq[0] = *reinterpret_cast<const float4*>(arow);
 #pragma unroll
   for (int m = 0; m < K8; ++m) {
-    const float4 a = *reinterpret_cast<const float4*>(arow + 8 * m);
-    acc = mfma32(a.x, b[m].x, acc);
-    acc = mfma32(a.y, b[m].y, acc);
-    acc = mfma32(a.z, b[m].z, acc);
-    acc = mfma32(a.w, b[m].w, acc);
+    if (m + 1 < K8) aq[(m + 1) & 1] = *reinterpret_cast<const float4*>(arow + 8 * (m + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 a = aq[m & 1];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.x, b[g][m].x, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.y, b[g][m].y, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.z, b[g][m].z, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.w, b[g][m].w, acc[g]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 template <int K8>
@@ -304,7 +288,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ax_kernel(TeArgs A) {
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    mma_lds_packed<2, NTW, K8, 2>(acc, lds, LDA, A.pUiT, nt);
+    mma_lds_packed<2, NTW, K8>(acc, lds, LDA, A.pUiT, nt);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       if (w + 4 * j >= NT) continue;
@@ -354,10 +338,10 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
 #pragma unroll
   for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
   // this wave's recurrent weights (own 32 columns of z, r, c): resident in registers for every step
-  float4 wz[K8], wr[K8], wc[K8];
-  load_bfrag<K8>(wz, A.pWhT, w);
-  load_bfrag<K8>(wr, A.pWhT, NTD + w);
-  load_bfrag<K8>(wc, A.pWhT, 2 * NTD + w);
+  float4 wzr[2][K8], wc[1][K8];
+  load_bfrag<K8>(wzr[0], A.pWhT, w);
+  load_bfrag<K8>(wzr[1], A.pWhT, NTD + w);
+  load_bfrag<K8>(wc[0], A.pWhT, 2 * NTD + w);
   float* Hp = Hb0; float* Hn = Hb1;
   // pre-activations of the NEXT step are fetched while the current step's MFMAs run: they do not
   // depend on the recurrence (G still holds X.ui^T + bi for rows not yet visited)
@@ -373,18 +357,17 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
   if (ns_max > 0) fetch(0, cz, cr, cc);
   for (int t = 0; t < ns_max; ++t) {
     if (t + 1 < ns_max) fetch(t + 1, nz, nr, nc);
-    f32x16 az[1][1], ar[1][1];
+    f32x16 azr[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { az[0][0][r] = cz[r]; ar[0][0][r] = cr[r]; }
-    mma_lds_regb<K8>(az[0][0], Hp, LDA, wz);
-    mma_lds_regb<K8>(ar[0][0], Hp, LDA, wr);
+    for (int r = 0; r < 16; ++r) { azr[0][r] = cz[r]; azr[1][r] = cr[r]; }
+    mma_lds_regb<K8, 2>(azr, Hp, LDA, wzr);
     float zv[16], hp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
       const bool on = t < nsr[r];
-      zv[r] = sigmoidf_(az[0][0][r]);
-      const float rv = sigmoidf_(ar[0][0][r]);
+      zv[r] = sigmoidf_(azr[0][r]);
+      const float rv = sigmoidf_(azr[1][r]);
       hp[r] = Hp[i * LDA + col];
       const float rh = rv * hp[r];
       RHb[i * LDA + col] = rh;
@@ -395,15 +378,15 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
       }
     }
     lds_barrier();
-    f32x16 ac[1][1];
+    f32x16 ac[1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ac[0][0][r] = cc[r];
-    mma_lds_regb<K8>(ac[0][0], RHb, LDA, wc);
+    for (int r = 0; r < 16; ++r) ac[0][r] = cc[r];
+    mma_lds_regb<K8, 1>(ac, RHb, LDA, wc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
       const bool on = t < nsr[r];
-      const float c = fast_tanh(ac[0][0][r]);
+      const float c = fast_tanh(ac[0][r]);
       const float hn = on ? (1.0f - zv[r]) * hp[r] + zv[r] * c : hp[r];
       Hn[i * LDA + col] = hn;
       if (on && !predict) {
@@ -505,7 +488,7 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-      mma_lds_stream<1, NTW, K8>(acc, Ht, LDH, A.pVsT, nto);
+      mma_lds_packed<1, NTW, K8>(acc, Ht, LDH, A.pVsT, nto);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         if (w + 4 * j >= NBT) continue;
@@ -589,7 +572,7 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
       for (int j = 0; j < DTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-      mma_lds_stream<1, DTW, KB8>(acc, Ot, LDO, A.pVs, ntd);
+      mma_lds_packed<1, DTW, KB8>(acc, Ot, LDO, A.pVs, ntd);
 #pragma unroll
       for (int j = 0; j < DTW; ++j) {
         if (w + 4 * j >= NTD) continue;
@@ -636,9 +619,9 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
   // this wave's columns of wh[2] (K = D) and of wh[0:2] (K = 2D) as B fragments: resident in registers
-  float4 wcb[K8], wzrb[2 * K8];
-  load_bfrag<K8>(wcb, A.pWhc, w);
-  load_bfrag<2 * K8>(wzrb, A.pWhzr, w);
+  float4 wcb[1][K8], wzrb[1][2 * K8];
+  load_bfrag<K8>(wcb[0], A.pWhc, w);
+  load_bfrag<2 * K8>(wzrb[0], A.pWhzr, w);
   float dhn[16], sbz = 0.f, sbr = 0.f, sbc = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dhn[r] = 0.f;
@@ -671,14 +654,14 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
       Ac[i * LDA + col] = dh * z * (1.0f - c * c);
     }
     lds_barrier();
-    f32x16 m[1][1];
+    f32x16 m[1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m[0][0][r] = 0.f;
-    mma_lds_regb<K8>(m[0][0], Ac, LDA, wcb);
+    for (int r = 0; r < 16; ++r) m[0][r] = 0.f;
+    mma_lds_regb<K8, 1>(m, Ac, LDA, wcb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = c_row(r, lane);
-      const float mv = m[0][0][r];
+      const float mv = m[0][r];
       const float dr = mv * hp[r];
       dhp[r] += mv * rv[r];
       const float daz = dz[r] * zv[r] * (1.0f - zv[r]);
@@ -694,13 +677,13 @@ __global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
       }
     }
     lds_barrier();
-    f32x16 acc[1][1];
+    f32x16 acc[1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    mma_lds_regb<2 * K8>(acc[0][0], Azr, LDB, wzrb);
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    mma_lds_regb<2 * K8, 1>(acc, Azr, LDB, wzrb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][0][r] : 0.f;
+      dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][r] : 0.f;
       fz[r] = gz[r]; fr[r] = gr_[r]; fc[r] = gc[r]; fh[r] = gh[r]; fd[r] = gd[r];
     }
     // No barrier here: Ac is free once every wave passed the second barrier (its readers ran before
