@@ -279,6 +279,35 @@ __global__ __launch_bounds__(POI_BLOCK) void selftest_kernel(float* buf, int* fa
   for (int t = 0; t < POI_BLOCK; ++t) ref += (float)(((t * 2654435761u) >> 20) & 1023) - 512.0f;
   if (bs != ref) atomicAdd(fail, 1);
   atomicAdd(&buf[tid & 7], 1.0f);
+  // operand / result layouts of the two f32 MFMA shapes the tile engine relies on (small integers: exact)
+  if (wave_id() == 0) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int l = lane_id();
+    auto Av = [](int i, int k) { return (float)((i * 7 + k * 3) % 11 - 5); };
+    auto Bv = [](int k, int j) { return (float)((k * 5 + j * 2) % 13 - 6); };
+    {   // 16x16x4: A[i][k] in lane i + 16k, B[k][j] in lane j + 16k, D[4*(lane/16) + r][lane%16] in register r
+      const int i = l & 15, g = l >> 4;
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(Av(i, g), Bv(g, i), c, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        float e = 0.f;
+        for (int k = 0; k < 4; ++k) e += Av(4 * g + r, k) * Bv(k, i);
+        if (c[r] != e) atomicAdd(fail, 1);
+      }
+    }
+    {   // 32x32x2: A[i][k] in lane i + 32k, B[k][j] in lane j + 32k, D[(r&3) + 8*(r>>2) + 4*(lane/32)][lane%32] in register r
+      const int i = l & 31, h = l >> 5;
+      f32x16 c;
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(Av(i, h), Bv(h, i), c, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float e = Av(row, 0) * Bv(0, i) + Av(row, 1) * Bv(1, i);
+        if (c[r] != e) atomicAdd(fail, 1);
+      }
+    }
+  }
 }
 
 hipError_t launch_auc(const float* users, const float* items, int n, int dim, const int* tp, const int* tq,

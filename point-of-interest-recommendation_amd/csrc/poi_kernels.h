@@ -81,7 +81,8 @@ struct TeArgs {
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_seq;
   float *X, *E, *G, *H, *RH, *DH, *DL, *rowloss;   // DL: d logits (T x padded bins)
-  float4 *pUiT, *pUi, *pWhT, *pWhc, *pWhzr, *pVsT, *pVs;
+  float4 *pUiT, *pUi, *pVsT, *pVs;
+  float4 *pWhT16, *pWhc16, *pWhzr16;  // 16-column fragments (16x16x4 MFMA) for the recurrent kernels
   float* slab;
   int n_slab, n_head, n_kc;
   float* hslab; int hstride;          // te_head's per-workgroup d bs | d wd partials (n_head x hstride)

@@ -1,20 +1,23 @@
 // Tile engine ("throughput mode"): the Distance2Pre training step for a BATCH of sequences, decomposed
-// so that every heavy contraction is a tile GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32,
-// exact f32 products / accumulation), with the recurrence confined to two small per-tile kernels:
+// so that every heavy contraction is a tile GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32
+// and v_mfma_f32_16x16x4_f32: exact f32 products / accumulation), with the recurrence confined to two
+// small per-tile kernels:
 //
-//   te_scan      exclusive scan of the per-sequence step counts -> packed row offsets
-//   te_rowmap    packed row -> CSR position; table-touch bookkeeping (multiplicity / distinct sequences)
+//   te_len/scan  per-sequence step counts -> exclusive scan -> packed row offsets
+//   te_rowmap    packed row -> CSR position; sorted-scatter slots (one per table touch); padding-row bookkeeping
 //   te_pack      weights -> MFMA B-fragment order (every weight load is then a coalesced 1-KiB stream)
+//   te_sort      (te_scatter.hip) stable radix sort of the slots by table row -> per-row entry segments
 //   te_gather    X[r] = [lt[p_t] | di[dp_t]],  E[r] = lt[p_{t+1}] - lt[q_{t+1}]          (HBM-bound)
 //   te_gemm_ax   G[r] = X[r] . ui^T + bi                      (all steps at once, K = 2D)
-//   te_rec_fwd   per 32-sequence tile, t ascending: gates from G + h_{t-1} . wh^T  -> G := z|r|c, H, RH
-//   te_head      per 32-row tile: logits = H . vs^T + bs, softmax, BPR + survival losses, d logits,
-//                DH = dlogits . vs + g * E, d vs partials, +-g*h scattered to the gradient table
-//   te_rec_bwd   per 32-sequence tile, t descending (BPTT): G := da_z|da_r|da_c, d bi partials
-//   te_wgrad     split-K  d ui = DA^T . X,  d wh = DA^T . [Hprev | RH]   -> per-chunk slabs
-//   te_gemm_dx   dx = DA . ui, scattered (float atomics) into the gradient tables
+//   te_rec_fwd16 per 16-sequence tile, t ascending: gates from G + h_{t-1} . wh^T  -> G := z|r|c, H, RH
+//   te_head      per 32-row tile: logits = H . vs^T + bs, softmax, BPR + survival losses, d logits -> DL,
+//                DH = dlogits . vs + g * E, g, d bs / d wd partials
+//   te_rec_bwd16 per 16-sequence tile, t descending (BPTT): G := da_z|da_r|da_c, d bi partials
+//   te_wgrad     split-K  d ui = DA^T . X,  d wh = DA^T . [Hprev | RH],  d vs = DL^T . H   -> per-chunk slabs
+//   te_gemm_dx   dx = DA . ui  (stored over X)
 //   te_finalize  per-sequence losses, loss-weight statistics
-// followed by the shared rows_apply / dense_apply write-back (seq_engine.hip).
+// followed by te_scatter (te_scatter.hip: ordered per-row sums of dx / g*h + sparse SGD write-back) and
+// the shared dense_apply (seq_engine.hip).
 //
 // Math and semantics are identical to the per-sequence engine (public/GRU_Spatial.py:127-229, batch
 // rule of include/poi_hip.h); only the summation order differs.
@@ -51,15 +54,18 @@ __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r 
 // MFMA step 4m+c consumes component c of both operands, so A (read as float4 at k = 8m+4h from a
 // row-major LDS tile) and B agree on a permuted k order and every loaded byte is used.
 // -------------------------------------------------------------------------------------------------
-struct PackJob { const float* src; int sk, sn, K, N, K8, NT; float4* dst; };
-struct PackJobs { PackJob j[8]; int n; };
+// n16 == 1: fragments of the 16x16x4 MFMA (n tiles of 16 columns, k groups of 16):
+//   P[(nt * KG + m) * 64 + lane] = float4{ B[16m + 4g + c][16 nt + j], c = 0..3 },  lane = g*16 + j  (K8 field = KG).
+struct PackJob { const float* src; int sk, sn, K, N, K8, NT; float4* dst; int n16; };
+struct PackJobs { PackJob j[12]; int n; };
 
 __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
   const PackJob& j = J.j[blockIdx.y];
   const int total = j.NT * j.K8 * 64;
   for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < total; e += gridDim.x * TE_BLOCK) {
     const int lane = e & 63, m = (e >> 6) % j.K8, nt = (e >> 6) / j.K8;
-    const int n = nt * 32 + (lane & 31), k0 = 8 * m + 4 * (lane >> 5);
+    const int n = j.n16 ? nt * 16 + (lane & 15) : nt * 32 + (lane & 31);
+    const int k0 = j.n16 ? 16 * m + 4 * (lane >> 4) : 8 * m + 4 * (lane >> 5);
     float v[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -113,35 +119,48 @@ __device__ __forceinline__ void mma_lds_packed(f32x16 (&acc)[MT][NTW], const flo
   }
 }
 
-// Same contraction with the B fragments already in registers (the recurrent kernels keep each wave's
-// own 32 weight columns of every gate resident for the whole sequence loop: D/8 float4 per gate);
-// NG gates share every A fragment.  A is read one k-group ahead (see mma_lds_packed).
-template <int K8, int NG>
-__device__ __forceinline__ void mma_lds_regb(f32x16 (&acc)[NG], const float* __restrict__ ldsA, int lda, const float4 (&b)[NG][K8]) {
-  const int lane = lane_id(), li = lane & 31, h = lane >> 5;
-  const float* arow = ldsA + li * lda + 4 * h;
-  float4 aq[2];
-  aq[0] = *reinterpret_cast<const float4*>(arow);
-#pragma unroll
-  for (int m = 0; m < K8; ++m) {
-    if (m + 1 < K8) aq[(m + 1) & 1] = *reinterpret_cast<const float4*>(arow + 8 * (m + 1));
-    __builtin_amdgcn_sched_barrier(0);
-    const float4 a = aq[m & 1];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.x, b[g][m].x, acc[g]);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.y, b[g][m].y, acc[g]);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.z, b[g][m].z, acc[g]);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma32(a.w, b[g][m].w, acc[g]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 template <int K8>
 __device__ __forceinline__ void load_bfrag(float4 (&b)[K8], const float4* __restrict__ bp, int nt) {
 #pragma unroll
   for (int m = 0; m < K8; ++m) b[m] = bp[((size_t)nt * K8 + m) * 64 + lane_id()];
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// 16-row tile x resident 16-column B fragments on v_mfma_f32_16x16x4_f32: A[i][k] is read as float4 at
+// k = 16m + 4g (lane = 16g + i), matching the n16 packing, so four MFMAs consume one LDS read.  NG
+// gates share the A fragments; with one gate the k-groups alternate between two accumulators (two
+// independent MFMA chains).  Result layout: acc[g][r] = D[4*(lane/16) + r][lane%16].
+template <int KG, int NG>
+__device__ __forceinline__ void mma16_regb(f32x4 (&acc)[NG], const float* __restrict__ ldsA, int lda, const float4 (&b)[NG][KG]) {
+  const int lane = lane_id();
+  const float* arow = ldsA + (lane & 15) * lda + 4 * (lane >> 4);
+  float4 aq[2];
+  aq[0] = *reinterpret_cast<const float4*>(arow);
+  f32x4 alt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < KG; ++m) {
+    if (m + 1 < KG) aq[(m + 1) & 1] = *reinterpret_cast<const float4*>(arow + 16 * (m + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 a = aq[m & 1];
+    if (NG == 1 && (m & 1)) {
+      alt = mfma16(a.x, b[0][m].x, alt); alt = mfma16(a.y, b[0][m].y, alt);
+      alt = mfma16(a.z, b[0][m].z, alt); alt = mfma16(a.w, b[0][m].w, alt);
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = mfma16(a.x, b[g][m].x, acc[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = mfma16(a.y, b[g][m].y, acc[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = mfma16(a.z, b[g][m].z, acc[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = mfma16(a.w, b[g][m].w, acc[g]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (NG == 1) acc[0] += alt;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -306,49 +325,46 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ax_kernel(TeArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// te_rec_fwd: one workgroup (D/32 waves) per tile of 32 sequences; wave w owns hidden columns
-// [32w, 32w+32) of z, r, c and h, so the state update is lane-local; h_{t-1} and r*h_{t-1} are
-// exchanged through LDS (two barriers per step).
+// te_rec_fwd16: one workgroup (D/16 waves) per tile of 16 sequences; wave w owns hidden columns
+// [16w, 16w+16) of z, r, c and h (96 registers of resident weights at D = 128), so the state update is
+// lane-local and two waves share each SIMD: one wave's gate math and stores overlap the other's
+// MFMAs.  The recurrence is a latency chain (longest sequence x step time), so the tile is kept small:
+// a 16-row step is half the matrix work of a 32-row step.  h_{t-1} / r*h_{t-1} cross waves through LDS
+// (two barriers per step).
 // -------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict) {
+__global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predict) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int K8 = D / 8, LDA = D + 4, NTD = D / 32;
-  float* Hb0 = lds;                      // h_{t-1}
-  float* Hb1 = Hb0 + 32 * LDA;           // h_t
-  float* RHb = Hb1 + 32 * LDA;           // r * h_{t-1}
-  __shared__ int s_r0[32], s_ns[32];
-  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
-  const int col = 32 * w + li;
+  constexpr int KG = D / 16, LDA = D + 4, NW = D / 16;
+  float* Hb = lds;                       // h_{t-1}, overwritten by h_t   16 x LDA
+  float* RHb = Hb + 16 * LDA;            // r * h_{t-1}
+  __shared__ int s_r0[16], s_ns[16];
+  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, g4 = 4 * (lane >> 4);
+  const int col = 16 * w + (lane & 15);
   const int tile = blockIdx.x;
-  if (tid < 32) {
-    const int k = tile * 32 + tid;
+  if (tid < 16) {
+    const int k = tile * 16 + tid;
     int r0 = 0, ns = 0;
-    if (k < A.n_seq) {
-      r0 = A.soff[k];
-      ns = A.soff[k + 1] - r0;
-    }
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
   }
-  for (int e = tid; e < 32 * LDA; e += blockDim.x) { Hb0[e] = 0.f; Hb1[e] = 0.f; }
+  for (int e = tid; e < 16 * LDA; e += blockDim.x) Hb[e] = 0.f;
   lds_barrier();
   int ns_max = 0;
-  for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
-  int rowb[16], nsr[16];
+  for (int i = 0; i < 16; ++i) ns_max = max(ns_max, s_ns[i]);
+  int rowb[4], nsr[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
-  // this wave's recurrent weights (own 32 columns of z, r, c): resident in registers for every step
-  float4 wzr[2][K8], wc[1][K8];
-  load_bfrag<K8>(wzr[0], A.pWhT, w);
-  load_bfrag<K8>(wzr[1], A.pWhT, NTD + w);
-  load_bfrag<K8>(wc[0], A.pWhT, 2 * NTD + w);
-  float* Hp = Hb0; float* Hn = Hb1;
-  // pre-activations of the NEXT step are fetched while the current step's MFMAs run: they do not
-  // depend on the recurrence (G still holds X.ui^T + bi for rows not yet visited)
-  float cz[16], cr[16], cc[16], nz[16], nr[16], nc[16];
-  auto fetch = [&](int t, float (&z)[16], float (&r)[16], float (&c)[16]) {
+  for (int r = 0; r < 4; ++r) { rowb[r] = s_r0[g4 + r]; nsr[r] = s_ns[g4 + r]; }
+  float4 wzr[2][KG], wc[1][KG];
+  load_bfrag<KG>(wzr[0], A.pWhT16, w);
+  load_bfrag<KG>(wzr[1], A.pWhT16, NW + w);
+  load_bfrag<KG>(wc[0], A.pWhT16, 2 * NW + w);
+  // pre-activations of the NEXT step are fetched while the current step computes (G still holds
+  // X.ui^T + bi for rows not yet visited)
+  float cz[4], cr[4], cc[4], nz[4], nr[4], nc[4];
+  auto fetch = [&](int t, float (&z)[4], float (&r)[4], float (&c)[4]) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const bool on = t < nsr[q];
       const float* g = A.G + (size_t)(rowb[q] + t) * 3 * D;
       z[q] = on ? g[col] : 0.f; r[q] = on ? g[D + col] : 0.f; c[q] = on ? g[2 * D + col] : 0.f;
@@ -357,18 +373,18 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
   if (ns_max > 0) fetch(0, cz, cr, cc);
   for (int t = 0; t < ns_max; ++t) {
     if (t + 1 < ns_max) fetch(t + 1, nz, nr, nc);
-    f32x16 azr[2];
+    f32x4 azr[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { azr[0][r] = cz[r]; azr[1][r] = cr[r]; }
-    mma_lds_regb<K8, 2>(azr, Hp, LDA, wzr);
-    float zv[16], hp[16];
+    for (int r = 0; r < 4; ++r) { azr[0][r] = cz[r]; azr[1][r] = cr[r]; }
+    mma16_regb<KG, 2>(azr, Hb, LDA, wzr);
+    float zv[4], hp[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = c_row(r, lane);
+    for (int r = 0; r < 4; ++r) {
+      const int i = g4 + r;
       const bool on = t < nsr[r];
       zv[r] = sigmoidf_(azr[0][r]);
       const float rv = sigmoidf_(azr[1][r]);
-      hp[r] = Hp[i * LDA + col];
+      hp[r] = Hb[i * LDA + col];
       const float rh = rv * hp[r];
       RHb[i * LDA + col] = rh;
       if (on) {
@@ -378,17 +394,17 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
       }
     }
     lds_barrier();
-    f32x16 ac[1];
+    f32x4 ac[1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ac[0][r] = cc[r];
-    mma_lds_regb<K8, 1>(ac, RHb, LDA, wc);
+    for (int r = 0; r < 4; ++r) ac[0][r] = cc[r];
+    mma16_regb<KG, 1>(ac, RHb, LDA, wc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = c_row(r, lane);
+    for (int r = 0; r < 4; ++r) {
+      const int i = g4 + r;
       const bool on = t < nsr[r];
       const float c = fast_tanh(ac[0][r]);
       const float hn = on ? (1.0f - zv[r]) * hp[r] + zv[r] * c : hp[r];
-      Hn[i * LDA + col] = hn;
+      Hb[i * LDA + col] = hn;          // nobody reads Hb between the two barriers of a step
       if (on && !predict) {
         float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
         g[col] = zv[r]; g[2 * D + col] = c;
@@ -396,16 +412,122 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwd_kernel(TeArgs A, int predict
       }
     }
     lds_barrier();
-    float* tmp = Hp; Hp = Hn; Hn = tmp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { cz[r] = nz[r]; cr[r] = nr[r]; cc[r] = nc[r]; }
+    for (int r = 0; r < 4; ++r) { cz[r] = nz[r]; cr[r] = nr[r]; cc[r] = nc[r]; }
   }
   if (predict) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = c_row(r, lane), k = tile * 32 + i;
-      if (k < A.n_seq) A.hts[(size_t)k * D + col] = Hp[i * LDA + col];
+    for (int r = 0; r < 4; ++r) {
+      const int i = g4 + r, k = tile * 16 + i;
+      if (k < A.n_seq) A.hts[(size_t)k * D + col] = Hb[i * LDA + col];
     }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_rec_bwd16: BPTT per 16-sequence tile, t descending; wave w owns hidden columns [16w, 16w+16)
+// (same layout and reasoning as te_rec_fwd16).
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int KG = D / 16, LDA = D + 4, LDB = 2 * D + 4;
+  float* Ac = lds;                       // da_c           16 x LDA
+  float* Azr = Ac + 16 * LDA;            // da_z | da_r    16 x LDB
+  __shared__ int s_r0[16], s_ns[16];
+  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, g4 = 4 * (lane >> 4);
+  const int col = 16 * w + (lane & 15);
+  const int tile = blockIdx.x;
+  if (tid < 16) {
+    const int k = tile * 16 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  lds_barrier();
+  int ns_max = 0;
+  for (int i = 0; i < 16; ++i) ns_max = max(ns_max, s_ns[i]);
+  int rowb[4], nsr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { rowb[r] = s_r0[g4 + r]; nsr[r] = s_ns[g4 + r]; }
+  float4 wcb[1][KG], wzrb[1][2 * KG];
+  load_bfrag<KG>(wcb[0], A.pWhc16, w);
+  load_bfrag<2 * KG>(wzrb[0], A.pWhzr16, w);
+  float dhn[4], sbz = 0.f, sbr = 0.f, sbc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dhn[r] = 0.f;
+  // operands of step t-1 (z, r, c, h_{t-2}, DH) are fetched while step t computes
+  float fz[4], fr[4], fc[4], fh[4], fd[4], gz[4], gr_[4], gc[4], gh[4], gd[4];
+  auto fetch = [&](int t, float (&z)[4], float (&r)[4], float (&c)[4], float (&h)[4], float (&d)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool on = t >= 0 && t < nsr[q];
+      const size_t row = (size_t)(rowb[q] + t);
+      const float* g = A.G + row * 3 * D;
+      z[q] = on ? g[col] : 0.f; r[q] = on ? g[D + col] : 0.f; c[q] = on ? g[2 * D + col] : 0.f;
+      h[q] = (on && t > 0) ? A.H[(row - 1) * D + col] : 0.f;
+      d[q] = on ? A.DH[row * D + col] : 0.f;
+    }
+  };
+  if (ns_max > 0) fetch(ns_max - 1, fz, fr, fc, fh, fd);
+  for (int t = ns_max - 1; t >= 0; --t) {
+    if (t > 0) fetch(t - 1, gz, gr_, gc, gh, gd);
+    float zv[4], rv[4], hp[4], dz[4], dhp[4], dacv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = g4 + r;
+      const bool on = t < nsr[r];
+      const float z = fz[r], rr = fr[r], c = fc[r], h = fh[r];
+      const float dh = on ? dhn[r] + fd[r] : 0.f;
+      zv[r] = z; rv[r] = rr; hp[r] = h;
+      dz[r] = dh * (c - h);
+      dhp[r] = dh * (1.0f - z);
+      dacv[r] = dh * z * (1.0f - c * c);
+      Ac[i * LDA + col] = dacv[r];
+    }
+    lds_barrier();
+    f32x4 m[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[0][r] = 0.f;
+    mma16_regb<KG, 1>(m, Ac, LDA, wcb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = g4 + r;
+      const float mv = m[0][r];
+      const float dr = mv * hp[r];
+      dhp[r] += mv * rv[r];
+      const float daz = dz[r] * zv[r] * (1.0f - zv[r]);
+      const float dar = dr * rv[r] * (1.0f - rv[r]);
+      Azr[i * LDB + col] = daz;
+      Azr[i * LDB + D + col] = dar;
+      if (t < nsr[r]) {
+        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
+        g[col] = daz; g[D + col] = dar; g[2 * D + col] = dacv[r];
+        sbz += daz; sbr += dar; sbc += dacv[r];
+      }
+    }
+    lds_barrier();
+    f32x4 acc[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[0][r] = 0.f;
+    mma16_regb<2 * KG, 1>(acc, Azr, LDB, wzrb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][r] : 0.f;
+      fz[r] = gz[r]; fr[r] = gr_[r]; fc[r] = gc[r]; fh[r] = gh[r]; fd[r] = gd[r];
+    }
+    // No barrier here: Ac is free once every wave passed the second barrier (its readers ran before
+    // it), and the next step's Azr writes come after the next first barrier, which every wave reaches
+    // only after finishing this step's MFMA block on Azr.
+  }
+  // d bi partial sums of this tile: the four 16-lane groups hold different sequences of the same column
+  float* slab = A.slab + (size_t)(tile % A.n_kc) * A.dl.total;
+  sbz += __shfl_xor(sbz, 16, 64); sbr += __shfl_xor(sbr, 16, 64); sbc += __shfl_xor(sbc, 16, 64);
+  sbz += __shfl_xor(sbz, 32, 64); sbr += __shfl_xor(sbr, 32, 64); sbc += __shfl_xor(sbc, 32, 64);
+  if (lane < 16 && ns_max > 0) {
+    atomicAdd(slab + A.dl.bi + col, sbz);
+    atomicAdd(slab + A.dl.bi + D + col, sbr);
+    atomicAdd(slab + A.dl.bi + 2 * D + col, sbc);
   }
 }
 
@@ -590,113 +712,6 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
     if (tid < NB) hs[tid] += dbs_acc;
     const float dw = block_sum(dwd_acc, s_red);
     if (tid == 0) hs[NB] += dw;
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// te_rec_bwd: BPTT per 32-sequence tile, t descending; wave w owns hidden columns [32w, 32w+32).
-// -------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(D * 2) void te_rec_bwd_kernel(TeArgs A) {
-  extern __shared__ __align__(16) float lds[];
-  constexpr int K8 = D / 8, LDA = D + 4, LDB = 2 * D + 4, NTD = D / 32;
-  float* Ac = lds;                       // da_c           32 x LDA
-  float* Azr = Ac + 32 * LDA;            // da_z | da_r    32 x LDB
-  __shared__ int s_r0[32], s_ns[32];
-  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
-  const int col = 32 * w + li;
-  const int tile = blockIdx.x;
-  if (tid < 32) {
-    const int k = tile * 32 + tid;
-    int r0 = 0, ns = 0;
-    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
-    s_r0[tid] = r0; s_ns[tid] = ns;
-  }
-  lds_barrier();
-  int ns_max = 0;
-  for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
-  int rowb[16], nsr[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); rowb[r] = s_r0[i]; nsr[r] = s_ns[i]; }
-  // this wave's columns of wh[2] (K = D) and of wh[0:2] (K = 2D) as B fragments: resident in registers
-  float4 wcb[1][K8], wzrb[1][2 * K8];
-  load_bfrag<K8>(wcb[0], A.pWhc, w);
-  load_bfrag<2 * K8>(wzrb[0], A.pWhzr, w);
-  float dhn[16], sbz = 0.f, sbr = 0.f, sbc = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) dhn[r] = 0.f;
-  // operands of step t-1 (z, r, c, h_{t-2}, DH) are fetched while step t computes
-  float fz[16], fr[16], fc[16], fh[16], fd[16], gz[16], gr_[16], gc[16], gh[16], gd[16];
-  auto fetch = [&](int t, float (&z)[16], float (&r)[16], float (&c)[16], float (&h)[16], float (&d)[16]) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const bool on = t >= 0 && t < nsr[q];
-      const size_t row = (size_t)(rowb[q] + t);
-      const float* g = A.G + row * 3 * D;
-      z[q] = on ? g[col] : 0.f; r[q] = on ? g[D + col] : 0.f; c[q] = on ? g[2 * D + col] : 0.f;
-      h[q] = (on && t > 0) ? A.H[(row - 1) * D + col] : 0.f;
-      d[q] = on ? A.DH[row * D + col] : 0.f;
-    }
-  };
-  if (ns_max > 0) fetch(ns_max - 1, fz, fr, fc, fh, fd);
-  for (int t = ns_max - 1; t >= 0; --t) {
-    if (t > 0) fetch(t - 1, gz, gr_, gc, gh, gd);
-    float zv[16], rv[16], hp[16], dz[16], dhp[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = c_row(r, lane);
-      const bool on = t < nsr[r];
-      const float z = fz[r], rr = fr[r], c = fc[r], h = fh[r];
-      const float dh = on ? dhn[r] + fd[r] : 0.f;
-      zv[r] = z; rv[r] = rr; hp[r] = h;
-      dz[r] = dh * (c - h);
-      dhp[r] = dh * (1.0f - z);
-      Ac[i * LDA + col] = dh * z * (1.0f - c * c);
-    }
-    lds_barrier();
-    f32x16 m[1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m[0][r] = 0.f;
-    mma_lds_regb<K8, 1>(m, Ac, LDA, wcb);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = c_row(r, lane);
-      const float mv = m[0][r];
-      const float dr = mv * hp[r];
-      dhp[r] += mv * rv[r];
-      const float daz = dz[r] * zv[r] * (1.0f - zv[r]);
-      const float dar = dr * rv[r] * (1.0f - rv[r]);
-      Azr[i * LDB + col] = daz;
-      Azr[i * LDB + D + col] = dar;
-      const bool on = t < nsr[r];
-      if (on) {
-        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
-        const float dac = Ac[i * LDA + col];
-        g[col] = daz; g[D + col] = dar; g[2 * D + col] = dac;
-        sbz += daz; sbr += dar; sbc += dac;
-      }
-    }
-    lds_barrier();
-    f32x16 acc[1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-    mma_lds_regb<2 * K8, 1>(acc, Azr, LDB, wzrb);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][r] : 0.f;
-      fz[r] = gz[r]; fr[r] = gr_[r]; fc[r] = gc[r]; fh[r] = gh[r]; fd[r] = gd[r];
-    }
-    // No barrier here: Ac is free once every wave passed the second barrier (its readers ran before
-    // it), and the next step's Azr writes come after the next first barrier, which every wave reaches
-    // only after finishing this step's MFMA block on Azr.
-  }
-  // d bi partial sums of this tile (columns owned by this lane in both half-waves)
-  float* slab = A.slab + (size_t)(tile % A.n_kc) * A.dl.total;
-  sbz += __shfl_xor(sbz, 32, 64); sbr += __shfl_xor(sbr, 32, 64); sbc += __shfl_xor(sbc, 32, 64);
-  if (lane < 32 && ns_max > 0) {
-    atomicAdd(slab + A.dl.bi + col, sbz);
-    atomicAdd(slab + A.dl.bi + D + col, sbr);
-    atomicAdd(slab + A.dl.bi + 2 * D + col, sbc);
   }
 }
 
@@ -937,20 +952,20 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   int n = 0;
   // B[k][n] = ui[n][k]   (K = 2D, N = 3D)
   J.j[n++] = PackJob{A.ui, 1, XW, XW, 3 * D, XW / 8, 3 * D / 32, A.pUiT};
-  // B[k][n] = wh_flat[n][k]   (K = D, N = 3D)
-  J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT};
   // B[k][n] = vs[n][k]   (K = D, N = NB -> NBP)
   J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 8, NBP / 32, A.pVsT};
   if (train) {
     // B[k][n] = vs[k][n]   (K = NB -> NBP, N = D)
     J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
-    // B[k][n] = wh[2][k][n]   (K = D, N = D)
-    J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 8, D / 32, A.pWhc};
-    // B[k][n] = wh_flat[k][n], k < 2D   (K = 2D, N = D)
-    J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 8, D / 32, A.pWhzr};
     // B[k][n] = ui_flat[k][n]   (K = 3D, N = 2D)
     J.j[n++] = PackJob{A.ui, XW, 1, 3 * D, XW, 3 * D / 8, XW / 32, A.pUi};
+    // 16-column fragments of the recurrent kernels (16x16x4 MFMA): B[k][n] = wh[2][k][n] (K = D, N = D) and
+    // B[k][n] = wh_flat[k][n], k < 2D (K = 2D, N = D)
+    J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 16, D / 16, A.pWhc16, 1};
+    J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 16, D / 16, A.pWhzr16, 1};
   }
+  // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments
+  J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
   J.n = n;
 }
 
@@ -972,14 +987,14 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_gemm_ax_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 64 * (2 * D + 4), st, A);
   tm->end(st);
   tm->begin("te_rec_fwd", st);
-  hipLaunchKernelGGL(te_rec_fwd_kernel<D>, dim3(tiles), dim3(D * 2), sizeof(float) * 3 * 32 * (D + 4), st, A, 0);
+  hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 0);
   tm->end(st);
   tm->begin("te_head", st);
   hipError_t e = te_head_dispatch<D>(A, 0, A.n_head, st);
   if (e != hipSuccess) return e;
   tm->end(st);
   tm->begin("te_rec_bwd", st);
-  hipLaunchKernelGGL(te_rec_bwd_kernel<D>, dim3(tiles), dim3(D * 2), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
+  hipLaunchKernelGGL(te_rec_bwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
   tm->end(st);
   tm->begin("te_wgrad", st);
   {
@@ -1015,7 +1030,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 1);
   hipLaunchKernelGGL(te_gemm_ax_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 64 * (2 * D + 4), st, A);
-  hipLaunchKernelGGL(te_rec_fwd_kernel<D>, dim3(tiles), dim3(D * 2), sizeof(float) * 3 * 32 * (D + 4), st, A, 1);
+  hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 1);
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
   tm->end(st);
