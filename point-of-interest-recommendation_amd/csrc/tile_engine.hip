@@ -307,18 +307,22 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ax_kernel(TeArgs A) {
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bias[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bias[j] = A.bi[nt[j] * 32 + li];
     mma_lds_packed<2, NTW, K8>(acc, lds, LDA, A.pUiT, nt);
+    // rows past the end go to the spare row T (never read): no branch, so the stores are not
+    // serialised by per-block s_waitcnt vmcnt(0)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       if (w + 4 * j >= NT) continue;
       const int col = nt[j] * 32 + li;
-      const float b = A.bi[col];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = r0 + 32 * i + c_row(r, lane);
-          if (row < T) A.G[(size_t)row * 3 * D + col] = acc[i][j][r] + b;
+          const int row = min(r0 + 32 * i + c_row(r, lane), T);
+          A.G[(size_t)row * 3 * D + col] = acc[i][j][r] + bias[j];
         }
     }
   }
@@ -362,17 +366,20 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
   // pre-activations of the NEXT step are fetched while the current step computes (G still holds
   // X.ui^T + bi for rows not yet visited)
   float cz[4], cr[4], cc[4], nz[4], nr[4], nc[4];
+  // Finished sequences read / write the spare packed row Tsp (= total rows; allocated, never
+  // consumed): every access is unconditional, so no branch - and no conservative s_waitcnt vmcnt(0)
+  // that would serialise the stores or turn the prefetch into a blocking load.
+  const int Tsp = A.soff[A.n_seq];
   auto fetch = [&](int t, float (&z)[4], float (&r)[4], float (&c)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const bool on = t < nsr[q];
-      const float* g = A.G + (size_t)(rowb[q] + t) * 3 * D;
-      z[q] = on ? g[col] : 0.f; r[q] = on ? g[D + col] : 0.f; c[q] = on ? g[2 * D + col] : 0.f;
+      const float* g = A.G + (size_t)(t < nsr[q] ? rowb[q] + t : Tsp) * 3 * D;
+      z[q] = g[col]; r[q] = g[D + col]; c[q] = g[2 * D + col];
     }
   };
-  if (ns_max > 0) fetch(0, cz, cr, cc);
+  fetch(0, cz, cr, cc);
   for (int t = 0; t < ns_max; ++t) {
-    if (t + 1 < ns_max) fetch(t + 1, nz, nr, nc);
+    fetch(t + 1, nz, nr, nc);
     f32x4 azr[2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { azr[0][r] = cz[r]; azr[1][r] = cr[r]; }
@@ -387,11 +394,9 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
       hp[r] = Hb[i * LDA + col];
       const float rh = rv * hp[r];
       RHb[i * LDA + col] = rh;
-      if (on) {
-        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
-        g[D + col] = rv;
-        if (!predict) A.RH[(size_t)(rowb[r] + t) * D + col] = rh;
-      }
+      const size_t row = (size_t)(on ? rowb[r] + t : Tsp);
+      A.G[row * 3 * D + D + col] = rv;
+      if (!predict) A.RH[row * D + col] = rh;
     }
     lds_barrier();
     f32x4 ac[1];
@@ -405,10 +410,10 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
       const float c = fast_tanh(ac[0][r]);
       const float hn = on ? (1.0f - zv[r]) * hp[r] + zv[r] * c : hp[r];
       Hb[i * LDA + col] = hn;          // nobody reads Hb between the two barriers of a step
-      if (on && !predict) {
-        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
-        g[col] = zv[r]; g[2 * D + col] = c;
-        A.H[(size_t)(rowb[r] + t) * D + col] = hn;
+      if (!predict) {
+        const size_t row = (size_t)(on ? rowb[r] + t : Tsp);
+        A.G[row * 3 * D + col] = zv[r]; A.G[row * 3 * D + 2 * D + col] = c;
+        A.H[row * D + col] = hn;
       }
     }
     lds_barrier();
@@ -458,26 +463,30 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
   for (int r = 0; r < 4; ++r) dhn[r] = 0.f;
   // operands of step t-1 (z, r, c, h_{t-2}, DH) are fetched while step t computes
   float fz[4], fr[4], fc[4], fh[4], fd[4], gz[4], gr_[4], gc[4], gh[4], gd[4];
+  // unconditional accesses (inactive lanes use the spare packed row Tsp): see te_rec_fwd16
+  const int Tsp = A.soff[A.n_seq];
   auto fetch = [&](int t, float (&z)[4], float (&r)[4], float (&c)[4], float (&h)[4], float (&d)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool on = t >= 0 && t < nsr[q];
-      const size_t row = (size_t)(rowb[q] + t);
+      const size_t row = (size_t)(on ? rowb[q] + t : Tsp);
       const float* g = A.G + row * 3 * D;
-      z[q] = on ? g[col] : 0.f; r[q] = on ? g[D + col] : 0.f; c[q] = on ? g[2 * D + col] : 0.f;
-      h[q] = (on && t > 0) ? A.H[(row - 1) * D + col] : 0.f;
-      d[q] = on ? A.DH[row * D + col] : 0.f;
+      // raw values; the consumer masks them (a select here would wait for the load at once)
+      z[q] = g[col]; r[q] = g[D + col]; c[q] = g[2 * D + col];
+      h[q] = A.H[(on && t > 0 ? row - 1 : (size_t)Tsp) * D + col];
+      d[q] = A.DH[row * D + col];
     }
   };
-  if (ns_max > 0) fetch(ns_max - 1, fz, fr, fc, fh, fd);
+  fetch(ns_max - 1, fz, fr, fc, fh, fd);
   for (int t = ns_max - 1; t >= 0; --t) {
-    if (t > 0) fetch(t - 1, gz, gr_, gc, gh, gd);
+    fetch(t - 1, gz, gr_, gc, gh, gd);
     float zv[4], rv[4], hp[4], dz[4], dhp[4], dacv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r;
       const bool on = t < nsr[r];
-      const float z = fz[r], rr = fr[r], c = fc[r], h = fh[r];
+      // the spare row holds arbitrary bits: select, do not multiply by zero
+      const float z = on ? fz[r] : 0.f, rr = on ? fr[r] : 0.f, c = on ? fc[r] : 0.f, h = (on && t > 0) ? fh[r] : 0.f;
       const float dh = on ? dhn[r] + fd[r] : 0.f;
       zv[r] = z; rv[r] = rr; hp[r] = h;
       dz[r] = dh * (c - h);
@@ -500,11 +509,9 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
       const float dar = dr * rv[r] * (1.0f - rv[r]);
       Azr[i * LDB + col] = daz;
       Azr[i * LDB + D + col] = dar;
-      if (t < nsr[r]) {
-        float* g = A.G + (size_t)(rowb[r] + t) * 3 * D;
-        g[col] = daz; g[D + col] = dar; g[2 * D + col] = dacv[r];
-        sbz += daz; sbr += dar; sbc += dacv[r];
-      }
+      float* g = A.G + (size_t)(t < nsr[r] ? rowb[r] + t : Tsp) * 3 * D;
+      g[col] = daz; g[D + col] = dar; g[2 * D + col] = dacv[r];
+      sbz += daz; sbr += dar; sbc += dacv[r];        // zero for inactive steps (dh == 0)
     }
     lds_barrier();
     f32x4 acc[1];
