@@ -146,7 +146,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
   A.dl = poi::dense_layout(D, 2 * D, P->n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 64;
-  const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D + (size_t)6 * D * D + 64;
+  const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D + (size_t)12 * D * D + 64;
   // sorted scatter (training): 3 slots per sequence position
   const bool sorted = !predict;
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
@@ -163,7 +163,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
   A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
   A.RH = take(Tcap * D); A.DH = take(Tcap * D); A.rowloss = take(Tcap * 2);
-  A.pUiT = (float4*)take((size_t)6 * D * D); A.pUi = (float4*)take((size_t)6 * D * D);
+  A.uiT = take((size_t)6 * D * D);
   A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
   A.pWhT16 = (float4*)take((size_t)3 * D * D); A.pWhc16 = (float4*)take((size_t)D * D); A.pWhzr16 = (float4*)take((size_t)2 * D * D);
   if (sorted) { A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP); }

@@ -81,7 +81,8 @@ struct TeArgs {
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_seq;
   float *X, *E, *G, *H, *RH, *DH, *DL, *rowloss;   // DL: d logits (T x padded bins)
-  float4 *pUiT, *pUi, *pVsT, *pVs;
+  float4 *pVsT, *pVs;
+  float* uiT;                         // ui transposed (2D x 3D), K-contiguous B operand of te_gemm_dx
   float4 *pWhT16, *pWhc16, *pWhzr16;  // 16-column fragments (16x16x4 MFMA) for the recurrent kernels
   float* slab;
   int n_slab, n_head, n_kc;

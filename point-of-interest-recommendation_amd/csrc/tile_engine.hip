@@ -8,13 +8,13 @@
 //   te_pack      weights -> MFMA B-fragment order (every weight load is then a coalesced 1-KiB stream)
 //   te_sort      (te_scatter.hip) stable radix sort of the slots by table row -> per-row entry segments
 //   te_gather    X[r] = [lt[p_t] | di[dp_t]],  E[r] = lt[p_{t+1}] - lt[q_{t+1}]          (HBM-bound)
-//   te_gemm_ax   G[r] = X[r] . ui^T + bi                      (all steps at once, K = 2D)
+//   te_gemm_ax   G[r] = X[r] . ui^T + bi       (te_gemm_nt: all steps at once, 128 x 128 tiles, K = 2D)
 //   te_rec_fwd16 per 16-sequence tile, t ascending: gates from G + h_{t-1} . wh^T  -> G := z|r|c, H, RH
 //   te_head      per 32-row tile: logits = H . vs^T + bs, softmax, BPR + survival losses, d logits -> DL,
 //                DH = dlogits . vs + g * E, g, d bs / d wd partials
 //   te_rec_bwd16 per 16-sequence tile, t descending (BPTT): G := da_z|da_r|da_c, d bi partials
 //   te_wgrad     split-K  d ui = DA^T . X,  d wh = DA^T . [Hprev | RH],  d vs = DL^T . H   -> per-chunk slabs
-//   te_gemm_dx   dx = DA . ui  (stored over X)
+//   te_gemm_dx   dx = DA . ui  (te_gemm_nt; stored over X)
 //   te_finalize  per-sequence losses, loss-weight statistics
 // followed by te_scatter (te_scatter.hip: ordered per-row sums of dx / g*h + sparse SGD write-back) and
 // the shared dense_apply (seq_engine.hip).
@@ -272,60 +272,119 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A, int predi
   }
 }
 
-// stage `rows` x `cols` floats (row r of the tile = global row r0 + r, zero beyond T) into LDS
-__device__ __forceinline__ void stage_rows(float* lds, int lda, const float* __restrict__ src, int ld_src, int cols,
-                                           int r0, int rows, int T) {
-  const int c4n = cols >> 2;
-  for (int e = threadIdx.x; e < rows * c4n; e += blockDim.x) {
-    const int r = e / c4n, c = (e % c4n) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 + r < T) v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + r) * ld_src + c);
-    *reinterpret_cast<float4*>(lds + (size_t)r * lda + c) = v;
-  }
-}
-
 // -------------------------------------------------------------------------------------------------
-// te_gemm_ax: G[r][0:3D] = X[r] . ui^T + bi      (64 rows per iteration, 4 waves split the 3D columns)
+// te_gemm_nt: C[r][n] = sum_k A[r][k] * B[n][k] (+ bias[n]) for the packed rows r < T: 128 x 128 output
+// tiles (persistent grid, n fastest so that neighbouring workgroups share the A rows in L2), both
+// operands staged in 32-wide k-chunks through LDS as [row][k] tiles (row pitch 36 floats: the float4
+// operand reads of 16 lanes hit 16 different bank groups).  Waves form a 2 x 2 grid of 64 x 64
+// sub-tiles.  Global loads run two chunks ahead in two register sets (written to LDS one iteration
+// later), LDS operand reads one k-group ahead of the MFMAs; rows >= T are clamped on load and stored
+// to the spare row T.  Used for G = X . ui^T + bi (te_gemm_ax) and dx = DA . ui (te_gemm_dx).
 // -------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ax_kernel(TeArgs A) {
-  extern __shared__ __align__(16) float lds[];
-  constexpr int XW = 2 * D, K8 = XW / 8, NT = 3 * D / 32, NTW = (NT + 3) / 4, LDA = XW + 4;
-  const int T = A.soff[A.n_seq];
-  const int lane = lane_id(), w = wave_id(), li = lane & 31;
-  int nt[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
-  for (int r0 = blockIdx.x * 64; r0 < T; r0 += gridDim.x * 64) {
-    lds_barrier();
-    stage_rows(lds, LDA, A.X, XW, XW, r0, 64, T);
-    lds_barrier();
-    f32x16 acc[2][NTW];
+#define NT_LDK 36
+template <bool BIAS>
+__global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(const float* __restrict__ Ag, int lda, const float* __restrict__ Bg, int ldb,
+                                                                 float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                                                 const int* __restrict__ Tptr, int N, int K) {
+  __shared__ __align__(16) float As[2][128][NT_LDK];
+  __shared__ __align__(16) float Bs[2][128][NT_LDK];
+  const int T = *Tptr;
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int ntl = (N + 127) / 128, ntile = ((T + 127) / 128) * ntl, nchunk = K / 32;
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int r0 = (tile / ntl) * 128, n0 = (tile % ntl) * 128;
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bias[NTW];
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    auto gload = [&](int kc, float4 (&ra)[4], float4 (&rb)[4]) {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) bias[j] = A.bi[nt[j] * 32 + li];
-    mma_lds_packed<2, NTW, K8>(acc, lds, LDA, A.pUiT, nt);
-    // rows past the end go to the spare row T (never read): no branch, so the stores are not
-    // serialised by per-block s_waitcnt vmcnt(0)
+      for (int s = 0; s < 4; ++s) {
+        const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
+        ra[s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(r0 + row, T - 1) * lda + kc * 32 + c);
+        rb[s] = *reinterpret_cast<const float4*>(Bg + (size_t)min(n0 + row, N - 1) * ldb + kc * 32 + c);
+      }
+    };
+    auto lstore = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      if (w + 4 * j >= NT) continue;
-      const int col = nt[j] * 32 + li;
+      for (int s = 0; s < 4; ++s) {
+        const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
+        // (component-wise: a whole-struct copy of the HIP float4 keeps the staging arrays in scratch)
+        *reinterpret_cast<float4*>(&As[buf][row][c]) = make_float4(ra[s].x, ra[s].y, ra[s].z, ra[s].w);
+        *reinterpret_cast<float4*>(&Bs[buf][row][c]) = make_float4(rb[s].x, rb[s].y, rb[s].z, rb[s].w);
+      }
+    };
+    auto mma = [&](int buf) {
+      float4 a[2][2], b[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[0][i] = *reinterpret_cast<const float4*>(&As[buf][wm + 32 * i + li][4 * h]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[0][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn + 32 * j + li][4 * h]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (m + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[(m + 1) & 1][i] = *reinterpret_cast<const float4*>(&As[buf][wm + 32 * i + li][8 * (m + 1) + 4 * h]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[(m + 1) & 1][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn + 32 * j + li][8 * (m + 1) + 4 * h]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float4 x = a[m & 1][i], y = b[m & 1][j];
+            acc[i][j] = mfma32(x.x, y.x, acc[i][j]);
+            acc[i][j] = mfma32(x.y, y.y, acc[i][j]);
+            acc[i][j] = mfma32(x.z, y.z, acc[i][j]);
+            acc[i][j] = mfma32(x.w, y.w, acc[i][j]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    __syncthreads();                       // previous tile's MFMAs are done with both LDS buffers
+    gload(0, ra0, rb0); lstore(0, ra0, rb0);
+    if (1 < nchunk) gload(1, ra0, rb0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunk; kc += 2) {
+      if (kc + 2 < nchunk) gload(kc + 2, ra1, rb1);
+      mma(0);
+      if (kc + 1 < nchunk) lstore(1, ra0, rb0);
+      __syncthreads();
+      if (kc + 1 >= nchunk) break;
+      if (kc + 3 < nchunk) gload(kc + 3, ra0, rb0);
+      mma(1);
+      if (kc + 2 < nchunk) lstore(0, ra1, rb1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + 32 * j + li;
+      if (n0 + wn + 32 * j >= N) continue;          // wave-uniform (N % 32 == 0)
+      const float bv = BIAS ? bias[col] : 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = min(r0 + 32 * i + c_row(r, lane), T);
-          A.G[(size_t)row * 3 * D + col] = acc[i][j][r] + bias[j];
+          const int row = min(r0 + wm + 32 * i + c_row(r, lane), T);
+          C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
         }
     }
   }
+}
+
+// uiT[c][r] = ui[r][c]   (ui is 3D x 2D row-major): the K-contiguous B operand of dx = DA . ui
+__global__ __launch_bounds__(256) void te_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32, x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  for (int k = y; k < 32; k += 8) if (by + k < rows && bx + x < cols) t[k][x] = src[(size_t)(by + k) * cols + bx + x];
+  __syncthreads();
+  for (int k = y; k < 32; k += 8) if (bx + k < cols && by + x < rows) dst[(size_t)(bx + k) * rows + by + x] = t[x][k];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -846,45 +905,6 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
       }
 }
 
-// -------------------------------------------------------------------------------------------------
-// te_gemm_dx: dx[r] = DA[r] . ui (K = 3D, N = 2D), stored over X[r]: columns [0, D) belong to table row
-// lt[p_t], [D, 2D) to di[dp_t] (summed per row by the sorted scatter, te_scatter.hip)
-// -------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(TE_BLOCK, 3) void te_gemm_dx_kernel(TeArgs A) {
-  extern __shared__ __align__(16) float lds[];
-  constexpr int K = 3 * D, K8 = K / 8, NT = 2 * D / 32, NTW = (NT + 3) / 4, LDA = K + 4;
-  const int T = A.soff[A.n_seq];
-  const int lane = lane_id(), w = wave_id(), li = lane & 31;
-  int nt[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) nt[j] = min(w + 4 * j, NT - 1);
-  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
-    lds_barrier();
-    stage_rows(lds, LDA, A.G, K, K, r0, 32, T);
-    lds_barrier();
-    f32x16 acc[1][NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-    mma_lds_packed<1, NTW, K8>(acc, lds, LDA, A.pUi, nt);
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      if (w + 4 * j >= NT) continue;
-      const int col = nt[j] * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = c_row(r, lane), gr = r0 + i;
-        if (gr < T) {
-          // dx overwrites X (dead after te_wgrad); te_reduce sums it per table row
-          A.X[(size_t)gr * 2 * D + col] = acc[0][j][r];
-        }
-      }
-    }
-  }
-}
-
 // per-sequence losses (deterministic row order) + loss-weight statistics
 __global__ __launch_bounds__(TE_BLOCK) void te_finalize_kernel(TeArgs A) {
   __shared__ float red[8];
@@ -957,15 +977,11 @@ static hipError_t te_head_dispatch(const TeArgs& A, int mode, int grid, hipStrea
 static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   const int D = A.dim, XW = 2 * D, NBP = nbt_for(A.n_dist + 1) * 32, NB = A.n_dist + 1;
   int n = 0;
-  // B[k][n] = ui[n][k]   (K = 2D, N = 3D)
-  J.j[n++] = PackJob{A.ui, 1, XW, XW, 3 * D, XW / 8, 3 * D / 32, A.pUiT};
   // B[k][n] = vs[n][k]   (K = D, N = NB -> NBP)
   J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 8, NBP / 32, A.pVsT};
   if (train) {
     // B[k][n] = vs[k][n]   (K = NB -> NBP, N = D)
     J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
-    // B[k][n] = ui_flat[k][n]   (K = 3D, N = 2D)
-    J.j[n++] = PackJob{A.ui, XW, 1, 3 * D, XW, 3 * D / 8, XW / 32, A.pUi};
     // 16-column fragments of the recurrent kernels (16x16x4 MFMA): B[k][n] = wh[2][k][n] (K = D, N = D) and
     // B[k][n] = wh_flat[k][n], k < 2D (K = 2D, N = D)
     J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 16, D / 16, A.pWhc16, 1};
@@ -985,13 +1001,14 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+  hipLaunchKernelGGL(te_transpose_kernel, dim3((2 * D + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, 2 * D);
   { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 0);
   tm->end(st);
   tm->begin("te_gemm_ax", st);
-  hipLaunchKernelGGL(te_gemm_ax_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 64 * (2 * D + 4), st, A);
+  hipLaunchKernelGGL(te_gemm_nt_kernel<true>, dim3(num_cu * 2), dim3(TE_BLOCK), 0, st, A.X, 2 * D, A.ui, 2 * D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, 2 * D);
   tm->end(st);
   tm->begin("te_rec_fwd", st);
   hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 0);
@@ -1011,7 +1028,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   tm->end(st);
   tm->begin("te_gemm_dx", st);
-  hipLaunchKernelGGL(te_gemm_dx_kernel<D>, dim3(num_cu * 3), dim3(TE_BLOCK), sizeof(float) * 32 * (3 * D + 4), st, A);
+  hipLaunchKernelGGL(te_gemm_nt_kernel<false>, dim3(num_cu * 2), dim3(TE_BLOCK), 0, st, A.G, 3 * D, A.uiT, 3 * D, A.X, 2 * D, (const float*)nullptr, A.soff + n, 2 * D, 3 * D);
   tm->end(st);
   tm->begin("te_finalize", st);
   hipLaunchKernelGGL(te_finalize_kernel, dim3((n + TE_BLOCK - 1) / TE_BLOCK), dim3(TE_BLOCK), 0, st, A);
@@ -1036,7 +1053,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 1);
-  hipLaunchKernelGGL(te_gemm_ax_kernel<D>, dim3(num_cu * 2), dim3(TE_BLOCK), sizeof(float) * 64 * (2 * D + 4), st, A);
+  hipLaunchKernelGGL(te_gemm_nt_kernel<true>, dim3(num_cu * 2), dim3(TE_BLOCK), 0, st, A.X, 2 * D, A.ui, 2 * D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, 2 * D);
   hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 1);
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
