@@ -140,6 +140,28 @@ int poi_auc_preference(poi_ctx* ctx, const float* users, const float* items, int
  * out[0] += sum x^2 (out is a device float64 accumulator the caller zeroes). */
 int poi_sumsq(poi_ctx* ctx, const float* x, int64_t n, double* out, void* stream);
 
+/* usrs_last_poi_to_all_intervals ("ulptai"): the reference computes the distance bin of every (user's last train
+ * POI, POI) pair ONCE per data set (prog_bpr_gru_spatial.py:90, fun_compute_distance, public/Load_Data_by_length.py:
+ * 183-216) and every evaluation only gathers prob[u][j] = sus[u][ulptai[u][j]] (zero where the bin is >= n_dist;
+ * fun_acquire_prob, :218-235, prog_bpr_gru_spatial.py:288).  poi_ulptai_build fills the resident bin matrix on the
+ * device with the exact host thresholds of poi_dist_prob (cphi, thr); bin_bytes = 1 (n_dist <= 255) or 2.  Layout:
+ * 32-user x 32-POI tiles of 1024 bins in the order the scoring kernel consumes them,
+ *   out[((ut * ntile + it) * 64 + lane) * 16 + r],  user = 32 ut + (r&3) + 8 (r>>2) + 4 (lane>>5),  POI = 32 it + (lane&31),
+ * ntile = ceil(n_item / 32); size ceil(n_user/32) * ntile * 1024 * bin_bytes bytes; out-of-range pairs hold n_dist. */
+int poi_ulptai_build(poi_ctx* ctx, const double* coords, const double* cphi, const double* thr, const int32_t* last_poi,
+                     int32_t n_user, int32_t n_item, int32_t n_dist, double dd, void* out, int32_t bin_bytes, void* stream);
+
+/* poi_score_topk with the distance term taken from the resident bin matrix instead of a dense float `prob`:
+ *   score[u][j] = users[u] . items[j] + wd * (bin < n_dist ? sts[u][bin] : 0),  bin = ulptai[u][j]
+ * (compute_sub_all_scores, public/GRU_Spatial.py:117-125, after fun_acquire_prob + update_prob).  `ulptai` points at
+ * the tile row of the batch's first user (the batch must start at a multiple of 32 users).  sts is the batch's
+ * (n, n_dist + 1) bin-probability table with the mask of fun_acquire_prob folded in: column n_dist ("too far") must
+ * hold 0, and the buffer must be readable for ceil(n / 32) * 32 rows (whole user tiles; the extra rows' values are
+ * irrelevant). */
+int poi_score_topk_ulptai(poi_ctx* ctx, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
+                          const float* wd, const float* sts, const void* ulptai, int32_t bin_bytes, int32_t n_dist,
+                          int32_t k, int32_t* idx_out, float* score_out, void* stream);
+
 /* ---- last-train-POI -> all-POI distance-bin probability rows (8f rank 2) ---------------------
  * public/Load_Data_by_length.py:183-235 (fun_compute_distance + fun_acquire_prob) for a user batch:
  * prob_out[k][j] = sts[k][bin] * (bin < n_dist), bin = cal_dis(coord[last_poi[k]], coord[j]).

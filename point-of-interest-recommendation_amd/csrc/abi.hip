@@ -303,9 +303,11 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
 }
 
 // ---------------------------------------------------------------------------------------------
+struct UlptaiArg { const void* bins; int bin_bytes; const float* sts; int n_dist; };
+
 static int score_common(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
                         const float* wd, const float* prob, float* scores, int32_t k, int32_t* idx_out, float* score_out,
-                        void* stream) {
+                        void* stream, const UlptaiArg* U = nullptr) {
   if (!c || !users || !items) return fail(c, POI_EINVAL, "score: NULL argument");
   if (dim <= 0 || dim % 4 != 0 || dim > 256) return fail(c, POI_ENOTSUP, "dim must be a multiple of 4 in [4, 256] (got %d)", dim);
   if (n < 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
@@ -318,12 +320,14 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   memset(&A, 0, sizeof A);
   A.users = users; A.items = items; A.n = n; A.n_item = n_item; A.dim = dim; A.wd = wd; A.prob = prob;
   A.scores = scores; A.k = k; A.idx_out = idx_out; A.score_out = score_out;
+  if (U) { A.ulptai = U->bins; A.bin_bytes = U->bin_bytes; A.sts = U->sts; A.n_dist = U->n_dist; }
   if (const char* e = getenv("POI_SCORE_DBG")) A.dbg = atoi(e);
   const int ntile = (n_item + 31) / 32;
   // variant: 0 = one item stream per wave (row-per-lane loads; small n), 1 = packed item stream per
   // wave, 2 = 4 user tiles per workgroup sharing each item tile through LDS (default for n >= 128)
   int variant = (n >= 128 && dim <= 128) ? 1 : 0;
   if (c->score_variant >= 0 && dim <= 128) variant = c->score_variant;
+  if (U) variant = 1;      // the bin matrix is laid out for the packed-stream kernel
   const int n_utile = variant == 2 ? ((n + 127) / 128) * 4 : (n + 31) / 32;
   const int units = variant == 2 ? n_utile / 4 : n_utile;
   // long item streams keep per-user thresholds high (few top-K compactions)
@@ -369,6 +373,31 @@ int poi_score_topk(poi_ctx* c, const float* users, const float* items, int32_t n
                    const float* wd, const float* prob, int32_t k, int32_t* idx_out, float* score_out, void* stream) {
   if (!idx_out || k <= 0) return fail(c, POI_EINVAL, "idx_out NULL or k <= 0");
   return score_common(c, users, items, n, n_item, dim, wd, prob, nullptr, k, idx_out, score_out, stream);
+}
+
+int poi_ulptai_build(poi_ctx* c, const double* coords, const double* cphi, const double* thr, const int32_t* last_poi,
+                     int32_t n_user, int32_t n_item, int32_t n_dist, double dd, void* out, int32_t bin_bytes, void* stream) {
+  if (!c || !coords || !cphi || !thr || !last_poi || !out) return fail(c, POI_EINVAL, "poi_ulptai_build: NULL argument");
+  if (n_user <= 0 || n_item <= 0 || n_dist <= 0 || !(dd > 0)) return fail(c, POI_EINVAL, "bad sizes");
+  if (bin_bytes != 1 && bin_bytes != 2) return fail(c, POI_EINVAL, "bin_bytes must be 1 or 2");
+  if ((bin_bytes == 1 && n_dist > 255) || n_dist > 65535) return fail(c, POI_EINVAL, "n_dist %d does not fit %d-byte bins", n_dist, bin_bytes);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->tm.begin("ulptai_build", (hipStream_t)stream);
+  HIPCHK(c, poi::launch_ulptai(coords, cphi, thr, last_poi, n_user, n_item, n_dist, dd, out, bin_bytes, (hipStream_t)stream));
+  c->tm.end((hipStream_t)stream);
+  return POI_OK;
+}
+
+int poi_score_topk_ulptai(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
+                          const float* wd, const float* sts, const void* ulptai, int32_t bin_bytes, int32_t n_dist,
+                          int32_t k, int32_t* idx_out, float* score_out, void* stream) {
+  if (!idx_out || k <= 0) return fail(c, POI_EINVAL, "idx_out NULL or k <= 0");
+  if (!wd || !sts || !ulptai) return fail(c, POI_EINVAL, "poi_score_topk_ulptai: wd / sts / ulptai NULL");
+  if (bin_bytes != 1 && bin_bytes != 2) return fail(c, POI_EINVAL, "bin_bytes must be 1 or 2");
+  if (dim > 128) return fail(c, POI_ENOTSUP, "the bin-matrix path supports dim <= 128 (got %d)", dim);
+  if (n_dist <= 0 || (int64_t)n * (n_dist + 1) >= (int64_t)1 << 31) return fail(c, POI_EINVAL, "n * (n_dist + 1) must stay below 2^31: score in batches");
+  const UlptaiArg U{ulptai, bin_bytes, sts, n_dist};
+  return score_common(c, users, items, n, n_item, dim, wd, nullptr, nullptr, k, idx_out, score_out, stream, &U);
 }
 
 int poi_topk(poi_ctx* c, const float* scores, int32_t n, int32_t n_item, int32_t k, int32_t* idx_out, float* score_out,

@@ -118,6 +118,60 @@ __global__ __launch_bounds__(POI_BLOCK) void dist_prob_kernel(const double* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// usrs_last_poi_to_all_intervals ("ulptai", prog_bpr_gru_spatial.py:90; fun_compute_distance,
+// public/Load_Data_by_length.py:183-216): the distance bin of every (user's last POI, POI) pair,
+// computed ONCE per data set as in the reference and kept resident.  Stored in the scoring kernel's
+// accumulator order: for user tile ut (32 users) and item tile it (32 POIs), lane l of the scoring
+// wavefront finds its 16 bins contiguous at  out[((ut * ntile + it) * 64 + l) * 16 + r]  (register r
+// of the 32x32 MFMA result = user row (r&3) + 8*(r>>2) + 4*(l>>5), POI column l&31), so that one
+// 16-byte (uint8 bins) or 32-byte (uint16) load per lane and tile replaces the float prob matrix.
+// Pairs outside the matrix (user >= n, POI >= N) hold n_dist (= "too far": probability 0).
+// ---------------------------------------------------------------------------------------------
+template <typename BT>
+__global__ __launch_bounds__(POI_BLOCK) void ulptai_kernel(const double* __restrict__ coords, const double* __restrict__ cphi,
+                                                            const double* __restrict__ thr, const int* __restrict__ last_poi,
+                                                            int n, int N, int n_dist, double dd, BT* __restrict__ out) {
+  extern __shared__ __align__(16) double s_thr[];       // n_dist thresholds, then 32 x {lat, lon, cos(lat)} of the user tile
+  double* s_u = s_thr + n_dist;
+  const int ut = blockIdx.y, lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
+  const int ntile = (N + 31) / 32;
+  for (int i = threadIdx.x; i < n_dist; i += POI_BLOCK) s_thr[i] = thr[i];
+  if (threadIdx.x < 32) {
+    const int u = ut * 32 + threadIdx.x;
+    const int lp = last_poi[min(u, n - 1)];
+    s_u[3 * threadIdx.x] = coords[2 * lp]; s_u[3 * threadIdx.x + 1] = coords[2 * lp + 1]; s_u[3 * threadIdx.x + 2] = cphi[lp];
+  }
+  __syncthreads();
+  const double pr = 0.017453292519943295;
+  const float scale = (float)(12742.0 * 1000.0 / dd);
+  for (int it = blockIdx.x * POI_NWAVE + w; it < ntile; it += gridDim.x * POI_NWAVE) {
+    const int j = it * 32 + li, jc = min(j, N - 1);
+    const double lat2 = coords[2 * jc], lon2 = coords[2 * jc + 1], c2 = cphi[jc];
+    BT b[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      int g;
+      {
+#pragma clang fp contract(off)
+        const double a = (s_u[3 * i] - lat2) * pr;
+        const double bb = (s_u[3 * i + 1] - lon2) * pr;
+        const double c = (1.0 - cos_small(a)) / 2 + s_u[3 * i + 2] * c2 * (1.0 - cos_small(bb)) / 2;
+        g = (int)(sqrtf((float)c) * scale);
+        g = g < 0 ? 0 : (g > n_dist ? n_dist : g);
+        while (g > 0 && c < s_thr[g - 1]) --g;
+        while (g < n_dist && c >= s_thr[g]) ++g;
+      }
+      if (j >= N || ut * 32 + i >= n) g = n_dist;
+      b[r] = (BT)g;
+    }
+    BT* o = out + (((size_t)ut * ntile + it) * 64 + lane) * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = b[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-epoch negative refresh on the device (prog_bpr_gru_spatial.py:221-228):
 //   fun_random_neg_masks_tra / _tes (public/Load_Data_by_length.py:127-162): one uniform draw over
 //   [0, n_item) per valid position, redrawn while it hits one of the user's own train (and, for the
@@ -331,6 +385,24 @@ hipError_t launch_dist_prob(const double* coords, const double* cphi, const doub
   if (gx < 1) gx = 1;
   const size_t lds = thr ? sizeof(double) * n_dist + sizeof(float) * (n_dist + 1) : 0;
   hipLaunchKernelGGL(dist_prob_kernel, dim3(gx, n), dim3(POI_BLOCK), lds, st, coords, cphi, thr, last_poi, sts, n, n_item, n_dist, dd, prob);
+  return hipGetLastError();
+}
+hipError_t launch_ulptai(const double* coords, const double* cphi, const double* thr, const int* last_poi, int n, int n_item,
+                         int n_dist, double dd, void* out, int bin_bytes, hipStream_t st) {
+  const int n_utile = (n + 31) / 32, ntile = (n_item + 31) / 32;
+  int gx = (ntile + POI_NWAVE - 1) / POI_NWAVE;
+  if (gx > 64) gx = 64;
+  const size_t lds = sizeof(double) * (n_dist + 96);
+  for (int u0 = 0; u0 < n_utile; u0 += 32768) {          // gridDim.y limit
+    const int m = n_utile - u0 < 32768 ? n_utile - u0 : 32768;
+    const size_t off = (size_t)u0 * ntile * 1024;
+    if (bin_bytes == 1)
+      hipLaunchKernelGGL(ulptai_kernel<uint8_t>, dim3(gx, m), dim3(POI_BLOCK), lds, st, coords, cphi, thr, last_poi + (size_t)u0 * 32,
+                         n - u0 * 32, n_item, n_dist, dd, (uint8_t*)out + off);
+    else
+      hipLaunchKernelGGL(ulptai_kernel<uint16_t>, dim3(gx, m), dim3(POI_BLOCK), lds, st, coords, cphi, thr, last_poi + (size_t)u0 * 32,
+                         n - u0 * 32, n_item, n_dist, dd, (uint16_t*)out + off);
+  }
   return hipGetLastError();
 }
 hipError_t launch_rank_metrics(const int* ranks, int n, int K, const int* tes_p, const int* tes_mask, int len_tes, const int* at_nums,

@@ -149,6 +149,9 @@ struct ScoreArgs {
   float4* items_packed;     // MFMA B-fragment order (large-n kernel), ctx scratch
   int n, n_item, dim;
   const float *wd, *prob;
+  // distance term through the resident bin matrix (ulptai_kernel layout) instead of `prob`:
+  // score += wd * (bin < n_dist ? sts[user][bin] : 0)
+  const void* ulptai; int bin_bytes; const float* sts; int n_dist;
   float* scores;            // (n, n_item) or null
   int k;                    // 0 = no top-K
   int n_split;              // item splits for the fused top-K
@@ -157,6 +160,8 @@ struct ScoreArgs {
   unsigned* gbound;         // (n_pad) per-user lower bound of the K-th best score shared by all item ranges
   int* idx_out; float* score_out;
 };
+hipError_t launch_ulptai(const double* coords, const double* cphi, const double* thr, const int* last_poi, int n, int n_item,
+                         int n_dist, double dd, void* out, int bin_bytes, hipStream_t st);
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm);
 hipError_t launch_score_packed(const ScoreArgs& A, hipStream_t st, Timing* tm);
 hipError_t launch_score_shared(const ScoreArgs& A, hipStream_t st, Timing* tm);

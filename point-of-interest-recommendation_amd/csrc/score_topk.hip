@@ -289,7 +289,11 @@ __global__ __launch_bounds__(POI_BLOCK) void pack_items_kernel(const float* __re
 // item range, B fragments double-buffered in registers straight from the packed stream); no LDS
 // staging and no workgroup barrier, so a wave that stops to compact a candidate list only delays
 // itself while its SIMD partner keeps the matrix core busy.
-template <int D8>
+// BINS: 0 = distance term from the float `prob` matrix (or none); 1 / 2 = from the resident bin matrix
+// (uint8 / uint16 bins in accumulator order, misc.hip::ulptai_kernel) and the users' bin probabilities:
+// the bins of the NEXT tile are fetched one iteration ahead (one 16/32-byte load per lane), the 16
+// probability gathers of a tile are issued before its MFMAs.
+template <int D8, int BINS>
 __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A) {
   extern __shared__ __align__(16) float dyn[];
   WaveTopk* tk = reinterpret_cast<WaveTopk*>(dyn);
@@ -319,32 +323,77 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
       af[m] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float wd = (A.prob && A.wd) ? A.wd[0] : 0.f;
+  const float wd = ((A.prob || BINS) && A.wd) ? A.wd[0] : 0.f;
   const float4* bp = A.items_packed + lane;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    // two wavefronts share each SIMD (launch bounds): while this one waits for its B stream or runs
-    // the top-K filter, its partner issues MFMAs - no software pipelining needed
-    float4 b0[D8];
+  const int NB = A.n_dist + 1;
+  constexpr int QN = BINS ? BINS : 1, DH = D8 / 2;
+  const uint4* qp = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)ut * ntile * 64 + lane) * QN;
+  uint4 qn[QN];
+  const int sbase = (ut * 32 + 4 * h) * NB;      // sts offsets fit 32 bits (checked by the host)
+  // The packed item stream is consumed in half tiles through two register sets: while the MFMAs of one
+  // half run, the other half (of this tile or of the next) is in flight.
+  float4 bA[DH], bB[DH];
+  if (t_begin < t_end) {
 #pragma unroll
-    for (int m = 0; m < D8; ++m) b0[m] = bp[((size_t)tile * D8 + m) * 64];
+    for (int m = 0; m < DH; ++m) bA[m] = bp[((size_t)t_begin * D8 + m) * 64];
+    if (BINS) {
+#pragma unroll
+      for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)t_begin * 64 * QN + q];
+    }
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+#pragma unroll
+    for (int m = 0; m < DH; ++m) bB[m] = bp[((size_t)tile * D8 + DH + m) * 64];
     const int j = tile * 32 + li;
     const bool jvalid = j < N;
     float pv[16];
+    if (BINS) {
+      // prob = sts[user][bin]: the bins are <= n_dist by construction and the caller's table has a zero
+      // in column n_dist ("too far": fun_acquire_prob's mask, Load_Data_by_length.py:231) and is readable
+      // for whole 32-user tiles, so the gather needs no clamp and no select
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        int bin;
+        if (BINS == 1) { const unsigned wv = r < 4 ? qn[0].x : r < 8 ? qn[0].y : r < 12 ? qn[0].z : qn[0].w; bin = (wv >> (8 * (r & 3))) & 255u; }
+        else { const uint4 qq = qn[(r >> 3) & (QN - 1)]; const int e = r & 7; const unsigned wv = e < 2 ? qq.x : e < 4 ? qq.y : e < 6 ? qq.z : qq.w; bin = (wv >> (16 * (e & 1))) & 65535u; }
+        pv[r] = A.sts[sbase + ((r & 3) + 8 * (r >> 2)) * NB + bin];
+      }
+      if (tile + 1 < t_end) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)(tile + 1) * 64 * QN + q];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int m = 0; m < D8; ++m) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, b0[m].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, b0[m].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, b0[m].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, b0[m].w, acc, 0, 0, 0);
+    for (int m = 0; m < DH; ++m) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bA[m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bA[m].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bA[m].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bA[m].w, acc, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + 1 < t_end) {
+#pragma unroll
+      for (int m = 0; m < DH; ++m) bA[m] = bp[((size_t)(tile + 1) * D8 + m) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < DH; ++m) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].x, bB[m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].y, bB[m].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].z, bB[m].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].w, bB[m].w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     tile_epilogue(A, T, acc, pv, thr, wd, ut, j, jvalid, K, tile - t_begin);
   }
   if (K > 0) {
@@ -558,7 +607,9 @@ static hipError_t launch_score_packed_t(const ScoreArgs& A, hipStream_t st, Timi
   tm->end(st);
   dim3 grid((A.n + 31) / 32, A.n_split / POI_NWAVE);
   tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
-  hipLaunchKernelGGL((score_kernel_packed<D8>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
+  if (A.ulptai && A.bin_bytes == 1) hipLaunchKernelGGL((score_kernel_packed<D8, 1>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
+  else if (A.ulptai) hipLaunchKernelGGL((score_kernel_packed<D8, 2>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
+  else hipLaunchKernelGGL((score_kernel_packed<D8, 0>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
   tm->end(st);
   return hipGetLastError();
 }

@@ -350,10 +350,72 @@ class OboSpatialGru(GruBasic):
         (n_user, n_dist+1) distance-bin probabilities; prob rows are rebuilt on the device per batch
         from the POI coordinates (needs coords= at construction)."""
         t = all_sus if isinstance(all_sus, torch.Tensor) else self._dev(np.asarray(all_sus, np.float64))
-        self.trained_sus = t.to(self.device, torch.float32).reshape(self.n_user, self.n_dist + 1).contiguous()
+        # rows padded to whole 32-user tiles (poi_score_topk_ulptai reads whole tiles); `trained_sus` is the
+        # caller's table, `_sus_masked` the same with column n_dist ("too far") zeroed as the scoring path expects
+        pad = ((self.n_user + 31) // 32) * 32
+        buf = torch.zeros((pad, self.n_dist + 1), dtype=torch.float32, device=self.device)
+        buf[:self.n_user] = t.to(self.device, torch.float32).reshape(self.n_user, self.n_dist + 1)
+        self.trained_sus = buf[:self.n_user]
+        self._sus_masked = buf.clone()
+        self._sus_masked[:, self.n_dist] = 0.0
         self.prob = None
         lens = torch.as_tensor(self._off_host[1:].astype(np.int64) - 1).to(self.device)
         self._last_poi = self.p.index_select(0, lens).contiguous()
+
+    def build_ulptai(self):
+        """usrs_last_poi_to_all_intervals (prog_bpr_gru_spatial.py:90): distance bins of (last train POI,
+        every POI), built once on the device and kept resident in the scoring kernel's tile order
+        (include/poi_hip.h, poi_ulptai_build).  Needs coords= at construction."""
+        if self.coords is None:
+            raise _lib.PoiError("build_ulptai needs coords= at construction")
+        bb = 1 if self.n_dist <= 255 else 2
+        nut, nt = (self.n_user + 31) // 32, (self.n_item + 31) // 32
+        lens = torch.as_tensor(self._off_host[1:].astype(np.int64) - 1).to(self.device)
+        last = self.p.index_select(0, lens).contiguous()
+        buf = torch.empty(nut * nt * 1024 * bb, dtype=torch.uint8, device=self.device)
+        self.ctx.check(self.lib.poi_ulptai_build(self.ctx.handle, _ptr(self.coords), _ptr(self._cphi), _ptr(self._binthr), _ptr(last),
+                                                 self.n_user, self.n_item, self.n_dist, self.dd * 1000.0, _ptr(buf), bb, self._stream()))
+        self._ulptai, self._ulptai_bytes, self._ulptai_row = buf, bb, nt * 1024 * bb
+        return buf
+
+    def ulptai_host(self):
+        """The (n_user, n_item) bin matrix decoded from the device layout (tests / inspection)."""
+        buf = getattr(self, "_ulptai", None)
+        if buf is None:
+            buf = self.build_ulptai()
+        bb = self._ulptai_bytes
+        nut, nt = (self.n_user + 31) // 32, (self.n_item + 31) // 32
+        a = buf.cpu().numpy().view(np.uint8 if bb == 1 else np.uint16).reshape(nut, nt, 64, 16)
+        lane, r = np.arange(64)[:, None], np.arange(16)[None, :]
+        row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)                 # (64, 16) user row within the tile
+        col = np.broadcast_to(lane & 31, (64, 16))
+        out = np.empty((nut * 32, nt * 32), np.int32)
+        for ut in range(nut):
+            blk = np.empty((32, nt, 32), np.int32)
+            blk[row, :, col] = a[ut].transpose(1, 2, 0)
+            out[ut * 32:(ut + 1) * 32] = blk.reshape(32, nt * 32)
+        return out[:self.n_user, :self.n_item]
+
+    def compute_sub_topk(self, start_end, k, return_scores=False):
+        """Fused scoring + top-K.  With bin probabilities (update_trained_sus) and coordinates, contiguous
+        user ranges starting at a multiple of 32 take the distance term from the resident bin matrix
+        (poi_score_topk_ulptai); anything else falls back to the dense prob rows."""
+        ids, lo = self._ids(start_end)
+        if self.prob is None and self.trained_sus is not None and self.coords is not None and lo is not None and lo % 32 == 0 \
+                and self.dim <= 128:
+            if getattr(self, "_ulptai", None) is None:
+                self.build_ulptai()
+            n = ids.numel()
+            users = self._rows(self.trained_users.t, ids, lo)
+            st = self._sus_masked[lo:lo + n]
+            idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
+            sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
+            bins = self._ulptai.data_ptr() + (lo // 32) * self._ulptai_row
+            self.ctx.check(self.lib.poi_score_topk_ulptai(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim,
+                                                          _ptr(self.wd.t), _ptr(st), bins, self._ulptai_bytes, self.n_dist, int(k),
+                                                          _ptr(idx), _ptr(sc), self._stream()))
+            return (idx, sc) if return_scores else idx
+        return super().compute_sub_topk(start_end, k, return_scores)
 
     def _prob_rows(self, ids, lo):
         if self.prob is not None:

@@ -316,6 +316,78 @@ def test_dist_prob_threshold_path_matches_oracle_at_scale(pa):
     assert np.array_equal(got, exp)
 
 
+def test_ulptai_matrix_and_fused_topk(pa, golden_dir):
+    """poi_ulptai_build == the reference's fun_compute_distance output (golden ulptai, decoded from the
+    tile layout, bit-exact) and == oracle cal_dis on synthetic coordinates; poi_score_topk_ulptai ranks ==
+    oracle top-K of  users.items + wd * fun_acquire_prob(sus, ulptai)  (bit-exact, checked gaps)."""
+    import torch
+    from poi_amd.data import bin_thresholds, cos_lat, make_synthetic
+    ctx = pa._lib.context(0)
+
+    def build(coords, last, n_user, n_item, B, dd):
+        bb = 1 if B <= 255 else 2
+        nut, nt = (n_user + 31) // 32, (n_item + 31) // 32
+        buf = torch.empty(nut * nt * 1024 * bb, dtype=torch.uint8, device="cuda")
+        dc = torch.as_tensor(np.asarray(coords, np.float64)).cuda()
+        cphi = torch.as_tensor(cos_lat(coords)).cuda(); thr = torch.as_tensor(bin_thresholds(dd, B)).cuda()
+        dl = torch.as_tensor(np.asarray(last, np.int32)).cuda()
+        ctx.check(ctx.lib.poi_ulptai_build(ctx.handle, dc.data_ptr(), cphi.data_ptr(), thr.data_ptr(), dl.data_ptr(), n_user, n_item, B, dd,
+                                           buf.data_ptr(), bb, None))
+        a = buf.cpu().numpy().view(np.uint8 if bb == 1 else np.uint16).reshape(nut, nt, 64, 16).astype(np.int32)
+        lane, r = np.arange(64)[:, None], np.arange(16)[None, :]
+        row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); col = np.broadcast_to(lane & 31, (64, 16))
+        out = np.empty((nut * 32, nt * 32), np.int32)
+        for ut in range(nut):
+            blk = np.empty((32, nt, 32), np.int32)
+            blk[row, :, col] = a[ut].transpose(1, 2, 0)
+            out[ut * 32:(ut + 1) * 32] = blk.reshape(32, nt * 32)
+        assert np.all(out[n_user:] == B) and np.all(out[:, n_item:] == B)      # padding = "too far"
+        return buf, bb, out[:n_user, :n_item]
+
+    g = np.load(os.path.join(golden_dir, "masks.npz"))
+    N, B, dd = int(g["n_item"]), int(g["n_dist"]), float(g["dd"])
+    ul = g["ulptai"]
+    last = g["pois_m"][np.arange(ul.shape[0]), g["msks"].sum(1) - 1]
+    _, _, got = build(g["coords"], last, ul.shape[0], N, B, dd)
+    assert np.array_equal(got, ul)
+    # uint16 bins (the reference's dd = 25 m / 1520 bins configuration)
+    B2 = 1520
+    _, bb2, got2 = build(g["coords"], last, ul.shape[0], N, B2, 25.0)
+    assert bb2 == 2
+    exp2 = np.array([[O.cal_dis(g["coords"][l][0], g["coords"][l][1], c[0], c[1], 25.0, B2) for c in g["coords"]] for l in last])
+    assert np.array_equal(got2, exp2)
+
+    ds = make_synthetic(150, 2100, 12, seed=11)
+    B, dd = ds.dist_num, ds.dd
+    last = ds.last_pois()
+    buf, bb, bins = build(ds.coords, last, 150, 2100, B, dd)
+    rng = np.random.default_rng(4)
+    D, K = 64, 20
+    users = rng.standard_normal((150, D)).astype(np.float32)
+    items = rng.standard_normal((2100, D)).astype(np.float32)
+    sus = rng.random((150, B + 1)).astype(np.float32)
+    wd = np.float32(0.7)
+    prob = O.acquire_prob(sus.astype(np.float64), bins, B)
+    full = users.astype(np.float64) @ items.astype(np.float64).T + float(wd) * prob
+    exp = O.topk_desc(full, K)
+    srt = np.sort(full, axis=1)[:, ::-1][:, :K + 1]
+    ok = np.min(srt[:, :-1] - srt[:, 1:], axis=1) > 1e-4                        # rows whose top-K order is unambiguous in f32
+    assert ok.sum() > 100
+    sus_m = np.zeros((160, B + 1), np.float32)             # whole 32-user tiles, "too far" column zeroed (ABI contract)
+    sus_m[:150, :B] = sus[:, :B]
+    du, di, dsus = torch.as_tensor(users).cuda(), torch.as_tensor(items).cuda(), torch.as_tensor(sus_m).cuda()
+    dwd = torch.as_tensor(np.array([wd])).cuda()
+    for lo, n in ((0, 150), (64, 86), (32, 64)):                               # whole matrix, ragged tail, interior batch
+        idx = torch.empty((n, K), dtype=torch.int32, device="cuda")
+        row_bytes = ((2100 + 31) // 32) * 1024 * bb
+        ctx.check(ctx.lib.poi_score_topk_ulptai(ctx.handle, du[lo:lo + n].data_ptr(), di.data_ptr(), n, 2100, D, dwd.data_ptr(),
+                                                dsus[lo:lo + n].data_ptr(), buf.data_ptr() + (lo // 32) * row_bytes, bb, B, K,
+                                                idx.data_ptr(), None, None))
+        got = idx.cpu().numpy()
+        sel = ok[lo:lo + n]
+        assert np.array_equal(got[sel], exp[lo:lo + n][sel])
+
+
 def test_l2_eval(pa):
     T = toy_problem(50, n_user=4, n_item=30, n_dist=7, dim=8)
     P = spatial_params(50, T)
