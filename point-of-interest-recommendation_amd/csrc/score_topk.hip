@@ -146,10 +146,17 @@ __device__ __forceinline__ void tile_epilogue(const ScoreArgs& A, WaveTopk& T, c
     }
   }
   if (!__any(any)) return;
+  // Row base of this half-wave, made opaque inside every block: otherwise the compiler hoists the 32
+  // per-row LDS addresses out of the tile loop, spills them (the loop is at the register limit) and
+  // reloads them from scratch right here.
+  const int urow0 = ut * 32 + 4 * h;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (any && sc[r] > thr[r] && ut * 32 + i < A.n) {
+    const int ic = (r & 3) + 8 * (r >> 2);
+    if (any && sc[r] > thr[r] && urow0 + ic < A.n) {
+      int hb = 4 * h;
+      asm volatile("" : "+v"(hb));
+      const int i = ic + hb;
       const int pos = atomicAdd(&T.cnt[i], 1);
       T.cs[i][pos] = sc[r]; T.ci[i][pos] = j;
     }
