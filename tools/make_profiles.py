@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 CSVs collected by tools/profile_gpu.sh into the committed summaries under profiles/:
+  <tag>_kernel_stats.csv / .md   per-kernel time (kernel trace + stats)
+  <tag>_pmc_traffic.json         HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes; gfx950 correction)
+  <tag>_sq_counters.md           SQ wave / wait / MFMA-busy ratios
+usage: python tools/make_profiles.py gpurun_out/prof_<tag> <tag>"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*", "", name)
+    return name.replace("poi::", "")
+
+
+def find(sub, pat):
+    g = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
+    return g[0] if g else None
+
+
+# ---- kernel stats -------------------------------------------------------------------------------
+st = find("stats", "*kernel_stats.csv")
+rows = list(csv.DictReader(open(st)))
+shutil.copy(st, os.path.join(P, tag + "_kernel_stats.csv"))
+bench = None
+try:
+    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+with open(os.path.join(P, tag + "_kernel_stats.md"), "w") as f:
+    f.write("# %s - rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`\n\n" % tag)
+    f.write("Gowalla-shape synthetic (100 k POIs, 50 k users, L <= 50, D = 128, 200 bins), one MI355X; 3 training epochs of\n"
+            "4 launches (12500 users each) + 2 evaluation passes.  Full CSV: `%s_kernel_stats.csv`.\n\n" % tag)
+    f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    for r in rows:
+        if float(r["Percentage"]) < 0.05:
+            continue
+        f.write("| `%s` | %s | %.3f | %.1f | %.2f |\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                         float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+    if bench:
+        f.write("\nLive HIP-event timings of the same build (`bench.py --steps 5 --warmup 2`): %.0f seq/s, %.2f ms/epoch, eval %.0f users/s.\n\n"
+                % (bench["value"], bench["ms_per_step"], bench.get("eval_users_per_s") or 0))
+        f.write("| timed region | ms/epoch | achieved | of peak |\n|---|---|---|---|\n")
+        for k, v in bench["kernels"].items():
+            f.write("| %s | %.3f | %s | %s |\n" % (k, v["ms_per_step"], ("%.1f %s" % (v["achieved"], v["unit"])) if "achieved" in v else "",
+                                                  ("%.0f %%" % (100 * v["frac"])) if "frac" in v else ""))
+
+
+# ---- PMC traffic --------------------------------------------------------------------------------
+def counters(sub):
+    fn = find(sub, "*counter_collection.csv")
+    acc = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(set)
+    for r in csv.DictReader(open(fn)):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        calls[k].add(r["Dispatch_Id"])
+    return acc, {k: len(v) for k, v in calls.items()}
+
+
+fa, fc = counters("fetch")
+wa, wc = counters("write")
+# timed regions of bench.py -> kernels
+REGION = {"te_gather": ["te_gather_kernel"], "te_gemm_ax": ["te_gemm_nt_kernel<true>"], "te_gemm_dx": ["te_gemm_nt_kernel<false>"],
+          "te_rec_fwd": ["te_rec_fwd16_kernel"], "te_rec_bwd": ["te_rec_bwd16_kernel"], "te_head": ["te_head_kernel"],
+          "te_wgrad": ["te_wgrad_kernel"], "te_scatter": ["te_reduce_kernel", "te_hot_reduce_kernel", "te_hot_apply_kernel"],
+          "dense_apply": ["dense_apply_kernel"], "te_finalize": ["te_finalize_kernel", "te_hslab_kernel"],
+          "te_prep": ["te_len_kernel", "te_scan_kernel", "te_rowmap_kernel", "te_pack_kernel", "te_transpose_kernel", "rs_hist_kernel",
+                      "rs_digit_scan_kernel", "rs_scatter_kernel", "te_segment_kernel"],
+          "score_topk": ["score_kernel_packed"], "te_predict": []}
+out = {"config": "bench.py default (gowalla shape, batch_users 12500)",
+       "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+               "(gfx950 reports half of wide coalesced reads); counter unit KB (x 1024); per launch of the TIMED REGION (sum over its kernels)",
+       "kernels": {}}
+for reg, pats in REGION.items():
+    fk = [k for k in fa if any(k.startswith(p) for p in pats)]
+    if not fk:
+        continue
+    n_launch = max(fc[k] for k in fk)
+    if reg == "te_prep":
+        n_launch = fc.get("te_rowmap_kernel", n_launch)
+    fetch = sum(fa[k]["FETCH_SIZE"] for k in fk)
+    write = sum(wa[k]["WRITE_SIZE"] for k in wa if any(k.startswith(p) for p in pats))
+    out["kernels"][reg] = {"launches": n_launch, "fetch_kb_raw": fetch / n_launch, "write_kb": write / n_launch,
+                           "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n_launch}
+json.dump(out, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
+
+# ---- SQ counters --------------------------------------------------------------------------------
+sa, sc = counters("sq")
+with open(os.path.join(P, tag + "_sq_counters.md"), "w") as f:
+    f.write("# %s - SQ counters per kernel (rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+            "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS)\n\n" % tag)
+    f.write("Same command as the kernel stats.  Percentages are of SQ_WAVE_CYCLES: WAIT_ANY = wave parked at s_waitcnt / barrier, WAIT_INST = issue "
+            "stall (MFMA dependency / pipe), ACTIVE = issuing.  MFMA_BUSY/BUSY is proportional to matrix-pipe utilisation.\n\n")
+    f.write("| kernel | launches | WAIT_ANY % | WAIT_INST % | ACTIVE % | MFMA_BUSY/BUSY | LDS_BANK_CONFLICT % | WAIT_INST_LDS % |\n|---|---|---|---|---|---|---|---|\n")
+    order = sorted(sa, key=lambda k: -sa[k]["SQ_BUSY_CYCLES"])
+    for k in order:
+        c = sa[k]
+        wv = c["SQ_WAVE_CYCLES"]
+        if wv <= 0 or not (k.startswith("te_") or k.startswith("score") or k.startswith("rs_") or "apply" in k or "topk" in k or "pack" in k):
+            continue
+        f.write("| `%s` | %d | %.0f | %.0f | %.0f | %.1f | %.1f | %.1f |\n" % (
+            k, sc[k], 100 * c["SQ_WAIT_ANY"] / wv, 100 * c["SQ_WAIT_INST_ANY"] / wv, 100 * c["SQ_ACTIVE_INST_ANY"] / wv,
+            c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_BUSY_CYCLES"], 1), 100 * c["SQ_LDS_BANK_CONFLICT"] / wv, 100 * c["SQ_WAIT_INST_LDS"] / wv))
+print("wrote", [x for x in os.listdir(P) if x.startswith(tag)])
