@@ -206,7 +206,8 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (tile) {
     n_head = c->num_cu * c->head_rounds;
     // te_wgrad launches (output-tile jobs) x n_kc K-chunks: fill the CUs exactly (no ragged second round)
-    n_kc = (c->num_cu * c->wgrad_rounds) / poi::te_wgrad_jobs(D, P->n_dist); if (n_kc < 1) n_kc = 1;
+    n_kc = (c->num_cu * c->wgrad_rounds) / poi::te_wgrad_jobs(D, P->n_dist);
+    if (n_kc < 1) n_kc = 1;
     n_slab = n_kc;
     if ((rc = ensure(c, c->hslab, sizeof(float) * (size_t)n_head * ((NB + 4) & ~3), st))) return rc;
   } else if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
