@@ -136,15 +136,17 @@ static void fill_args(poi::SeqArgs& A, const poi_gru_params* P, const poi_seq_ta
 
 // Carve the tile engine's packed-row workspace out of one grow-only buffer.
 static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int n,
-                    bool predict, hipStream_t st) {
+                    bool predict, bool spatial, hipStream_t st) {
   memset(&A, 0, sizeof A);
-  const int D = P->dim, NBP = poi::te_nbp(P->n_dist);
+  const int n_dist = spatial ? P->n_dist : -1;            // the plain GRU has no distance-bin table: zero rows
+  const int D = P->dim, NBP = poi::te_nbp(n_dist);
   A.lt = P->lt; A.di = P->di; A.ui = P->ui; A.wh = P->wh; A.bi = P->bi; A.vs = P->vs; A.bs = P->bs; A.wd = P->wd; A.lw = P->lw;
-  A.n_item = P->n_item; A.n_dist = P->n_dist; A.dim = D;
+  A.n_item = P->n_item; A.n_dist = n_dist; A.dim = D;
+  A.spatial = spatial ? 1 : 0; A.xw = spatial ? 2 * D : D;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
-  A.dl = poi::dense_layout(D, 2 * D, P->n_dist + 1);
+  A.dl = poi::dense_layout(D, A.xw, n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 64;
   const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D + (size_t)12 * D * D + 64;
   // sorted scatter (training): 3 slots per sequence position
@@ -157,7 +159,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t nin = Tcap * 3 + (size_t)n + 16 + sin;
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
-  const int R = P->n_item + 1 + P->n_dist + 1;
+  const int R = P->n_item + 1 + n_dist + 1;
   if (sorted && ((rc = ensure(c, c->seg_s, sizeof(int) * (size_t)(R + 1), st)) || (rc = ensure(c, c->seg_e, sizeof(int) * (size_t)(R + 1), st)))) return rc;
   float* f = (float*)c->te_ws.p;
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
@@ -184,7 +186,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
 }
 
 static bool use_tile(const poi_ctx* c, const poi_gru_params* P, bool spatial, int n) {
-  if (!spatial || c->engine == 1 || !poi::te_supported(P->dim, P->n_dist)) return false;
+  if (c->engine == 1 || !poi::te_supported(P->dim, spatial ? P->n_dist : -1)) return false;
   return c->engine == 2 || n >= 64;
 }
 
@@ -206,7 +208,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (tile) {
     n_head = c->num_cu * c->head_rounds;
     // te_wgrad launches (output-tile jobs) x n_kc K-chunks: fill the CUs exactly (no ragged second round)
-    n_kc = (c->num_cu * c->wgrad_rounds) / poi::te_wgrad_jobs(D, P->n_dist);
+    n_kc = (c->num_cu * c->wgrad_rounds) / poi::te_wgrad_jobs(D, spatial ? P->n_dist : -1, spatial);
     if (n_kc < 1) n_kc = 1;
     n_slab = n_kc;
     if ((rc = ensure(c, c->hslab, sizeof(float) * (size_t)n_head * ((NB + 4) & ~3), st))) return rc;
@@ -229,13 +231,13 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   A.g_di = (float*)c->g_di.p; A.mult_di = (int*)c->mult_di.p; A.nseq_di = (int*)c->nseq_di.p;
   if (tile) {
     poi::TeArgs E;
-    if ((rc = te_setup(c, E, P, T, uidx, n, false, st))) return rc;
+    if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
     E.out = out; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
     HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));
-    HIPCHK(c, poi::launch_dense_apply(A, true, n_kc, n_kc, alpha, lambda, st, &c->tm));
+    HIPCHK(c, poi::launch_dense_apply(A, spatial, n_kc, n_kc, alpha, lambda, st, &c->tm));
     return POI_OK;
   }
   HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st, &c->tm));
@@ -262,7 +264,7 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   HIPCHK(c, hipSetDevice(c->device));
   if (use_tile(c, P, spatial, n)) {
     poi::TeArgs E;
-    if ((rc = te_setup(c, E, P, T, uidx, n, true, (hipStream_t)stream))) return rc;
+    if ((rc = te_setup(c, E, P, T, uidx, n, true, spatial, (hipStream_t)stream))) return rc;
     E.hts = hts; E.sts = sts;
     HIPCHK(c, poi::launch_te_predict(E, c->num_cu, (hipStream_t)stream, &c->tm));
     return POI_OK;

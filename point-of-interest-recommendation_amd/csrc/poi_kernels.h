@@ -77,6 +77,7 @@ struct TeArgs {
   int n_seq;
   float* out;
   int predict;                        // 1: forward over all L positions, no bookkeeping
+  int spatial, xw;                    // 1 / 2D: Distance2Pre (POI + distance-bin input); 0 / D: plain GRU + BPR (n_dist == -1)
   int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_seq;
@@ -117,7 +118,7 @@ struct TeArgs {
 #define RS_GRID 256
 #define RS_HIST_INTS (RS_MAXBIN * RS_GRID)   // radix histogram: bins x blocks
 bool te_supported(int D, int n_dist);
-int te_wgrad_jobs(int D, int n_dist);
+int te_wgrad_jobs(int D, int n_dist, bool spatial);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 int te_nbp(int n_dist);

@@ -160,7 +160,7 @@ template <int D>
 __device__ __forceinline__ float4 ent_contrib(const TeArgs& A, int e, int doff, int c) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   const size_t rr = (size_t)(e & TE_ENT_ROW);
-  if (e & TE_ENT_DX) v = *reinterpret_cast<const float4*>(A.X + rr * 2 * D + doff + c);
+  if (e & TE_ENT_DX) v = *reinterpret_cast<const float4*>(A.X + rr * A.xw + doff + c);
   if (e & TE_ENT_GH) {
     float g = A.gcoef[rr - 1];
     if (e & TE_ENT_NEG) g = -g;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   for (int k = b; k < e; ++k) { const int v = A.soff[k]; A.soff[k] = run; run += v; }
   if (tid == 1023) {
     A.soff[n] = part[1023];
-    if (A.cnt) { A.cnt[0] = 3 * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; }   // slots, hot rows, hot chunks
+    if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; }   // slots, hot rows, hot chunks
   }
 }
 
@@ -200,13 +200,14 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
 // literal occurrences of the two padding rows (their analytic multiplicity is added by the caller).
 __device__ __forceinline__ void te_slots(const TeArgs& A, int k, int base, int L, int ns, int r0, int* pads_lt, int* pads_di) {
   const int lane = lane_id();
-  const int S0 = 3 * (r0 + k), nslot = 3 * (ns + 1), sentinel = A.n_item + 1 + A.n_dist + 1;
+  const int nsec = A.spatial ? 3 : 2;      // the plain GRU has no distance-bin section (n_dist == -1)
+  const int S0 = nsec * (r0 + k), nslot = nsec * (ns + 1), sentinel = A.n_item + 1 + A.n_dist + 1;
   int plt = 0, pdi = 0;
   for (int e0 = 0; e0 < nslot; e0 += 64) {
     const int e = e0 + lane;
     int key = sentinel, code = 0;
     bool is_plt = false, is_pdi = false;
-    if (e < nslot && e < 3 * L) {
+    if (e < nslot && e < nsec * L) {
       const int sec = e / L, j = e - sec * L;
       code = r0 + j;
       if (sec == 0) { key = A.p[base + j]; code |= (j < ns ? TE_ENT_DX : 0) | (j >= 1 ? TE_ENT_GH : 0); is_plt = key == A.n_item; }
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
   if (A.predict) return;
   if (lane == 0) { s_pad[w][0] = m_lt; s_pad[w][1] = n_lt; s_pad[w][2] = m_di; s_pad[w][3] = n_di; }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < (A.spatial ? 4 : 2)) {
     const int t = s_pad[0][threadIdx.x] + s_pad[1][threadIdx.x] + s_pad[2][threadIdx.x] + s_pad[3][threadIdx.x];
     int* dst = threadIdx.x == 0 ? A.mult_lt + A.n_item : threadIdx.x == 1 ? A.nseq_lt + A.n_item
              : threadIdx.x == 2 ? A.mult_di + A.n_dist : A.nseq_di + A.n_dist;
@@ -256,18 +257,42 @@ template <int D>
 __global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A, int predict) {
   constexpr int LPR = D / 4;                    // lanes per table row
   constexpr int RPB = TE_BLOCK / LPR;           // rows per block pass
-  const int T = A.soff[A.n_seq];
+  const int T = A.soff[A.n_seq], XW = A.xw;
   const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
   for (int r = blockIdx.x * RPB + sub; r < T; r += gridDim.x * RPB) {
     const int s = A.row_src[r];
     const float4 xp = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s] * D + c);
-    const float4 xd = *reinterpret_cast<const float4*>(A.di + (size_t)A.dp[s] * D + c);
-    *reinterpret_cast<float4*>(A.X + (size_t)r * 2 * D + c) = xp;
-    *reinterpret_cast<float4*>(A.X + (size_t)r * 2 * D + D + c) = xd;
+    *reinterpret_cast<float4*>(A.X + (size_t)r * XW + c) = xp;
+    if (A.spatial) {
+      const float4 xd = *reinterpret_cast<const float4*>(A.di + (size_t)A.dp[s] * D + c);
+      *reinterpret_cast<float4*>(A.X + (size_t)r * XW + D + c) = xd;
+    }
     if (!predict) {
       const float4 a = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s + 1] * D + c);
       const float4 b = *reinterpret_cast<const float4*>(A.lt + (size_t)A.q[s + 1] * D + c);
       *reinterpret_cast<float4*>(A.E + (size_t)r * D + c) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    }
+  }
+}
+
+// Plain GRU + BPR head (public/GRU.py:349-357): u = h_t . (x_p' - x_q'), loss -= log sigmoid(u),
+// g = -sigmoid(-u), DH = g * E.  D/4 lanes per packed row, float4 per lane (HBM-bound).
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_bpr_head_kernel(TeArgs A) {
+  constexpr int LPR = D / 4, RPB = TE_BLOCK / LPR;
+  const int T = A.soff[A.n_seq];
+  const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
+  for (int r0 = blockIdx.x * RPB; r0 < T; r0 += gridDim.x * RPB) {
+    const int r = min(r0 + sub, T - 1);
+    const float4 h = *reinterpret_cast<const float4*>(A.H + (size_t)r * D + c);
+    const float4 e = *reinterpret_cast<const float4*>(A.E + (size_t)r * D + c);
+    float u = (h.x * e.x + h.y * e.y) + (h.z * e.z + h.w * e.w);
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) u += __shfl_xor(u, o, 64);
+    const float g = -sigmoidf_(-u);
+    if (r0 + sub < T) {
+      *reinterpret_cast<float4*>(A.DH + (size_t)r * D + c) = make_float4(g * e.x, g * e.y, g * e.z, g * e.w);
+      if (c == 0) { A.gcoef[r] = g; A.rowloss[2 * (size_t)r] = 0.f; A.rowloss[2 * (size_t)r + 1] = log_sigmoidf_(u); }
     }
   }
 }
@@ -798,11 +823,13 @@ __host__ __device__ inline int te_nbp_dev(int n_dist) { const int t = (n_dist + 
 
 template <int D, int T>
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc) {
-  constexpr int XW = 2 * D, LDT = T + 4, Q = T / 64;         // Q x Q accumulators per wave
+  constexpr int LDT = T + 4, Q = T / 64;         // Q x Q accumulators per wave
+  const int XW = A.xw;
   constexpr int F4 = 32 * (T / 4) / TE_BLOCK;                // float4 per thread per operand per stage
   __shared__ __align__(16) float At[2][32][LDT];
   __shared__ __align__(16) float Bt[2][32][LDT];
-  constexpr int NB_UI = (3 * D / T) * (XW / T), NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
+  constexpr int NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
+  const int NB_UI = (3 * D / T) * (XW / T);
   const int Trows = A.soff[A.n_seq];
   // (an XCD-aware (chunk, job) order - all jobs of a K-chunk on one XCD - measured 10 % slower than this plain
   // order: it needs a chunk count that is a multiple of 8, which leaves CU slots empty)
@@ -918,6 +945,16 @@ __global__ __launch_bounds__(TE_BLOCK) void te_finalize_kernel(TeArgs A) {
   __shared__ float red[8];
   const int k = blockIdx.x * TE_BLOCK + threadIdx.x;
   float sur = 0.f, bpr = 0.f;
+  if (!A.spatial) {
+    // plain GRU (public/GRU.py:352-357,380): loss = -sum_t log sigmoid(u_t); the t = 0 term has
+    // h_0 = 0, i.e. u = 0 and no gradient - only its constant log sigmoid(0) = -ln 2
+    if (k < A.n_seq) {
+      for (int r = A.soff[k]; r < A.soff[k + 1]; ++r) bpr += A.rowloss[2 * (size_t)r + 1];
+      const int u = A.uidx[k];
+      A.out[k] = -(bpr + (A.off[u + 1] > A.off[u] ? -0.69314718056f : 0.f));
+    }
+    return;
+  }
   float ls0, ls1;
   {
     const float a = A.lw[0], b = A.lw[1], m = fmaxf(a, b);
@@ -952,12 +989,12 @@ __global__ __launch_bounds__(TE_BLOCK) void te_hslab_kernel(TeArgs A) {
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-int te_wgrad_jobs(int D, int n_dist) {
-  const int T = (D % 128 == 0) ? 128 : 64;
-  return (3 * D / T) * (2 * D / T) + (2 * D / T) * (D / T) + (D / T) * (D / T) + ((te_nbp_dev(n_dist) + T - 1) / T) * (D / T);
+int te_wgrad_jobs(int D, int n_dist, bool spatial) {
+  const int T = (D % 128 == 0) ? 128 : 64, XW = spatial ? 2 * D : D;
+  return (3 * D / T) * (XW / T) + (2 * D / T) * (D / T) + (D / T) * (D / T) + (spatial ? ((te_nbp_dev(n_dist) + T - 1) / T) * (D / T) : 0);
 }
 
-bool te_supported(int D, int n_dist) { return (D == 64 || D == 128) && n_dist + 1 <= 256; }
+bool te_supported(int D, int n_dist) { return (D == 64 || D == 128) && n_dist + 1 <= 256; }   // plain GRU: n_dist == -1
 
 int te_nbp(int n_dist);
 static int nbt_for(int nb) { const int t = (nb + 31) / 32; return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8; }
@@ -983,13 +1020,13 @@ static hipError_t te_head_dispatch(const TeArgs& A, int mode, int grid, hipStrea
 }
 
 static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
-  const int D = A.dim, XW = 2 * D, NBP = nbt_for(A.n_dist + 1) * 32, NB = A.n_dist + 1;
+  const int D = A.dim, NBP = nbt_for(A.n_dist + 1) * 32, NB = A.n_dist + 1;
   int n = 0;
   // B[k][n] = vs[n][k]   (K = D, N = NB -> NBP)
-  J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 8, NBP / 32, A.pVsT};
+  if (A.spatial) J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 8, NBP / 32, A.pVsT};
   if (train) {
     // B[k][n] = vs[k][n]   (K = NB -> NBP, N = D)
-    J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
+    if (A.spatial) J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
     // 16-column fragments of the recurrent kernels (16x16x4 MFMA): B[k][n] = wh[2][k][n] (K = D, N = D) and
     // B[k][n] = wh_flat[k][n], k < 2D (K = 2D, N = D)
     J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 16, D / 16, A.pWhc16, 1};
@@ -1009,21 +1046,26 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
-  hipLaunchKernelGGL(te_transpose_kernel, dim3((2 * D + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, 2 * D);
+  const int XW = A.xw;
+  hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, XW);
   { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 0);
   tm->end(st);
   tm->begin("te_gemm_ax", st);
-  hipLaunchKernelGGL(te_gemm_nt_kernel<true>, dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, A.X, 2 * D, A.ui, 2 * D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, 2 * D);
+  hipLaunchKernelGGL(te_gemm_nt_kernel<true>, dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, A.X, XW, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW);
   tm->end(st);
   tm->begin("te_rec_fwd", st);
   hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 0);
   tm->end(st);
   tm->begin("te_head", st);
-  hipError_t e = te_head_dispatch<D>(A, 0, A.n_head, st);
-  if (e != hipSuccess) return e;
+  if (A.spatial) {
+    hipError_t e = te_head_dispatch<D>(A, 0, A.n_head, st);
+    if (e != hipSuccess) return e;
+  } else {
+    hipLaunchKernelGGL(te_bpr_head_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
+  }
   tm->end(st);
   tm->begin("te_rec_bwd", st);
   hipLaunchKernelGGL(te_rec_bwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
@@ -1031,16 +1073,16 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->begin("te_wgrad", st);
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
-    const int jobs = te_wgrad_jobs(D, A.n_dist);
+    const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0);
     hipLaunchKernelGGL((te_wgrad_kernel<D, T>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
   tm->begin("te_gemm_dx", st);
-  hipLaunchKernelGGL(te_gemm_nt_kernel<false>, dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, A.G, 3 * D, A.uiT, 3 * D, A.X, 2 * D, (const float*)nullptr, A.soff + n, 2 * D, 3 * D);
+  hipLaunchKernelGGL(te_gemm_nt_kernel<false>, dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, A.G, 3 * D, A.uiT, 3 * D, A.X, XW, (const float*)nullptr, A.soff + n, XW, 3 * D);
   tm->end(st);
   tm->begin("te_finalize", st);
   hipLaunchKernelGGL(te_finalize_kernel, dim3((n + TE_BLOCK - 1) / TE_BLOCK), dim3(TE_BLOCK), 0, st, A);
-  hipLaunchKernelGGL(te_hslab_kernel, dim3((A.n_dist + 2 + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
+  if (A.spatial) hipLaunchKernelGGL(te_hslab_kernel, dim3((A.n_dist + 2 + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
   tm->end(st);
   return hipGetLastError();
 }

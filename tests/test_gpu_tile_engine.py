@@ -123,3 +123,65 @@ def test_tile_sorted_scatter_hot_rows_are_exact_and_reproducible(pa):
     for k in ("lt", "di"):
         assert np.array_equal(runs[0][k], runs[1][k]), k + " differs between two identical launches"
     pa._lib.context(0).set_engine("auto")
+
+
+GRU_NAMES = ("lt", "ui", "wh", "bi")
+
+
+def _gru_model(pa, T, P):
+    return pa.models.OboGru(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=T["n_user"],
+                            n_item=T["n_item"], n_in=T["dim"], n_hidden=T["dim"], init=P)
+
+
+def _get_gru(model):
+    return {k: getattr(model, k).get_value() for k in GRU_NAMES}
+
+
+@pytest.mark.parametrize("dim", [64, 128])
+def test_tile_plain_gru_single_sequence_is_the_reference_step(pa, dim):
+    """OboGru.seq_train (public/GRU.py:313-389) through the tile engine: one sequence per launch ==
+    the reference step, several users in a row (state carried on the device)."""
+    from tests.gpu_util import gru_params
+    T = toy_problem(110 + dim, n_user=5, n_item=80, dim=dim, len_max=9)
+    P = gru_params(110 + dim, T)
+    model = _gru_model(pa, T, P)
+    model.ctx.set_engine("tile")
+    Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
+    for u in [3, 0, 3, 1]:
+        P, loss = O.gru_step(P, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
+        got_loss = model.train(np.int32(u))
+        assert_close(got_loss, loss, "loss")
+        got = _get_gru(model)
+        for k in GRU_NAMES:
+            assert_close(got[k], P[k], "%s after user %d" % (k, u))
+        P = round_f32({**P, **got})
+    model.ctx.set_engine("auto")
+
+
+@pytest.mark.parametrize("dim,n_user", [(64, 77), (128, 150)])
+def test_tile_plain_gru_batch_matches_mean_rule_and_seq_engine(pa, dim, n_user):
+    from tests.gpu_util import gru_params
+    T = toy_problem(120 + dim, n_user=n_user, n_item=60, dim=dim, len_max=12, hot=20)
+    P = gru_params(120 + dim, T)
+    users = np.random.default_rng(1).permutation(n_user)[: n_user - 2].astype(np.int32)
+    Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
+    news, touched, losses = [], [], []
+    for u in users:
+        Pn, loss = O.gru_step(P, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
+        news.append(Pn); losses.append(loss)
+        touched.append(dict(lt=np.unique(np.concatenate((Pm[u], Qm[u])))))
+    exp = batch_mean_update(P, news, touched, ("lt",), ("ui", "wh", "bi"))
+    res = {}
+    for eng in ("tile", "seq"):
+        model = _gru_model(pa, T, P)
+        model.ctx.set_engine(eng)
+        got_loss = model.train_batch(users)
+        assert_close(np.asarray(got_loss).reshape(-1), np.asarray(losses), eng + " losses", rtol=2e-5)
+        got = _get_gru(model)
+        for k in GRU_NAMES:
+            assert_close(got[k], exp[k], "%s %s" % (eng, k))
+        model.train_batch(users[:70])
+        res[eng] = _get_gru(model)
+    for k in GRU_NAMES:
+        assert_close(res["tile"][k], res["seq"][k], "tile vs seq second launch " + k, rtol=2e-5)
+    pa._lib.context(0).set_engine("auto")
