@@ -337,6 +337,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   int want = variant == 2 ? (c->num_cu + units - 1) / units : (c->num_cu * 8 + units - 1) / units;   // 8 waves per CU
   if (want > ntile / 8) want = ntile / 8;      // >= 8 tiles per stream: amortise the per-wave top-K epilogue
   if (want < 1) want = 1;
+  if (want < (ntile + 2046) / 2047) want = (ntile + 2046) / 2047;      // candidate lists hold 16-bit item offsets: < 65536 items per range
   int n_split = variant == 2 ? want : ((want + 3) / 4) * 4;
   A.n_split = n_split;
   const int n_pad = n_utile * 32;

@@ -20,8 +20,8 @@ namespace poi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define TK_CAP 72   // candidate slots per user per wave (>= K + 32; compaction when cnt > TK_CAP - 32).
-                    // 4 waves x 32 users x 72 x 8 B = 74 KB per workgroup -> two workgroups per CU
+#define TK_CAP 80   // candidate slots per user per wave (>= K + 32; compaction when cnt > TK_CAP - 32).
+                    // 4 waves x 32 users x 80 x 6 B = 61 KB per workgroup (+ 16 KB of A fragments: two workgroups per CU)
 
 __device__ __forceinline__ bool better(float s, int i, float ps, int pi) {
   return (s > ps) || (s == ps && i < pi);
@@ -47,10 +47,11 @@ __device__ __forceinline__ void wave_sort_desc(float& s, int& idx) {
 
 struct WaveTopk {   // LDS state of one wavefront
   float cs[32][TK_CAP];
-  int ci[32][TK_CAP];
+  unsigned short ci[32][TK_CAP];   // item index relative to the first item of this wave's range (< 65536: host-checked)
   int cnt[32];
   float thr[32];
   unsigned gseen[32];   // last global bound seen / published per user (order-mapped)
+  unsigned gtmp[32];    // staging of a bound refresh
 };
 
 // Orders this wavefront's LDS traffic only (LDS is in-order per wave; the waitcnt makes returned data
@@ -82,21 +83,33 @@ __device__ __forceinline__ void compact_user(WaveTopk& T, int i, int K, unsigned
   if (n <= K) { if (lane == 0) T.thr[i] = -INFINITY; return; }
   const bool v0 = lane < n, v1 = lane + 64 < n;
   const float s0 = v0 ? T.cs[i][lane] : -INFINITY, s1 = v1 ? T.cs[i][lane + 64] : -INFINITY;
-  const int i0 = v0 ? T.ci[i][lane] : INT_MAX, i1 = v1 ? T.ci[i][lane + 64] : INT_MAX;
+  const int i0 = v0 ? (int)T.ci[i][lane] : 0xFFFF, i1 = v1 ? (int)T.ci[i][lane + 64] : 0xFFFF;
+  // one 64-bit key per candidate (order-mapped score, then reversed index): "beats" is a single compare.
+  // The list is walked with v_readlane (the candidates already sit two per lane) - no LDS round trip per
+  // element, which made this loop ~10 k cycles.
+  const unsigned long long k0 = ((unsigned long long)f2ord(s0) << 32) | (unsigned)(0xFFFF - i0);
+  const unsigned long long k1 = ((unsigned long long)f2ord(s1) << 32) | (unsigned)(0xFFFF - i1);
+  const unsigned h0 = (unsigned)(k0 >> 32), l0 = (unsigned)k0, h1 = (unsigned)(k1 >> 32), l1 = (unsigned)k1;
   int r0 = 0, r1 = 0;
-  for (int j = 0; j < n; ++j) {
-    const float sj = T.cs[i][j];          // same address in every lane: LDS broadcast
-    const int ij = T.ci[i][j];
-    r0 += (sj > s0 || (sj == s0 && ij < i0)) ? 1 : 0;
-    r1 += (sj > s1 || (sj == s1 && ij < i1)) ? 1 : 0;
+  const int na = n < 64 ? n : 64;
+#pragma unroll 4
+  for (int j = 0; j < na; ++j) {
+    const unsigned long long kj = ((unsigned long long)__builtin_amdgcn_readlane(h0, j) << 32) | (unsigned)__builtin_amdgcn_readlane(l0, j);
+    r0 += kj > k0 ? 1 : 0;
+    r1 += kj > k1 ? 1 : 0;
+  }
+  for (int j = 64; j < n; ++j) {
+    const unsigned long long kj = ((unsigned long long)__builtin_amdgcn_readlane(h1, j - 64) << 32) | (unsigned)__builtin_amdgcn_readlane(l1, j - 64);
+    r0 += kj > k0 ? 1 : 0;
+    r1 += kj > k1 ? 1 : 0;
   }
   const bool keep0 = v0 && r0 < K, keep1 = v1 && r1 < K;
   // the K-th best (rank K-1) sits in exactly one slot
   const unsigned long long kb0 = __ballot(v0 && r0 == K - 1), kb1 = __ballot(v1 && r1 == K - 1);
   const float kth = kb0 ? readlane_f(s0, __builtin_ctzll(kb0)) : readlane_f(s1, __builtin_ctzll(kb1 | (1ull << 63)));
   wave_fence();
-  if (keep0) { T.cs[i][r0] = s0; T.ci[i][r0] = i0; }     // ranks 0..K-1 are distinct: sorted, gap-free
-  if (keep1) { T.cs[i][r1] = s1; T.ci[i][r1] = i1; }
+  if (keep0) { T.cs[i][r0] = s0; T.ci[i][r0] = (unsigned short)i0; }     // ranks 0..K-1 are distinct: sorted, gap-free
+  if (keep1) { T.cs[i][r1] = s1; T.ci[i][r1] = (unsigned short)i1; }
   if (lane == 0) {
     T.cnt[i] = K;
     T.thr[i] = kth;
@@ -117,7 +130,7 @@ __device__ __forceinline__ void compact_user(WaveTopk& T, int i, int K, unsigned
 // branch-free and ONE wave-uniform branch skips the whole insertion block when no lane passes - the
 // common case once the thresholds have risen - so the fast path has no LDS round trips at all.
 __device__ __forceinline__ void tile_epilogue(const ScoreArgs& A, WaveTopk& T, const f32x16& acc, const float (&pv)[16],
-                                              float (&thr)[16], float wd, int ut, int j, bool jvalid, int K, int tile_no) {
+                                              float (&thr)[16], float wd, int ut, int j, int jrel, bool jvalid, int K, int tile_no) {
   const int lane = lane_id(), h = lane >> 5, N = A.n_item;
   float sc[16];
   bool any = false;
@@ -138,11 +151,18 @@ __device__ __forceinline__ void tile_epilogue(const ScoreArgs& A, WaveTopk& T, c
   if (K > 0 && A.gbound && (tile_no & 7) == 7 && A.dbg != 2) {
     // fold the bounds published by the other item ranges into the register thresholds (stale values
     // are merely weaker bounds, so relaxed device-scope loads suffice)
+    // ONE coalesced load of the tile's 32 bounds, redistributed through LDS (sixteen dependent
+    // device-scope loads per lane serialise: ~24 k cycles per refresh)
+    if (lane < 32) {
+      const unsigned g = __hip_atomic_load(A.gbound + ut * 32 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      T.gtmp[lane] = g;
+      if (g > T.gseen[lane]) T.gseen[lane] = g;
+    }
+    wave_fence();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const unsigned g = __hip_atomic_load(A.gbound + ut * 32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (g) { thr[r] = fmaxf(thr[r], ord2f(g)); if ((lane & 31) == 0 && g > T.gseen[i]) T.gseen[i] = g; }
+      const unsigned g = T.gtmp[(r & 3) + 8 * (r >> 2) + 4 * h];
+      thr[r] = g ? fmaxf(thr[r], ord2f(g)) : thr[r];
     }
   }
   if (!__any(any)) return;
@@ -158,7 +178,7 @@ __device__ __forceinline__ void tile_epilogue(const ScoreArgs& A, WaveTopk& T, c
       asm volatile("" : "+v"(hb));
       const int i = ic + hb;
       const int pos = atomicAdd(&T.cnt[i], 1);
-      T.cs[i][pos] = sc[r]; T.ci[i][pos] = j;
+      T.cs[i][pos] = sc[r]; T.ci[i][pos] = (unsigned short)jrel;
     }
   }
   wave_fence();
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
         const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
       }
-      tile_epilogue(A, T, acc, pv, thr, wd, ut, j, jvalid, K, tile - t_begin);
+      tile_epilogue(A, T, acc, pv, thr, wd, ut, j, j - t_begin * 32, jvalid, K, tile - t_begin);
     }
     if constexpr (DB) {
 #pragma unroll
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
       if (lane < K) {
         const size_t o = ((size_t)split * n_pad + ut * 32 + i) * K + lane;
         A.cand_score[o] = lane < n ? T.cs[i][lane] : -INFINITY;
-        A.cand_idx[o] = lane < n ? T.ci[i][lane] : INT_MAX;
+        A.cand_idx[o] = lane < n ? t_begin * 32 + (int)T.ci[i][lane] : INT_MAX;
       }
     }
   }
@@ -304,6 +324,9 @@ template <int D8, int BINS>
 __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A) {
   extern __shared__ __align__(16) float dyn[];
   WaveTopk* tk = reinterpret_cast<WaveTopk*>(dyn);
+  // the user tile's A fragments (identical for the four waves of the workgroup: same users, different
+  // item ranges) live in LDS, [k-group][lane] float4: 64 registers freed for a full tile of B prefetch
+  float4* af = reinterpret_cast<float4*>(tk + POI_NWAVE);
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
   const int D = A.dim, N = A.n_item, K = A.k;
   const int ut = blockIdx.x;
@@ -315,42 +338,59 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
   WaveTopk& T = tk[w];
   if (K > 0) {
     if (lane < 32) { T.cnt[lane] = 0; T.thr[lane] = -INFINITY; T.gseen[lane] = 0; }
-    wave_fence();
   }
-  float thr[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
-  float4 af[D8];
   {
     const int urow = min(ut * 32 + li, A.n - 1);
     const float* up = A.users + (size_t)urow * D;
-#pragma unroll
-    for (int m = 0; m < D8; ++m) {
+    for (int m = w; m < D8; m += POI_NWAVE) {
       const int k0 = 8 * m + 4 * h;
-      af[m] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      af[m * 64 + lane] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  __syncthreads();
+  float thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
   const float wd = ((A.prob || BINS) && A.wd) ? A.wd[0] : 0.f;
   const float4* bp = A.items_packed + lane;
+  const float4* ap = af + lane;
   const int NB = A.n_dist + 1;
   constexpr int QN = BINS ? BINS : 1, DH = D8 / 2;
   const uint4* qp = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)ut * ntile * 64 + lane) * QN;
   uint4 qn[QN];
   const int sbase = (ut * 32 + 4 * h) * NB;      // sts offsets fit 32 bits (checked by the host)
-  // The packed item stream is consumed in half tiles through two register sets: while the MFMAs of one
-  // half run, the other half (of this tile or of the next) is in flight.
-  float4 bA[DH], bB[DH];
+  // The packed item stream runs a full tile ahead: two register sets of two half tiles each; while tile t
+  // is multiplied out of set p, tile t+1 lands in set 1-p.
+  float4 bA[2][DH], bB[2][DH];
   if (t_begin < t_end) {
 #pragma unroll
-    for (int m = 0; m < DH; ++m) bA[m] = bp[((size_t)t_begin * D8 + m) * 64];
+    for (int m = 0; m < DH; ++m) { bA[0][m] = bp[((size_t)t_begin * D8 + m) * 64]; bB[0][m] = bp[((size_t)t_begin * D8 + DH + m) * 64]; }
     if (BINS) {
 #pragma unroll
       for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)t_begin * 64 * QN + q];
     }
   }
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  auto half = [&](f32x16& acc, const float4 (&b)[DH], int m0) {
+    float4 a2[2];
+    a2[0] = ap[m0 * 64];
 #pragma unroll
-    for (int m = 0; m < DH; ++m) bB[m] = bp[((size_t)tile * D8 + DH + m) * 64];
+    for (int m = 0; m < DH; ++m) {
+      if (m + 1 < DH) a2[(m + 1) & 1] = ap[(m0 + m + 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 a = a2[m & 1];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[m].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[m].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[m].w, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto do_tile = [&](int tile, float4 (&cA)[DH], float4 (&cB)[DH], float4 (&nA)[DH], float4 (&nB)[DH]) {
+    const bool more = tile + 1 < t_end;
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < DH; ++m) nA[m] = bp[((size_t)(tile + 1) * D8 + m) * 64];
+    }
     const int j = tile * 32 + li;
     const bool jvalid = j < N;
     float pv[16];
@@ -365,7 +405,7 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
         else { const uint4 qq = qn[(r >> 3) & (QN - 1)]; const int e = r & 7; const unsigned wv = e < 2 ? qq.x : e < 4 ? qq.y : e < 6 ? qq.z : qq.w; bin = (wv >> (16 * (e & 1))) & 65535u; }
         pv[r] = A.sts[sbase + ((r & 3) + 8 * (r >> 2)) * NB + bin];
       }
-      if (tile + 1 < t_end) {
+      if (more) {
 #pragma unroll
         for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)(tile + 1) * 64 * QN + q];
       }
@@ -380,28 +420,18 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    half(acc, cA, 0);
+    if (more) {
 #pragma unroll
-    for (int m = 0; m < DH; ++m) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bA[m].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bA[m].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bA[m].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bA[m].w, acc, 0, 0, 0);
+      for (int m = 0; m < DH; ++m) nB[m] = bp[((size_t)(tile + 1) * D8 + DH + m) * 64];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (tile + 1 < t_end) {
-#pragma unroll
-      for (int m = 0; m < DH; ++m) bA[m] = bp[((size_t)(tile + 1) * D8 + m) * 64];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < DH; ++m) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].x, bB[m].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].y, bB[m].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].z, bB[m].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[DH + m].w, bB[m].w, acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, jvalid, K, tile - t_begin);
+    half(acc, cB, DH);
+    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, j - t_begin * 32, jvalid, K, tile - t_begin);
+  };
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    do_tile(tile, bA[0], bB[0], bA[1], bB[1]);
+    if (tile + 1 < t_end) do_tile(tile + 1, bA[1], bB[1], bA[0], bB[0]);
   }
   if (K > 0) {
     const int n_pad = gridDim.x * 32;
@@ -411,7 +441,7 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
       if (lane < K) {
         const size_t o = ((size_t)split * n_pad + ut * 32 + i) * K + lane;
         A.cand_score[o] = lane < n ? T.cs[i][lane] : -INFINITY;
-        A.cand_idx[o] = lane < n ? T.ci[i][lane] : INT_MAX;
+        A.cand_idx[o] = lane < n ? t_begin * 32 + (int)T.ci[i][lane] : INT_MAX;
       }
     }
   }
@@ -502,7 +532,7 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel_shared(ScoreArgs A) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, b.w, acc, 0, 0, 0);
     }
     if (more) stage_store(sv, Bn);
-    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, jvalid, K, tile - t_begin);
+    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, j - t_begin * 32, jvalid, K, tile - t_begin);
     __syncthreads();
     float* t = Bc; Bc = Bn; Bn = t;
   }
@@ -514,7 +544,7 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel_shared(ScoreArgs A) {
       if (lane < K) {
         const size_t o = ((size_t)split * n_pad + ut * 32 + i) * K + lane;
         A.cand_score[o] = lane < n ? T.cs[i][lane] : -INFINITY;
-        A.cand_idx[o] = lane < n ? T.ci[i][lane] : INT_MAX;
+        A.cand_idx[o] = lane < n ? t_begin * 32 + (int)T.ci[i][lane] : INT_MAX;
       }
     }
   }
@@ -614,9 +644,9 @@ static hipError_t launch_score_packed_t(const ScoreArgs& A, hipStream_t st, Timi
   tm->end(st);
   dim3 grid((A.n + 31) / 32, A.n_split / POI_NWAVE);
   tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
-  if (A.ulptai && A.bin_bytes == 1) hipLaunchKernelGGL((score_kernel_packed<D8, 1>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
-  else if (A.ulptai) hipLaunchKernelGGL((score_kernel_packed<D8, 2>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
-  else hipLaunchKernelGGL((score_kernel_packed<D8, 0>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE, st, A);
+  if (A.ulptai && A.bin_bytes == 1) hipLaunchKernelGGL((score_kernel_packed<D8, 1>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE + sizeof(float4) * D8 * 64, st, A);
+  else if (A.ulptai) hipLaunchKernelGGL((score_kernel_packed<D8, 2>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE + sizeof(float4) * D8 * 64, st, A);
+  else hipLaunchKernelGGL((score_kernel_packed<D8, 0>), grid, dim3(POI_BLOCK), sizeof(WaveTopk) * POI_NWAVE + sizeof(float4) * D8 * 64, st, A);
   tm->end(st);
   return hipGetLastError();
 }

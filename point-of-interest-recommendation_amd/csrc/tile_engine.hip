@@ -449,9 +449,9 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
   int rowb[4], nsr[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { rowb[r] = s_r0[g4 + r]; nsr[r] = s_ns[g4 + r]; }
-  float4 wzr[2][KG], wc[1][KG];
-  load_bfrag<KG>(wzr[0], A.pWhT16, w);
-  load_bfrag<KG>(wzr[1], A.pWhT16, NW + w);
+  float4 wz[1][KG], wr[1][KG], wc[1][KG];
+  load_bfrag<KG>(wz[0], A.pWhT16, w);
+  load_bfrag<KG>(wr[0], A.pWhT16, NW + w);
   load_bfrag<KG>(wc[0], A.pWhT16, 2 * NW + w);
   // pre-activations of the NEXT step are fetched while the current step computes (G still holds
   // X.ui^T + bi for rows not yet visited)
@@ -468,38 +468,41 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
     }
   };
   fetch(0, cz, cr, cc);
+  float hcur[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's elements of h_{t-1} (it wrote them itself)
   for (int t = 0; t < ns_max; ++t) {
     fetch(t + 1, nz, nr, nc);
-    f32x4 azr[2];
+    // r gate first: its sigmoid, the r*h exchange and the stores then overlap the z-gate MFMAs (of this
+    // wave and of its SIMD partner) instead of sitting between the MFMA block and the barrier
+    f32x4 ar[1], az[1], ac[1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { azr[0][r] = cz[r]; azr[1][r] = cr[r]; }
-    mma16_regb<KG, 2>(azr, Hb, LDA, wzr);
-    float zv[4], hp[4];
+    for (int r = 0; r < 4; ++r) ar[0][r] = cr[r];
+    mma16_regb<KG, 1>(ar, Hb, LDA, wr);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r;
-      const bool on = t < nsr[r];
-      zv[r] = sigmoidf_(azr[0][r]);
-      const float rv = sigmoidf_(azr[1][r]);
-      hp[r] = Hb[i * LDA + col];
-      const float rh = rv * hp[r];
+      const float rv = sigmoidf_(ar[0][r]);
+      const float rh = rv * hcur[r];
       RHb[i * LDA + col] = rh;
-      const size_t row = (size_t)(on ? rowb[r] + t : Tsp);
+      const size_t row = (size_t)(t < nsr[r] ? rowb[r] + t : Tsp);
       A.G[row * 3 * D + D + col] = rv;
       if (!predict) A.RH[row * D + col] = rh;
     }
-    lds_barrier();
-    f32x4 ac[1];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ac[0][r] = cc[r];
+    for (int r = 0; r < 4; ++r) az[0][r] = cz[r];
+    mma16_regb<KG, 1>(az, Hb, LDA, wz);
+    lds_barrier();
+    float zv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { zv[r] = sigmoidf_(az[0][r]); ac[0][r] = cc[r]; }
     mma16_regb<KG, 1>(ac, RHb, LDA, wc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r;
       const bool on = t < nsr[r];
       const float c = fast_tanh(ac[0][r]);
-      const float hn = on ? (1.0f - zv[r]) * hp[r] + zv[r] * c : hp[r];
+      const float hn = on ? (1.0f - zv[r]) * hcur[r] + zv[r] * c : hcur[r];
       Hb[i * LDA + col] = hn;          // nobody reads Hb between the two barriers of a step
+      hcur[r] = hn;
       if (!predict) {
         const size_t row = (size_t)(on ? rowb[r] + t : Tsp);
         A.G[row * 3 * D + col] = zv[r]; A.G[row * 3 * D + 2 * D + col] = c;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r, k = tile * 16 + i;
-      if (k < A.n_seq) A.hts[(size_t)k * D + col] = Hb[i * LDA + col];
+      if (k < A.n_seq) A.hts[(size_t)k * D + col] = hcur[r];
     }
   }
 }
