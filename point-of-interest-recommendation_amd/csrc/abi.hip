@@ -28,7 +28,7 @@ struct poi_ctx {
   int engine = 0;   // 0 auto, 1 per-sequence, 2 tile
   int wgrad_rounds = 2;
   int head_rounds = 3;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
-  int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1|2 (tuning only)
+  int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
   // BPR
@@ -92,7 +92,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_SEQ_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) c->wg_per_cu = v; }
   if (const char* e = getenv("POI_HEAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->head_rounds = v; }
   if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
-  if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 2) c->score_variant = v; }
+  if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   *out = c;
@@ -326,19 +326,19 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   if (U) { A.ulptai = U->bins; A.bin_bytes = U->bin_bytes; A.sts = U->sts; A.n_dist = U->n_dist; }
   if (const char* e = getenv("POI_SCORE_DBG")) A.dbg = atoi(e);
   const int ntile = (n_item + 31) / 32;
-  // variant: 0 = one item stream per wave (row-per-lane loads; small n), 1 = packed item stream per
-  // wave, 2 = 4 user tiles per workgroup sharing each item tile through LDS (default for n >= 128)
+  // variant: 0 = one item stream per wave (row-per-lane loads; small n or dim > 128), 1 = packed item
+  // stream per wave with the user tile's A fragments in LDS (default for n >= 128)
   int variant = (n >= 128 && dim <= 128) ? 1 : 0;
   if (c->score_variant >= 0 && dim <= 128) variant = c->score_variant;
   if (U) variant = 1;      // the bin matrix is laid out for the packed-stream kernel
-  const int n_utile = variant == 2 ? ((n + 127) / 128) * 4 : (n + 31) / 32;
-  const int units = variant == 2 ? n_utile / 4 : n_utile;
+  const int n_utile = (n + 31) / 32;
+  const int units = n_utile;
   // long item streams keep per-user thresholds high (few top-K compactions)
-  int want = variant == 2 ? (c->num_cu + units - 1) / units : (c->num_cu * 8 + units - 1) / units;   // 8 waves per CU
+  int want = (c->num_cu * 8 + units - 1) / units;   // 8 waves per CU
   if (want > ntile / 8) want = ntile / 8;      // >= 8 tiles per stream: amortise the per-wave top-K epilogue
   if (want < 1) want = 1;
   if (want < (ntile + 2046) / 2047) want = (ntile + 2046) / 2047;      // candidate lists hold 16-bit item offsets: < 65536 items per range
-  int n_split = variant == 2 ? want : ((want + 3) / 4) * 4;
+  int n_split = ((want + 3) / 4) * 4;
   A.n_split = n_split;
   const int n_pad = n_utile * 32;
   int rc;
@@ -358,8 +358,6 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
     A.items_packed = (float4*)c->items_pk.p;
     HIPCHK(c, poi::launch_score_packed(A, st, &c->tm));
-  } else if (variant == 2) {
-    HIPCHK(c, poi::launch_score_shared(A, st, &c->tm));
   } else {
     HIPCHK(c, poi::launch_score(A, st, &c->tm));
   }

@@ -10,8 +10,8 @@
 // lane (i = lane&31, h = lane>>5) holds row i of the tile, k-columns {8m+4h .. 8m+4h+3}, one float4
 // per m; MFMA step s = 4m+c consumes component c, so A and B agree on a permuted k order and every
 // byte loaded is used.  The 32x32 result tile stays in registers; the top-K filter compares it with
-// the per-user thresholds and appends survivors to per-user LDS candidate lists, compacted by a
-// 64-lane bitonic sort (wavefront shuffles) whenever a list could overflow.
+// the per-user thresholds and appends survivors to per-user LDS candidate lists (f32 score + 16-bit
+// item offset), compacted by rank counting over v_readlane whenever a list could overflow.
 #include "poi_common.h"
 #include "poi_kernels.h"
 #include <limits.h>
@@ -447,109 +447,6 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
   }
 }
 
-// Shared-tile variant: a workgroup = 4 wavefronts = 4 user tiles (128 users) sharing every 32-item
-// tile through LDS (4x less L2/MALL traffic than one stream per wave).  The item tile is loaded once
-// per workgroup with coalesced float4 loads, double-buffered, one barrier per tile; the global loads
-// of the next tile and of this tile's `prob` values are issued BEFORE the MFMA block and the LDS
-// write happens after it (async-stage split), so their latency hides under the matrix work.
-template <int D8>
-__global__ __launch_bounds__(POI_BLOCK) void score_kernel_shared(ScoreArgs A) {
-  extern __shared__ __align__(16) float dyn[];
-  constexpr int DP = D8 * 8, LDB = DP + 4;
-  constexpr int C4N = DP / 4;
-  constexpr int SPT = (32 * C4N + POI_BLOCK - 1) / POI_BLOCK;
-  float* Bt0 = dyn;
-  float* Bt1 = dyn + 32 * LDB;
-  WaveTopk* tk = reinterpret_cast<WaveTopk*>(dyn + 2 * 32 * LDB);
-  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
-  const int D = A.dim, N = A.n_item, K = A.k;
-  const int ut = blockIdx.x * POI_NWAVE + w;
-  const int split = blockIdx.y;
-  const int ntile = (N + 31) / 32;
-  const int tps = (ntile + A.n_split - 1) / A.n_split;
-  const int t_begin = split * tps;
-  const int t_end = min(ntile, t_begin + tps);
-  WaveTopk& T = tk[w];
-  if (K > 0) {
-    if (lane < 32) { T.cnt[lane] = 0; T.thr[lane] = -INFINITY; T.gseen[lane] = 0; }
-    wave_fence();
-  }
-  float thr[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
-  float4 af[D8];
-  {
-    const int urow = min(ut * 32 + li, A.n - 1);
-    const float* up = A.users + (size_t)urow * D;
-#pragma unroll
-    for (int m = 0; m < D8; ++m) {
-      const int k0 = 8 * m + 4 * h;
-      af[m] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  const float wd = (A.prob && A.wd) ? A.wd[0] : 0.f;
-  auto stage_load = [&](float4 (&sv)[SPT], int tile) {
-#pragma unroll
-    for (int s = 0; s < SPT; ++s) {
-      const int e = tid + s * POI_BLOCK;
-      const int r = e / C4N, c = (e % C4N) * 4;
-      const int irow = min(tile * 32 + r, N - 1);
-      sv[s] = (e < 32 * C4N && c < D) ? *reinterpret_cast<const float4*>(A.items + (size_t)irow * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto stage_store = [&](const float4 (&sv)[SPT], float* Bt) {
-#pragma unroll
-    for (int s = 0; s < SPT; ++s) {
-      const int e = tid + s * POI_BLOCK;
-      if (e < 32 * C4N) *reinterpret_cast<float4*>(Bt + (e / C4N) * LDB + (e % C4N) * 4) = sv[s];
-    }
-  };
-  float4 sv[SPT];
-  if (t_begin < t_end) { stage_load(sv, t_begin); stage_store(sv, Bt0); }
-  __syncthreads();
-  float* Bc = Bt0; float* Bn = Bt1;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const bool more = tile + 1 < t_end;
-    if (more) stage_load(sv, tile + 1);
-    const int j = tile * 32 + li;
-    const bool jvalid = j < N;
-    float pv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* brow = Bc + li * LDB + 4 * h;
-#pragma unroll
-    for (int m = 0; m < D8; ++m) {
-      const float4 b = *reinterpret_cast<const float4*>(brow + 8 * m);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, b.w, acc, 0, 0, 0);
-    }
-    if (more) stage_store(sv, Bn);
-    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, j - t_begin * 32, jvalid, K, tile - t_begin);
-    __syncthreads();
-    float* t = Bc; Bc = Bn; Bn = t;
-  }
-  if (K > 0) {
-    const int n_pad = gridDim.x * POI_NWAVE * 32;
-    for (int i = 0; i < 32; ++i) {
-      compact_user(T, i, K);
-      const int n = T.cnt[i];
-      if (lane < K) {
-        const size_t o = ((size_t)split * n_pad + ut * 32 + i) * K + lane;
-        A.cand_score[o] = lane < n ? T.cs[i][lane] : -INFINITY;
-        A.cand_idx[o] = lane < n ? t_begin * 32 + (int)T.ci[i][lane] : INT_MAX;
-      }
-    }
-  }
-}
-
 // Merge n_lists sorted K-lists per user into the final top-K (one wavefront per user).
 __global__ __launch_bounds__(POI_BLOCK) void topk_merge_kernel(ScoreArgs A, int n_lists, int n_pad) {
   const int lane = lane_id();
@@ -658,22 +555,6 @@ hipError_t launch_score_packed(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   return hipErrorInvalidValue;
 }
 
-template <int D8>
-static hipError_t launch_score_shared_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
-  dim3 grid((A.n + 127) / 128, A.n_split);
-  const size_t lds = sizeof(float) * 2 * 32 * (D8 * 8 + 4) + sizeof(WaveTopk) * POI_NWAVE;
-  tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
-  hipLaunchKernelGGL((score_kernel_shared<D8>), grid, dim3(POI_BLOCK), lds, st, A);
-  tm->end(st);
-  return hipGetLastError();
-}
-
-hipError_t launch_score_shared(const ScoreArgs& A, hipStream_t st, Timing* tm) {
-  if (A.dim <= 32) return launch_score_shared_t<4>(A, st, tm);
-  if (A.dim <= 64) return launch_score_shared_t<8>(A, st, tm);
-  if (A.dim <= 128) return launch_score_shared_t<16>(A, st, tm);
-  return hipErrorInvalidValue;
-}
 
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   if (A.dim <= 32) return launch_score_t<4, true>(A, st, tm);
