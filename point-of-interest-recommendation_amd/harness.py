@@ -4,6 +4,8 @@ per-epoch negative refresh -> shuffled user order -> train (one user per step li
 (train / user vectors / test, :232,264,299,305-310) is kept."""
 from __future__ import annotations
 
+import os
+import pickle
 import time
 
 import numpy as np
@@ -21,7 +23,8 @@ def compute_start_end(user_num, size):
 def default_params():
     """The in-source config of prog_bpr_gru_spatial.py:54-78 (flag 2 = Distance2Pre)."""
     return dict(at_nums=[5, 10, 15, 20], epochs=3, latent_size=20, alpha=0.01, **{"lambda": 0.001}, gru=2,
-                batch_size_test=32, batch_users=1, seed=123)
+                batch_size_test=32, batch_users=1, seed=123,
+                dataset="synthetic", UD=40, dd=200, load_epoch=0, save_per_epoch=0)       # :54-78 (checkpoint naming / cadence)
 
 
 def build_model(ds, p, device="cuda:0", seed=None):
@@ -39,8 +42,49 @@ def build_model(ds, p, device="cuda:0", seed=None):
                                 coords=ds.coords)
 
 
+CKPT_ORDER = ("loss_weight", "wd", "lt", "di", "ui", "wh", "bi", "vs", "bs")      # prog_bpr_gru_spatial.py:325-327
+
+
+def checkpoint_path(p, model_name, epoch, root="./model"):
+    """File name of prog_bpr_gru_spatial.py:207-209,321-322."""
+    return os.path.join(root, str(p["dataset"]), "%s_size%s_UD%s_dd%s_epoch%s" % (model_name, p["latent_size"], p["UD"], p["dd"], epoch))
+
+
+def dump_checkpoint(values, path):
+    """The reference's checkpoint file (prog_bpr_gru_spatial.py:323-330): a pickled list of the nine parameter
+    arrays [loss_weight, wd, lt, di, ui, wh, bi, vs, bs] as float64 (Theano's floatX there), protocol 2 =
+    cPickle.HIGHEST_PROTOCOL of Python 2 - readable by the reference and by load_checkpoint."""
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(path, "wb") as f:
+        pickle.dump([np.asarray(v, np.float64) for v in values], f, protocol=2)
+
+
+def read_checkpoint(path):
+    """List of nine arrays from a checkpoint written by dump_checkpoint or by the reference (Python 2 pickle)."""
+    with open(path, "rb") as f:
+        objs = pickle.load(f, encoding="latin1")
+    if len(objs) != len(CKPT_ORDER):
+        raise ValueError("checkpoint %s holds %d objects, expected %d" % (path, len(objs), len(CKPT_ORDER)))
+    return [np.asarray(o) for o in objs]
+
+
+def save_checkpoint(model, path):
+    dump_checkpoint([getattr(model, k).get_value() for k in CKPT_ORDER], path)
+
+
+def load_checkpoint(model, path):
+    """model.load_params(cPickle.load(f)) of prog_bpr_gru_spatial.py:210-213."""
+    model.load_params(read_checkpoint(path))
+
+
 def train_valid_or_test(ds, p, device="cuda:0", log=print):
     model = build_model(ds, p, device, seed=p.get("seed"))
+    ini_epoch = 0
+    if p["gru"] == 2 and p.get("load_epoch", 0):                  # prog_bpr_gru_spatial.py:204-214
+        load_checkpoint(model, checkpoint_path(p, model.__class__.__name__, p["load_epoch"], p.get("model_root", "./model")))
+        ini_epoch = p["load_epoch"] + 1
     best = GlobalBest(p["at_nums"])
     U = ds.n_user
     ses_tes = compute_start_end(U, p["batch_size_test"])
@@ -50,8 +94,8 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
     history = []
     rng_neg = np.random.default_rng(p.get("seed", 0) + 1000)
     B = int(p.get("batch_users", 1))
-    for epoch in range(p["epochs"]):
-        if epoch > 0:                                               # :221-228
+    for epoch in range(ini_epoch, p["epochs"]):
+        if epoch > 0:                                               # :221-228 (every epoch after the first, also after a resume)
             if p.get("device_negatives", True):                     # on the GPU: ~0.1 ms instead of ~0.4 s of numpy
                 model.resample_negatives_device(p.get("seed", 0) * 1000003 + epoch)
             else:
@@ -99,4 +143,6 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
                             times=(t1 - t0, t2 - t1, t3 - t2)))
         log("epoch %d  sum_loss = %.3f = %.3f + %.3f  auc %.4f  recall@%d %.4f  time (train, user, test) %.2fs %.2fs %.2fs"
             % (epoch, loss + l2, loss, l2, m["auc"], p["at_nums"][-1], m["at"][p["at_nums"][-1]]["recall"], t1 - t0, t2 - t1, t3 - t2))
+        if p["gru"] == 2 and p.get("save_per_epoch", 0) and epoch % p["save_per_epoch"] == 0 and epoch != 0:      # :320-330
+            save_checkpoint(model, checkpoint_path(p, model.__class__.__name__, epoch, p.get("model_root", "./model")))
     return model, best, history

@@ -96,3 +96,17 @@ def test_replica_sync_hip_delta_kernels(pa):
     want = t[0].clone()
     sync.end_epoch()
     assert torch.equal(t[0], want) and torch.equal(sync.base[:400].view(50, 8), want)
+
+
+def test_checkpoint_resume_reproduces_an_uninterrupted_run(pa, tmp_path):
+    """Save at epoch 1 (reference cadence/naming), resume from it, and land on the same parameters as the
+    uninterrupted 3-epoch run (same per-epoch shuffles and device negative seeds)."""
+    from poi_amd import harness
+    from poi_amd.data import make_synthetic
+    ds = make_synthetic(96, 300, 10, seed=21)
+    base = harness.default_params()
+    base.update(latent_size=64, epochs=3, gru=2, batch_users=96, seed=9, dataset="ck", model_root=str(tmp_path), save_per_epoch=1)
+    full, _, _ = harness.train_valid_or_test(ds, dict(base), log=lambda *a: None)
+    resumed, _, _ = harness.train_valid_or_test(make_synthetic(96, 300, 10, seed=21), dict(base, load_epoch=1), log=lambda *a: None)
+    for k in harness.CKPT_ORDER:
+        assert_close(np.asarray(resumed.__dict__[k].get_value(), np.float64), np.asarray(full.__dict__[k].get_value(), np.float64), k, rtol=1e-5)

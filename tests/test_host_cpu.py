@@ -137,3 +137,32 @@ def test_rank_metrics_match_reference_golden(golden_dir):
     assert m["hits"] == g["zero_one"].sum()
     assert np.isclose(m["map"], g["map"].mean(), rtol=1e-12) and np.isclose(m["ndcg"], g["ndcg"].mean(), rtol=1e-12)
     assert np.isclose(m["recall"], g["zero_one"].sum() / g["test_mask"].sum())
+
+
+def test_checkpoint_file_is_the_reference_pickle(tmp_path):
+    """prog_bpr_gru_spatial.py:323-330 writes cPickle.dump([loss_weight, wd, lt, di, ui, wh, bi, vs, bs], protocol 2);
+    :210-213 reads it back into load_params.  Same bytes-level contract here (Python-2-readable protocol, float64,
+    reference order), and a Python 2 style pickle is accepted on load."""
+    import pickle
+    from poi_amd import harness
+    rng = np.random.default_rng(0)
+    vals = [rng.random(2), np.array(0.3), rng.random((7, 4)), rng.random((5, 4)), rng.random((3, 4, 8)), rng.random((3, 4, 4)),
+            rng.random((3, 4)), rng.random((5, 4)), rng.random(5)]
+    p = harness.default_params(); p.update(latent_size=4, dataset="toy")
+    path = harness.checkpoint_path(p, "OboSpatialGru", 20, root=str(tmp_path))
+    assert path.endswith("toy/OboSpatialGru_size4_UD40_dd200_epoch20")
+    harness.dump_checkpoint([v.astype(np.float32) for v in vals], path)
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"\x80\x02"                                  # pickle protocol 2
+    back = harness.read_checkpoint(path)
+    assert len(back) == 9 and all(b.dtype == np.float64 for b in back)
+    for a, b in zip(vals, back):
+        assert np.allclose(a, b, rtol=1e-6) and a.shape == b.shape
+    with open(path, "wb") as f:                                     # what a Python 2 reference run would have left
+        pickle.dump([np.asarray(v) for v in vals], f, protocol=2)
+    for a, b in zip(vals, harness.read_checkpoint(path)):
+        assert np.array_equal(a, b)
+    with open(path, "wb") as f:
+        pickle.dump(vals[:8], f, protocol=2)
+    with pytest.raises(ValueError):
+        harness.read_checkpoint(path)
