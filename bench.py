@@ -183,7 +183,9 @@ def main():
             "te_head": ("flop", 4.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_wgrad": ("flop", (18 * D2 + 2.0 * NB * D) * steps_per_epoch),     # d ui, d wh and d vs (split-K)
             "te_gemm_dx": ("flop", 12 * D2 * steps_per_epoch),
-            "te_gather": ("byte", (3.0 * D * 4 + 16) * float(lens_local.sum())),
+            # te_gather now only builds E = lt[p'] - lt[q'] (two table rows + two indices per step); the gather of the
+            # step input [lt[p] | di[dp]] is fused into te_gemm_ax / te_wgrad (rows go straight into their LDS tiles)
+            "te_gather": ("byte", (2.0 * D * 4 + 8) * steps_per_epoch),
             "rows_apply": ("byte", 2.0 * uniq * D * 4.0),      # read + write of every touched row
             # sorted scatter: per step dx (2D floats) + g*h (D floats) in, every touched row read + written
             "te_scatter": ("byte", 3.0 * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0)}

@@ -7,8 +7,9 @@
 //   te_rowmap    packed row -> CSR position; sorted-scatter slots (one per table touch); padding-row bookkeeping
 //   te_pack      weights -> MFMA B-fragment order (every weight load is then a coalesced 1-KiB stream)
 //   te_sort      (te_scatter.hip) stable radix sort of the slots by table row -> per-row entry segments
-//   te_gather    X[r] = [lt[p_t] | di[dp_t]],  E[r] = lt[p_{t+1}] - lt[q_{t+1}]          (HBM-bound)
-//   te_gemm_ax   G[r] = X[r] . ui^T + bi       (te_gemm_nt: all steps at once, 128 x 128 tiles, K = 2D)
+//   te_gather    E[r] = lt[p_{t+1}] - lt[q_{t+1}]                                         (HBM-bound)
+//   te_gemm_ax   G[r] = [lt[p_t] | di[dp_t]] . ui^T + bi   (te_gemm_nt: the input rows are gathered from the
+//                tables straight into the LDS tiles; all steps at once, 128 x 128 tiles, K = 2D)
 //   te_rec_fwd16 per 16-sequence tile, t ascending: gates from G + h_{t-1} . wh^T  -> G := z|r|c, H, RH
 //   te_head      per 32-row tile: logits = H . vs^T + bs, softmax, BPR + survival losses, d logits -> DL,
 //                DH = dlogits . vs + g * E, g, d bs / d wd partials
@@ -233,7 +234,11 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
     const int k = (blockIdx.x * POI_NWAVE + w) * TE_SEQ_PER_WAVE + i;
     if (k >= A.n_seq) break;
     const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = A.soff[k];
-    for (int t = lane; t < ns; t += 64) { A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t; A.row_seq[r0 + t] = k; }
+    for (int t = lane; t < ns; t += 64) {
+      A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t;
+      A.row_p[r0 + t] = A.p[base + t];                       // table rows of the step's input: the GEMMs gather them
+      if (A.spatial) A.row_dp[r0 + t] = A.dp[base + t];      // straight into their LDS tiles (no packed copy of X)
+    }
     if (A.predict) continue;
     int plt, pdi;
     te_slots(A, k, base, L, ns, r0, &plt, &pdi);
@@ -252,26 +257,20 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
   }
 }
 
-// X[r] = [lt[p_t] | di[dp_t]], E[r] = lt[p_{t+1}] - lt[q_{t+1}].  LPR lanes per row, float4 per lane.
+// E[r] = lt[p_{t+1}] - lt[q_{t+1}] (the BPR difference row of step t).  LPR lanes per row, float4 per lane.
+// The step's input x_t = [lt[p_t] | di[dp_t]] is NOT materialised: te_gemm_nt / te_wgrad gather those table
+// rows straight into their LDS tiles through row_p / row_dp.
 template <int D>
-__global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A, int predict) {
+__global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A) {
   constexpr int LPR = D / 4;                    // lanes per table row
   constexpr int RPB = TE_BLOCK / LPR;           // rows per block pass
-  const int T = A.soff[A.n_seq], XW = A.xw;
+  const int T = A.soff[A.n_seq];
   const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
   for (int r = blockIdx.x * RPB + sub; r < T; r += gridDim.x * RPB) {
     const int s = A.row_src[r];
-    const float4 xp = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s] * D + c);
-    *reinterpret_cast<float4*>(A.X + (size_t)r * XW + c) = xp;
-    if (A.spatial) {
-      const float4 xd = *reinterpret_cast<const float4*>(A.di + (size_t)A.dp[s] * D + c);
-      *reinterpret_cast<float4*>(A.X + (size_t)r * XW + D + c) = xd;
-    }
-    if (!predict) {
-      const float4 a = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s + 1] * D + c);
-      const float4 b = *reinterpret_cast<const float4*>(A.lt + (size_t)A.q[s + 1] * D + c);
-      *reinterpret_cast<float4*>(A.E + (size_t)r * D + c) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-    }
+    const float4 a = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s + 1] * D + c);
+    const float4 b = *reinterpret_cast<const float4*>(A.lt + (size_t)A.q[s + 1] * D + c);
+    *reinterpret_cast<float4*>(A.E + (size_t)r * D + c) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
   }
 }
 
@@ -307,13 +306,22 @@ __global__ __launch_bounds__(TE_BLOCK) void te_bpr_head_kernel(TeArgs A) {
 // to the spare row T.  Used for G = X . ui^T + bi (te_gemm_ax) and dx = DA . ui (te_gemm_dx).
 // -------------------------------------------------------------------------------------------------
 #define NT_LDK 36
-template <bool BIAS>
-__global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(const float* __restrict__ Ag, int lda, const float* __restrict__ Bg, int ldb,
-                                                                 float* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                                                 const int* __restrict__ Tptr, int N, int K) {
+// GATHER: the A operand is not a packed matrix but x_r = [tab0[idx0[r]] | tab1[idx1[r]]] (Dg columns each):
+// the embedding gather of the training step (lt[p_t] | di[dp_t]) happens here, straight into the LDS tile.
+struct NtArgs {
+  const float* A; int lda;            // packed A (GATHER == false)
+  const float *tab0, *tab1; const int *idx0, *idx1; int Dg;      // gathered A
+  const float* B; int ldb; float* C; int ldc; const float* bias; const int* Tptr; int N, K;
+};
+template <bool BIAS, bool GATHER>
+__global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
   __shared__ __align__(16) float As[2][128][NT_LDK];
   __shared__ __align__(16) float Bs[2][128][NT_LDK];
-  const int T = *Tptr;
+  __shared__ int s_idx[2][128];
+  const float* __restrict__ Ag = P.A; const float* __restrict__ Bg = P.B; float* __restrict__ C = P.C;
+  const float* __restrict__ bias = P.bias;
+  const int lda = P.lda, ldb = P.ldb, ldc = P.ldc, N = P.N, K = P.K;
+  const int T = *P.Tptr;
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
   const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
   const int ntl = (N + 127) / 128, mtl = (T + 127) / 128, nchunk = K / 32;
@@ -333,11 +341,23 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    __syncthreads();                       // previous tile's MFMAs are done with both LDS buffers (and s_idx)
+    if (GATHER) {
+      if (tid < 128) {
+        const int r = min(r0 + tid, T - 1);
+        s_idx[0][tid] = P.idx0[r]; s_idx[1][tid] = P.idx1 ? P.idx1[r] : 0;
+      }
+      __syncthreads();
+    }
     auto gload = [&](int kc, float4 (&ra)[4], float4 (&rb)[4]) {
+      const int half = (GATHER && kc * 32 >= P.Dg) ? 1 : 0;                 // chunk-uniform: which table
+      const float* tab = half ? P.tab1 : P.tab0;
+      const int coff = kc * 32 - half * P.Dg;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
-        ra[s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(r0 + row, T - 1) * lda + kc * 32 + c);
+        if (GATHER) ra[s] = *reinterpret_cast<const float4*>(tab + (size_t)s_idx[half][row] * P.Dg + coff + c);
+        else ra[s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(r0 + row, T - 1) * lda + kc * 32 + c);
         rb[s] = *reinterpret_cast<const float4*>(Bg + (size_t)min(n0 + row, N - 1) * ldb + kc * 32 + c);
       }
     };
@@ -378,7 +398,6 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(const float* __
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    __syncthreads();                       // previous tile's MFMAs are done with both LDS buffers
     gload(0, ra0, rb0); lstore(0, ra0, rb0);
     if (1 < nchunk) gload(1, ra0, rb0);
     __syncthreads();
@@ -859,12 +878,20 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   // unconditional (clamped addresses) and masked when they are written to LDS: no branch, no wait.
   const float* Ap = bsel != 3 ? A.G + m0 : A.DL + m0;
   const int lda = bsel != 3 ? 3 * D : NBP;
-  const float* Bp = bsel == 0 ? A.X + n0 : bsel == 2 ? A.RH + n0 : A.H + n0;
-  const int ldb = bsel == 0 ? XW : D;
+  const float* Bp = bsel == 2 ? A.RH + n0 : A.H + n0;
+  const int ldb = D;
   const int acols = bsel != 3 ? T : max(0, min(T, NBP - m0));     // valid columns of the A block
   const int bshift = bsel == 1 ? 1 : 0;
+  // d ui jobs (bsel 0): the B operand is the step input x = [lt[p_t] | di[dp_t]], gathered from the tables
+  // through row_p / row_dp (no packed copy of X exists).  The row indices of a stage are loaded one gload
+  // call earlier (`ni`), so the gather is not a dependent load inside the pipeline.
+  const bool gdi = n0 >= D;
+  const float* gtab = (gdi ? A.di : A.lt) + (n0 - (gdi ? D : 0));
+  const int* gidx = bsel == 0 ? (gdi ? A.row_dp : A.row_p) : A.row_t;
   float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
-  int rt0[F4], rt1[F4];
+  int rt0[F4], rt1[F4], ni[F4];
+#pragma unroll
+  for (int s = 0; s < F4; ++s) ni[s] = gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), Trows - 1)];
   auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4]) {
 #pragma unroll
     for (int s = 0; s < F4; ++s) {
@@ -873,7 +900,9 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
       const int gr = min(r0 + r, Trows - 1);
       rt[s] = A.row_t[gr];                                      // h_{t-1} operand (bsel 1): none at the first step
       ra[s] = *reinterpret_cast<const float4*>(Ap + (size_t)gr * lda + (c < acols ? c : 0));
-      rbv[s] = *reinterpret_cast<const float4*>(Bp + (size_t)max(gr - bshift, 0) * ldb + c);
+      const float* bptr = bsel == 0 ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
+      rbv[s] = *reinterpret_cast<const float4*>(bptr);
+      ni[s] = gidx[min(r0 + 32 + r, Trows - 1)];                // indices of the next stage
     }
   };
   auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4]) {
@@ -1054,10 +1083,13 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
   tm->begin("te_gather", st);
-  hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 0);
+  hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
   tm->end(st);
   tm->begin("te_gemm_ax", st);
-  hipLaunchKernelGGL(te_gemm_nt_kernel<true>, dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, A.X, XW, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW);
+  {
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW};
+    hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+  }
   tm->end(st);
   tm->begin("te_rec_fwd", st);
   hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 0);
@@ -1081,7 +1113,10 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   tm->end(st);
   tm->begin("te_gemm_dx", st);
-  hipLaunchKernelGGL(te_gemm_nt_kernel<false>, dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, A.G, 3 * D, A.uiT, 3 * D, A.X, XW, (const float*)nullptr, A.soff + n, XW, 3 * D);
+  {
+    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, XW, 3 * D};
+    hipLaunchKernelGGL((te_gemm_nt_kernel<false, false>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+  }
   tm->end(st);
   tm->begin("te_finalize", st);
   hipLaunchKernelGGL(te_finalize_kernel, dim3((n + TE_BLOCK - 1) / TE_BLOCK), dim3(TE_BLOCK), 0, st, A);
@@ -1105,8 +1140,10 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
-  hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A, 1);
-  hipLaunchKernelGGL(te_gemm_nt_kernel<true>, dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, A.X, 2 * D, A.ui, 2 * D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, 2 * D);
+  {
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, A.xw, A.G, 3 * D, A.bi, A.soff + n, 3 * D, A.xw};
+    hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+  }
   hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 1);
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
