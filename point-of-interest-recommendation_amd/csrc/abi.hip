@@ -153,7 +153,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const bool sorted = !predict;
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
   const size_t n_hot = Ncap / (TE_COLD_MAX + 1) + 2, n_chunk = Ncap / TE_HOT_CHUNK + n_hot + 2;
-  const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + 64 : 0;
+  const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)((n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
   const size_t sin = sorted ? 7 * Ncap + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl;
   const size_t nin = Tcap * 4 + (size_t)n + 32 + sin;
@@ -168,7 +168,10 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.uiT = take((size_t)6 * D * D);
   A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
   A.pWhT16 = (float4*)take((size_t)3 * D * D); A.pWhc16 = (float4*)take((size_t)D * D); A.pWhzr16 = (float4*)take((size_t)2 * D * D);
-  if (sorted) { A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP); }
+  if (sorted) {
+    A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP);
+    A.bi_part = take((size_t)((n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);
+  }
   int* ip = (int*)f;
   auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
   A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_p = itake(Tcap); A.row_dp = itake(Tcap);

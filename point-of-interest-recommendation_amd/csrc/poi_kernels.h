@@ -87,6 +87,7 @@ struct TeArgs {
   float4 *pWhT16, *pWhc16, *pWhzr16;  // 16-column fragments (16x16x4 MFMA) for the recurrent kernels
   float* slab;
   int n_slab, n_head, n_kc;
+  float *bi_part, *fin_part;           // per recurrent tile d bi partials (n_tile x 3D); per te_finalize block loss sums
   float* hslab; int hstride;          // te_head's per-workgroup d bs | d wd partials (n_head x hstride)
   DenseLayout dl;
   int *mult_lt, *nseq_lt, *mult_di, *nseq_di;    // only the padding rows' entries are used (analytic touches)

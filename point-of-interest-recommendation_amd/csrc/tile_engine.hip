@@ -639,14 +639,13 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
     // it), and the next step's Azr writes come after the next first barrier, which every wave reaches
     // only after finishing this step's MFMA block on Azr.
   }
-  // d bi partial sums of this tile: the four 16-lane groups hold different sequences of the same column
-  float* slab = A.slab + (size_t)(tile % A.n_kc) * A.dl.total;
+  // d bi partial sums of this tile: the four 16-lane groups hold different sequences of the same column;
+  // written per tile and summed in tile order by te_parts_kernel (no float atomics: reproducible)
   sbz += __shfl_xor(sbz, 16, 64); sbr += __shfl_xor(sbr, 16, 64); sbc += __shfl_xor(sbc, 16, 64);
   sbz += __shfl_xor(sbz, 32, 64); sbr += __shfl_xor(sbr, 32, 64); sbc += __shfl_xor(sbc, 32, 64);
-  if (lane < 16 && ns_max > 0) {
-    atomicAdd(slab + A.dl.bi + col, sbz);
-    atomicAdd(slab + A.dl.bi + D + col, sbr);
-    atomicAdd(slab + A.dl.bi + 2 * D + col, sbc);
+  if (lane < 16) {
+    float* bp = A.bi_part + (size_t)tile * 3 * D;
+    bp[col] = sbz; bp[D + col] = sbr; bp[2 * D + col] = sbc;
   }
 }
 
@@ -1000,22 +999,31 @@ __global__ __launch_bounds__(TE_BLOCK) void te_finalize_kernel(TeArgs A) {
   }
   const float s1 = block_sum(sur, red);
   const float s2 = block_sum(-bpr, red);
-  if (threadIdx.x == 0) {
-    float* slab = A.slab + (size_t)(blockIdx.x % A.n_kc) * A.dl.total;
-    atomicAdd(slab + A.dl.sur, s1);
-    atomicAdd(slab + A.dl.upq, s2);
-  }
+  if (threadIdx.x == 0) { A.fin_part[2 * blockIdx.x] = s1; A.fin_part[2 * blockIdx.x + 1] = s2; }   // summed in order by te_parts_kernel
 }
 
-// te_head's per-workgroup d bs | d wd partials -> slab 0 (fixed order: lane-strided sums + DPP tree);
-// one wavefront per element, partials re-zeroed
-__global__ __launch_bounds__(TE_BLOCK) void te_hslab_kernel(TeArgs A) {
-  const int j = blockIdx.x * POI_NWAVE + wave_id(), NB = A.n_dist + 1;
-  if (j > NB) return;
+// Per-workgroup / per-tile partial sums -> slab 0 in a fixed order (lane-strided sums + DPP tree), one
+// wavefront per output element: d bi (3D elements, one partial row per recurrent tile), and for the
+// Distance2Pre model d bs | d wd (te_head workgroups; re-zeroed) and the two loss sums (te_finalize blocks).
+__global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile, int n_fin) {
+  const int j = blockIdx.x * POI_NWAVE + wave_id(), D3 = 3 * A.dim, NB = A.n_dist + 1;
+  const int lane = lane_id();
   float s = 0.f;
-  for (int k = lane_id(); k < A.n_head; k += 64) { float* p = A.hslab + (size_t)k * A.hstride + j; s += *p; *p = 0.f; }
-  s = wave_sum(s);
-  if (lane_id() == 0) A.slab[A.dl.bs + j] += s;
+  if (j < D3) {
+    for (int k = lane; k < n_tile; k += 64) s += A.bi_part[(size_t)k * D3 + j];
+    s = wave_sum(s);
+    if (lane == 0) A.slab[A.dl.bi + j] += s;
+  } else if (A.spatial && j < D3 + NB + 1) {
+    const int e = j - D3;
+    for (int k = lane; k < A.n_head; k += 64) { float* p = A.hslab + (size_t)k * A.hstride + e; s += *p; *p = 0.f; }
+    s = wave_sum(s);
+    if (lane == 0) A.slab[A.dl.bs + e] += s;
+  } else if (A.spatial && j < D3 + NB + 3) {
+    const int e = j - (D3 + NB + 1);
+    for (int k = lane; k < n_fin; k += 64) s += A.fin_part[2 * k + e];
+    s = wave_sum(s);
+    if (lane == 0) A.slab[(e ? A.dl.upq : A.dl.sur)] += s;
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1119,8 +1127,9 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   tm->end(st);
   tm->begin("te_finalize", st);
-  hipLaunchKernelGGL(te_finalize_kernel, dim3((n + TE_BLOCK - 1) / TE_BLOCK), dim3(TE_BLOCK), 0, st, A);
-  if (A.spatial) hipLaunchKernelGGL(te_hslab_kernel, dim3((A.n_dist + 2 + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A);
+  const int n_fin = (n + TE_BLOCK - 1) / TE_BLOCK, n_out = 3 * D + (A.spatial ? A.n_dist + 4 : 0);
+  hipLaunchKernelGGL(te_finalize_kernel, dim3(n_fin), dim3(TE_BLOCK), 0, st, A);
+  hipLaunchKernelGGL(te_parts_kernel, dim3((n_out + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A, (n + 15) / 16, n_fin);
   tm->end(st);
   return hipGetLastError();
 }

@@ -44,12 +44,14 @@ def test_full_size_launch_touches_exactly_its_rows_and_is_reproducible(setup):
         m = make()
         lt0, di0 = m.lt.t.clone(), m.di.t.clone()
         out = m.train_batch(users)
-        runs.append((m.lt.t.clone(), m.di.t.clone(), out))
-    lt1, di1, out = runs[0]
+        runs.append((m.lt.t.clone(), m.di.t.clone(), out, [getattr(m, k).t.clone() for k in ("ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")]))
+    lt1, di1, out, _ = runs[0]
     assert torch.isfinite(lt1).all() and torch.isfinite(di1).all() and np.isfinite(out).all()
     same = (lt1 == lt0).all(dim=1).cpu().numpy()
     assert np.array_equal(~same, touched), "rows changed != rows touched"
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), "lt / di differ between identical launches"
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][3], runs[1][3])), "dense parameters differ between identical launches"
+    assert np.array_equal(runs[0][2], runs[1][2]), "losses differ between identical launches"
     # launch composition does not change a sequence's forward values
     m = make()
     sub = users[:2048]

@@ -120,7 +120,7 @@ def test_tile_sorted_scatter_hot_rows_are_exact_and_reproducible(pa):
         runs.append(_get(model))
     for k in SP_NAMES:
         assert_close(runs[0][k], exp[k], "hot rows " + k)
-    for k in ("lt", "di"):
+    for k in SP_NAMES:                      # no float atomics anywhere in the tile engine: every tensor is reproducible
         assert np.array_equal(runs[0][k], runs[1][k]), k + " differs between two identical launches"
     pa._lib.context(0).set_engine("auto")
 
