@@ -87,11 +87,21 @@ class _Base:
         return table[lo:lo + n] if lo is not None else table.index_select(0, ids.long()).contiguous()
 
     # ---- tables -------------------------------------------------------------------------------
+    @staticmethod
+    def _check_ids(name, ids, hi):
+        """The reference gathers with Theano advanced indexing, which raises IndexError on an id outside the
+        table; the kernels would read out of bounds - so ids are checked where they enter."""
+        a = np.asarray(ids)
+        if a.size and (a.min() < 0 or a.max() > hi):
+            raise IndexError("%s: ids must lie in [0, %d] (found %d..%d)" % (name, hi, int(a.min()), int(a.max())))
+
     def _load_tables(self, train, test):
         self._csr = train if isinstance(train, CsrTables) else None
         if self._csr is not None:
             c = self._csr
             off = np.ascontiguousarray(c.off, np.int32)
+            self._check_ids("train POIs", c.p, self.n_item); self._check_ids("train negatives", c.q, self.n_item)
+            self._check_ids("test POIs", c.tes_p, self.n_item); self._check_ids("test negatives", c.tes_q, self.n_item)
             self._lens = np.diff(off.astype(np.int64))
             self.len_max, self.max_len = int(c.len_max), int(self._lens.max())
             self._off_host = off
@@ -102,6 +112,9 @@ class _Base:
             return
         tra_buys_masks, tra_masks, tra_buys_neg_masks = train
         tes_buys_masks, tes_masks, tes_buys_neg_masks = test
+        for nm, t in (("train POIs", tra_buys_masks), ("train negatives", tra_buys_neg_masks), ("test POIs", tes_buys_masks),
+                      ("test negatives", tes_buys_neg_masks)):
+            self._check_ids(nm, t, self.n_item)
         tra_masks = np.asarray(tra_masks)
         self._lens = tra_masks.sum(axis=1).astype(np.int64)
         self.len_max = int(tra_masks.shape[1])                 # padded length LM of the reference tables
@@ -117,6 +130,7 @@ class _Base:
 
     def update_neg_masks(self, tra_buys_neg_masks, tes_buys_neg_masks):
         """public/GRU.py:79-82 / public/BPR.py:61-64 - new negatives every epoch."""
+        self._check_ids("train negatives", tra_buys_neg_masks, self.n_item); self._check_ids("test negatives", tes_buys_neg_masks, self.n_item)
         _, q = padded_to_csr(tra_buys_neg_masks, self._lens)
         self.q = torch.as_tensor(q).to(self.device)
         self.tes_buys_neg_masks = self._dev(tes_buys_neg_masks, torch.int32)
@@ -302,6 +316,8 @@ class OboSpatialGru(GruBasic):
             tra_dist_masks, tes_dist_masks, tra_dist_neg_masks = dist
             _, dp = padded_to_csr(tra_dist_masks, self._lens)
             _, dq = padded_to_csr(tra_dist_neg_masks, self._lens)
+        self._check_ids("train distance bins", dp, self.n_dist); self._check_ids("negative distance bins", dq, self.n_dist)
+        self._check_ids("test distance bins", tes_dist_masks, self.n_dist)
         self.dp, self.dq = torch.as_tensor(dp).to(self.device), torch.as_tensor(dq).to(self.device)
         self.tes_dist_masks = self._dev(tes_dist_masks, torch.int32)
         rng = np.random.default_rng(None if seed is None else seed + 1) if seed is not None else np.random

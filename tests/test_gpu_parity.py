@@ -396,6 +396,25 @@ def test_l2_eval(pa):
     assert abs(model.l2.eval() - exp) <= 1e-6 * exp
 
 
+def test_out_of_range_ids_raise_index_error(pa):
+    """Theano's advanced indexing raises IndexError on an id outside the table; so do the constructors and
+    update_neg_masks (the kernels themselves never see an unchecked id)."""
+    T = toy_problem(52, n_user=4, n_item=30, n_dist=7, dim=8)
+    bad = [np.array(T["train"][0]), T["train"][1], T["train"][2]]
+    bad[0] = bad[0].copy(); bad[0][1, 0] = 31
+    kw = dict(alpha_lambda=[0.01, 0.001], n_user=4, n_item=30, n_in=8, n_hidden=8)
+    with pytest.raises(IndexError):
+        pa.models.OboGru(train=bad, test=T["test"], **kw)
+    dist = [np.array(T["dist"][0]).copy(), T["dist"][1], T["dist"][2]]
+    dist[0][2, 1] = 9
+    with pytest.raises(IndexError):
+        pa.models.OboSpatialGru(train=T["train"], test=T["test"], dist=dist, n_dists=[7, 0.2], **kw)
+    m = pa.models.OboGru(train=T["train"], test=T["test"], **kw)
+    neg = np.array(T["train"][2]).copy(); neg[0, 0] = -1
+    with pytest.raises(IndexError):
+        m.update_neg_masks(neg, T["test"][2])
+
+
 def test_errors_are_loud(pa):
     ctx = pa._lib.context(0)
     rc = ctx.lib.poi_topk(ctx.handle, None, 1, 10, 5, None, None, None)

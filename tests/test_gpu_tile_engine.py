@@ -185,3 +185,40 @@ def test_tile_plain_gru_batch_matches_mean_rule_and_seq_engine(pa, dim, n_user):
     for k in GRU_NAMES:
         assert_close(res["tile"][k], res["seq"][k], "tile vs seq second launch " + k, rtol=2e-5)
     pa._lib.context(0).set_engine("auto")
+
+
+def test_tile_degenerate_lengths(pa):
+    """Launch mixing sequences of length 1 (no GRU step at all: only the L2 decay of their rows), 2 (a single
+    step) and longer ones, spatial and plain: == batch rule of the oracle, == per-sequence engine."""
+    from tests.gpu_util import gru_params
+    T = toy_problem(131, n_user=90, n_item=70, n_dist=11, dim=64, len_max=9, min_len=1)
+    assert (T["lens"] == 1).any() and (T["lens"] == 2).any()
+    users = np.arange(90, dtype=np.int32)
+    P = spatial_params(131, T)
+    exp, outs = _oracle_batch(P, T, users)
+    for eng in ("tile", "seq"):
+        model = _model(pa, T, P)
+        model.ctx.set_engine(eng)
+        got_out = model.train_batch(users)
+        for k, out in enumerate(outs):
+            assert_close(got_out[k][:3], out[:3], "%s losses[%d]" % (eng, k), rtol=2e-5)
+        got = _get(model)
+        for k in SP_NAMES:
+            assert_close(got[k], exp[k], "%s %s" % (eng, k))
+    Pg = gru_params(131, T)
+    Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
+    news, touched, losses = [], [], []
+    for u in users:
+        Pn, loss = O.gru_step(Pg, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
+        news.append(Pn); losses.append(loss)
+        touched.append(dict(lt=np.unique(np.concatenate((Pm[u], Qm[u])))))
+    expg = batch_mean_update(Pg, news, touched, ("lt",), ("ui", "wh", "bi"))
+    for eng in ("tile", "seq"):
+        model = _gru_model(pa, T, Pg)
+        model.ctx.set_engine(eng)
+        got_loss = model.train_batch(users)
+        assert_close(np.asarray(got_loss).reshape(-1), np.asarray(losses), eng + " gru losses", rtol=2e-5)
+        got = _get_gru(model)
+        for k in GRU_NAMES:
+            assert_close(got[k], expg[k], "%s gru %s" % (eng, k))
+    pa._lib.context(0).set_engine("auto")
