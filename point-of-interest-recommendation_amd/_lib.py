@@ -79,6 +79,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PoiError("%s is not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(no CPU fallback exists for the hot path)" % LIB_PATH)
+    # PyTorch is the device-memory container: its HIP runtime (torch/lib/libamdhip64.so) must be the one this
+    # library binds to - loading libpoi_hip.so first would pull in a second runtime from /opt/rocm, which
+    # knows nothing about torch's allocations and streams ("no HIP device visible").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError -> missing export
