@@ -30,6 +30,7 @@ struct poi_ctx {
   int head_rounds = 3;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
   int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
+  hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
@@ -95,6 +96,15 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
+  const char* sd = getenv("POI_TE_SIDE");
+  if (!sd || atoi(sd) != 0) {
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_slots, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      c->side = nullptr;                     // fall back to the inline sort
+    }
+  }
   *out = c;
   return POI_OK;
 }
@@ -105,6 +115,7 @@ int poi_ctx_destroy(poi_ctx* c) {
                    &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
+  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c;
   return POI_OK;
@@ -237,6 +248,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
     E.out = out; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
+    E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
     HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));

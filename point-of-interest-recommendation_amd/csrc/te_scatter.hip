@@ -328,6 +328,7 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   const int R = A.n_item + 1 + A.n_dist + 1;
   int grid = (R + 3) / 4;
   if (grid > num_cu * 32) grid = num_cu * 32;
+  if (A.side && hipStreamWaitEvent(st, A.ev_sorted, 0) != hipSuccess) return hipGetLastError();     // the sorted entries
   tm->begin("te_scatter", st);
   hipLaunchKernelGGL(te_reduce_kernel<D>, dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);

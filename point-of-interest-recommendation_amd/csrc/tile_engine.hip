@@ -1088,7 +1088,14 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   const int XW = A.xw;
   hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, XW);
-  { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
+  if (A.side) {
+    // slots are written (te_rowmap): sort them on the side stream while the main stream goes on
+    if (hipEventRecord(A.ev_slots, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_slots, 0) != hipSuccess) return hipGetLastError();
+    hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
+    if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
+  } else {
+    hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se;
+  }
   tm->end(st);
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
