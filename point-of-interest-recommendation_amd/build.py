@@ -30,7 +30,7 @@ def build_lib(force=False, verbose=True):
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB + ".tmp"] + os.environ.get("POI_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -158,7 +158,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
   A.dl = poi::dense_layout(D, A.xw, n_dist + 1);
-  const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 64;
+  const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 192;   // + spare rows: row T and the rest of the last 128-row tile
   const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D + (size_t)12 * D * D + 64;
   // sorted scatter (training): 3 slots per sequence position
   const bool sorted = !predict;

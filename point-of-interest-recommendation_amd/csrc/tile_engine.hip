@@ -312,6 +312,7 @@ struct NtArgs {
   const float* A; int lda;            // packed A (GATHER == false)
   const float *tab0, *tab1; const int *idx0, *idx1; int Dg;      // gathered A
   const float* B; int ldb; float* C; int ldc; const float* bias; const int* Tptr; int N, K;
+  int dbg;
 };
 template <bool BIAS, bool GATHER>
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
@@ -425,6 +426,157 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
           C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
         }
     }
+  }
+}
+
+// te_gemm_ntk: the same product with K (and, when gathering, the table width DG) known at compile time, for
+// K >= 128.  Differences that matter (measured: ax 1.79 -> see DESIGN.md):
+//  * the chunk loop is fully unrolled, so one tile is straight-line code and the compiler's s_waitcnt
+//    vmcnt(n) values are exact - the runtime-K loop above has branches around its loads, and every
+//    join there degrades to vmcnt(0);
+//  * the operand pipeline runs ACROSS tiles: the last two stages of a tile already fetch chunks 0 and 1
+//    of the workgroup's next tile (and stage 0 fetches its gather indices), so neither the load latency
+//    at the start of a tile nor the 64 C stores per lane at its end are exposed (on gfx9 stores count
+//    in vmcnt too; the loads of the next tile are issued BEFORE them and vmcnt retires in order);
+//  * the epilogue is branch-free: columns beyond N (N % 128 != 0) go to the spare row T.
+template <bool BIAS, bool GATHER, int K, int DG, int N>
+__global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
+  constexpr int NCH = K / 32, ldb = K, ldc = N;           // B is N x K, C is T x N, both dense
+  static_assert(K % 64 == 0 && NCH >= 4, "te_gemm_ntk: K must be a multiple of 64, >= 128");
+  __shared__ __align__(16) float As[2][128][NT_LDK];
+  __shared__ __align__(16) float Bs[2][128][NT_LDK];
+  // gather indices of 128 rows x 2 slots.  LDS is the occupancy limit here (two workgroups per CU fit only up
+  // to ~74.8 KB each - a third KB of indices halves the occupancy and costs 25%), so there is ONE KB of them:
+  //  * two tables (DG < K): slot = table.  Table 0 is read by the fetches of chunks < NCH/2, i.e. in stages
+  //    NCH-2 .. NCH/2-3 (wrapping over the tile boundary), table 1 in stages NCH/2-2 .. NCH-3; the next tile's
+  //    indices are written in the gaps (stage NCH/2-1 and stage NCH-2), a barrier away from any reader.
+  //  * one table (DG == K): no gap, slot = tile parity.
+  constexpr bool ONE_TAB = (DG == K);
+  __shared__ int s_idx[2][128];
+  const float* __restrict__ Ag = P.A; const float* __restrict__ Bg = P.B; float* __restrict__ C = P.C;
+  const float* __restrict__ bias = P.bias;
+  const int lda = P.lda;
+  const int T = *P.Tptr;
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  constexpr int ntl = (N + 127) / 128;
+  const int mtl = (T + 127) / 128;
+  const int xcd = blockIdx.x & 7, gx = gridDim.x >> 3;          // XCD-aware tile order, as above
+  int L = blockIdx.x >> 3;
+  if ((L / ntl) * 8 + xcd >= mtl) return;
+  int r0 = ((L / ntl) * 8 + xcd) * 128, n0 = (L % ntl) * 128, par = 0;
+  const int irow = tid & 127;                                   // (both halves of the workgroup: duplicates are harmless)
+  const int* __restrict__ idx0 = P.idx0; const int* __restrict__ idx1 = ONE_TAB ? P.idx0 : P.idx1;
+  float4 ra[2][4], rb[2][4];
+  // chunk kc of the tile at (tr0, tn0), whose gather indices are in s_idx[tp], -> register set `set`
+  auto gload = [&](int set, int tr0, int tn0, int tp, int kc) {
+    const int half = (GATHER && kc * 32 >= DG) ? 1 : 0;
+    const float* tab = half ? P.tab1 : P.tab0;
+    const int coff = kc * 32 - half * DG;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
+      if (GATHER) ra[set][s] = *reinterpret_cast<const float4*>(tab + (size_t)s_idx[ONE_TAB ? tp : half][row] * DG + coff + c);
+      else ra[set][s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(tr0 + row, T - 1) * lda + kc * 32 + c);
+      rb[set][s] = *reinterpret_cast<const float4*>(Bg + (size_t)min(tn0 + row, N - 1) * ldb + kc * 32 + c);
+    }
+  };
+  auto lstore = [&](int buf, int set) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
+      *reinterpret_cast<float4*>(&As[buf][row][c]) = make_float4(ra[set][s].x, ra[set][s].y, ra[set][s].z, ra[set][s].w);
+      *reinterpret_cast<float4*>(&Bs[buf][row][c]) = make_float4(rb[set][s].x, rb[set][s].y, rb[set][s].z, rb[set][s].w);
+    }
+  };
+  f32x16 acc[2][2];
+  auto mma = [&](int buf) {
+    float4 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[0][i] = *reinterpret_cast<const float4*>(&As[buf][wm + 32 * i + li][4 * h]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[0][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn + 32 * j + li][4 * h]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[(m + 1) & 1][i] = *reinterpret_cast<const float4*>(&As[buf][wm + 32 * i + li][8 * (m + 1) + 4 * h]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[(m + 1) & 1][j] = *reinterpret_cast<const float4*>(&Bs[buf][wn + 32 * j + li][8 * (m + 1) + 4 * h]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float4 x = a[m & 1][i], y = b[m & 1][j];
+          acc[i][j] = mfma32(x.x, y.x, acc[i][j]);
+          acc[i][j] = mfma32(x.y, y.y, acc[i][j]);
+          acc[i][j] = mfma32(x.z, y.z, acc[i][j]);
+          acc[i][j] = mfma32(x.w, y.w, acc[i][j]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // prologue: LDS buffer 0 <- chunk 0, register set 1 <- chunk 1 (in flight): the state every tile starts from
+  if (GATHER) {
+    s_idx[0][irow] = idx0[min(r0 + irow, T - 1)];
+    if (!ONE_TAB) s_idx[1][irow] = idx1[min(r0 + irow, T - 1)];
+    __syncthreads();
+  }
+  gload(0, r0, n0, 0, 0); lstore(0, 0); gload(1, r0, n0, 0, 1);
+  __syncthreads();
+  for (;;) {
+    // the workgroup's next tile; past the end the current one is fetched again (harmless, never used)
+    const int Ln = L + gx, tmn = (Ln / ntl) * 8 + xcd;
+    const bool more = tmn < mtl;
+    const int r0n = more ? tmn * 128 : r0, n0n = more ? (Ln % ntl) * 128 : n0;
+    int nidx0 = 0, nidx1 = 0;
+    if (GATHER) { nidx0 = idx0[min(r0n + irow, T - 1)]; if (!ONE_TAB) nidx1 = idx1[min(r0n + irow, T - 1)]; }
+    float bvj[2];                            // fetched here so that the epilogue never waits on a load
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bvj[j] = BIAS ? bias[min(n0 + wn + 32 * j + li, N - 1)] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      // stage kc: fetch chunk kc + 2 (set kc & 1 is free: chunk kc went to LDS at the end of stage kc - 1),
+      // multiply chunk kc, then move chunk kc + 1 from its registers to the other LDS buffer
+      if (kc + 2 < NCH) gload(kc & 1, r0, n0, par, kc + 2);
+      else gload(kc & 1, r0n, n0n, par ^ 1, kc + 2 - NCH);
+      mma(kc & 1);
+      if (GATHER && ONE_TAB && kc == 1) s_idx[par ^ 1][irow] = nidx0;        // read from stage NCH - 2 on
+      if (GATHER && !ONE_TAB && kc == NCH / 2 - 1) s_idx[0][irow] = nidx0;
+      if (GATHER && !ONE_TAB && kc == NCH - 2) s_idx[1][irow] = nidx1;
+      lstore((kc + 1) & 1, (kc + 1) & 1);
+      if (kc == NCH - 1) {
+        // C tile.  One base pointer per 32x32 block and compile-time row offsets; the sched_barrier keeps
+        // the address arithmetic HERE (hoisted to the top of the tile it spills).  Rows past T of the last
+        // tile land in the spare rows of C; columns past N (N % 128 != 0) are sent there too.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wn + 32 * j + li;
+          const bool cok = col < N;
+          const int cc = cok ? col : N - 1;
+          const float bv = bvj[j];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float* cb = C + (size_t)(cok ? r0 + wm + 32 * i + 4 * h : T) * ldc + cc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cb[((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r] + bv;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+    if (!more) break;
+    L = Ln; r0 = r0n; n0 = n0n; par ^= 1;
   }
 }
 
@@ -1077,6 +1229,19 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   J.n = n;
 }
 
+// ax = gather(lt | di) . ui^T + bi: the compile-time-K kernel when the operand is wide enough for its pipeline
+template <int D>
+static void te_launch_ax(const TeArgs& A, const NtArgs& P, int num_cu, hipStream_t st) {
+  const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
+  if (A.dbg == 32) { hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), grid, block, 0, st, P); return; }
+  if (A.spatial) {
+    hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, 2 * D, D, 3 * D>), grid, block, 0, st, P);
+  } else {
+    if constexpr (D >= 128) hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, D, D, 3 * D>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), grid, block, 0, st, P);
+  }
+}
+
 template <int D>
 static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
   const int n = A.n_seq, tiles = (n + 31) / 32;
@@ -1102,8 +1267,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_gemm_ax", st);
   {
-    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW};
-    hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW, A.dbg};
+    te_launch_ax<D>(A, P, num_cu, st);
   }
   tm->end(st);
   tm->begin("te_rec_fwd", st);
@@ -1129,8 +1294,10 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_gemm_dx", st);
   {
-    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, XW, 3 * D};
-    hipLaunchKernelGGL((te_gemm_nt_kernel<false, false>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, XW, 3 * D, A.dbg};
+    if (A.dbg != 32 && A.spatial) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+    else if (A.dbg != 32) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+    else hipLaunchKernelGGL((te_gemm_nt_kernel<false, false>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
   }
   tm->end(st);
   tm->begin("te_finalize", st);
@@ -1157,8 +1324,8 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   {
-    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, A.xw, A.G, 3 * D, A.bi, A.soff + n, 3 * D, A.xw};
-    hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, A.xw, A.G, 3 * D, A.bi, A.soff + n, 3 * D, A.xw, A.dbg};
+    te_launch_ax<D>(A, P, num_cu, st);
   }
   hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 1);
   hipError_t e = hipSuccess;
