@@ -1253,14 +1253,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   const int XW = A.xw;
   hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, XW);
-  if (A.side) {
-    // slots are written (te_rowmap): sort them on the side stream while the main stream goes on
-    if (hipEventRecord(A.ev_slots, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_slots, 0) != hipSuccess) return hipGetLastError();
-    hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
-    if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
-  } else {
-    hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se;
-  }
+  if (!A.side) { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
@@ -1271,6 +1264,15 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     te_launch_ax<D>(A, P, num_cu, st);
   }
   tm->end(st);
+  if (A.side) {
+    // The slot sort is needed only by te_scatter, so it runs on the side stream - next to te_rec_fwd, a
+    // latency chain that leaves most of the chip idle.  NOT next to the GEMMs: their grids are exactly two
+    // persistent workgroups per CU, and a co-resident sort kernel whose LDS displaces one of them pushes that
+    // workgroup's whole tile list into a second round (measured: ax 1.6 -> 2.3 ms when its LDS grew by 1 KB).
+    if (hipEventRecord(A.ev_slots, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_slots, 0) != hipSuccess) return hipGetLastError();
+    hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
+    if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
+  }
   tm->begin("te_rec_fwd", st);
   hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 0);
   tm->end(st);
