@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   __shared__ __align__(16) float Bt[2][32][LDT];
   constexpr int NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
   const int NB_UI = (3 * D / T) * (XW / T);
-  const int Trows = A.soff[A.n_seq];
+  const int Trows = A.soff[A.n_seq], rmax = max(Trows - 1, 0);        // (loads are clamped to row rmax)
   // (an XCD-aware (chunk, job) order - all jobs of a K-chunk on one XCD - measured 10 % slower than this plain
   // order: it needs a chunk count that is a multiple of 8, which leaves CU slots empty)
   const int job = blockIdx.x, kc = blockIdx.y;
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   else if (job < NB_UI + NB_ZR + NB_C) { const int j = job - NB_UI - NB_ZR, bn = D / T; m0 = 2 * D + (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
   else { const int j = job - NB_UI - NB_ZR - NB_C, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.vs; bsel = 3; }   // d vs = DL^T . H
   const int NBP = te_nbp_dev(A.n_dist), NB = A.n_dist + 1;
-  const int chunk = (((Trows + nkc - 1) / nkc) + 31) & ~31;
+  const int chunk = (((Trows + nkc - 1) / nkc) + 63) & ~63;
   const int rb = kc * chunk, re = min(Trows, rb + chunk);
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
   const int wm = (w >> 1) * (T / 2), wn = (w & 1) * (T / 2);
@@ -1040,20 +1040,21 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   const float* gtab = (gdi ? A.di : A.lt) + (n0 - (gdi ? D : 0));
   const int* gidx = bsel == 0 ? (gdi ? A.row_dp : A.row_p) : A.row_t;
   float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
-  int rt0[F4], rt1[F4], ni[F4];
+  int rt0[F4], rt1[F4];
+  unsigned ni[F4];      // unsigned: a signed index is sign-extended right behind its load, i.e. the wave waits for it there
 #pragma unroll
-  for (int s = 0; s < F4; ++s) ni[s] = gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), Trows - 1)];
+  for (int s = 0; s < F4; ++s) ni[s] = gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)];
   auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4]) {
 #pragma unroll
     for (int s = 0; s < F4; ++s) {
       const int e = tid + s * TE_BLOCK;
       const int r = e / (T / 4), c = (e % (T / 4)) * 4;
-      const int gr = min(r0 + r, Trows - 1);
+      const int gr = min(r0 + r, rmax);
       rt[s] = A.row_t[gr];                                      // h_{t-1} operand (bsel 1): none at the first step
       ra[s] = *reinterpret_cast<const float4*>(Ap + (size_t)gr * lda + (c < acols ? c : 0));
       const float* bptr = bsel == 0 ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
       rbv[s] = *reinterpret_cast<const float4*>(bptr);
-      ni[s] = gidx[min(r0 + 32 + r, Trows - 1)];                // indices of the next stage
+      ni[s] = gidx[min(r0 + 32 + r, rmax)];                // indices of the next stage
     }
   };
   auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4]) {
@@ -1092,22 +1093,23 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (rb < re) {
-    gload(rb, ra0, rb0, rt0); lstore(0, rb, ra0, rb0, rt0);
-    if (rb + 32 < re) gload(rb + 32, ra0, rb0, rt0);
-  }
+  // Branch-free pipeline (every load is clamped, every LDS write masked by `r < re`): with no control flow
+  // around the loads the s_waitcnt vmcnt(n) before each LDS write is exact, i.e. it leaves the stage that
+  // was fetched just before the MFMA block in flight.  A chunk is a multiple of 64 rows, so the odd stage
+  // of the last iteration is the only work that can be empty.
+  gload(rb, ra0, rb0, rt0); lstore(0, rb, ra0, rb0, rt0);
+  gload(rb + 32, ra0, rb0, rt0);
   __syncthreads();
   for (int r0 = rb; r0 < re; r0 += 64) {
     // even stage: LDS buffer 0; set 0 holds stage +1, set 1 receives stage +2
-    if (r0 + 64 < re) gload(r0 + 64, ra1, rb1, rt1);
+    gload(r0 + 64, ra1, rb1, rt1);
     mma(0);
-    if (r0 + 32 < re) lstore(1, r0 + 32, ra0, rb0, rt0);
+    lstore(1, r0 + 32, ra0, rb0, rt0);
     __syncthreads();
-    if (r0 + 32 >= re) break;
     // odd stage: LDS buffer 1; set 1 holds stage +1, set 0 receives stage +2
-    if (r0 + 96 < re) gload(r0 + 96, ra0, rb0, rt0);
+    gload(r0 + 96, ra0, rb0, rt0);
     mma(1);
-    if (r0 + 64 < re) lstore(0, r0 + 64, ra1, rb1, rt1);
+    lstore(0, r0 + 64, ra1, rb1, rt1);
     __syncthreads();
   }
   float* out = A.slab + (size_t)kc * A.dl.total + oo;
@@ -1119,7 +1121,9 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + 32 * i + c_row(r, lane);
-        if (bsel != 3 || m < NB) out[(size_t)m * ldo + n0 + wn + 32 * j + li] += acc[i][j][r];
+        // plain stores: the slabs are zero on entry (dense_apply re-zeroes what it reads) and every element has
+        // one writer per step - a read-modify-write here is 64 dependent round trips per lane
+        if (bsel != 3 || m < NB) out[(size_t)m * ldo + n0 + wn + 32 * j + li] = acc[i][j][r];
       }
 }
 
