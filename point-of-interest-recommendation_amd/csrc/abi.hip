@@ -167,7 +167,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)((n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
   const size_t sin = sorted ? 7 * Ncap + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl;
-  const size_t nin = Tcap * 4 + (size_t)n + 32 + sin;
+  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin;
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
@@ -185,7 +185,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   }
   int* ip = (int*)f;
   auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
-  A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_p = itake(Tcap); A.row_dp = itake(Tcap);
+  A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_p = itake(Tcap); A.row_dp = itake(Tcap); A.row_ab = itake(Tcap);
   if (sorted) {
     int bits = 1; while ((1 << bits) <= R) ++bits;      // keys 0..R (R = sentinel)
     A.key_bits = bits;

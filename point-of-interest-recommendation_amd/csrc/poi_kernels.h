@@ -80,7 +80,7 @@ struct TeArgs {
   int spatial, xw;                    // 1 / 2D: Distance2Pre (POI + distance-bin input); 0 / D: plain GRU + BPR (n_dist == -1)
   int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
   // packed-row workspace
-  int *soff, *row_src, *row_t, *row_p, *row_dp;   // packed row -> CSR position, step index, input table rows (lt, di)
+  int *soff, *row_src, *row_t, *row_p, *row_dp, *row_ab;   // packed row -> CSR position, step index, input table rows (lt, di)
   float *X, *E, *G, *H, *RH, *DH, *DL, *rowloss;   // DL: d logits (T x padded bins)
   float4 *pVsT, *pVs;
   float* uiT;                         // ui transposed (2D x 3D), K-contiguous B operand of te_gemm_dx

@@ -238,6 +238,8 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
       A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t;
       A.row_p[r0 + t] = A.p[base + t];                       // table rows of the step's input: the GEMMs gather them
       if (A.spatial) A.row_dp[r0 + t] = A.dp[base + t];      // straight into their LDS tiles (no packed copy of X)
+      // target bins of the step (positive | negative << 16) for te_head: one load instead of a dependent chain
+      if (A.spatial && !A.predict) A.row_ab[r0 + t] = A.dp[base + t + 1] | (A.dq[base + t + 1] << 16);
     }
     if (A.predict) continue;
     int plt, pdi;
@@ -808,8 +810,8 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
 // sequences, H = hts).  Small enough in registers (no d vs accumulators) and LDS (E never staged) for
 // three workgroups per CU, whose MFMA / softmax / staging phases overlap.
 // -------------------------------------------------------------------------------------------------
-template <int D, int NBT>
-__global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode) {
+template <int D, int NBT, int MODE>
+__global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int K8 = D / 8, LDH = D + 4, NBP = NBT * 32, LDO = NBP + 4, NTW = (NBT + 3) / 4, NTD = D / 32;
   constexpr int KB8 = NBP / 8, DTW = (NTD + 3) / 4, LPR = D / 4;
@@ -818,9 +820,11 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
   __shared__ float s_g[32], s_he[32], s_red[8];
   __shared__ int s_a[32], s_b[32];   // target bins of the tile's rows
   const int NB = A.n_dist + 1;
-  const int T = mode ? A.n_seq : A.soff[A.n_seq];
-  const float* Hsrc = mode ? A.hts : A.H;
+  const int T = MODE ? A.n_seq : A.soff[A.n_seq];
+  const float* __restrict__ Hsrc = MODE ? A.hts : A.H;
+  const float* __restrict__ Esrc = A.E;
   const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  if ((int)blockIdx.x * 32 >= T) return;        // (grid <= number of tiles: not taken; keeps T >= 1 below)
   float ls0 = 0.f, ls1 = 1.f, wd = 0.f;
   {
     const float a = A.lw[0], b = A.lw[1], m = fmaxf(a, b);
@@ -828,52 +832,51 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
     ls0 = ea / (ea + eb); ls1 = eb / (ea + eb); wd = A.wd[0];
   }
   int nto[NTW];
+  float bsv[NTW];                   // bias of this lane's bins (-inf for the padding bins): loop-invariant
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) nto[j] = min(w + 4 * j, NBT - 1);
+  for (int j = 0; j < NTW; ++j) {
+    nto[j] = min(w + 4 * j, NBT - 1);
+    const int bin = nto[j] * 32 + li;
+    bsv[j] = bin < NB ? A.bs[bin] : -INFINITY;
+  }
   float dbs_acc = 0.f;      // thread tid < NBP accumulates d bs[tid]
   float dwd_acc = 0.f;      // meaningful in the row-owner lanes, reduced at the end
 
-  // async-stage split: the NEXT tile's H rows, h.e partial dot products and target bins are fetched
-  // into registers while the current tile computes, and written to LDS at the top of the next iteration
+  // The kernel is a latency chain per workgroup (five barriers per tile), so nothing in the loop may wait for
+  // a load it has just issued.  Every global access is therefore branch-free - rows past T are clamped to
+  // row T - 1 for loads and redirected to the spare row T for stores, and masked where they are consumed -
+  // which lets the compiler count its s_waitcnt vmcnt exactly; and the NEXT tile's H / E rows and target bins
+  // are fetched in the middle of the current tile (before its second MFMA block) and only touched at the top
+  // of the next iteration.
   constexpr int SF4 = 32 * LPR / TE_BLOCK;          // float4 per thread per staged tile
-  float4 ph[SF4];
-  float phe[SF4];
-  int pm[2] = {0, 0};
+  float4 ph[SF4], pe[SF4];
+  int pab = 0;
   auto prefetch = [&](int r0) {
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
       const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
-      float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), ve = vh;
-      if (r0 + r < T) {
-        vh = *reinterpret_cast<const float4*>(Hsrc + (size_t)(r0 + r) * D + c);
-        if (!mode) ve = *reinterpret_cast<const float4*>(A.E + (size_t)(r0 + r) * D + c);
-      }
-      ph[q] = vh;
-      phe[q] = (vh.x * ve.x + vh.y * ve.y) + (vh.z * ve.z + vh.w * ve.w);
+      const size_t gr = (size_t)min(r0 + r, T - 1);
+      ph[q] = *reinterpret_cast<const float4*>(Hsrc + gr * D + c);
+      if (!MODE) pe[q] = *reinterpret_cast<const float4*>(Esrc + gr * D + c);
     }
-    if (!mode && tid < 32) {
-      const int gr = r0 + tid;
-      pm[0] = pm[1] = 0;
-      if (gr < T) { const int s = A.row_src[gr]; pm[0] = A.dp[s + 1]; pm[1] = A.dq[s + 1]; }
-    }
+    if (!MODE) pab = A.row_ab[min(r0 + (tid & 31), T - 1)];
   };
-  if ((int)blockIdx.x * 32 < T) prefetch(blockIdx.x * 32);
+  prefetch(blockIdx.x * 32);
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
       const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
-      *reinterpret_cast<float4*>(Ht + r * LDH + c) = ph[q];
-      if (!mode) {     // h . e of row r: sum over the LPR lanes that hold the row
-        float d = phe[q];
+      *reinterpret_cast<float4*>(Ht + r * LDH + c) = make_float4(ph[q].x, ph[q].y, ph[q].z, ph[q].w);
+      if (!MODE) {     // h . e of row r: sum over the LPR lanes that hold the row
+        float d = (ph[q].x * pe[q].x + ph[q].y * pe[q].y) + (ph[q].z * pe[q].z + ph[q].w * pe[q].w);
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
         if ((tid % LPR) == 0) s_he[r] = d;
       }
     }
-    if (!mode && tid < 32) { s_a[tid] = pm[0]; s_b[tid] = pm[1]; }
+    if (!MODE && tid < 32) { s_a[tid] = pab & 0xffff; s_b[tid] = pab >> 16; }
     lds_barrier();
-    if (r0 + (int)gridDim.x * 32 < T) prefetch(r0 + gridDim.x * 32);
     {   // logits
       f32x16 acc[1][NTW];
 #pragma unroll
@@ -885,9 +888,8 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
       for (int j = 0; j < NTW; ++j) {
         if (w + 4 * j >= NBT) continue;
         const int bin = nto[j] * 32 + li;
-        const float b = bin < NB ? A.bs[bin] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + bin] = bin < NB ? acc[0][j][r] + b : -INFINITY;
+        for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + bin] = acc[0][j][r] + bsv[j];
       }
     }
     lds_barrier();
@@ -895,52 +897,52 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
       const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
       float* o = Ot + row * LDO;
       float mx = -INFINITY;
+#pragma unroll
       for (int k = sub; k < NBP; k += 8) mx = fmaxf(mx, o[k]);
       mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx));
       float sum = 0.f;
+#pragma unroll
       for (int k = sub; k < NBP; k += 8) { const float e = expf(o[k] - mx); o[k] = e; sum += e; }
       sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
       const float inv = 1.0f / sum;
-      if (mode) {
+      if (MODE) {
         if (gr < T) for (int k = sub; k < NB; k += 8) A.sts[(size_t)gr * NB + k] = o[k] * inv;
       } else {
         const int a = s_a[row], b = s_b[row];
         const float he = s_he[row];
+        const bool live = gr < T;
         float cum = 0.f;
+#pragma unroll
         for (int k = sub; k < NBP; k += 8) { const float s = o[k] * inv; o[k] = s; if (k <= a) cum += s; }
         cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
         // (the 8 lanes of a row now hold identical cum; they all wrote disjoint o[k])
         __builtin_amdgcn_wave_barrier();
         const float sa = o[a], sb = o[b];
-        float g = 0.f, dot = 0.f;
-        if (gr < T) {
-          const float u = he + wd * (sa - sb);
-          g = -ls1 * sigmoidf_(-u);
-          dot = ls0 * cum - ls0 + g * wd * (sa - sb);
-          if (sub == 0) {
-            A.rowloss[2 * (size_t)gr] = cum - logf(sa);
-            A.rowloss[2 * (size_t)gr + 1] = log_sigmoidf_(u);
-            A.gcoef[gr] = g;
-            dwd_acc += g * (sa - sb);
-          }
+        const float u = he + wd * (sa - sb);
+        const float g = live ? -ls1 * sigmoidf_(-u) : 0.f;
+        const float dot = ls0 * cum - ls0 + g * wd * (sa - sb);
+        {   // all 8 lanes of the row store the same values (no lane branch around the stores); dead rows -> row T
+          const size_t rs = (size_t)min(gr, T);
+          A.rowloss[2 * rs] = cum - logf(sa);
+          A.rowloss[2 * rs + 1] = log_sigmoidf_(u);
+          A.gcoef[rs] = g;
         }
+        dwd_acc += sub == 0 ? g * (sa - sb) : 0.f;
         if (sub == 0) s_g[row] = g;
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
         for (int k = sub; k < NBP; k += 8) {
-          float dl = 0.f;
-          if (gr < T && k < NB) {
-            float ds = (k <= a ? ls0 : 0.f);
-            if (k == a) ds += g * wd - ls0 / sa;
-            if (k == b) ds -= g * wd;
-            dl = o[k] * (ds - dot);
-          }
-          o[k] = dl;
+          float ds = (k <= a ? ls0 : 0.f);
+          if (k == a) ds += g * wd - ls0 / sa;
+          if (k == b) ds -= g * wd;
+          o[k] = (live && k < NB) ? o[k] * (ds - dot) : 0.f;
         }
       }
     }
     lds_barrier();
-    if (!mode) {
-      // g * E of this lane's DH elements: issued now, consumed after the MFMAs
+    if (!MODE) {
+      // g * E of this lane's DH elements and the next tile's staging rows: issued now, consumed after the MFMAs
+      // and at the top of the next iteration
       int ntd[DTW];
 #pragma unroll
       for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
@@ -948,16 +950,20 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
 #pragma unroll
       for (int j = 0; j < DTW; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = c_row(r, lane), gr = r0 + i;
-          ge[j][r] = gr < T ? A.E[(size_t)gr * D + ntd[j] * 32 + li] : 0.f;
-        }
+        for (int r = 0; r < 16; ++r)
+          ge[j][r] = Esrc[(size_t)min(r0 + c_row(r, lane), T - 1) * D + ntd[j] * 32 + li];
+      prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
       // d logits -> DL (A operand of the d vs job of te_wgrad), d bs partials
       for (int e = tid; e < 32 * (NBP / 4); e += TE_BLOCK) {
         const int r = e / (NBP / 4), c = (e % (NBP / 4)) * 4;
-        if (r0 + r < T) *reinterpret_cast<float4*>(A.DL + (size_t)(r0 + r) * NBP + c) = *reinterpret_cast<const float4*>(Ot + r * LDO + c);
+        *reinterpret_cast<float4*>(A.DL + (size_t)min(r0 + r, T) * NBP + c) = *reinterpret_cast<const float4*>(Ot + r * LDO + c);
       }
-      if (tid < NBP) { float s = 0.f; for (int r = 0; r < 32; ++r) s += Ot[r * LDO + tid]; dbs_acc += s; }
+      if (tid < NBP) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += Ot[r * LDO + tid];
+        dbs_acc += s;
+      }
       // DH = d logits . vs + g * E
       f32x16 acc[1][DTW];
 #pragma unroll
@@ -971,13 +977,15 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A, int mode
         const int col = ntd[j] * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int i = c_row(r, lane), gr = r0 + i;
-          if (gr < T) A.DH[(size_t)gr * D + col] = acc[0][j][r] + s_g[i] * ge[j][r];
+          const int i = c_row(r, lane);
+          A.DH[(size_t)min(r0 + i, T) * D + col] = acc[0][j][r] + s_g[i] * ge[j][r];
         }
       }
+    } else {
+      prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
     }
   }
-  if (!mode) {
+  if (!MODE) {
     float* hs = A.hslab + (size_t)blockIdx.x * A.hstride;
     if (tid < NB) hs[tid] += dbs_acc;
     const float dw = block_sum(dwd_acc, s_red);
@@ -1200,7 +1208,8 @@ int te_nbp(int n_dist) { return nbt_for(n_dist + 1) * 32; }
 template <int D, int NBT>
 static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (NBT * 32 + 4));
-  hipLaunchKernelGGL((te_head_kernel<D, NBT>), dim3(grid), dim3(TE_BLOCK), lds, st, A, mode);
+  if (mode) hipLaunchKernelGGL((te_head_kernel<D, NBT, 1>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
+  else hipLaunchKernelGGL((te_head_kernel<D, NBT, 0>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
   return hipGetLastError();
 }
 
