@@ -861,9 +861,11 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
     }
     if (!MODE) pab = A.row_ab[min(r0 + (tid & 31), T - 1)];
   };
-  prefetch(blockIdx.x * 32);
-  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
-    lds_barrier();
+  // registers -> LDS (H rows, h . e, target bins).  Called at the END of an iteration for the next tile: the
+  // wait for the prefetch then sits in straight-line code behind the stores that followed it and is counted
+  // exactly; at the top of the loop it would merge with the first iteration's "just issued" state, i.e. be a
+  // vmcnt(0) that also waits for the previous tile's DH stores.
+  auto stage = [&]() {
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
       const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
@@ -876,7 +878,11 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
       }
     }
     if (!MODE && tid < 32) { s_a[tid] = pab & 0xffff; s_b[tid] = pab >> 16; }
-    lds_barrier();
+  };
+  prefetch(blockIdx.x * 32);
+  stage();
+  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    lds_barrier();        // staged tile visible; every wave is done with Ot (DH MFMAs of the previous tile)
     {   // logits
       f32x16 acc[1][NTW];
 #pragma unroll
@@ -898,11 +904,11 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
       float* o = Ot + row * LDO;
       float mx = -INFINITY;
 #pragma unroll
-      for (int k = sub; k < NBP; k += 8) mx = fmaxf(mx, o[k]);
+      for (int i = 0; i < NBP / 8; ++i) mx = fmaxf(mx, o[sub + 8 * i]);     // (uniform trip counts: unrollable)
       mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx));
       float sum = 0.f;
 #pragma unroll
-      for (int k = sub; k < NBP; k += 8) { const float e = expf(o[k] - mx); o[k] = e; sum += e; }
+      for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float e = expf(o[k] - mx); o[k] = e; sum += e; }
       sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
       const float inv = 1.0f / sum;
       if (MODE) {
@@ -913,7 +919,7 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
         const bool live = gr < T;
         float cum = 0.f;
 #pragma unroll
-        for (int k = sub; k < NBP; k += 8) { const float s = o[k] * inv; o[k] = s; if (k <= a) cum += s; }
+        for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float s = o[k] * inv; o[k] = s; cum += k <= a ? s : 0.f; }
         cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
         // (the 8 lanes of a row now hold identical cum; they all wrote disjoint o[k])
         __builtin_amdgcn_wave_barrier();
@@ -931,7 +937,8 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
         if (sub == 0) s_g[row] = g;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = sub; k < NBP; k += 8) {
+        for (int i = 0; i < NBP / 8; ++i) {
+          const int k = sub + 8 * i;
           float ds = (k <= a ? ls0 : 0.f);
           if (k == a) ds += g * wd - ls0 / sa;
           if (k == b) ds -= g * wd;
@@ -984,6 +991,7 @@ __global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
     } else {
       prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
     }
+    stage();              // Ht / s_he / s_a / s_b were last read before the previous barrier
   }
   if (!MODE) {
     float* hs = A.hslab + (size_t)blockIdx.x * A.hstride;
