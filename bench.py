@@ -198,10 +198,13 @@ def main():
         ms, nl = kt[k]
         if nl == 0:
             continue
-        ent = {"ms_per_step": ms / a.steps, "launches": nl, "avg_ms": ms / nl}
+        # per-step time from the per-launch average: the event recorder keeps at most 8192 regions, so on long
+        # runs (--steps > ~180) only the first launches are timed - their average is still the launch duration
+        per_step = (ms / nl) * len(batches)
+        ent = {"ms_per_step": per_step, "launches": nl, "avg_ms": ms / nl}
         if k in work:
             kind, w = work[k]
-            rate = w * a.steps / (ms * 1e-3)
+            rate = w / (per_step * 1e-3)
             if kind == "flop":
                 ent.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=rate / 1e12 / PEAK_F32_TFLOPS)
             else:
