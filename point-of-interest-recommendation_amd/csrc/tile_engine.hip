@@ -45,7 +45,9 @@ __device__ __forceinline__ void lds_barrier() {
 }
 // tanh on the hardware exp: 1 - 2 / (1 + e^{2x}); saturates correctly (e^{2x} -> inf gives 1, -> 0 gives -1);
 // absolute error ~1e-7, far inside the 1e-5 parity bar.  The library tanhf is a long branchy routine.
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+// (v_rcp_f32, 1 ulp, instead of the IEEE division sequence: the gate math sits on the per-step latency chain)
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // C/D layout of the 32x32 tile: element (row, col) of register r in lane l
 __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -599,8 +601,8 @@ __global__ __launch_bounds__(256) void te_transpose_kernel(const float* __restri
 // a 16-row step is half the matrix work of a 32-row step.  h_{t-1} / r*h_{t-1} cross waves through LDS
 // (two barriers per step).
 // -------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predict) {
+template <int D, bool predict>      // (compile-time: a runtime flag puts a branch around every store of the step)
+__global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int KG = D / 16, LDA = D + 4, NW = D / 16;
   float* Hb = lds;                       // h_{t-1}, overwritten by h_t   16 x LDA
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r;
-      const float rv = sigmoidf_(ar[0][r]);
+      const float rv = fast_sigmoid(ar[0][r]);
       const float rh = rv * hcur[r];
       RHb[i * LDA + col] = rh;
       const size_t row = (size_t)(t < nsr[r] ? rowb[r] + t : Tsp);
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
     lds_barrier();
     float zv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { zv[r] = sigmoidf_(az[0][r]); ac[0][r] = cc[r]; }
+    for (int r = 0; r < 4; ++r) { zv[r] = fast_sigmoid(az[0][r]); ac[0][r] = cc[r]; }
     mma16_regb<KG, 1>(ac, RHb, LDA, wc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -683,8 +685,14 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A, int predi
       }
     }
     lds_barrier();
+    // Opaque use of the prefetched values HERE: the wait for them is then counted in straight-line code behind
+    // this step's stores (vmcnt(#stores)).  Left to the first use at the top of the next iteration, it merges
+    // with the loop-entry state and becomes a wait for most of the stores as well - a store round trip per step.
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { cz[r] = nz[r]; cr[r] = nr[r]; cc[r] = nc[r]; }
+    for (int r = 0; r < 4; ++r) {
+      asm volatile("" : "+v"(nz[r]), "+v"(nr[r]), "+v"(nc[r]));
+      cz[r] = nz[r]; cr[r] = nr[r]; cc[r] = nc[r];
+    }
   }
   if (predict) {
 #pragma unroll
@@ -1295,7 +1303,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
   }
   tm->begin("te_rec_fwd", st);
-  hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 0);
+  hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
   tm->end(st);
   tm->begin("te_head", st);
   if (A.spatial) {
@@ -1350,7 +1358,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
     NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, A.xw, A.G, 3 * D, A.bi, A.soff + n, 3 * D, A.xw, A.dbg};
     te_launch_ax<D>(A, P, num_cu, st);
   }
-  hipLaunchKernelGGL(te_rec_fwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A, 1);
+  hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
   tm->end(st);
