@@ -316,7 +316,6 @@ struct NtArgs {
   const float* A; int lda;            // packed A (GATHER == false)
   const float *tab0, *tab1; const int *idx0, *idx1; int Dg;      // gathered A
   const float* B; int ldb; float* C; int ldc; const float* bias; const int* Tptr; int N, K;
-  int dbg;
 };
 template <bool BIAS, bool GATHER>
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
@@ -1262,7 +1261,6 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
 template <int D>
 static void te_launch_ax(const TeArgs& A, const NtArgs& P, int num_cu, hipStream_t st) {
   const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
-  if (A.dbg == 32) { hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), grid, block, 0, st, P); return; }
   if (A.spatial) {
     hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, 2 * D, D, 3 * D>), grid, block, 0, st, P);
   } else {
@@ -1289,7 +1287,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_gemm_ax", st);
   {
-    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW, A.dbg};
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW};
     te_launch_ax<D>(A, P, num_cu, st);
   }
   tm->end(st);
@@ -1325,10 +1323,11 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_gemm_dx", st);
   {
-    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, XW, 3 * D, A.dbg};
-    if (A.dbg != 32 && A.spatial) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
-    else if (A.dbg != 32) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
-    else hipLaunchKernelGGL((te_gemm_nt_kernel<false, false>), dim3(((num_cu * 2 + 7) / 8) * 8), dim3(TE_BLOCK), 0, st, P);
+    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, XW, 3 * D};
+    // dx = DA . ui: K = 3D is always wide enough for the compile-time-K kernel
+    const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
+    if (A.spatial) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D>), grid, block, 0, st, P);
   }
   tm->end(st);
   tm->begin("te_finalize", st);
@@ -1355,7 +1354,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   {
-    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, A.xw, A.G, 3 * D, A.bi, A.soff + n, 3 * D, A.xw, A.dbg};
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, A.xw, A.G, 3 * D, A.bi, A.soff + n, 3 * D, A.xw};
     te_launch_ax<D>(A, P, num_cu, st);
   }
   hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
