@@ -222,3 +222,43 @@ def test_tile_degenerate_lengths(pa):
         for k in GRU_NAMES:
             assert_close(got[k], expg[k], "%s gru %s" % (eng, k))
     pa._lib.context(0).set_engine("auto")
+
+
+def test_tile_multi_tile_workgroups_match_seq_engine(pa):
+    """~50 k packed rows: every persistent GEMM workgroup walks several 128-row tiles, i.e. the cross-tile
+    operand pipeline of te_gemm_ntk (next tile's chunks and gather indices fetched inside the current tile)
+    and the multi-iteration paths of te_wgrad / te_head run for real.  The toy sizes above give each workgroup
+    at most one tile.  Reference: the per-sequence engine (itself pinned to the oracle above)."""
+    T = toy_problem(901, n_user=2600, n_item=3000, n_dist=200, dim=128, len_max=41, hot=300)
+    P = spatial_params(901, T)
+    users = np.random.default_rng(3).permutation(2600)[:2500].astype(np.int32)
+    res, outs = {}, {}
+    for eng in ("tile", "seq"):
+        model = _model(pa, T, P)
+        model.ctx.set_engine(eng)
+        outs[eng] = np.asarray(model.train_batch(users))
+        res[eng] = _get(model)
+    pa._lib.context(0).set_engine("auto")
+    assert_close(outs["tile"][:, :3], outs["seq"][:, :3], "losses", rtol=2e-5)
+    for k in SP_NAMES:
+        assert_close(res["tile"][k], res["seq"][k], "tile vs seq " + k, rtol=2e-5)
+
+
+@pytest.mark.parametrize("dim", [64, 128])
+def test_tile_plain_gru_multi_tile_workgroups_match_seq_engine(pa, dim):
+    """Plain GRU at ~50 k packed rows: the one-table variant of te_gemm_ntk (gather indices double-buffered by
+    tile parity, D = 128) and the runtime-K fallback (D = 64) with several tiles per workgroup."""
+    from tests.gpu_util import gru_params
+    T = toy_problem(930 + dim, n_user=2600, n_item=3000, dim=dim, len_max=41, hot=300)
+    P = gru_params(930 + dim, T)
+    users = np.random.default_rng(4).permutation(2600)[:2500].astype(np.int32)
+    res, losses = {}, {}
+    for eng in ("tile", "seq"):
+        model = _gru_model(pa, T, P)
+        model.ctx.set_engine(eng)
+        losses[eng] = np.asarray(model.train_batch(users)).reshape(-1)
+        res[eng] = _get_gru(model)
+    pa._lib.context(0).set_engine("auto")
+    assert_close(losses["tile"], losses["seq"], "losses", rtol=2e-5)
+    for k in GRU_NAMES:
+        assert_close(res["tile"][k], res["seq"][k], "tile vs seq " + k, rtol=2e-5)
