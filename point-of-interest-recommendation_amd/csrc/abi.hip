@@ -154,6 +154,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.lt = P->lt; A.di = P->di; A.ui = P->ui; A.wh = P->wh; A.bi = P->bi; A.vs = P->vs; A.bs = P->bs; A.wd = P->wd; A.lw = P->lw;
   A.n_item = P->n_item; A.n_dist = n_dist; A.dim = D;
   A.spatial = spatial ? 1 : 0; A.xw = spatial ? 2 * D : D;
+  A.bintab = poi::te_bintab(D, spatial) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
@@ -166,7 +167,10 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t n_hot = Ncap / (TE_COLD_MAX + 1) + 2, n_chunk = Ncap / TE_HOT_CHUNK + n_hot + 2;
   const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)((n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
   const size_t sin = sorted ? 7 * Ncap + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
-  const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl;
+  // per-bin tables (bintab): ztab + per-bin sums + d di sums, and (training) the sliced partial sums of DA
+  const size_t NBt = (size_t)(n_dist + 1);
+  const size_t bfl = A.bintab ? NBt * (size_t)(3 * D) * 2 + NBt * D + (sorted ? NBt * TE_DS_SLICES * (size_t)(3 * D) : 0) + 64 : 0;
+  const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl;
   const size_t nin = Tcap * 5 + (size_t)n + 32 + sin;
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
@@ -179,6 +183,10 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.uiT = take((size_t)6 * D * D);
   A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
   A.pWhT16 = (float4*)take((size_t)3 * D * D); A.pWhc16 = (float4*)take((size_t)D * D); A.pWhzr16 = (float4*)take((size_t)2 * D * D);
+  if (A.bintab) {
+    A.ztab = take(NBt * 3 * D); A.dsum = take(NBt * 3 * D); A.dgd = take(NBt * D);
+    if (sorted) A.dpart = take(NBt * TE_DS_SLICES * (size_t)(3 * D));
+  }
   if (sorted) {
     A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP);
     A.bi_part = take((size_t)((n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);

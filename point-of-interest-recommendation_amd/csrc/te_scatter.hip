@@ -160,7 +160,8 @@ template <int D>
 __device__ __forceinline__ float4 ent_contrib(const TeArgs& A, int e, int doff, int c) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   const size_t rr = (size_t)(e & TE_ENT_ROW);
-  if (e & TE_ENT_DX) v = *reinterpret_cast<const float4*>(A.X + rr * A.xw + doff + c);
+  // (bintab: a distance-bin row's dx sum comes from the per-bin sums of DA, see te_dsum below - no di half of X exists)
+  if ((e & TE_ENT_DX) && !(A.bintab && doff)) v = *reinterpret_cast<const float4*>(A.X + rr * A.xw + doff + c);
   if (e & TE_ENT_GH) {
     float g = A.gcoef[rr - 1];
     if (e & TE_ENT_NEG) g = -g;
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
       continue;
     }
     int nf = 0;
-    const float4 g = seg_sum<D>(A, start, cnt, ri.doff, &nf);
+    float4 g = seg_sum<D>(A, start, cnt, ri.doff, &nf);
+    if (A.bintab && ri.doff) g = *reinterpret_cast<const float4*>(A.dgd + (size_t)(row - A.n_item - 1) * D + (lane % (D / 4)) * 4);
     apply_sum<D>(ri.trow, g, cnt + am, ri.pn ? an : nf, alpha, lambda);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
@@ -318,9 +320,75 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
     for (int i = lane; i < nch; i += 64) nf += A.hot_nf[c0 + i];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) nf += __shfl_xor(nf, o, 64);
+    if (A.bintab && ri.doff) acc = *reinterpret_cast<const float4*>(A.dgd + (size_t)(row - A.n_item - 1) * D + c);
     apply_sum<D>(ri.trow, acc, cnt + am, ri.pn ? an : nf, alpha, lambda);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Per-bin sums of DA (bintab, see te_ztab_kernel in tile_engine.hip).  The distance-bin half of the step input
+// takes n_dist + 1 values, so everything the backward pass needs from it is linear in
+//   S[b] = sum over the packed rows t with dp_t = b of DA_t                      ((n_dist + 1) x 3D):
+//   d di[b]        (the row's dx sum of the batch rule)  = S[b] . ui[:, D:2D]    -> dgd, used by te_reduce / te_hot_apply
+//   d ui[:, D:2D]  (dense gradient)                      = S^T . di              -> slab 0
+// which replaces the di halves of te_gemm_dx and of te_wgrad's d ui jobs (a quarter of the step's flops).
+// The rows of a bin are the DX entries of its segment in the sorted entry list; a bin is cut into TE_DS_SLICES
+// interleaved slices of 64-entry chunks (one workgroup each, fixed order), summed in slice order: reproducible.
+// -------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
+  const int b = blockIdx.x, y = blockIdx.y, col = threadIdx.x;
+  const int row = A.n_item + 1 + b;
+  const int end = A.seg_end[row], start = end ? A.seg_start[row] : 0;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int c0 = start + 64 * y; c0 < end; c0 += 64 * TE_DS_SLICES) {
+    const int ce = min(end, c0 + 64);
+    for (int i = c0; i < ce; i += 8) {
+      int e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = A.ent[min(i + u, ce - 1)];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = A.G[(size_t)(e[u] & TE_ENT_ROW) * 3 * D + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i + u < ce && (e[u] & TE_ENT_DX)) ? v[u] : 0.f;
+      s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
+    }
+  }
+  A.dpart[((size_t)b * TE_DS_SLICES + y) * 3 * D + col] = (s0 + s1) + (s2 + s3);
+}
+
+// S[b] = sum of the bin's slices (in order); dgd[b] = S[b] . ui[:, D:2D]
+template <int D>
+__global__ __launch_bounds__(3 * D) void te_dfin_kernel(TeArgs A) {
+  __shared__ float S[3 * D];
+  const int b = blockIdx.x, col = threadIdx.x;
+  float s = 0.f;
+  for (int y = 0; y < TE_DS_SLICES; ++y) s += A.dpart[((size_t)b * TE_DS_SLICES + y) * 3 * D + col];
+  S[col] = s;
+  A.dsum[(size_t)b * 3 * D + col] = s;
+  __syncthreads();
+  if (col < D) {
+    const float* u = A.ui + D + col;           // ui[k][D + col], row pitch 2D
+    float g0 = 0.f, g1 = 0.f;
+    for (int k = 0; k < 3 * D; k += 2) { g0 = fmaf(S[k], u[(size_t)k * 2 * D], g0); g1 = fmaf(S[k + 1], u[(size_t)(k + 1) * 2 * D], g1); }
+    A.dgd[(size_t)b * D + col] = g0 + g1;
+  }
+}
+
+// d ui[k][D + c] = sum_b S[b][k] * di[b][c]  (di BEFORE this launch's write-back) -> slab 0 (zero on entry: plain store)
+template <int D>
+__global__ __launch_bounds__(D) void te_dui_kernel(TeArgs A) {
+  const int k = blockIdx.x, c = threadIdx.x, NB = A.n_dist + 1;
+  float a0 = 0.f, a1 = 0.f;
+  int b = 0;
+  for (; b + 1 < NB; b += 2) {
+    a0 = fmaf(A.dsum[(size_t)b * 3 * D + k], A.di[(size_t)b * D + c], a0);
+    a1 = fmaf(A.dsum[(size_t)(b + 1) * 3 * D + k], A.di[(size_t)(b + 1) * D + c], a1);
+  }
+  if (b < NB) a0 = fmaf(A.dsum[(size_t)b * 3 * D + k], A.di[(size_t)b * D + c], a0);
+  A.slab[A.dl.ui + (size_t)k * 2 * D + D + c] = a0 + a1;
 }
 
 template <int D>
@@ -330,6 +398,11 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   if (grid > num_cu * 32) grid = num_cu * 32;
   if (A.side && hipStreamWaitEvent(st, A.ev_sorted, 0) != hipSuccess) return hipGetLastError();     // the sorted entries
   tm->begin("te_scatter", st);
+  if (A.bintab) {
+    hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(A.n_dist + 1, TE_DS_SLICES), dim3(3 * D), 0, st, A);
+    hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A);
+    hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(D), 0, st, A);
+  }
   hipLaunchKernelGGL(te_reduce_kernel<D>, dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu), dim3(256), 0, st, A, alpha, lambda);

@@ -316,6 +316,7 @@ struct NtArgs {
   const float* A; int lda;            // packed A (GATHER == false)
   const float *tab0, *tab1; const int *idx0, *idx1; int Dg;      // gathered A
   const float* B; int ldb; float* C; int ldc; const float* bias; const int* Tptr; int N, K;
+  const float* ztab; const int* zidx;         // ZADD: C[r][:] += ztab[zidx[r]][:]   (ztab rows of N floats)
 };
 template <bool BIAS, bool GATHER>
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
@@ -442,9 +443,11 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
 //    at the start of a tile nor the 64 C stores per lane at its end are exposed (on gfx9 stores count
 //    in vmcnt too; the loads of the next tile are issued BEFORE them and vmcnt retires in order);
 //  * the epilogue is branch-free: columns beyond N (N % 128 != 0) go to the spare row T.
-template <bool BIAS, bool GATHER, int K, int DG, int N>
+//  * ZADD: the epilogue adds row zidx[r] of a small table instead of a bias (te_gemm_ax: the distance-bin half
+//    of the step input only takes n_dist + 1 values, so its product with ui is a table, see te_ztab_kernel).
+template <bool BIAS, bool GATHER, int K, int DG, int N, int LDB = K, int LDC = N, bool ZADD = false>
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
-  constexpr int NCH = K / 32, ldb = K, ldc = N;           // B is N x K, C is T x N, both dense
+  constexpr int NCH = K / 32, ldb = LDB, ldc = LDC;       // B is N x K (row pitch LDB), C is T x N (row pitch LDC)
   static_assert(K % 64 == 0 && NCH >= 4, "te_gemm_ntk: K must be a multiple of 64, >= 128");
   __shared__ __align__(16) float As[2][128][NT_LDK];
   __shared__ __align__(16) float Bs[2][128][NT_LDK];
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
   //  * one table (DG == K): no gap, slot = tile parity.
   constexpr bool ONE_TAB = (DG == K);
   __shared__ int s_idx[2][128];
+  __shared__ int s_z[ZADD ? 2 : 1][128];       // ZADD: table rows of the tile's 128 rows, by tile parity
   const float* __restrict__ Ag = P.A; const float* __restrict__ Bg = P.B; float* __restrict__ C = P.C;
   const float* __restrict__ bias = P.bias;
   const int lda = P.lda;
@@ -522,9 +526,10 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
     }
   };
   // prologue: LDS buffer 0 <- chunk 0, register set 1 <- chunk 1 (in flight): the state every tile starts from
-  if (GATHER) {
-    s_idx[0][irow] = idx0[min(r0 + irow, T - 1)];
-    if (!ONE_TAB) s_idx[1][irow] = idx1[min(r0 + irow, T - 1)];
+  if (GATHER || ZADD) {
+    if (GATHER) s_idx[0][irow] = idx0[min(r0 + irow, T - 1)];
+    if (GATHER && !ONE_TAB) s_idx[1][irow] = idx1[min(r0 + irow, T - 1)];
+    if (ZADD) s_z[0][irow] = P.zidx[min(r0 + irow, T - 1)];
     __syncthreads();
   }
   gload(0, r0, n0, 0, 0); lstore(0, 0); gload(1, r0, n0, 0, 1);
@@ -536,6 +541,8 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
     const int r0n = more ? tmn * 128 : r0, n0n = more ? (Ln % ntl) * 128 : n0;
     int nidx0 = 0, nidx1 = 0;
     if (GATHER) { nidx0 = idx0[min(r0n + irow, T - 1)]; if (!ONE_TAB) nidx1 = idx1[min(r0n + irow, T - 1)]; }
+    int nzi = 0;
+    if (ZADD) nzi = P.zidx[min(r0n + irow, T - 1)];
     float bvj[2];                            // fetched here so that the epilogue never waits on a load
 #pragma unroll
     for (int j = 0; j < 2; ++j) bvj[j] = BIAS ? bias[min(n0 + wn + 32 * j + li, N - 1)] : 0.f;
@@ -555,23 +562,53 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
       if (GATHER && ONE_TAB && kc == 1) s_idx[par ^ 1][irow] = nidx0;        // read from stage NCH - 2 on
       if (GATHER && !ONE_TAB && kc == NCH / 2 - 1) s_idx[0][irow] = nidx0;
       if (GATHER && !ONE_TAB && kc == NCH - 2) s_idx[1][irow] = nidx1;
+      if (ZADD && kc == 1) s_z[(par ^ 1) & (ZADD ? 1 : 0)][irow] = nzi;          // read by the NEXT tile's epilogue
       lstore((kc + 1) & 1, (kc + 1) & 1);
       if (kc == NCH - 1) {
         // C tile.  One base pointer per 32x32 block and compile-time row offsets; the sched_barrier keeps
         // the address arithmetic HERE (hoisted to the top of the tile it spills).  Rows past T of the last
         // tile land in the spare rows of C; columns past N (N % 128 != 0) are sent there too.
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = n0 + wn + 32 * j + li;
-          const bool cok = col < N;
-          const int cc = cok ? col : N - 1;
-          const float bv = bvj[j];
+        if (ZADD) {
+          // all table loads of the tile are issued before the first store (one L2 round trip per tile)
+          float zr[2][2][16];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            float* cb = C + (size_t)(cok ? r0 + wm + 32 * i + 4 * h : T) * ldc + cc;
+            int zi[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cb[((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r] + bv;
+            for (int r = 0; r < 16; ++r) zi[r] = s_z[par & (ZADD ? 1 : 0)][wm + 32 * i + 4 * h + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int cc = min(n0 + wn + 32 * j + li, N - 1);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) zr[i][j][r] = P.ztab[(size_t)zi[r] * N + cc];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + li;
+            const bool cok = col < N;
+            const int cc = cok ? col : N - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              float* cb = C + (size_t)(cok ? r0 + wm + 32 * i + 4 * h : T) * ldc + cc;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cb[((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r] + zr[i][j][r];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + li;
+            const bool cok = col < N;
+            const int cc = cok ? col : N - 1;
+            const float bv = bvj[j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              float* cb = C + (size_t)(cok ? r0 + wm + 32 * i + 4 * h : T) * ldc + cc;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cb[((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r] + bv;
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -581,6 +618,26 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
     if (!more) break;
     L = Ln; r0 = r0n; n0 = n0n; par ^= 1;
   }
+}
+
+// ztab[b][n] = bi[n] + sum_c di[b][c] * ui[n][D + c]: the distance-bin half of x_t . ui^T (+ bias) for each of the
+// n_dist + 1 bins.  x_t = [lt[p_t] | di[dp_t]] takes only that many values in its second half, so te_gemm_ax
+// multiplies the POI half alone (K = D instead of 2D) and adds row dp_t of this table in its epilogue; in the
+// same way the backward pass needs only per-bin sums of DA (te_dsum in te_scatter.hip) for d di and the
+// di half of d ui, instead of the di halves of dx = DA . ui and of d ui = DA^T . x.
+__global__ __launch_bounds__(1024) void te_ztab_kernel(TeArgs A, float* __restrict__ ztab) {
+  __shared__ float drow[256];
+  const int D = A.dim, XW = A.xw, b = blockIdx.x, n = threadIdx.x;
+  if (n < D) drow[n] = A.di[(size_t)b * D + n];
+  __syncthreads();
+  if (n >= 3 * D) return;
+  const float* u = A.ui + (size_t)n * XW + D;
+  float z0 = A.bi[n], z1 = 0.f, z2 = 0.f, z3 = 0.f;
+  for (int c = 0; c < D; c += 4) {
+    const float4 uv = *reinterpret_cast<const float4*>(u + c);
+    z0 = fmaf(drow[c], uv.x, z0); z1 = fmaf(drow[c + 1], uv.y, z1); z2 = fmaf(drow[c + 2], uv.z, z2); z3 = fmaf(drow[c + 3], uv.w, z3);
+  }
+  ztab[(size_t)b * 3 * D + n] = (z0 + z1) + (z2 + z3);
 }
 
 // uiT[c][r] = ui[r][c]   (ui is 3D x 2D row-major): the K-contiguous B operand of dx = DA . ui
@@ -1025,13 +1082,14 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   __shared__ __align__(16) float At[2][32][LDT];
   __shared__ __align__(16) float Bt[2][32][LDT];
   constexpr int NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
-  const int NB_UI = (3 * D / T) * (XW / T);
+  const int XWJ = A.bintab ? D : XW;                         // d ui columns that are GEMM jobs (bintab: POI half only)
+  const int NB_UI = (3 * D / T) * (XWJ / T);
   const int Trows = A.soff[A.n_seq], rmax = max(Trows - 1, 0);        // (loads are clamped to row rmax)
   // (an XCD-aware (chunk, job) order - all jobs of a K-chunk on one XCD - measured 10 % slower than this plain
   // order: it needs a chunk count that is a multiple of 8, which leaves CU slots empty)
   const int job = blockIdx.x, kc = blockIdx.y;
   int m0, n0, ldo, bsel; size_t oo;
-  if (job < NB_UI) { const int bn = XW / T; m0 = (job / bn) * T; n0 = (job % bn) * T; ldo = XW; oo = A.dl.ui; bsel = 0; }
+  if (job < NB_UI) { const int bn = XWJ / T; m0 = (job / bn) * T; n0 = (job % bn) * T; ldo = XW; oo = A.dl.ui; bsel = 0; }
   else if (job < NB_UI + NB_ZR) { const int j = job - NB_UI, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.wh; bsel = 1; }
   else if (job < NB_UI + NB_ZR + NB_C) { const int j = job - NB_UI - NB_ZR, bn = D / T; m0 = 2 * D + (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
   else { const int j = job - NB_UI - NB_ZR - NB_C, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.vs; bsel = 3; }   // d vs = DL^T . H
@@ -1209,9 +1267,12 @@ __global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile
 // host side
 // -------------------------------------------------------------------------------------------------
 int te_wgrad_jobs(int D, int n_dist, bool spatial) {
-  const int T = (D % 128 == 0) ? 128 : 64, XW = spatial ? 2 * D : D;
+  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial)) ? 2 * D : D;
   return (3 * D / T) * (XW / T) + (2 * D / T) * (D / T) + (D / T) * (D / T) + (spatial ? ((te_nbp_dev(n_dist) + T - 1) / T) * (D / T) : 0);
 }
+
+// Distance2Pre at D >= 128: the distance-bin half of the input goes through per-bin tables (te_ztab / te_dsum)
+bool te_bintab(int D, bool spatial) { return spatial && D >= 128; }
 
 bool te_supported(int D, int n_dist) { return (D == 64 || D == 128) && n_dist + 1 <= 256; }   // plain GRU: n_dist == -1
 
@@ -1257,13 +1318,23 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   J.n = n;
 }
 
-// ax = gather(lt | di) . ui^T + bi: the compile-time-K kernel when the operand is wide enough for its pipeline
+// ax = x . ui^T + bi.  Spatial: POI half through the GEMM (K = D, B = the first D columns of ui), distance-bin
+// half + bias from the per-bin table (te_ztab_kernel).  Plain GRU: one table, bias in the epilogue.
 template <int D>
-static void te_launch_ax(const TeArgs& A, const NtArgs& P, int num_cu, hipStream_t st) {
+static void te_launch_ax(const TeArgs& A, int num_cu, hipStream_t st) {
   const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
-  if (A.spatial) {
+  const int n = A.n_seq;
+  if (A.bintab) {
+    if constexpr (D >= 128) {
+      hipLaunchKernelGGL(te_ztab_kernel, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A, A.ztab);
+      NtArgs P{nullptr, 0, A.lt, nullptr, A.row_p, nullptr, D, A.ui, 2 * D, A.G, 3 * D, nullptr, A.soff + n, 3 * D, D, A.ztab, A.row_dp};
+      hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true>), grid, block, 0, st, P);
+    }
+  } else if (A.spatial) {
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.row_dp, D, A.ui, 2 * D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, 2 * D, nullptr, nullptr};
     hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, 2 * D, D, 3 * D>), grid, block, 0, st, P);
   } else {
+    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, nullptr, D, A.ui, D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, D, nullptr, nullptr};
     if constexpr (D >= 128) hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, D, D, 3 * D>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), grid, block, 0, st, P);
   }
@@ -1286,10 +1357,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
   tm->end(st);
   tm->begin("te_gemm_ax", st);
-  {
-    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, XW, A.G, 3 * D, A.bi, A.soff + n, 3 * D, XW};
-    te_launch_ax<D>(A, P, num_cu, st);
-  }
+  te_launch_ax<D>(A, num_cu, st);
   tm->end(st);
   if (A.side) {
     // The slot sort is needed only by te_scatter, so it runs on the side stream - next to te_rec_fwd, a
@@ -1323,10 +1391,12 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_gemm_dx", st);
   {
-    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, XW, 3 * D};
-    // dx = DA . ui: K = 3D is always wide enough for the compile-time-K kernel
+    // dx = DA . ui: K = 3D is always wide enough for the compile-time-K kernel.  With the per-bin table only the
+    // POI half of dx is needed (N = D, written into the first D columns of the 2D-wide X rows).
+    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, A.bintab ? D : XW, 3 * D, nullptr, nullptr};
     const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
-    if (A.spatial) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D>), grid, block, 0, st, P);
+    if (A.bintab) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D, 3 * D, 2 * D>), grid, block, 0, st, P);
+    else if (A.spatial) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D>), grid, block, 0, st, P);
   }
   tm->end(st);
@@ -1353,10 +1423,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
-  {
-    NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.spatial ? A.row_dp : nullptr, D, A.ui, A.xw, A.G, 3 * D, A.bi, A.soff + n, 3 * D, A.xw};
-    te_launch_ax<D>(A, P, num_cu, st);
-  }
+  te_launch_ax<D>(A, num_cu, st);
   hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
