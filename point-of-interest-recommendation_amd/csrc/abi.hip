@@ -168,10 +168,10 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)((n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
   const size_t sin = sorted ? 7 * Ncap + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
   // per-bin tables (bintab): ztab + per-bin sums + d di sums, and (training) the sliced partial sums of DA
-  const size_t NBt = (size_t)(n_dist + 1);
-  const size_t bfl = A.bintab ? NBt * (size_t)(3 * D) * 2 + NBt * D + (sorted ? NBt * TE_DS_SLICES * (size_t)(3 * D) : 0) + 64 : 0;
+  const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2;      // 64-entry chunks of the bins' entry segments
+  const size_t bfl = A.bintab ? NBt * (size_t)(3 * D) * 2 + NBt * D + (sorted ? n_dchunk * (size_t)(3 * D) : 0) + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl;
-  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin;
+  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512;
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
@@ -185,7 +185,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.pWhT16 = (float4*)take((size_t)3 * D * D); A.pWhc16 = (float4*)take((size_t)D * D); A.pWhzr16 = (float4*)take((size_t)2 * D * D);
   if (A.bintab) {
     A.ztab = take(NBt * 3 * D); A.dsum = take(NBt * 3 * D); A.dgd = take(NBt * D);
-    if (sorted) A.dpart = take(NBt * TE_DS_SLICES * (size_t)(3 * D));
+    if (sorted) A.dpart = take(n_dchunk * (size_t)(3 * D));
   }
   if (sorted) {
     A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP);
@@ -203,6 +203,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.cnt = itake(4);
     A.hot_rows = (int4*)itake(4 * n_hot); A.hot_chunks = (int2*)itake(2 * n_chunk); A.hot_nf = itake(n_chunk);
     A.seg_start = (int*)c->seg_s.p; A.seg_end = (int*)c->seg_e.p;
+    A.dch0 = itake(260);
   }
   return POI_OK;
 }

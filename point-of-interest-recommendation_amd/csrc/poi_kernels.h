@@ -79,7 +79,8 @@ struct TeArgs {
   int predict;                        // 1: forward over all L positions, no bookkeeping
   int spatial, xw;                    // 1 / 2D: Distance2Pre (POI + distance-bin input); 0 / D: plain GRU + BPR (n_dist == -1)
   int bintab;                         // spatial && D >= 128: distance-bin half through per-bin tables (te_ztab / te_dsum)
-  float *ztab, *dpart, *dsum, *dgd;   // (n_dist+1) x 3D table; per (bin, slice) partial sums of DA; per-bin sums; per-bin d di sums
+  float *ztab, *dpart, *dsum, *dgd;   // (n_dist+1) x 3D table; per-chunk partial sums of DA; per-bin sums; per-bin d di sums
+  int* dch0;                          // first 64-entry chunk of each bin (+ total)
   int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_p, *row_dp, *row_ab;   // packed row -> CSR position, step index, input table rows (lt, di)
@@ -124,7 +125,6 @@ struct TeArgs {
 #define RS_HIST_INTS (RS_MAXBIN * RS_GRID)   // radix histogram: bins x blocks
 bool te_supported(int D, int n_dist);
 bool te_bintab(int D, bool spatial);
-#define TE_DS_SLICES 64            // te_dsum: slices per distance bin
 int te_wgrad_jobs(int D, int n_dist, bool spatial);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);

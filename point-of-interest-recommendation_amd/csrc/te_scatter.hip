@@ -333,62 +333,98 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
 //   d di[b]        (the row's dx sum of the batch rule)  = S[b] . ui[:, D:2D]    -> dgd, used by te_reduce / te_hot_apply
 //   d ui[:, D:2D]  (dense gradient)                      = S^T . di              -> slab 0
 // which replaces the di halves of te_gemm_dx and of te_wgrad's d ui jobs (a quarter of the step's flops).
-// The rows of a bin are the DX entries of its segment in the sorted entry list; a bin is cut into TE_DS_SLICES
-// interleaved slices of 64-entry chunks (one workgroup each, fixed order), summed in slice order: reproducible.
+// The rows of a bin are the DX entries of its segment in the sorted entry list, cut into 64-entry chunks (one
+// workgroup iteration each; the bins are very uneven), whose partial sums are added in chunk order: reproducible.
 // -------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
-  const int b = blockIdx.x, y = blockIdx.y, col = threadIdx.x;
-  const int row = A.n_item + 1 + b;
-  const int end = A.seg_end[row], start = end ? A.seg_start[row] : 0;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int c0 = start + 64 * y; c0 < end; c0 += 64 * TE_DS_SLICES) {
-    const int ce = min(end, c0 + 64);
-    for (int i = c0; i < ce; i += 8) {
-      int e[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) e[u] = A.ent[min(i + u, ce - 1)];
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = A.G[(size_t)(e[u] & TE_ENT_ROW) * 3 * D + col];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (i + u < ce && (e[u] & TE_ENT_DX)) ? v[u] : 0.f;
-      s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
-    }
-  }
-  A.dpart[((size_t)b * TE_DS_SLICES + y) * 3 * D + col] = (s0 + s1) + (s2 + s3);
+// chunk table: dch0[b] = first 64-entry chunk of bin b (exclusive scan of the bins' chunk counts), dch0[NB] = total
+__global__ __launch_bounds__(256) void te_dprep_kernel(TeArgs A) {
+  __shared__ int s[256];
+  const int NB = A.n_dist + 1, t = threadIdx.x;
+  int n = 0;
+  if (t < NB) { const int row = A.n_item + 1 + t, end = A.seg_end[row]; n = end ? (end - A.seg_start[row] + 63) / 64 : 0; }
+  s[t] = n;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) { const int v = t >= o ? s[t - o] : 0; __syncthreads(); s[t] += v; __syncthreads(); }
+  if (t < NB) A.dch0[t] = s[t] - n;
+  if (t == 255) A.dch0[NB] = s[255];
 }
 
-// S[b] = sum of the bin's slices (in order); dgd[b] = S[b] . ui[:, D:2D]
+// one 64-entry chunk of one bin per workgroup iteration, thread = column of DA
+template <int D>
+__global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
+  const int NB = A.n_dist + 1, col = threadIdx.x;
+  const int total = A.dch0[NB];
+  for (int ci = blockIdx.x; ci < total; ci += gridDim.x) {
+    int lo = 0, hi = NB - 1;                    // last bin with dch0[b] <= ci
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.dch0[mid] <= ci) lo = mid; else hi = mid - 1; }
+    const int row = A.n_item + 1 + lo;
+    const int c0 = A.seg_start[row] + 64 * (ci - A.dch0[lo]), ce = min(A.seg_end[row], c0 + 64);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = c0; i < ce; i += 16) {
+      int e[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) e[u] = A.ent[min(i + u, ce - 1)];
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = A.G[(size_t)(e[u] & TE_ENT_ROW) * 3 * D + col];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (i + u < ce && (e[u] & TE_ENT_DX)) ? v[u] : 0.f;
+      s0 += (v[0] + v[4]) + (v[8] + v[12]); s1 += (v[1] + v[5]) + (v[9] + v[13]);
+      s2 += (v[2] + v[6]) + (v[10] + v[14]); s3 += (v[3] + v[7]) + (v[11] + v[15]);
+    }
+    A.dpart[(size_t)ci * 3 * D + col] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+// S[b] = sum of the bin's chunk partials (in chunk order); dgd[b] = S[b] . ui[:, D:2D]
 template <int D>
 __global__ __launch_bounds__(3 * D) void te_dfin_kernel(TeArgs A) {
   __shared__ float S[3 * D];
+  __shared__ float gp[3][D];
   const int b = blockIdx.x, col = threadIdx.x;
-  float s = 0.f;
-  for (int y = 0; y < TE_DS_SLICES; ++y) s += A.dpart[((size_t)b * TE_DS_SLICES + y) * 3 * D + col];
+  const int c0 = A.dch0[b], c1 = A.dch0[b + 1];
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int c = c0;
+  for (; c + 7 < c1; c += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += A.dpart[(size_t)(c + u) * 3 * D + col];
+  }
+  for (; c < c1; ++c) a[0] += A.dpart[(size_t)c * 3 * D + col];
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   S[col] = s;
   A.dsum[(size_t)b * 3 * D + col] = s;
   __syncthreads();
-  if (col < D) {
-    const float* u = A.ui + D + col;           // ui[k][D + col], row pitch 2D
-    float g0 = 0.f, g1 = 0.f;
-    for (int k = 0; k < 3 * D; k += 2) { g0 = fmaf(S[k], u[(size_t)k * 2 * D], g0); g1 = fmaf(S[k + 1], u[(size_t)(k + 1) * 2 * D], g1); }
-    A.dgd[(size_t)b * D + col] = g0 + g1;
+  {   // matvec: thread (part, cc) sums k in [part*D, (part+1)*D), three parts added in order
+    const int part = col / D, cc = col % D;
+    const float* u = A.ui + (size_t)part * D * 2 * D + D + cc;      // ui[part*D + k][D + cc], row pitch 2D
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < D; k += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q] = fmaf(S[part * D + k + q], u[(size_t)(k + q) * 2 * D], g[q]);
+    }
+    gp[part][cc] = (g[0] + g[1]) + (g[2] + g[3]);
   }
+  __syncthreads();
+  if (col < D) A.dgd[(size_t)b * D + col] = (gp[0][col] + gp[1][col]) + gp[2][col];
 }
 
-// d ui[k][D + c] = sum_b S[b][k] * di[b][c]  (di BEFORE this launch's write-back) -> slab 0 (zero on entry: plain store)
+// d ui[k][D + c] = sum_b S[b][k] * di[b][c]  (di BEFORE this launch's write-back) -> slab 0 (zero on entry: plain store).
+// Workgroup = one row k, thread = (quarter of the bins, column c).
 template <int D>
-__global__ __launch_bounds__(D) void te_dui_kernel(TeArgs A) {
-  const int k = blockIdx.x, c = threadIdx.x, NB = A.n_dist + 1;
-  float a0 = 0.f, a1 = 0.f;
-  int b = 0;
-  for (; b + 1 < NB; b += 2) {
-    a0 = fmaf(A.dsum[(size_t)b * 3 * D + k], A.di[(size_t)b * D + c], a0);
-    a1 = fmaf(A.dsum[(size_t)(b + 1) * 3 * D + k], A.di[(size_t)(b + 1) * D + c], a1);
+__global__ __launch_bounds__(4 * D) void te_dui_kernel(TeArgs A) {
+  __shared__ float qp[4][D];
+  const int k = blockIdx.x, c = threadIdx.x % D, qtr = threadIdx.x / D, NB = A.n_dist + 1;
+  const int per = (NB + 3) / 4, b0 = qtr * per, b1 = min(NB, b0 + per);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = fmaf(A.dsum[(size_t)(b + u) * 3 * D + k], A.di[(size_t)(b + u) * D + c], a[u]);
   }
-  if (b < NB) a0 = fmaf(A.dsum[(size_t)b * 3 * D + k], A.di[(size_t)b * D + c], a0);
-  A.slab[A.dl.ui + (size_t)k * 2 * D + D + c] = a0 + a1;
+  for (; b < b1; ++b) a[0] = fmaf(A.dsum[(size_t)b * 3 * D + k], A.di[(size_t)b * D + c], a[0]);
+  qp[qtr][c] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+  if (qtr == 0) A.slab[A.dl.ui + (size_t)k * 2 * D + D + c] = (qp[0][c] + qp[1][c]) + (qp[2][c] + qp[3][c]);
 }
 
 template <int D>
@@ -399,9 +435,10 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   if (A.side && hipStreamWaitEvent(st, A.ev_sorted, 0) != hipSuccess) return hipGetLastError();     // the sorted entries
   tm->begin("te_scatter", st);
   if (A.bintab) {
-    hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(A.n_dist + 1, TE_DS_SLICES), dim3(3 * D), 0, st, A);
+    hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, st, A);
     hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A);
-    hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(D), 0, st, A);
+    hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(4 * D), 0, st, A);
   }
   hipLaunchKernelGGL(te_reduce_kernel<D>, dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
