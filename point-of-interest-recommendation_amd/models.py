@@ -86,6 +86,17 @@ class _Base:
         n = ids.numel()
         return table[lo:lo + n] if lo is not None else table.index_select(0, ids.long()).contiguous()
 
+    def _by_length(self, ids):
+        """(ids sorted by descending sequence length, order) for the recurrent kernels: a 16-sequence tile runs for
+        its longest member, so homogeneous tiles halve the forward pass of a full evaluation.  `order` maps the
+        sorted position back: out[order] = out_sorted.  None when the launch is too small to matter."""
+        if ids.numel() < 64:
+            return ids, None
+        if getattr(self, "_lens_dev", None) is None:
+            self._lens_dev = torch.as_tensor(np.asarray(self._lens, np.int32)).to(self.device)
+        order = torch.argsort(self._lens_dev.index_select(0, ids.long()), descending=True, stable=True)
+        return ids.index_select(0, order).contiguous(), order
+
     # ---- tables -------------------------------------------------------------------------------
     @staticmethod
     def _check_ids(name, ids, hi):
@@ -269,12 +280,13 @@ class GruBasic(_Base):
 
     def predict_device(self, idxs):
         ids, _ = self._ids(idxs)
+        ids, order = self._by_length(ids)
         n = ids.numel()
         hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         P, T = self._params(snapshot=True), self._tables()
         self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n, _ptr(hts), None,
                                                 self._stream()))
-        return hts
+        return hts if order is None else torch.empty_like(hts).index_copy_(0, order, hts)
 
 
 class OboGru(GruBasic):
@@ -484,13 +496,16 @@ class OboSpatialGru(GruBasic):
 
     def predict_device(self, idxs):
         ids, _ = self._ids(idxs)
+        ids, order = self._by_length(ids)
         n = ids.numel()
         hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         sts = torch.empty((n, self.n_dist + 1), dtype=torch.float32, device=self.device)
         P, T = self._params(snapshot=True), self._tables()
         self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n, _ptr(hts), _ptr(sts),
                                                 self._stream()))
-        return hts, sts
+        if order is None:
+            return hts, sts
+        return torch.empty_like(hts).index_copy_(0, order, hts), torch.empty_like(sts).index_copy_(0, order, sts)
 
 
 # =================================================================================================
