@@ -30,7 +30,7 @@ struct poi_ctx {
   int head_rounds = 3;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
   int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
-  hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
+  hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
@@ -100,7 +100,9 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (!sd || atoi(sd) != 0) {
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_slots, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_bwd, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       c->side = nullptr;                     // fall back to the inline sort
     }
@@ -115,7 +117,7 @@ int poi_ctx_destroy(poi_ctx* c) {
                    &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
-  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); }
+  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c;
   return POI_OK;
@@ -257,7 +259,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
     E.out = out; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
-    E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted;
+    E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
     HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));

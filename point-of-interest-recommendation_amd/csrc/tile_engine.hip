@@ -1382,6 +1382,20 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->begin("te_rec_bwd", st);
   hipLaunchKernelGGL(te_rec_bwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
   tm->end(st);
+  // per-sequence losses and the fixed-order partial sums only need te_head / te_rec_bwd: two small kernels that
+  // fit beside the GEMMs' workgroups (14 registers, no LDS) instead of two more serial launches at the end
+  const int n_fin = (n + TE_BLOCK - 1) / TE_BLOCK, n_out = 3 * D + (A.spatial ? A.n_dist + 4 : 0);
+  auto finalize = [&](hipStream_t s) {
+    tm->begin("te_finalize", s);
+    hipLaunchKernelGGL(te_finalize_kernel, dim3(n_fin), dim3(TE_BLOCK), 0, s, A);
+    hipLaunchKernelGGL(te_parts_kernel, dim3((n_out + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, s, A, (n + 15) / 16, n_fin);
+    tm->end(s);
+  };
+  if (A.side) {
+    if (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_bwd, 0) != hipSuccess) return hipGetLastError();
+    finalize(A.side);
+    if (hipEventRecord(A.ev_fin, A.side) != hipSuccess) return hipGetLastError();
+  }
   tm->begin("te_wgrad", st);
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
@@ -1400,11 +1414,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     else hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D>), grid, block, 0, st, P);
   }
   tm->end(st);
-  tm->begin("te_finalize", st);
-  const int n_fin = (n + TE_BLOCK - 1) / TE_BLOCK, n_out = 3 * D + (A.spatial ? A.n_dist + 4 : 0);
-  hipLaunchKernelGGL(te_finalize_kernel, dim3(n_fin), dim3(TE_BLOCK), 0, st, A);
-  hipLaunchKernelGGL(te_parts_kernel, dim3((n_out + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, st, A, (n + 15) / 16, n_fin);
-  tm->end(st);
+  if (A.side) { if (hipStreamWaitEvent(st, A.ev_fin, 0) != hipSuccess) return hipGetLastError(); }
+  else finalize(st);
   return hipGetLastError();
 }
 
