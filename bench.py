@@ -83,7 +83,10 @@ def main():
     # the ids are sorted by descending length so that 32-sequence tiles are homogeneous.  Resident on device.
     lens_local = np.diff(tab.off.astype(np.int64))
     perm = np.random.default_rng(123).permutation(n_local)
-    B = min(a.batch_users, n_local)
+    # launches of equal size, about --batch-users each: a shard of 12600 users is ONE launch, not 12500 + 100
+    # (a tiny trailing launch costs the full latency chain of the recurrent kernels)
+    n_launch = max(1, int(round(n_local / float(a.batch_users))))
+    B = -(-n_local // n_launch)
     batches = []
     for b0 in range(0, n_local, B):
         ids = perm[b0:b0 + B]

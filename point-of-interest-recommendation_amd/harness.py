@@ -119,8 +119,10 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
                 r = model.train(np.int32(uidx))
                 loss += r[0] if p["gru"] == 2 else r
         else:
-            for b0 in range(0, U, B):
-                ids = order[b0:b0 + B]
+            # launches of equal size (about B users each): no tiny trailing launch
+            Be = -(-U // max(1, int(round(U / float(B)))))
+            for b0 in range(0, U, Be):
+                ids = order[b0:b0 + Be]
                 ids = ids[np.argsort(-lens[ids], kind="stable")]
                 out = model.train_batch(ids)
                 loss += float(out[:, 0].sum()) if p["gru"] == 2 else float(out.sum())
