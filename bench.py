@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla"])
     ap.add_argument("--batch-users", type=int, default=12500)
     ap.add_argument("--eval-steps", type=int, default=2)
-    ap.add_argument("--eval-chunk", type=int, default=4096)
+    ap.add_argument("--eval-chunk", type=int, default=16384,
+                    help="users per scoring call: 16384 = 512 user tiles = one workgroup per tile and two per CU with 4 item ranges each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
