@@ -223,10 +223,10 @@ def main():
         kernels[k] = ent
     dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs, gfx950 correction applied - profiles/r01e_pmc_traffic.json); only valid for the profiled workload
+    # runs, gfx950 correction applied - profiles/r01f_pmc_traffic.json); only valid for the profiled workload
     traffic = {}
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")))
         if a.shape == "gowalla" and B == 12500 and world == 1:
             traffic = {k: v["hbm_bytes_per_launch"] for k, v in pj["kernels"].items()}
     except Exception:
