@@ -45,6 +45,25 @@ def rank_metrics(all_ranks, tes_buys_masks, tes_masks, at_nums):
     return out
 
 
+def coalesce_ranges(starts_ends, target=16384):
+    """Merge consecutive contiguous id ranges into calls of up to `target` users.  The reference evaluates in
+    batch_size_test users per call (Params.compute_start_end); the metrics are sums over users, so the grouping is
+    free - and the scoring kernel is at its best at 16384 users per call (call sizes)."""
+    out, cur = [], None
+    for se in starts_ends:
+        se = np.asarray(se)
+        contiguous = len(se) > 0 and np.all(np.diff(se) == 1)
+        if cur is not None and contiguous and len(cur) and cur[-1] + 1 == se[0] and len(cur) + len(se) <= target:
+            cur = np.concatenate((cur, se))
+        else:
+            if cur is not None:
+                out.append(cur)
+            cur = se
+    if cur is not None:
+        out.append(cur)
+    return out
+
+
 def device_rank_metrics(model, starts_ends_tes, at_nums):
     """Fused top-K + metric accumulation on the device: only (len(at_nums), 3) doubles reach the host."""
     import ctypes
@@ -52,7 +71,7 @@ def device_rank_metrics(model, starts_ends_tes, at_nums):
     kmax = at_nums[-1]
     acc = torch.zeros((len(at_nums), 3), dtype=torch.float64, device=model.device)
     at = torch.as_tensor(np.asarray(at_nums, np.int32)).to(model.device)
-    for se in starts_ends_tes:
+    for se in coalesce_ranges(starts_ends_tes):
         ids, lo = model._ids(se)
         idx = model.compute_sub_topk(se, kmax)
         tp, tm = model._rows(model.tes_buys_masks, ids, lo), model._rows(model.tes_masks, ids, lo)

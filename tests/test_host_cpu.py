@@ -166,3 +166,14 @@ def test_checkpoint_file_is_the_reference_pickle(tmp_path):
         pickle.dump(vals[:8], f, protocol=2)
     with pytest.raises(ValueError):
         harness.read_checkpoint(path)
+
+
+def test_coalesce_ranges_merges_contiguous_batches_only():
+    import importlib
+    ev = importlib.import_module("poi_amd.evaluate")
+    batches = [np.arange(s, min(s + 32, 100), dtype=np.int32) for s in range(0, 100, 32)]
+    out = ev.coalesce_ranges(batches, target=70)
+    assert [len(o) for o in out] == [64, 36] and np.array_equal(np.concatenate(out), np.arange(100))
+    odd = [np.array([5, 6, 7]), np.array([9, 10]), np.array([11, 12]), np.array([3, 1])]
+    out = ev.coalesce_ranges(odd, target=100)
+    assert [list(o) for o in out] == [[5, 6, 7], [9, 10, 11, 12], [3, 1]]
