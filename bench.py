@@ -127,7 +127,7 @@ def main():
     barrier()
     dt = rank_max(time.perf_counter() - t0)
     KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx",
-          "te_finalize", "te_scatter", "rows_apply", "dense_apply"]
+          "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "rows_apply", "dense_apply"]
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
     seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
@@ -203,7 +203,9 @@ def main():
             "rows_apply": ("byte", 2.0 * uniq * D * 4.0),      # read + write of every touched row
             # sorted scatter: per step dx (2D floats; bintab: D floats + the 3D floats of DA for the per-bin sums)
             # + g*h (D floats) in, every touched row read + written
-            "te_scatter": ("byte", (5.0 if bintab else 3.0) * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0)}
+            "te_scatter": ("byte", (2.0 if bintab else 3.0) * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0),
+            # per-bin sums of DA (bintab): one read of the 3D-wide DA rows
+            "te_dsum": ("byte", 3.0 * D * 4 * steps_per_epoch)}
     kernels = {}
     for k in KN:
         ms, nl = kt[k]
@@ -238,11 +240,12 @@ def main():
             kernels[k]["traffic_bytes_per_launch"] = traffic[k]
     roofline = dict(kernel=dom, traffic=traffic.get(dom), **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
     roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
-    gs_ms = sum(kernels[k]["ms_per_step"] for k in ("te_gather", "te_scatter", "rows_apply") if k in kernels)
-    gs_bytes = sum(work[k][1] for k in ("te_gather", "te_scatter", "rows_apply") if k in kernels)
-    hbm = {"kernels": [k for k in ("te_gather", "te_scatter", "rows_apply") if k in kernels], "bound": "hbm",
+    GS = ("te_gather", "te_dsum", "te_scatter", "rows_apply")
+    gs_ms = sum(kernels[k]["ms_per_step"] for k in GS if k in kernels)
+    gs_bytes = sum(work[k][1] for k in GS if k in kernels)
+    hbm = {"kernels": [k for k in GS if k in kernels], "bound": "hbm",
            "achieved": gs_bytes * a.steps / (gs_ms * a.steps * 1e-3) / 1e9 if gs_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "traffic": sum(traffic.get(k, 0) for k in ("te_gather", "te_scatter", "rows_apply")) or None}
+           "traffic": sum(traffic.get(k, 0) for k in GS) or None}
     hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
     total_flops = step_flops(D, NB) * steps_per_epoch
     executed_flops = sum(w for k, (kind, w) in work.items() if kind == "flop" and k in kernels and k != "seq_train") or total_flops

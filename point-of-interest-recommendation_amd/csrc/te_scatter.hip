@@ -433,13 +433,19 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   int grid = (R + 3) / 4;
   if (grid > num_cu * 32) grid = num_cu * 32;
   if (A.side && hipStreamWaitEvent(st, A.ev_sorted, 0) != hipSuccess) return hipGetLastError();     // the sorted entries
-  tm->begin("te_scatter", st);
   if (A.bintab) {
+    // the per-bin reduction of DA rows is scatter traffic (te_dsum: one pass over DA at HBM speed); the two small
+    // dense products that follow (S . ui[:, D:], S^T . di) are timed on their own
+    tm->begin("te_dsum", st);
     hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(256), 0, st, A);
     hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, st, A);
+    tm->end(st);
+    tm->begin("te_bin_gemm", st);
     hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A);
     hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(4 * D), 0, st, A);
+    tm->end(st);
   }
+  tm->begin("te_scatter", st);
   hipLaunchKernelGGL(te_reduce_kernel<D>, dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu), dim3(256), 0, st, A, alpha, lambda);
