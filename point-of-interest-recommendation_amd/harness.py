@@ -50,15 +50,35 @@ def checkpoint_path(p, model_name, epoch, root="./model"):
     return os.path.join(root, str(p["dataset"]), "%s_size%s_UD%s_dd%s_epoch%s" % (model_name, p["latent_size"], p["UD"], p["dd"], epoch))
 
 
+def _py2_compatible(stream):
+    """Rewrite the GLOBAL opcodes of a protocol-2 pickle so that numpy >= 2's private module path
+    (numpy._core.multiarray) becomes the public one every numpy since 1.x exports (numpy.core.multiarray): the
+    reference unpickles these files with Python 2 + an old numpy, which has no numpy._core.  GLOBAL arguments are
+    newline-terminated text ("c<module>\\n<name>\\n"), so the opcode is rewritten in place, opcode by opcode
+    (pickletools.genops), never by a blind byte replace that could hit array payload."""
+    import pickletools
+    ops = list(pickletools.genops(stream))
+    out, prev = bytearray(), 0
+    for i, (op, arg, pos) in enumerate(ops):
+        if op.name == "GLOBAL" and arg.startswith("numpy._core."):
+            end = ops[i + 1][2] if i + 1 < len(ops) else len(stream)
+            mod, name = arg.split(" ")
+            out += stream[prev:pos] + b"c" + mod.replace("numpy._core.", "numpy.core.").encode() + b"\n" + name.encode() + b"\n"
+            prev = end
+    out += stream[prev:]
+    return bytes(out)
+
+
 def dump_checkpoint(values, path):
     """The reference's checkpoint file (prog_bpr_gru_spatial.py:323-330): a pickled list of the nine parameter
     arrays [loss_weight, wd, lt, di, ui, wh, bi, vs, bs] as float64 (Theano's floatX there), protocol 2 =
-    cPickle.HIGHEST_PROTOCOL of Python 2 - readable by the reference and by load_checkpoint."""
+    cPickle.HIGHEST_PROTOCOL of Python 2, with module paths an old numpy can import (_py2_compatible) - readable
+    by the reference's cPickle.load and by load_checkpoint."""
     d = os.path.dirname(path)
     if d:
         os.makedirs(d, exist_ok=True)
     with open(path, "wb") as f:
-        pickle.dump([np.asarray(v, np.float64) for v in values], f, protocol=2)
+        f.write(_py2_compatible(pickle.dumps([np.asarray(v, np.float64) for v in values], protocol=2)))
 
 
 def read_checkpoint(path):

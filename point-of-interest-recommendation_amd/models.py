@@ -19,6 +19,11 @@ from . import _lib
 from .data import CsrTables, bin_thresholds, cos_lat, padded_to_csr
 
 
+import os
+
+_CHECK_DEVICE_IDS = os.environ.get("POI_CHECK_IDS", "0") == "1"
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -73,10 +78,20 @@ class _Base:
 
     def _ids(self, idxs):
         """(int32 device tensor of user ids, lo) - lo is the first id when the ids are a contiguous
-        ascending range (then the tensor is a zero-copy view of a resident arange), else None."""
+        ascending range (then the tensor is a zero-copy view of a resident arange), else None.
+        Host ids (scalars, lists, numpy) are range-checked and raise IndexError like the reference's Theano
+        gather - the kernels would read off[u] out of bounds.  A DEVICE tensor is trusted (checking it
+        costs a host sync per launch); set POI_CHECK_IDS=1 to check those too."""
         if isinstance(idxs, torch.Tensor):
-            return idxs.to(device=self.device, dtype=torch.int32).contiguous(), None
+            t = idxs.to(device=self.device, dtype=torch.int32).contiguous()
+            if _CHECK_DEVICE_IDS and t.numel():
+                lo_, hi_ = int(t.min().item()), int(t.max().item())
+                if lo_ < 0 or hi_ >= self.n_user:
+                    raise IndexError("user ids must lie in [0, %d) (found %d..%d)" % (self.n_user, lo_, hi_))
+            return t, None
         a = np.atleast_1d(np.asarray(idxs)).astype(np.int64)
+        if a.size and (a.min() < 0 or a.max() >= self.n_user):
+            raise IndexError("user ids must lie in [0, %d) (found %d..%d)" % (self.n_user, int(a.min()), int(a.max())))
         if len(a) and np.all(np.diff(a) == 1):
             lo = int(a[0])
             return self._arange[lo:lo + len(a)], lo

@@ -413,6 +413,12 @@ def test_out_of_range_ids_raise_index_error(pa):
     neg = np.array(T["train"][2]).copy(); neg[0, 0] = -1
     with pytest.raises(IndexError):
         m.update_neg_masks(neg, T["test"][2])
+    # user ids: a list with an id >= n_user, a negative id, and a contiguous range running past the table
+    for ids in ([0, 4], [-1], np.arange(2, 6)):
+        with pytest.raises(IndexError):
+            m.train_batch(ids)
+        with pytest.raises(IndexError):
+            m.predict(ids)
 
 
 def test_errors_are_loud(pa):

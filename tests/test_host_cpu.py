@@ -154,6 +154,12 @@ def test_checkpoint_file_is_the_reference_pickle(tmp_path):
     harness.dump_checkpoint([v.astype(np.float32) for v in vals], path)
     raw = open(path, "rb").read()
     assert raw[:2] == b"\x80\x02"                                  # pickle protocol 2
+    # every GLOBAL must name a module Python 2 + an old numpy can import: numpy >= 2 pickles arrays through
+    # numpy._core.multiarray, which numpy < 1.26 does not have (the reference's cPickle.load would fail)
+    import pickletools
+    mods = {arg.split(" ")[0] for op, arg, _ in pickletools.genops(raw) if op.name == "GLOBAL"}
+    assert mods <= {"numpy.core.multiarray", "numpy", "_codecs"}, mods
+    assert not any(op.name == "STACK_GLOBAL" for op, _, _ in pickletools.genops(raw))
     back = harness.read_checkpoint(path)
     assert len(back) == 9 and all(b.dtype == np.float64 for b in back)
     for a, b in zip(vals, back):
