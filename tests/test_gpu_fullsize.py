@@ -1,5 +1,9 @@
-"""-m gpu: size-independent properties at BASELINE.json's full Gowalla shape (100 k POIs, 50 k users,
-L <= 50, D = 128, 200 bins) - where the float64 oracle is too slow to be the checker:
+"""-m gpu: BASELINE.json's full shapes.  (1) The TIMED path against the oracle: a 12500-user launch of the
+Gowalla shape (configs[2]: what bench.py times) and the whole-shard launch + a sequential reference-schedule
+run of the Foursquare shape (configs[1]) are compared with the plain-C float64 restatement of the batch rule /
+the sequential epoch (oracle/poi_oracle_c.c, threaded over the launch), all nine tensors, weights within 1e-5
+AND updates within 1e-4 per row.  (2) Size-independent properties at the Gowalla shape (100 k POIs, 50 k users,
+L <= 50, D = 128, 200 bins):
   * a 12500-user launch leaves every table row that no sequence of the launch touches bit-identical,
     moves every touched row, keeps everything finite and is bitwise reproducible (lt / di);
   * the per-sequence losses of a launch do not depend on which other sequences share the launch
@@ -86,3 +90,92 @@ def test_full_size_topk_matches_explicit_scores(setup):
     wd, prob = pa.models.OboSpatialGru._prob_rows(m, torch.as_tensor(ids).cuda(), 0)
     full2 = full + wd[0] * prob
     check(idx2, full2)
+
+
+SP_NAMES = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
+
+
+def _state(m):
+    out = {}
+    for k in SP_NAMES:
+        v = getattr(m, k).get_value()
+        out[k] = float(v) if k == "wd" else np.asarray(v, np.float64)
+    return out
+
+
+def test_gowalla_timed_launch_matches_the_oracle_batch_rule(setup):
+    """One 12500-user launch of bench.py's configuration (tile engine, per-bin tables, sorted scatter) against the
+    float64 oracle of the batch rule on the same launch: per-sequence losses, the nine tensors to 1e-5 of their
+    max-norm and every row's UPDATE to 1e-4 (tests/gpu_util.assert_delta_close)."""
+    from oracle import c_oracle as C
+    from tests.gpu_util import assert_close, assert_step_close
+    pa, ds, tab, make = setup
+    users = np.random.default_rng(5).permutation(ds.n_user)[:12500].astype(np.int32)
+    lens = np.diff(tab.off.astype(np.int64))
+    users = users[np.argsort(-lens[users], kind="stable")]            # bench.py sorts a launch by length
+    m = make()
+    P = _state(m)
+    P["h0"] = np.zeros(P["lt"].shape[1])
+    out = np.asarray(m.train_batch(users))
+    got = _state(m)
+    exp, eout, touched = C.spatial_batch_mean(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, users, tab.len_max, 0.01, 0.001)
+    assert_close(out[:, :3], eout[:, :3], "losses of the launch", rtol=2e-5)
+    worst = assert_step_close(got, exp, P, SP_NAMES, "gowalla 12500-user launch")
+    assert np.array_equal((got["lt"] != P["lt"]).any(axis=1), touched["lt"])
+    print("gowalla launch vs oracle: worst weight rel err %.2e" % worst)
+
+
+def test_foursquare_shape_full_size_against_the_oracle():
+    """configs[1] (10 k POIs, 5 k users, L <= 20, D = 64 - the two-table path of the tile engine) at FULL size:
+    (a) the whole shard in one launch == the oracle's batch rule; (b) the reference schedule (one user per step,
+    prog_bpr_gru_spatial.py:249-250) over 300 users of the shuffled order == the sequential float64 epoch (errors
+    compound over the steps: 2e-4); (c) predict + all-POI top-20 == float64 scores' ranks on gap-checked rows."""
+    import torch
+    import poi_amd
+    from oracle import c_oracle as C
+    from oracle import poi_oracle as O
+    from poi_amd import data as pdata
+    from tests.gpu_util import assert_close, assert_step_close
+    n_item, n_user, max_len, D = pdata.SHAPES["foursquare"]
+    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=78)
+    tab = ds.shard(0, n_user)
+
+    def make():
+        return poi_amd.models.OboSpatialGru(train=tab, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item,
+                                            n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=D, n_hidden=D, seed=4, coords=ds.coords)
+    m = make()
+    P = _state(m); P["h0"] = np.zeros(D)
+    users = np.random.default_rng(6).permutation(n_user).astype(np.int32)
+    out = np.asarray(m.train_batch(users))
+    got = _state(m)
+    exp, eout, _ = C.spatial_batch_mean(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, users, tab.len_max, 0.01, 0.001)
+    assert_close(out[:, :3], eout[:, :3], "losses", rtol=2e-5)
+    assert_step_close(got, exp, P, SP_NAMES, "foursquare whole-shard launch")
+    # (b) reference schedule
+    m = make()
+    Pc = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in P.items()}
+    order = users[:300]
+    eo = C.spatial_epoch(Pc, tab.off, tab.p, tab.q, tab.dp, tab.dq, order, tab.len_max, 0.01, 0.001)
+    go = np.array([[r[0], r[1], r[2]] for r in (m.train(np.int32(u)) for u in order)])
+    assert_close(go, eo[:, :3], "sequential losses", rtol=2e-4)
+    got = _state(m)
+    for k in SP_NAMES:
+        assert_close(got[k], Pc[k], "after 300 sequential steps: " + k, rtol=2e-4)
+    # (c) predict + score + top-K at full size
+    m.update_trained_items(); m.update_trained_dists()
+    ids = np.arange(n_user, dtype=np.int32)
+    hts, sts = m.predict(ids)
+    sub = np.arange(0, n_user, 16)
+    off = tab.off.astype(np.int64)
+    rows = lambda flat, pad: [np.r_[flat[off[u]:off[u + 1]], np.full(max_len - (off[u + 1] - off[u]), pad)] for u in sub]
+    masks = [np.r_[np.ones(off[u + 1] - off[u], int), np.zeros(max_len - (off[u + 1] - off[u]), int)] for u in sub]
+    eh, es = O.spatial_predict(got | {"h0": np.zeros(D)}, got["lt"], got["di"], rows(tab.p, n_item), rows(tab.dp, ds.dist_num), masks)
+    assert_close(hts[sub], eh, "hts"); assert_close(sts[sub], es, "sts")
+    m.update_trained_users(hts)
+    idx = m.compute_sub_topk(ids, 20).cpu().numpy()
+    sc = np.asarray(hts, np.float64) @ got["lt"][:-1].T
+    top = O.topk_desc(sc[sub], 21)
+    tv = np.take_along_axis(sc[sub], top, axis=1)
+    ok = (tv[:, :-1] - tv[:, 1:]).min(axis=1) > 1e-5 * np.abs(tv).max()
+    assert ok.sum() > 0.8 * len(sub)
+    assert np.array_equal(idx[sub][ok], top[ok][:, :20])

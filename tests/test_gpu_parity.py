@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import poi_oracle as O
-from tests.gpu_util import (RTOL, assert_close, batch_mean_update, gru_params, rel_err, round_f32, spatial_params,
+from tests.gpu_util import (RTOL, assert_close, assert_delta_close, assert_step_close, batch_mean_update, delta_excess, gru_params, rel_err, round_f32, spatial_params,
                             toy_problem)
 
 pytestmark = pytest.mark.gpu
@@ -45,7 +45,7 @@ def test_selftest_primitives(pa):
     ctx.check(ctx.lib.poi_selftest(ctx.handle, None))
 
 
-@pytest.mark.parametrize("seed,dim,n_dist,n_item", [(0, 8, 11, 50), (1, 20, 37, 80), (2, 64, 200, 400), (3, 128, 200, 300)])
+@pytest.mark.parametrize("seed,dim,n_dist,n_item", [(0, 8, 11, 50), (1, 20, 37, 80), (4, 32, 200, 600), (2, 64, 200, 400), (3, 128, 200, 300)])
 def test_spatial_step_parity_sequential(pa, seed, dim, n_dist, n_item):
     """model.train(uidx) one user after another == the reference's hot loop #1
     (prog_bpr_gru_spatial.py:249-250): every step must match, and the state carried between steps
@@ -56,13 +56,13 @@ def test_spatial_step_parity_sequential(pa, seed, dim, n_dist, n_item):
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     worst = 0.0
     for u in [3, 0, 4, 1, 0]:
+        old = P
         P, out = O.spatial_step(P, Pm[u], Qm[u], DPm[u], DQm[u], Mm[u], 0.01, 0.001)
         los, sur, upq, ls = model.train(np.int32(u))
         assert_close([los, sur, upq], [out[0], out[1], out[2]], "losses")
         assert_close(ls, out[3], "ls")
         got = _get(model, SP_NAMES)
-        for k in SP_NAMES:
-            worst = max(worst, assert_close(got[k], P[k], "%s after user %d" % (k, u)))
+        worst = max(worst, assert_step_close(got, P, old, SP_NAMES, "after user %d" % u))
         # continue BOTH sides from the device's float32 state so errors do not compound across steps
         P = round_f32({**P, **{k: got[k] for k in SP_NAMES}})
     print("spatial sequential worst rel err %.2e" % worst)
@@ -97,8 +97,34 @@ def test_spatial_batch_matches_mean_rule(pa):
     for k, out in enumerate(outs):
         assert_close(got_out[k][:3], out[:3], "losses[%d]" % k)
     got = _get(model, SP_NAMES)
-    for k in SP_NAMES:
-        assert_close(got[k], exp[k], k)
+    assert_step_close(got, exp, P, SP_NAMES)
+
+
+def test_delta_tolerance_catches_a_padding_multiplicity_off_by_one(pa):
+    """The 1e-5 max-norm bar on the weights cannot see an L2-decay multiplicity that is off by one on a padding
+    row (alpha*lambda*|row| = 5e-6 absolute); the per-row delta bar must.  The oracle is run on the same sequence
+    padded to len_max + 1 (one more padding id in p, q and dp: multiplicity +2 on lt[n_item], +1 on di[n_dist]):
+    the device result has to FAIL the delta check against that perturbed expectation while it still passes the
+    weight check - and pass both against the true one."""
+    T = toy_problem(13, n_user=4, n_item=300, n_dist=200, dim=64, len_max=12)
+    P = spatial_params(13, T)
+    model = _spatial_model(pa, T, P)
+    u = 2
+    assert T["lens"][u] < T["len_max"]
+    Pm, Qm, DPm, DQm, Mm = (np.asarray(T["train"][0]), np.asarray(T["train"][2]), np.asarray(T["dist"][0]), np.asarray(T["dist"][2]),
+                            np.asarray(T["train"][1]))
+    exp, _ = O.spatial_step(P, Pm[u], Qm[u], DPm[u], DQm[u], Mm[u], 0.01, 0.001)
+    pad = lambda row, v: np.append(row, v)
+    bad, _ = O.spatial_step(P, pad(Pm[u], T["n_item"]), pad(Qm[u], T["n_item"]), pad(DPm[u], T["n_dist"]), pad(DQm[u], T["n_dist"]),
+                            pad(Mm[u], 0), 0.01, 0.001)
+    model.train(np.int32(u))
+    got = _get(model, SP_NAMES)
+    assert_step_close(got, exp, P, SP_NAMES)
+    for k in ("lt", "di"):
+        if k == "di":         # one extra padding bin: alpha*lambda*|row| <= 5e-6 absolute, invisible at 1e-5 of max|theta| ~ 0.5
+            assert rel_err(got[k], bad[k]) <= 1.5 * RTOL, "the max-norm bar was expected to miss the off-by-one on " + k
+        ex, row = delta_excess(got[k], bad[k], P[k])
+        assert ex > 3.0 and row == (T["n_item"] if k == "lt" else T["n_dist"]), (k, ex, row)
 
 
 @pytest.mark.parametrize("seed,dim", [(0, 8), (1, 64)])
@@ -109,12 +135,12 @@ def test_gru_step_parity_sequential(pa, seed, dim):
                              n_item=T["n_item"], n_in=dim, n_hidden=dim, init=P)
     Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
     for u in [2, 0, 4, 2]:
+        old = P
         P, loss = O.gru_step(P, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
         got_loss = model.train(np.int32(u))
         assert_close(got_loss, loss, "loss")
         got = _get(model, GRU_NAMES)
-        for k in GRU_NAMES:
-            assert_close(got[k], P[k], "%s after user %d" % (k, u))
+        assert_step_close(got, P, old, GRU_NAMES, "after user %d" % u)
         P = round_f32({**P, **got})
 
 
@@ -127,11 +153,11 @@ def test_bpr_step_parity(pa, mode, dim):
     model = pa.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=T["n_user"],
                              n_item=T["n_item"], n_in=dim, n_hidden=dim, init=P)
     for (u, p, q) in [(0, 3, 17), (4, 3, 9), (0, 17, 2)]:
+        old = P
         P, loss = O.bpr_step(P, u, p, q, 0.01, 0.001)
         got = float(model.train_batch([u], [p], [q], mode=mode)[0])
         assert_close(got, loss, "loss")
-        for k in ("ux", "lt"):
-            assert_close(getattr(model, k).get_value(), P[k], k)
+        assert_step_close({k: getattr(model, k).get_value() for k in ("ux", "lt")}, P, old, ("ux", "lt"))
         P = round_f32({k: getattr(model, k).get_value() for k in ("ux", "lt")})
 
 

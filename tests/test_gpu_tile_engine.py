@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import poi_oracle as O
-from tests.gpu_util import assert_close, batch_mean_update, round_f32, spatial_params, toy_problem
+from tests.gpu_util import assert_close, assert_step_close, batch_mean_update, round_f32, spatial_params, toy_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -55,12 +55,12 @@ def test_tile_single_sequence_is_the_reference_step(pa, dim, n_dist):
     model.ctx.set_engine("tile")
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     for u in [2, 0, 2]:
+        old = P
         P, out = O.spatial_step(P, Pm[u], Qm[u], DPm[u], DQm[u], Mm[u], 0.01, 0.001)
         los, sur, upq, ls = model.train(np.int32(u))
         assert_close([los, sur, upq], out[:3], "losses")
         got = _get(model)
-        for k in SP_NAMES:
-            assert_close(got[k], P[k], "%s after user %d" % (k, u))
+        assert_step_close(got, P, old, SP_NAMES, "after user %d" % u)
         P = round_f32({**P, **got})
     model.ctx.set_engine("auto")
 
@@ -79,8 +79,7 @@ def test_tile_batch_matches_mean_rule_and_seq_engine(pa, dim, n_dist, n_user):
         for k, out in enumerate(outs):
             assert_close(got_out[k][:3], out[:3], "%s losses[%d]" % (eng, k), rtol=2e-5)
         got = _get(model)
-        for k in SP_NAMES:
-            assert_close(got[k], exp[k], "%s %s" % (eng, k))
+        assert_step_close(got, exp, P, SP_NAMES, eng)
         res[eng] = got
         # a second launch on the updated state exercises the re-zeroed gradient tables / slabs
         model.train_batch(users[:40])
@@ -118,8 +117,7 @@ def test_tile_sorted_scatter_hot_rows_are_exact_and_reproducible(pa):
         model.ctx.set_engine("tile")
         model.train_batch(users)
         runs.append(_get(model))
-    for k in SP_NAMES:
-        assert_close(runs[0][k], exp[k], "hot rows " + k)
+    assert_step_close(runs[0], exp, P, SP_NAMES, "hot rows")
     for k in SP_NAMES:                      # no float atomics anywhere in the tile engine: every tensor is reproducible
         assert np.array_equal(runs[0][k], runs[1][k]), k + " differs between two identical launches"
     pa._lib.context(0).set_engine("auto")
@@ -148,12 +146,12 @@ def test_tile_plain_gru_single_sequence_is_the_reference_step(pa, dim):
     model.ctx.set_engine("tile")
     Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
     for u in [3, 0, 3, 1]:
+        old = P
         P, loss = O.gru_step(P, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
         got_loss = model.train(np.int32(u))
         assert_close(got_loss, loss, "loss")
         got = _get_gru(model)
-        for k in GRU_NAMES:
-            assert_close(got[k], P[k], "%s after user %d" % (k, u))
+        assert_step_close(got, P, old, GRU_NAMES, "after user %d" % u)
         P = round_f32({**P, **got})
     model.ctx.set_engine("auto")
 
@@ -178,8 +176,7 @@ def test_tile_plain_gru_batch_matches_mean_rule_and_seq_engine(pa, dim, n_user):
         got_loss = model.train_batch(users)
         assert_close(np.asarray(got_loss).reshape(-1), np.asarray(losses), eng + " losses", rtol=2e-5)
         got = _get_gru(model)
-        for k in GRU_NAMES:
-            assert_close(got[k], exp[k], "%s %s" % (eng, k))
+        assert_step_close(got, exp, P, GRU_NAMES, eng)
         model.train_batch(users[:70])
         res[eng] = _get_gru(model)
     for k in GRU_NAMES:
@@ -203,8 +200,7 @@ def test_tile_degenerate_lengths(pa):
         for k, out in enumerate(outs):
             assert_close(got_out[k][:3], out[:3], "%s losses[%d]" % (eng, k), rtol=2e-5)
         got = _get(model)
-        for k in SP_NAMES:
-            assert_close(got[k], exp[k], "%s %s" % (eng, k))
+        assert_step_close(got, exp, P, SP_NAMES, eng)
     Pg = gru_params(131, T)
     Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
     news, touched, losses = [], [], []
@@ -219,8 +215,7 @@ def test_tile_degenerate_lengths(pa):
         got_loss = model.train_batch(users)
         assert_close(np.asarray(got_loss).reshape(-1), np.asarray(losses), eng + " gru losses", rtol=2e-5)
         got = _get_gru(model)
-        for k in GRU_NAMES:
-            assert_close(got[k], expg[k], "%s gru %s" % (eng, k))
+        assert_step_close(got, expg, Pg, GRU_NAMES, eng + " gru")
     pa._lib.context(0).set_engine("auto")
 
 
@@ -242,6 +237,16 @@ def test_tile_multi_tile_workgroups_match_seq_engine(pa):
     assert_close(outs["tile"][:, :3], outs["seq"][:, :3], "losses", rtol=2e-5)
     for k in SP_NAMES:
         assert_close(res["tile"][k], res["seq"][k], "tile vs seq " + k, rtol=2e-5)
+    # ... and both against the float64 oracle of the batch rule (plain-C restatement, threaded over the launch)
+    from oracle import c_oracle as C
+    from poi_amd.data import padded_to_csr
+    lens = T["lens"]
+    off, p = padded_to_csr(T["train"][0], lens); _, q = padded_to_csr(T["train"][2], lens)
+    _, dp = padded_to_csr(T["dist"][0], lens); _, dq = padded_to_csr(T["dist"][2], lens)
+    exp, eout, _ = C.spatial_batch_mean(P, off, p, q, dp, dq, users, T["len_max"], 0.01, 0.001)
+    for eng in ("tile", "seq"):
+        assert_close(outs[eng][:, :3], eout[:, :3], eng + " losses vs oracle", rtol=2e-5)
+        assert_step_close(res[eng], exp, P, SP_NAMES, eng + " vs oracle")
 
 
 @pytest.mark.parametrize("dim", [64, 128])
