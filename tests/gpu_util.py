@@ -51,13 +51,32 @@ def assert_delta_close(new_hip, new_oracle, old, name, rtol=DELTA_RTOL):
     return ex
 
 
-def assert_step_close(got, exp, old, names, what=""):
-    """Both bars for every tensor of a step: weights within RTOL (north star) AND the update within DELTA_RTOL."""
+def assert_step_close(got, exp, old, names, what="", rtol=RTOL, delta_rtol=DELTA_RTOL, loose=None):
+    """Both bars for every tensor of a step: weights within RTOL (north star) AND the update within DELTA_RTOL.
+    `loose` = {name: (rtol, delta_rtol)} overrides for named tensors (full-size launches, see FULL_SIZE_LT)."""
     worst = 0.0
     for k in names:
-        worst = max(worst, assert_close(got[k], exp[k], "%s %s" % (k, what)))
-        assert_delta_close(got[k], exp[k], old[k], "%s %s" % (k, what))
+        rt, dr = (loose or {}).get(k, (rtol, delta_rtol))
+        worst = max(worst, assert_close(got[k], exp[k], "%s %s" % (k, what), rtol=rt))
+        assert_delta_close(got[k], exp[k], old[k], "%s %s" % (k, what), rtol=dr)
     return worst
+
+
+# Full BASELINE shapes (D = 128, L up to 50, the reference's uniform(-0.5, 0.5) init at every dim): the GRU is
+# saturated and BPTT amplifies - single-occurrence POI rows receive gradients of |g| ~ 20-60 (updates of 0.2-0.6 per
+# step), and float32 BPTT carries a relative error of ~1e-4 on exactly those rows.  Measured on MI355X (tools/
+# diag_fullsize.py, 12500-user Gowalla launch): tile engine 3.0e-5 of max|theta| on the worst of 100 001 rows (mean row
+# error 7e-8, 99.9 % of the rows below 5e-6), per-sequence engine 2.4e-5 on the same kind of rows, both unchanged with
+# libm-exact expf / tanhf / IEEE division in the gates - i.e. conditioning of the problem in float32, not an
+# implementation error.  The full-size tests therefore hold lt to (6e-5, 3e-4 per-row update) plus a quantile bar
+# (rows_within), and every other tensor to the toy-size bars.
+FULL_SIZE_LT = {"lt": (6e-5, 3e-4)}
+
+
+def rows_within(a, b, rtol=RTOL):
+    """Fraction of rows of `a` within rtol * max|b| of `b` (max-norm per row)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float((np.abs(a - b).max(axis=1) <= rtol * np.abs(b).max()).mean())
 
 
 def toy_problem(seed, n_user=6, n_item=50, n_dist=11, dim=8, len_max=10, min_len=4, hot=8):
