@@ -77,8 +77,7 @@ def main():
                                          n_item=n_item, n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=D, n_hidden=D,
                                          device=dev, seed=7, coords=ds.coords)
     ctx = model.ctx
-    sync = poi_amd.dist.ReplicaSync([getattr(model, k).t for k in ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")], ctx=ctx,
-                                    force=os.environ.get("POI_BENCH_FORCE_SYNC") == "1")
+    sync = poi_amd.dist.model_sync(model, group=None, force=os.environ.get("POI_BENCH_FORCE_SYNC") == "1")
 
     # shuffled user order (prog_bpr_gru_spatial.py:236-238), cut into launches of B users; inside a launch
     # the ids are sorted by descending length so that 32-sequence tiles are homogeneous.  Resident on device.

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define POI_ABI_VERSION 1
+#define POI_ABI_VERSION 2
 
 enum {
   POI_OK = 0,
@@ -194,9 +194,54 @@ int poi_sample_negatives(poi_ctx* ctx, const int32_t* off, const int32_t* p, int
 int poi_neg_dist_bins(poi_ctx* ctx, const int32_t* off, const int32_t* p, const int32_t* q, int32_t n_user, const double* coords,
                       const double* cphi, const double* thr, int32_t n_dist, double dd, int32_t* dq_out, void* stream);
 
-/* ---- multi-GPU reconciliation helpers (8e): delta = cur - base ; cur = base + sum_delta ------ */
+/* ---- multi-GPU reconciliation (8e; new - the reference is single-process) ----------------------
+ * Users are sharded across ranks, every rank trains on a full parameter replica with no data-path collective,
+ * and replicas are reconciled ONCE PER EPOCH:  theta <- theta_start + combine(sum_r (theta_r - theta_start)),
+ * one RCCL all-reduce over xGMI of ONE flat buffer (BASELINE.json north_star: "POI embedding table replicated and
+ * kept consistent by an RCCL all-reduce once per epoch").
+ *
+ * elementwise helpers (kept from ABI 1): delta = cur - base ; cur = base + delta_sum */
 int poi_delta_make(poi_ctx* ctx, const float* cur, const float* base, float* delta, int64_t n, void* stream);
 int poi_delta_apply(poi_ctx* ctx, float* cur, const float* base, const float* delta_sum, int64_t n, void* stream);
+
+/* The library's own RCCL communicator (librccl is bound with dlopen at first use: the .so loads without it).
+ * Rank 0 calls poi_comm_unique_id and hands the 128 bytes to the other ranks over any host channel (bench.py:
+ * one torch.distributed broadcast); every rank then calls poi_comm_init_rank (collective). */
+#define POI_UNIQUE_ID_BYTES 128
+typedef struct poi_comm poi_comm;
+int poi_comm_unique_id(char* id_host);
+int poi_comm_init_rank(const char* id_host, int world, int rank, int device, poi_comm** out);
+int poi_comm_destroy(poi_comm* comm);
+int poi_comm_world(const poi_comm* comm);
+int poi_comm_rank(const poi_comm* comm);
+
+/* In-place SUM all-reduce of a device float buffer over the communicator (SURVEY.md 8b export list). */
+int poi_allreduce_tables(poi_ctx* ctx, poi_comm* comm, float* buf, int64_t n, void* stream);
+
+/* Per-epoch reconciliation object over a list of parameter tensors ("segments": rows x width floats, in place).
+ * Combine rule per segment:
+ *   POI_SYNC_SUM           theta_start + sum_r delta_r            every replica's epoch counts in full
+ *   POI_SYNC_MEAN          theta_start + sum_r delta_r / world    model averaging
+ *   POI_SYNC_MEAN_TOUCHED  per ROW: sum_r delta_r / #{r : replica r changed the row}  (the launch-level batch rule
+ *                          one level up; a per-row flag travels in the same flat buffer)
+ * All rules are the identity at world == 1.  poi_sync_end_epoch = make_delta + all-reduce + apply (the result
+ * is also the next epoch's theta_start); the three steps are exported separately so that a host can run the
+ * collective elsewhere (tests: gloo on CPU copies; single-GPU emulation of N replicas). */
+enum { POI_SYNC_SUM = 0, POI_SYNC_MEAN = 1, POI_SYNC_MEAN_TOUCHED = 2 };
+typedef struct poi_sync_seg { float* cur; int64_t rows; int64_t width; int32_t rule; } poi_sync_seg;
+typedef struct poi_sync poi_sync;
+int poi_sync_create(poi_ctx* ctx, int device, const poi_sync_seg* segs_host, int32_t n_seg, poi_sync** out);
+int poi_sync_destroy(poi_sync* s);
+int poi_sync_begin_epoch(poi_sync* s, void* stream);                  /* theta_start <- theta */
+int poi_sync_make_delta(poi_sync* s, void* stream);                   /* flat buffer <- theta - theta_start | row flags */
+int poi_sync_buffer(poi_sync* s, float** delta_dev, int64_t* n);      /* the flat buffer to SUM-all-reduce */
+int poi_sync_apply(poi_sync* s, int32_t world, void* stream);         /* theta <- theta_start + combine(buffer); theta_start <- theta */
+int poi_sync_end_epoch(poi_sync* s, poi_comm* comm, void* stream);
+int poi_sync_stats(poi_sync* s, double* allreduce_ms, int64_t* allreduce_bytes);   /* last end_epoch; synchronises */
+const char* poi_sync_last_error(void);
+/* out_dev[0] += 64-bit sum of the 32-bit patterns of x[0..n): replicas are bit-identical after a reconciliation
+ * iff their checksums agree (caller zeroes out_dev). */
+int poi_checksum(poi_ctx* ctx, const float* x, int64_t n, uint64_t* out_dev, void* stream);
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's live roofline figures).
  * Kernel names: "seq_train", "rows_apply", "dense_apply", "seq_predict", "bpr_hogwild", "bpr_grad",

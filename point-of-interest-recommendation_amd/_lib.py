@@ -6,7 +6,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpoi_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 BPR_SNAPSHOT, BPR_HOGWILD = 0, 1
 
@@ -18,6 +18,13 @@ class PoiError(RuntimeError):
 class GruParams(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "lw")] + \
                [("n_item", c_int32), ("n_dist", c_int32), ("dim", c_int32)]
+
+
+class SyncSeg(ctypes.Structure):
+    _fields_ = [("cur", c_void_p), ("rows", c_int64), ("width", c_int64), ("rule", c_int32)]
+
+
+SYNC_SUM, SYNC_MEAN, SYNC_MEAN_TOUCHED = 0, 1, 2
 
 
 class SeqTables(ctypes.Structure):
@@ -62,6 +69,22 @@ SIGNATURES = {
                                   c_void_p, c_void_p]),
     "poi_delta_make": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "poi_delta_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "poi_comm_unique_id": (c_int, [c_void_p]),
+    "poi_comm_init_rank": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "poi_comm_destroy": (c_int, [c_void_p]),
+    "poi_comm_world": (c_int, [c_void_p]),
+    "poi_comm_rank": (c_int, [c_void_p]),
+    "poi_allreduce_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "poi_sync_create": (c_int, [c_void_p, c_int, POINTER(SyncSeg), c_int32, POINTER(c_void_p)]),
+    "poi_sync_destroy": (c_int, [c_void_p]),
+    "poi_sync_begin_epoch": (c_int, [c_void_p, c_void_p]),
+    "poi_sync_make_delta": (c_int, [c_void_p, c_void_p]),
+    "poi_sync_buffer": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "poi_sync_apply": (c_int, [c_void_p, c_int32, c_void_p]),
+    "poi_sync_end_epoch": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "poi_sync_stats": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    "poi_sync_last_error": (c_char_p, []),
+    "poi_checksum": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "poi_timing_enable": (c_int, [c_void_p, c_int]),
     "poi_timing_reset": (c_int, [c_void_p]),
     "poi_timing_get": (c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64)]),

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpoi_hip.so")
-SOURCES = ["abi.hip", "seq_engine.hip", "tile_engine.hip", "te_scatter.hip", "bpr.hip", "score_topk.hip", "misc.hip"]
+SOURCES = ["abi.hip", "seq_engine.hip", "tile_engine.hip", "te_scatter.hip", "bpr.hip", "score_topk.hip", "misc.hip", "sync.hip"]
 HEADERS = ["poi_common.h", "poi_kernels.h", os.path.join("..", "..", "include", "poi_hip.h")]
 
 
@@ -30,7 +30,7 @@ def build_lib(force=False, verbose=True):
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB + ".tmp"] + os.environ.get("POI_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
+           "-ldl", "-o", LIB + ".tmp"] + os.environ.get("POI_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

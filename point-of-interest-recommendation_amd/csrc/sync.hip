@@ -1,0 +1,288 @@
+// Replica reconciliation of the user-sharded multi-GPU path (new - the reference is single-process):
+// every rank trains its user shard on a full parameter replica with no data-path collective, and ONCE PER EPOCH
+//      delta_r = theta_r - theta_start            (poi_sync_make_delta; per table row also "did this replica move it")
+//      D       = sum_r delta_r                    (poi_allreduce_tables: one RCCL all-reduce over xGMI of ONE flat buffer)
+//      theta   = theta_start + combine(D)         (poi_sync_apply; the result is the next epoch's theta_start)
+// with a combine rule per tensor: SUM (every replica's epoch counts in full: to first order in alpha the epoch
+// of a single process over all users), MEAN (model averaging) or MEAN_TOUCHED (per table row: mean over the replicas
+// that moved the row - the launch-level batch rule of include/poi_hip.h one level up).
+//
+// RCCL is bound at run time (dlopen of the librccl.so.1 the process already holds - torch's - or the system one), so
+// the library itself links against nothing but the HIP runtime and loads on a box without RCCL.
+#include "../../include/poi_hip.h"
+#include "poi_common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace poi {
+
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+
+static Rccl* rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy this process already mapped (torch's)
+    for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { R.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+    R.h = h;
+    *(void**)&R.GetUniqueId = dlsym(h, "ncclGetUniqueId");
+    *(void**)&R.CommInitRank = dlsym(h, "ncclCommInitRank");
+    *(void**)&R.CommDestroy = dlsym(h, "ncclCommDestroy");
+    *(void**)&R.AllReduce = dlsym(h, "ncclAllReduce");
+    *(void**)&R.GetErrorString = dlsym(h, "ncclGetErrorString");
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce || !R.GetErrorString) { R.err = "librccl lacks the nccl* entry points"; R.h = nullptr; }
+  });
+  return &R;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels: one wavefront per row of a segment (rows x width floats, width % 4 == 0 or handled by the scalar tail)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sync_delta_kernel(const float* __restrict__ cur, const float* __restrict__ base,
+                                                         float* __restrict__ delta, float* __restrict__ touched,
+                                                         long long rows, long long width) {
+  const int lane = lane_id();
+  for (long long r = (long long)blockIdx.x * 4 + wave_id(); r < rows; r += (long long)gridDim.x * 4) {
+    const float* c = cur + r * width; const float* b = base + r * width; float* d = delta + r * width;
+    bool any = false;
+    for (long long j = lane; j < width; j += 64) { const float v = c[j] - b[j]; d[j] = v; any |= (v != 0.f); }
+    if (touched) { const bool t = __ballot(any) != 0ull; if (lane == 0) touched[r] = t ? 1.f : 0.f; }
+  }
+}
+
+// cur <- base + scale * dsum ; base <- cur.   rule 0: scale 1, 1: 1 / world, 2: 1 / max(count[row], 1)
+__global__ __launch_bounds__(256) void sync_apply_kernel(float* __restrict__ cur, float* __restrict__ base,
+                                                         const float* __restrict__ dsum, const float* __restrict__ count,
+                                                         long long rows, long long width, int rule, float inv_world) {
+  const int lane = lane_id();
+  for (long long r = (long long)blockIdx.x * 4 + wave_id(); r < rows; r += (long long)gridDim.x * 4) {
+    float sc = rule == 1 ? inv_world : 1.f;
+    if (rule == 2) { const float n = count[r]; sc = 1.f / fmaxf(n, 1.f); }
+    float* c = cur + r * width; float* b = base + r * width; const float* d = dsum + r * width;
+    for (long long j = lane; j < width; j += 64) { const float v = fmaf(sc, d[j], b[j]); c[j] = v; b[j] = v; }
+  }
+}
+
+__global__ __launch_bounds__(256) void sync_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+// order-independent checksum of a float buffer: 64-bit sum of the 32-bit patterns (equal buffers <=> equal sums,
+// up to collisions; used to show that replicas are bit-identical after a reconciliation)
+__global__ __launch_bounds__(256) void checksum_kernel(const unsigned* __restrict__ x, long long n, unsigned long long* __restrict__ out) {
+  unsigned long long s = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane_id() == 0) atomicAdd(out, s);
+}
+
+}  // namespace poi
+
+struct poi_comm {
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0, device = 0;
+};
+
+struct poi_sync {
+  poi_ctx* ctx = nullptr;
+  int device = 0;
+  std::vector<poi_sync_seg> segs;
+  std::vector<long long> off, cnt_off;          // element offsets into the flat buffers (cnt_off < 0: no touch counts)
+  long long n_data = 0, n_total = 0;
+  float *base = nullptr, *delta = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double last_ms = 0;
+  std::string err;
+};
+
+namespace {
+thread_local std::string g_sync_err;
+int sfail(poi_sync* s, int code, const std::string& m) { g_sync_err = m; if (s) s->err = m; return code; }
+int grid_rows(long long rows) { long long g = (rows + 3) / 4; return (int)(g < 1 ? 1 : g > 8192 ? 8192 : g); }
+}
+
+extern "C" {
+
+const char* poi_sync_last_error(void) { return g_sync_err.c_str(); }
+
+int poi_comm_unique_id(char* id_host) {
+  if (!id_host) return sfail(nullptr, POI_EINVAL, "poi_comm_unique_id: NULL");
+  poi::Rccl* R = poi::rccl();
+  if (!R->h) return sfail(nullptr, POI_ENOTSUP, R->err);
+  ncclUniqueId id;
+  const ncclResult_t rc = R->GetUniqueId(&id);
+  if (rc != ncclSuccess) return sfail(nullptr, POI_EHIP, std::string("ncclGetUniqueId: ") + R->GetErrorString(rc));
+  static_assert(sizeof(id) == POI_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  memcpy(id_host, &id, sizeof id);
+  return POI_OK;
+}
+
+int poi_comm_init_rank(const char* id_host, int world, int rank, int device, poi_comm** out) {
+  if (!id_host || !out || world < 1 || rank < 0 || rank >= world) return sfail(nullptr, POI_EINVAL, "poi_comm_init_rank: bad argument");
+  poi::Rccl* R = poi::rccl();
+  if (!R->h) return sfail(nullptr, POI_ENOTSUP, R->err);
+  if (hipSetDevice(device) != hipSuccess) return sfail(nullptr, POI_EHIP, "hipSetDevice failed");
+  ncclUniqueId id;
+  memcpy(&id, id_host, sizeof id);
+  poi_comm* c = new poi_comm();
+  c->world = world; c->rank = rank; c->device = device;
+  const ncclResult_t rc = R->CommInitRank(&c->comm, world, id, rank);
+  if (rc != ncclSuccess) { delete c; return sfail(nullptr, POI_EHIP, std::string("ncclCommInitRank: ") + R->GetErrorString(rc)); }
+  *out = c;
+  return POI_OK;
+}
+
+int poi_comm_destroy(poi_comm* c) {
+  if (!c) return POI_OK;
+  poi::Rccl* R = poi::rccl();
+  if (R->h && c->comm) R->CommDestroy(c->comm);
+  delete c;
+  return POI_OK;
+}
+
+int poi_comm_world(const poi_comm* c) { return c ? c->world : POI_EINVAL; }
+int poi_comm_rank(const poi_comm* c) { return c ? c->rank : POI_EINVAL; }
+
+int poi_allreduce_tables(poi_ctx* ctx, poi_comm* comm, float* buf, int64_t n, void* stream) {
+  (void)ctx;
+  if (!comm || !buf || n < 0) return sfail(nullptr, POI_EINVAL, "poi_allreduce_tables: bad argument");
+  if (n == 0) return POI_OK;
+  poi::Rccl* R = poi::rccl();
+  if (!R->h) return sfail(nullptr, POI_ENOTSUP, R->err);
+  if (hipSetDevice(comm->device) != hipSuccess) return sfail(nullptr, POI_EHIP, "hipSetDevice failed");
+  const ncclResult_t rc = R->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, comm->comm, (hipStream_t)stream);
+  if (rc != ncclSuccess) return sfail(nullptr, POI_EHIP, std::string("ncclAllReduce: ") + R->GetErrorString(rc));
+  return POI_OK;
+}
+
+int poi_sync_create(poi_ctx* ctx, int device, const poi_sync_seg* segs_host, int32_t n_seg, poi_sync** out) {
+  if (!segs_host || n_seg <= 0 || !out) return sfail(nullptr, POI_EINVAL, "poi_sync_create: bad argument");
+  if (hipSetDevice(device) != hipSuccess) return sfail(nullptr, POI_EHIP, "hipSetDevice failed");
+  poi_sync* s = new poi_sync();
+  s->ctx = ctx; s->device = device;
+  long long o = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    const poi_sync_seg& g = segs_host[i];
+    if (!g.cur || g.rows <= 0 || g.width <= 0 || g.rule < POI_SYNC_SUM || g.rule > POI_SYNC_MEAN_TOUCHED) { delete s; return sfail(nullptr, POI_EINVAL, "poi_sync_create: bad segment"); }
+    s->segs.push_back(g); s->off.push_back(o);
+    o += g.rows * g.width;
+    o = (o + 3) & ~3ll;
+  }
+  s->n_data = o;
+  for (int i = 0; i < n_seg; ++i) {
+    if (segs_host[i].rule == POI_SYNC_MEAN_TOUCHED) { s->cnt_off.push_back(o); o += segs_host[i].rows; o = (o + 3) & ~3ll; }
+    else s->cnt_off.push_back(-1);
+  }
+  s->n_total = o;
+  if (hipMalloc(&s->base, sizeof(float) * (size_t)s->n_data) != hipSuccess || hipMalloc(&s->delta, sizeof(float) * (size_t)s->n_total) != hipSuccess ||
+      hipEventCreate(&s->e0) != hipSuccess || hipEventCreate(&s->e1) != hipSuccess) {
+    (void)hipGetLastError();
+    if (s->base) (void)hipFree(s->base);
+    if (s->delta) (void)hipFree(s->delta);
+    delete s;
+    return sfail(nullptr, POI_ENOMEM, "poi_sync_create: allocation failed");
+  }
+  *out = s;
+  return POI_OK;
+}
+
+int poi_sync_destroy(poi_sync* s) {
+  if (!s) return POI_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipDeviceSynchronize();
+  if (s->base) (void)hipFree(s->base);
+  if (s->delta) (void)hipFree(s->delta);
+  if (s->e0) (void)hipEventDestroy(s->e0);
+  if (s->e1) (void)hipEventDestroy(s->e1);
+  delete s;
+  return POI_OK;
+}
+
+int poi_sync_begin_epoch(poi_sync* s, void* stream) {
+  if (!s) return sfail(s, POI_EINVAL, "poi_sync_begin_epoch: NULL");
+  if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
+  for (size_t i = 0; i < s->segs.size(); ++i) {
+    const long long n = s->segs[i].rows * s->segs[i].width;
+    hipLaunchKernelGGL(poi::sync_copy_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       s->segs[i].cur, s->base + s->off[i], n);
+  }
+  return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_begin_epoch: launch failed");
+}
+
+int poi_sync_make_delta(poi_sync* s, void* stream) {
+  if (!s) return sfail(s, POI_EINVAL, "poi_sync_make_delta: NULL");
+  if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
+  for (size_t i = 0; i < s->segs.size(); ++i) {
+    const poi_sync_seg& g = s->segs[i];
+    hipLaunchKernelGGL(poi::sync_delta_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base + s->off[i],
+                       s->delta + s->off[i], s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr, (long long)g.rows, (long long)g.width);
+  }
+  return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_make_delta: launch failed");
+}
+
+int poi_sync_buffer(poi_sync* s, float** delta, int64_t* n) {
+  if (!s || !delta || !n) return sfail(s, POI_EINVAL, "poi_sync_buffer: NULL");
+  *delta = s->delta; *n = s->n_total;
+  return POI_OK;
+}
+
+int poi_sync_apply(poi_sync* s, int32_t world, void* stream) {
+  if (!s || world < 1) return sfail(s, POI_EINVAL, "poi_sync_apply: bad argument");
+  if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
+  for (size_t i = 0; i < s->segs.size(); ++i) {
+    const poi_sync_seg& g = s->segs[i];
+    hipLaunchKernelGGL(poi::sync_apply_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base + s->off[i],
+                       s->delta + s->off[i], s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr, (long long)g.rows, (long long)g.width,
+                       (int)g.rule, 1.0f / (float)world);
+  }
+  return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_apply: launch failed");
+}
+
+int poi_sync_end_epoch(poi_sync* s, poi_comm* comm, void* stream) {
+  if (!s || !comm) return sfail(s, POI_EINVAL, "poi_sync_end_epoch: NULL");
+  int rc = poi_sync_make_delta(s, stream);
+  if (rc) return rc;
+  (void)hipEventRecord(s->e0, (hipStream_t)stream);
+  if ((rc = poi_allreduce_tables(s->ctx, comm, s->delta, s->n_total, stream))) return rc;
+  (void)hipEventRecord(s->e1, (hipStream_t)stream);
+  return poi_sync_apply(s, comm->world, stream);
+}
+
+int poi_sync_stats(poi_sync* s, double* allreduce_ms, int64_t* allreduce_bytes) {
+  if (!s) return sfail(s, POI_EINVAL, "poi_sync_stats: NULL");
+  if (allreduce_bytes) *allreduce_bytes = (int64_t)s->n_total * 4;
+  if (allreduce_ms) {
+    float ms = 0.f;
+    *allreduce_ms = (hipEventSynchronize(s->e1) == hipSuccess && hipEventElapsedTime(&ms, s->e0, s->e1) == hipSuccess) ? ms : -1.0;
+  }
+  return POI_OK;
+}
+
+int poi_checksum(poi_ctx* ctx, const float* x, int64_t n, uint64_t* out_dev, void* stream) {
+  (void)ctx;
+  if (!x || !out_dev || n < 0) return sfail(nullptr, POI_EINVAL, "poi_checksum: bad argument");
+  if (n == 0) return POI_OK;
+  const long long g = (n + 255) / 256;
+  hipLaunchKernelGGL(poi::checksum_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, (hipStream_t)stream, (const unsigned*)x, (long long)n,
+                     (unsigned long long*)out_dev);
+  return hipGetLastError() == hipSuccess ? POI_OK : sfail(nullptr, POI_EHIP, "poi_checksum: launch failed");
+}
+
+}  // extern "C"

@@ -248,9 +248,33 @@ SHAPES = {
 }
 
 
-def make_synthetic(n_user, n_item, max_len, seed, dd=200, ud_km=40, min_len=4, box_km=40.0, zipf=1.0):
+def _local_transitions(rng, coords, w, raw, local, n_nbr):
+    """Check-in sequences with a learnable next-POI signal: with probability `local` the next POI is drawn among the
+    n_nbr nearest neighbours of the current one (weights = global popularity), otherwise from the global Zipf law.
+    Real check-in data is dominated by short hops (the premise of Distance2Pre's distance-interval head); i.i.d. Zipf
+    draws carry nothing a sequence model could learn beyond popularity."""
+    from scipy.spatial import cKDTree
+    n_item, n_user = len(coords), len(raw)
+    xy = np.stack([coords[:, 0] * 111.19, coords[:, 1] * 111.19 * np.cos(coords[:, 0].mean() * DEG)], 1)      # km, locally flat
+    nbr = cKDTree(xy).query(xy, k=n_nbr + 1)[1][:, 1:]                                   # (n_item, n_nbr), self dropped
+    cw = np.cumsum(w[nbr], axis=1); cw /= cw[:, -1:]
+    cdf = np.cumsum(w / w.sum())
+    lmax = int(raw.max())
+    seq = np.empty((n_user, lmax), np.int64)
+    seq[:, 0] = np.minimum(np.searchsorted(cdf, rng.random(n_user)), n_item - 1)
+    for t in range(1, lmax):
+        cur = seq[:, t - 1]
+        loc = nbr[cur, np.minimum((cw[cur] < rng.random(n_user)[:, None]).sum(axis=1), n_nbr - 1)]
+        glob = np.minimum(np.searchsorted(cdf, rng.random(n_user)), n_item - 1)
+        seq[:, t] = np.where(rng.random(n_user) < local, loc, glob)
+    return seq[np.arange(lmax)[None, :] < raw[:, None]]                                   # flat, user-major
+
+
+def make_synthetic(n_user, n_item, max_len, seed, dd=200, ud_km=40, min_len=4, box_km=40.0, zipf=1.0, local=0.0, n_nbr=32):
     """Synthetic Foursquare/Gowalla-shaped data: lognormal sequence lengths clipped to
-    [min_len, max_len] (+1 held-out check-in), Zipf POI popularity, POIs uniform in a ~box_km square."""
+    [min_len, max_len] (+1 held-out check-in), Zipf POI popularity, POIs uniform in a ~box_km square.
+    local = 0: every check-in is an independent Zipf draw (round-1 generator; nothing but popularity to learn);
+    local > 0: that fraction of the transitions goes to one of the n_nbr nearest POIs of the current one."""
     rng = np.random.default_rng(seed)
     dist_num = int(ud_km * 1000 / dd)                    # prog_bpr_gru_spatial.py:81
     mu, sigma = np.log(max(max_len / 3.0, min_len)), 0.6
@@ -259,11 +283,15 @@ def make_synthetic(n_user, n_item, max_len, seed, dd=200, ud_km=40, min_len=4, b
     w = 1.0 / np.power(np.arange(1, n_item + 1, dtype=np.float64), zipf)
     cdf = np.cumsum(w / w.sum())
     perm = rng.permutation(n_item)
-    ranks = np.minimum(np.searchsorted(cdf, rng.random(int(raw.sum()))), n_item - 1)
-    pois = perm[ranks].astype(np.int32)
+    if local <= 0.0:
+        ranks = np.minimum(np.searchsorted(cdf, rng.random(int(raw.sum()))), n_item - 1)
+        pois = perm[ranks].astype(np.int32)
     lat = 40.0 + rng.random(n_item) * (box_km / 111.19)
     lon = -74.0 + rng.random(n_item) * (box_km / (111.19 * np.cos(40.0 * DEG)))
     coords = np.stack([lat, lon], 1)
+    if local > 0.0:
+        wp = np.empty(n_item); wp[perm] = w               # popularity weight of POI id i
+        pois = _local_transitions(rng, coords, wp / wp.sum(), raw, float(local), int(n_nbr)).astype(np.int32)
     roff = np.zeros(n_user + 1, np.int64)
     np.cumsum(raw, out=roff[1:])
     rdist = dist_pos_bins(roff, pois, coords, dd, dist_num)

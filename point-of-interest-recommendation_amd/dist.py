@@ -1,12 +1,21 @@
-"""Multi-GPU path: users are sharded across ranks, every rank holds a full replica of
-the parameters, and replicas are reconciled ONCE PER EPOCH by summing each rank's delta relative to
-the epoch-start snapshot (one all-reduce over xGMI per tensor group; RCCL via torch.distributed):
+"""Multi-GPU path: users are sharded across ranks, every rank holds a full replica of the
+parameters and trains its shard with no data-path collective; replicas are reconciled ONCE PER EPOCH:
 
-        theta <- theta_start + sum_r (theta_r - theta_start)
+        theta <- theta_start + combine( sum_r (theta_r - theta_start) )
 
-With world_size == 1 this is the identity.  No collective touches the per-step data path.
-The elementwise delta arithmetic is the HIP kernels poi_delta_make / poi_delta_apply; tests inject
-their own arithmetic to exercise the protocol under gloo on CPU tensors."""
+one all-reduce over xGMI of ONE flat buffer.  The arithmetic (delta, per-row touch flags, combine rule, next
+epoch's snapshot) and the collective itself live in libpoi_hip.so (include/poi_hip.h: poi_sync_*, poi_comm_*,
+poi_allreduce_tables - the library owns an RCCL communicator); this module only wires them to the model's
+tensors and, for the communicator's one-time rendezvous, broadcasts the 128-byte RCCL id over torch.distributed.
+
+Combine rules (per tensor; identity at world size 1), see DESIGN.md "Multi-GPU":
+  sum            every replica's epoch counts in full - to first order in alpha the sequential epoch of ONE process
+                 over all users (what the reference's loop does, prog_bpr_gru_spatial.py:249-250)
+  mean           model averaging (local SGD)
+  mean_touched   per table row, the mean over the replicas that moved it (the launch-level batch rule one level up)
+DEFAULT_RULES is what bench.py and the harness use.
+
+Tests drive the same protocol on CPU tensors under gloo with a host backend (tests/test_dist_gloo.py)."""
 from __future__ import annotations
 
 import ctypes
@@ -14,53 +23,179 @@ import ctypes
 import torch
 import torch.distributed as dist
 
+from . import _lib
 
-def _hip_delta_ops(ctx, stream_fn):
-    def make(cur, base, out):
-        ctx.check(ctx.lib.poi_delta_make(ctx.handle, cur.data_ptr(), base.data_ptr(), out.data_ptr(), cur.numel(), stream_fn()))
+RULES = {"sum": _lib.SYNC_SUM, "mean": _lib.SYNC_MEAN, "mean_touched": _lib.SYNC_MEAN_TOUCHED}
+# the embedding tables: every replica's sparse updates count in full (a row touched by one replica only keeps its whole
+# update, as inside a launch); the dense weights and the 201 distance-bin rows, which EVERY replica moves in every
+# launch, are averaged - a sum would multiply their step (and their L2 decay) by the world size.
+DEFAULT_RULES = {"lt": "sum", "ux": "sum", "di": "mean", "ui": "mean", "wh": "mean", "bi": "mean", "vs": "mean", "bs": "mean",
+                 "wd": "mean", "loss_weight": "mean"}
 
-    def apply(cur, base, dsum):
-        ctx.check(ctx.lib.poi_delta_apply(ctx.handle, cur.data_ptr(), base.data_ptr(), dsum.data_ptr(), cur.numel(), stream_fn()))
-    return make, apply
+
+class _DevArray:
+    """Zero-copy torch view of a device buffer owned by the library (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class HipSyncBackend:
+    """poi_sync_* on the model's device tensors (+ the library's own RCCL communicator when asked for)."""
+
+    def __init__(self, tensors, rules, ctx, device):
+        self.ctx, self.lib, self.device = ctx, ctx.lib, device
+        self.tensors = list(tensors)              # keep them alive: the library holds raw pointers
+        for t in self.tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
+                raise TypeError("ReplicaSync needs contiguous float32 tensors on %s" % device)
+        segs = (_lib.SyncSeg * len(self.tensors))()
+        for s, t, r in zip(segs, self.tensors, rules):
+            width = t.shape[-1] if t.dim() >= 1 and t.shape[-1] > 0 else 1
+            s.cur, s.rows, s.width, s.rule = t.data_ptr(), t.numel() // width, width, RULES[r]
+        h = ctypes.c_void_p()
+        self._check(self.lib.poi_sync_create(ctx.handle, device.index, segs, len(self.tensors), ctypes.byref(h)))
+        self.handle = h
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._check(self.lib.poi_sync_buffer(h, ctypes.byref(p), ctypes.byref(n)))
+        self.n = n.value
+        self.flat = torch.as_tensor(_DevArray(p.value, n.value), device=device)
+        self.comm = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.PoiError("libpoi_hip sync error %d: %s" % (rc, self.lib.poi_sync_last_error().decode()))
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def init_comm(self, group=None):
+        """The library's own RCCL communicator: rank 0 draws the id, one broadcast hands it to the others."""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = (ctypes.c_char * 128)()
+        if rank == 0:
+            self._check(self.lib.poi_comm_unique_id(buf))
+        t = torch.tensor(list(buf.raw), dtype=torch.uint8)
+        t = t.to(self.device) if dist.get_backend(group) == "nccl" else t
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(t.cpu().tolist())
+        h = ctypes.c_void_p()
+        self._check(self.lib.poi_comm_init_rank(raw, world, rank, self.device.index, ctypes.byref(h)))
+        self.comm = h
+
+    def begin_epoch(self):
+        self._check(self.lib.poi_sync_begin_epoch(self.handle, self._stream()))
+
+    def make_delta(self):
+        self._check(self.lib.poi_sync_make_delta(self.handle, self._stream()))
+        return self.flat
+
+    def apply(self, world):
+        self._check(self.lib.poi_sync_apply(self.handle, int(world), self._stream()))
+
+    def end_epoch_rccl(self):
+        self._check(self.lib.poi_sync_end_epoch(self.handle, self.comm, self._stream()))
+
+    def stats(self):
+        ms, nb = ctypes.c_double(), ctypes.c_int64()
+        self._check(self.lib.poi_sync_stats(self.handle, ctypes.byref(ms), ctypes.byref(nb)))
+        return ms.value, nb.value
+
+    def checksum(self):
+        """64-bit checksum over all synchronised tensors (bit-identical replicas <=> equal checksums)."""
+        acc = torch.zeros(1, dtype=torch.int64, device=self.device)
+        for t in self.tensors:
+            self._check(self.lib.poi_checksum(self.ctx.handle, t.data_ptr(), t.numel(), acc.data_ptr(), self._stream()))
+        return int(acc.item())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.flat = None
+            self.lib.poi_sync_destroy(self.handle); self.handle = None
+        if getattr(self, "comm", None):
+            self.lib.poi_comm_destroy(self.comm); self.comm = None
 
 
 class ReplicaSync:
-    """Keeps the epoch-start snapshot of a list of parameter tensors and reconciles replicas."""
+    """Per-epoch replica reconciliation of a list of parameter tensors.
 
-    def __init__(self, tensors, group=None, delta_ops=None, ctx=None, force=False):
+    tensors / rules : the tensors (updated in place) and one rule name per tensor ("sum" | "mean" | "mean_touched")
+    backend         : object with begin_epoch() / make_delta() -> flat tensor / apply(world); default = the HIP
+                      kernels of libpoi_hip.so (needs ctx=); tests pass a host backend
+    own_comm        : all-reduce through the library's own RCCL communicator (poi_allreduce_tables) instead of
+                      torch.distributed.all_reduce on the same buffer (default: when the backend is nccl)
+    force           : run the whole delta / all-reduce / apply path even at world size 1 (self-check)"""
+
+    def __init__(self, tensors, rules=None, group=None, backend=None, ctx=None, force=False, own_comm=None):
         self.tensors = list(tensors)
-        if delta_ops is None and any(t.dtype != torch.float32 for t in self.tensors):
-            raise TypeError("ReplicaSync with the HIP delta kernels needs float32 tensors")
+        rules = list(rules) if rules is not None else ["sum"] * len(self.tensors)
+        if len(rules) != len(self.tensors) or any(r not in RULES for r in rules):
+            raise ValueError("one rule of %s per tensor" % sorted(RULES))
+        self.rules = rules
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.force = bool(force) and dist.is_initialized()      # run the full delta/all-reduce path even at world size 1 (self-check)
-        if delta_ops is None:
+        self.force = bool(force) and dist.is_initialized()
+        self.active = self.world > 1 or self.force
+        if backend is None:
             if ctx is None:
-                raise ValueError("ReplicaSync needs a poi context (HIP delta kernels) or explicit delta_ops")
-            dev = self.tensors[0].device
-            delta_ops = _hip_delta_ops(ctx, lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-        self.make, self.apply = delta_ops
-        # one flat buffer for all tensors: a single large all-reduce instead of many small ones
-        n = sum(t.numel() for t in self.tensors)
-        self.base = torch.empty(n, dtype=self.tensors[0].dtype, device=self.tensors[0].device)
-        self.delta = torch.empty_like(self.base)
-        self._views = []
-        o = 0
-        for t in self.tensors:
-            self._views.append((o, t.numel()))
-            o += t.numel()
-        self.begin_epoch()
+                raise ValueError("ReplicaSync needs ctx= (HIP kernels of libpoi_hip.so) or an explicit backend")
+            backend = HipSyncBackend(self.tensors, rules, ctx, self.tensors[0].device)
+            if own_comm is None:
+                own_comm = self.active and dist.get_backend(group) == "nccl"
+            if own_comm and self.active:
+                backend.init_comm(group)
+        self.backend = backend
+        self.own_comm = bool(own_comm) and getattr(backend, "comm", None) is not None
+        self.epochs = 0
+        if self.active:
+            self.begin_epoch()
 
     def begin_epoch(self):
-        for t, (o, n) in zip(self.tensors, self._views):
-            self.base[o:o + n].copy_(t.reshape(-1))
+        self.backend.begin_epoch()
 
     def end_epoch(self):
-        """All-reduce the deltas and rebuild every replica; then start the next epoch's snapshot."""
-        if self.world > 1 or self.force:
-            for t, (o, n) in zip(self.tensors, self._views):
-                self.make(t.reshape(-1), self.base[o:o + n], self.delta[o:o + n])
-            dist.all_reduce(self.delta, op=dist.ReduceOp.SUM, group=self.group)
-            for t, (o, n) in zip(self.tensors, self._views):
-                self.apply(t.reshape(-1), self.base[o:o + n], self.delta[o:o + n])
-        self.begin_epoch()
+        """All-reduce the deltas and rebuild every replica (the result is the next epoch's snapshot)."""
+        if not self.active:
+            return
+        if self.own_comm:
+            self.backend.end_epoch_rccl()
+        else:
+            flat = self.backend.make_delta()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.backend.apply(self.world)
+        self.epochs += 1
+
+    def report(self):
+        """Self-validation block for bench.py: what the collective saw and whether the replicas agree bit for bit."""
+        out = {"world_size": self.world, "rules": dict(zip(("t%d" % i for i in range(len(self.rules))), self.rules)),
+               "collective": "rccl (library communicator, poi_allreduce_tables)" if self.own_comm else
+               ("torch.distributed.all_reduce" if self.active else "none (world size 1)"), "epochs_synced": self.epochs}
+        if isinstance(self.backend, HipSyncBackend):
+            if self.own_comm and self.epochs:
+                ms, nb = self.backend.stats()
+                out["allreduce_ms_last"], out["allreduce_bytes"] = ms, nb
+                out["rccl_world_size"] = self.backend.lib.poi_comm_world(self.backend.comm)
+            else:
+                out["allreduce_bytes"] = self.backend.n * 4
+            cs = self.backend.checksum()
+            if dist.is_initialized():
+                t = torch.tensor([cs], dtype=torch.int64, device=self.tensors[0].device)
+                lst = [torch.zeros_like(t) for _ in range(self.world)]
+                dist.all_gather(lst, t, group=self.group)
+                allcs = [int(x.item()) for x in lst]
+            else:
+                allcs = [cs]
+            out["replica_checksums_equal"] = len(set(allcs)) == 1
+            out["replica_checksum"] = "%016x" % (allcs[0] & 0xFFFFFFFFFFFFFFFF)
+        return out
+
+    def close(self):
+        if hasattr(self.backend, "close"):
+            self.backend.close()
+
+
+def model_sync(model, names=None, rules=None, **kw):
+    """ReplicaSync over a model's parameters with DEFAULT_RULES (override per name with rules={...})."""
+    names = names or [n for n in ("lt", "di", "ux", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight") if hasattr(model, n)]
+    r = dict(DEFAULT_RULES); r.update(rules or {})
+    return ReplicaSync([getattr(model, n).t for n in names], rules=[r[n] for n in names], ctx=model.ctx, **kw)

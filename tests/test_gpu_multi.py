@@ -1,0 +1,153 @@
+"""-m gpu: the product's multi-GPU arithmetic run for real on ONE device.  Replicas are emulated as separate model
+instances on the same GPU that start from one snapshot and train different user shards; the reconciliation goes
+through the library's poi_sync_* kernels (the flat buffers of the replicas are added where RCCL would add them) and is
+compared with the oracle's  theta_start + combine(sum of the shards' deltas).  Plus: the RCCL entry points themselves
+(poi_comm_*, poi_allreduce_tables, poi_sync_end_epoch) at world size 1 under torch.distributed."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as C
+from poi_amd.data import padded_to_csr
+from tests.gpu_util import assert_close, assert_delta_close, spatial_params, toy_problem
+
+pytestmark = pytest.mark.gpu
+SP_NAMES = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import torch
+    assert torch.cuda.is_available()
+    import poi_amd
+    poi_amd._lib.load()
+    return poi_amd
+
+
+def test_sync_kernels_three_emulated_replicas_all_rules(pa):
+    """make_delta / apply for the three combine rules against the same arithmetic in torch (float32, same order)."""
+    import torch
+    ctx = pa._lib.context(0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g, dtype=torch.float32)
+    shapes = [(1001, 64), (203, 128), (3, 64, 128), (7,), (1,)]
+    rules = ["sum", "mean_touched", "mean", "mean", "sum"]
+    base = [rnd(*s) for s in shapes]
+    cur = [b.clone() for b in base]
+    sync = pa.dist.ReplicaSync(cur, rules=rules, ctx=ctx)
+    sync.backend.begin_epoch()                              # (world size 1: ReplicaSync itself stays passive)
+    world = 3
+    total = torch.zeros_like(sync.backend.flat)
+    deltas = []
+    for r in range(world):
+        d = [rnd(*s) * 0.1 - 0.05 for s in shapes]
+        d[0][torch.arange(1001, device="cuda") % 3 != r] = 0.0        # table 0: every row moved by exactly one replica
+        d[1][torch.arange(203, device="cuda") % (r + 2) == 0] = 0.0    # table 1: rows moved by 0..3 replicas
+        for c, b, x in zip(cur, base, d):
+            c.copy_(b + x)
+        total += sync.backend.make_delta()
+        deltas.append([c - b for c, b in zip(cur, base)])
+    sync.backend.flat.copy_(total)
+    sync.backend.apply(world)
+    for i, (c, b, rule) in enumerate(zip(cur, base, rules)):
+        s = deltas[0][i] + deltas[1][i] + deltas[2][i]
+        if rule == "mean":
+            s = s / world
+        elif rule == "mean_touched":
+            cnt = sum((dl[i].reshape(dl[i].shape[0], -1) != 0).any(dim=1).float() for dl in deltas).clamp(min=1.0)
+            s = s / cnt[:, None]
+        exp = b + s
+        assert torch.allclose(c, exp, rtol=0, atol=2e-7), (i, rule, float((c - exp).abs().max()))
+    # the result is the next epoch's snapshot: an immediate second reconciliation with no training changes nothing
+    before = [c.clone() for c in cur]
+    sync.backend.flat.copy_(sync.backend.make_delta())
+    assert float(sync.backend.flat.abs().max()) == 0.0
+    sync.backend.apply(world)
+    assert all(torch.equal(a, b) for a, b in zip(before, cur))
+    cs = sync.backend.checksum()
+    cur[2][1, 2, 3] += 1e-3
+    assert sync.backend.checksum() != cs
+    sync.close()
+
+
+@pytest.mark.parametrize("engine,rules", [("seq", None), ("tile", None), ("tile", {"lt": "mean_touched", "di": "sum", "ui": "sum"})])
+def test_two_shards_from_one_snapshot_reconcile_to_the_oracle(pa, engine, rules):
+    """Shard A and shard B are trained (batch rule, one launch each) by two model instances that start from the same
+    parameters; reconciling A's replica with B's deltas must give the oracle's theta_start + combine(dA + dB)."""
+    import torch
+    dim, n_user = 64, 90
+    T = toy_problem(301, n_user=n_user, n_item=150, n_dist=23, dim=dim, len_max=11, hot=40)
+    P = spatial_params(301, T)
+    lens = T["lens"]
+    off, p = padded_to_csr(T["train"][0], lens); _, q = padded_to_csr(T["train"][2], lens)
+    _, dp = padded_to_csr(T["dist"][0], lens); _, dq = padded_to_csr(T["dist"][2], lens)
+    shards = [np.arange(0, 48, dtype=np.int32), np.arange(48, n_user, dtype=np.int32)]
+    mk = lambda: pa.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=n_user,
+                                         n_item=T["n_item"], n_dists=[T["n_dist"], 0.2], n_in=dim, n_hidden=dim, init=P)
+    models = [mk(), mk()]
+    models[0].ctx.set_engine(engine)
+    syncs = [pa.dist.model_sync(m, rules=rules) for m in models]
+    r = dict(pa.dist.DEFAULT_RULES); r.update(rules or {})
+    flats = []
+    for m, s, ids in zip(models, syncs, shards):
+        s.backend.begin_epoch()
+        m.train_batch(ids)
+        flats.append(s.backend.make_delta().clone())
+    models[0].ctx.set_engine("auto")
+    for s in syncs:                                          # both replicas receive the same all-reduced buffer
+        s.backend.flat.copy_(flats[0] + flats[1])
+        s.backend.apply(2)
+    got = [{k: (float(getattr(m, k).get_value()) if k == "wd" else np.asarray(getattr(m, k).get_value(), np.float64)) for k in SP_NAMES}
+           for m in models]
+    assert syncs[0].backend.checksum() == syncs[1].backend.checksum(), "replicas differ after the reconciliation"
+    # oracle: each shard's launch by the batch rule from the common snapshot, then the combine rule
+    news = [C.spatial_batch_mean(P, off, p, q, dp, dq, ids, T["len_max"], 0.01, 0.001) for ids in shards]
+    exp = {}
+    for k in SP_NAMES:
+        b = np.asarray(P[k], np.float64)
+        d = [np.asarray(n[0][k], np.float64) - b for n in news]
+        if r[k] == "sum":
+            exp[k] = b + d[0] + d[1]
+        elif r[k] == "mean":
+            exp[k] = b + (d[0] + d[1]) / 2
+        else:
+            cnt = np.maximum(sum((np.abs(x).reshape(x.shape[0], -1) > 0).any(axis=1).astype(float) for x in d), 1.0)
+            exp[k] = b + (d[0] + d[1]) / cnt.reshape(-1, *([1] * (b.ndim - 1)))
+    for k in SP_NAMES:
+        assert_close(got[0][k], exp[k], "%s after reconciling two shards (%s)" % (k, r[k]))
+        assert_delta_close(got[0][k], exp[k], P[k], "%s after reconciling two shards (%s)" % (k, r[k]), rtol=3e-4)
+    for s in syncs:
+        s.close()
+
+
+def test_rccl_entry_points_world_size_1(pa):
+    """poi_comm_unique_id / poi_comm_init_rank / poi_allreduce_tables / poi_sync_end_epoch through the library's own RCCL
+    communicator, under a one-rank torch.distributed group (the all-reduce of one rank is the identity)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ctx = pa._lib.context(0)
+        t = [torch.rand(300, 64, device="cuda"), torch.rand(3, 64, 64, device="cuda")]
+        before = [x.clone() for x in t]
+        sync = pa.dist.ReplicaSync(t, rules=["sum", "mean"], ctx=ctx, force=True)
+        assert sync.own_comm and sync.backend.lib.poi_comm_world(sync.backend.comm) == 1
+        t[0] += 0.5; t[1] *= 2.0
+        want = [x.clone() for x in t]
+        sync.end_epoch()
+        torch.cuda.synchronize()
+        assert all(torch.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(t, want))
+        rep = sync.report()
+        assert rep["rccl_world_size"] == 1 and rep["replica_checksums_equal"] and rep["allreduce_bytes"] == 4 * (300 * 64 + 3 * 64 * 64)
+        assert rep["allreduce_ms_last"] >= 0.0
+        sync.end_epoch()                                   # nothing trained since: identity
+        assert all(torch.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(t, want))
+        sync.close()
+        del before
+    finally:
+        if created:
+            dist.destroy_process_group()
