@@ -1,16 +1,23 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path on MI355X: Distance2Pre training epochs (check-in sequences / s) and
-all-POI top-20 evaluation (users / s) on synthetic Gowalla-shaped data (BASELINE.json configs[2]).
+"""Benchmark of the hot path on MI355X: Distance2Pre training epochs (check-in sequences / s) and all-POI top-20
+evaluation (users / s) on synthetic Gowalla-shaped data (BASELINE.json configs[2]).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 200 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one training epoch over the rank's user shard: ceil(users/B) launches of the batched
-training step (B users per launch, batch semantics of include/poi_hip.h) plus, for N > 1, the
-per-epoch replica reconciliation (one RCCL all-reduce of the parameter deltas).  Users are sharded
-across ranks (total work fixed: strong scaling); every rank holds the full parameter replica.
-Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+A "step" is one training epoch over the rank's user shard: ceil(users/B) launches of the batched training step
+(B users per launch, batch rule of include/poi_hip.h with --batch-cap) plus, for N > 1, the per-epoch replica
+reconciliation (one RCCL all-reduce of the parameter deltas through the library's own communicator).  Users are
+sharded across ranks (total work fixed: strong scaling); every rank holds the full parameter replica.  Inputs are
+resident in HBM before the timed region.  One JSON line is printed by rank 0.  Besides the contract fields it carries
+  roofline / roofline_gather_scatter / kernels   live HIP-event timings of the timed region against gfx950 peaks
+  reference_schedule                             the reference's own schedule (one user per step) on the same GPU
+  quality                                        recall@20 / AUC after a fixed training wall time: headline mode vs the
+                                                 reference schedule, on the same data (which has a next-POI signal)
+  multi_gpu                                      what the collective saw + replica checksum equality (self-validating)
+  secondary                                      Foursquare-shape numbers (BASELINE.json configs[1])
+  cpu_baseline                                   plain-C float64 port of the reference step on the host cores
 """
 import argparse
 import json
@@ -25,21 +32,30 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+PROFILE_TAG = "r02"         # profiles/<tag>_pmc_traffic.json: committed rocprofv3 PMC passes of this command
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200, help="timed training epochs (default: a >= 2 s timed window)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla"])
     ap.add_argument("--batch-users", type=int, default=12500)
-    ap.add_argument("--eval-steps", type=int, default=2)
+    ap.add_argument("--batch-cap", type=float, default=64.0,
+                    help="batch rule cap (poi_ctx_set_batch_cap): a row touched by k sequences of a launch moves by min(k, cap)/k x the sum of "
+                         "their reference updates; 1 = mean rule.  64 is the setting whose recall matches the reference schedule (quality block)")
+    ap.add_argument("--local", type=float, default=0.8, help="fraction of check-in transitions that go to one of the 32 nearest POIs (0: i.i.d. Zipf draws)")
+    ap.add_argument("--eval-steps", type=int, default=5)
     ap.add_argument("--eval-chunk", type=int, default=16384,
                     help="users per scoring call: 16384 = 512 user tiles = one workgroup per tile and two per CU with 4 item ranges each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-quality", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--quality-seconds", type=float, default=3.0, help="training wall time of the batched modes in the quality block")
+    ap.add_argument("--reference-seconds", type=float, default=15.0, help="training wall time of the reference schedule (one user per step)")
     ap.add_argument("--emulate-world", type=int, default=0, help="tuning aid: train only rank 0's shard of an N-way split on one GPU")
     return ap.parse_args()
 
@@ -48,6 +64,38 @@ def step_flops(D, NB):
     """Algorithmic flops of one GRU step of one sequence, forward + backward:
     54 D^2 for the cell (2D-wide input) + 6 (B+1) D for the distance-softmax head."""
     return 54.0 * D * D + 6.0 * NB * D
+
+
+def make_batches(n_local, lens_local, batch_users, seed=123):
+    """Shuffled user order (prog_bpr_gru_spatial.py:236-238) cut into launches of equal size (about batch_users each: a
+    shard of 12600 users is ONE launch, not 12500 + 100); inside a launch the ids are sorted by descending length so that
+    the 16-sequence recurrent tiles are homogeneous."""
+    perm = np.random.default_rng(seed).permutation(n_local)
+    n_launch = max(1, int(round(n_local / float(batch_users))))
+    B = -(-n_local // n_launch)
+    batches = []
+    for b0 in range(0, n_local, B):
+        ids = perm[b0:b0 + B]
+        batches.append(ids[np.argsort(-lens_local[ids], kind="stable")])
+    return perm, B, batches
+
+
+def evaluate_model(model, tab, n_local, dev, chunk=16384):
+    """(recall@20, AUC) through the product's evaluation path (snapshot -> predict -> fused score + top-K; AUC flags)."""
+    import torch
+    ids = np.arange(n_local, dtype=np.int32)
+    model.update_trained_items(); model.update_trained_dists()
+    hts, sts = model.predict_device(ids)
+    model.update_trained_users(hts); model.update_trained_sus(sts)
+    tes = torch.as_tensor(tab.tes_p.reshape(-1).astype(np.int32)).to(dev)
+    hits = 0
+    auc = 0
+    for c0 in range(0, n_local, chunk):
+        sub = ids[c0:min(c0 + chunk, n_local)]
+        idx = model.compute_sub_topk(sub, 20)
+        hits += int((idx == tes[c0:c0 + len(sub), None]).any(dim=1).sum().item())
+        auc += int(model.compute_sub_auc_preference(sub).sum())
+    return hits / float(n_local), auc / float(n_local)
 
 
 def main():
@@ -68,36 +116,32 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
-    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2)
+    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local)
     lo, hi = pdata.shard_users(n_user, a.emulate_world or world, rank, ds.lens)
     tab = ds.shard(lo, hi)
     n_local = hi - lo
     NB = ds.dist_num + 1
-    model = poi_amd.models.OboSpatialGru(train=tab, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=n_local,
-                                         n_item=n_item, n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=D, n_hidden=D,
-                                         device=dev, seed=7, coords=ds.coords)
-    ctx = model.ctx
-    sync = poi_amd.dist.model_sync(model, group=None, force=os.environ.get("POI_BENCH_FORCE_SYNC") == "1")
 
-    # shuffled user order (prog_bpr_gru_spatial.py:236-238), cut into launches of B users; inside a launch
-    # the ids are sorted by descending length so that 32-sequence tiles are homogeneous.  Resident on device.
+    def new_model(tab_, n_users, dim=D, seed=7):
+        return poi_amd.models.OboSpatialGru(train=tab_, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=n_users,
+                                            n_item=len(ds.coords), n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=dim, n_hidden=dim,
+                                            device=dev, seed=seed, coords=ds.coords)
+    model = new_model(tab, n_local)
+    ctx = model.ctx
+    ctx.set_batch_cap(a.batch_cap)
+    sync = poi_amd.dist.model_sync(model, force=os.environ.get("POI_BENCH_FORCE_SYNC") == "1")
+
     lens_local = np.diff(tab.off.astype(np.int64))
-    perm = np.random.default_rng(123).permutation(n_local)
-    # launches of equal size, about --batch-users each: a shard of 12600 users is ONE launch, not 12500 + 100
-    # (a tiny trailing launch costs the full latency chain of the recurrent kernels)
-    n_launch = max(1, int(round(n_local / float(a.batch_users))))
-    B = -(-n_local // n_launch)
-    batches = []
-    for b0 in range(0, n_local, B):
-        ids = perm[b0:b0 + B]
-        batches.append(ids[np.argsort(-lens_local[ids], kind="stable")])
+    perm, B, batches = make_batches(n_local, lens_local, a.batch_users)
     order = torch.as_tensor(np.concatenate(batches).astype(np.int32)).to(dev)
     steps_per_epoch = float(np.maximum(lens_local - 1, 0).sum())
 
-    def train_epoch():
-        for b0 in range(0, n_local, B):
-            model.train_batch(order[b0:b0 + B], sync=False)
-        sync.end_epoch()
+    def train_epoch(m=None, order_=None, B_=None, n_=None):
+        m = m or model; order_ = order if order_ is None else order_; B_ = B_ or B; n_ = n_ or n_local
+        for b0 in range(0, n_, B_):
+            m.train_batch(order_[b0:b0 + B_], sync=False)
+        if m is model:
+            sync.end_epoch()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -130,6 +174,7 @@ def main():
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
     seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
+    multi = sync.report()
 
     # ---- evaluation: snapshot -> user vectors -> fused distance term + all-POI score + top-20 -------
     eval_users_per_s = None
@@ -166,7 +211,7 @@ def main():
         ctx.timing(False)
         eval_users_per_s = n_user * a.eval_steps / dte
         fl = 2.0 * n_local * n_item * D * a.eval_steps
-        eval_detail = {"ms_per_eval": 1e3 * dte / a.eval_steps, "recall_at_20": float(hits.item()) / n_local,
+        eval_detail = {"ms_per_eval": 1e3 * dte / a.eval_steps, "recall_at_20_after_timed_training": float(hits.item()) / n_local,
                        "score_topk_tflops": fl / (ms_score * 1e-3) / 1e12 if ms_score > 0 else None,
                        "score_topk_frac_of_f32_mfma_peak": fl / (ms_score * 1e-3) / 1e12 / PEAK_F32_TFLOPS if ms_score > 0 else None,
                        "ms_predict_per_eval": ms_pred / a.eval_steps, "ms_score_topk_per_eval": ms_score / a.eval_steps,
@@ -174,16 +219,22 @@ def main():
                        "eval_chunk_users": a.eval_chunk}
 
     # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region) -----------
-    # algorithmic work per GRU step of one sequence: flops for the contractions, bytes
-    # for the gather (3 rows + 4 indices) and the sparse write-back (unique rows per sequence).
-    # rows actually written by the sparse write-back: unique table rows per LAUNCH (batch rule: one write per row)
     off64 = tab.off.astype(np.int64)
     order_host = order.cpu().numpy()
-    uniq = 0
+    uniq = 0                       # table rows written per epoch: unique rows per LAUNCH (one write per row and launch)
+    uniq_seq = 0                   # n_unique(p U q) + n_unique(dp) per SEQUENCE, summed
+    pos = 0
     for b0 in range(0, n_local, B):
         ids = order_host[b0:b0 + B]
         sel = np.concatenate([np.arange(off64[u], off64[u + 1]) for u in ids])
         uniq += len(np.unique(np.concatenate((tab.p[sel], tab.q[sel])))) + 1 + len(np.unique(np.append(tab.dp[sel], ds.dist_num)))
+        pos += len(sel)
+    if n_local <= 60000:
+        # per-sequence unique counts, vectorised: sort (user, id) pairs
+        user_of = np.repeat(np.arange(n_local), lens_local)
+        for arrs in ((tab.p, tab.q), (tab.dp,)):
+            key = np.concatenate([user_of.astype(np.int64) * (n_item + NB + 2) + np.asarray(x, np.int64) for x in arrs])
+            uniq_seq += len(np.unique(key))
     D2 = float(D * D)
     # EXECUTED flops per kernel (the roofline fractions are matrix-pipe utilisation).  At D >= 128 the distance-bin
     # half of the step input goes through per-bin tables: te_gemm_ax / te_gemm_dx / the d ui jobs of
@@ -196,23 +247,24 @@ def main():
             "te_head": ("flop", 4.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_wgrad": ("flop", ((6 + xk) * D2 + 2.0 * NB * D) * steps_per_epoch),     # d ui, d wh and d vs (split-K)
             "te_gemm_dx": ("flop", xk * D2 * steps_per_epoch),
-            # te_gather now only builds E = lt[p'] - lt[q'] (two table rows + two indices per step); the gather of the
-            # step input [lt[p] | di[dp]] is fused into te_gemm_ax / te_wgrad (rows go straight into their LDS tiles)
-            "te_gather": ("byte", (2.0 * D * 4 + 8) * steps_per_epoch),
+            # implementation bytes of the HBM-bound kernels (what each kernel has to move given the decomposition):
+            # te_gather builds E = lt[p'] - lt[q'] (two table rows + two indices in, one packed row out per step)
+            "te_gather": ("byte", (3.0 * D * 4 + 8) * steps_per_epoch),
             "rows_apply": ("byte", 2.0 * uniq * D * 4.0),      # read + write of every touched row
-            # sorted scatter: per step dx (2D floats; bintab: D floats + the 3D floats of DA for the per-bin sums)
-            # + g*h (D floats) in, every touched row read + written
-            "te_scatter": ("byte", (2.0 if bintab else 3.0) * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0),
+            # sorted scatter: per step dx (D floats; two-table path: 2D) + h twice (the g*h term of the positive and of the
+            # negative row) in, every touched row read + written
+            "te_scatter": ("byte", (3.0 if bintab else 4.0) * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0),
             # per-bin sums of DA (bintab): one read of the 3D-wide DA rows
             "te_dsum": ("byte", 3.0 * D * 4 * steps_per_epoch)}
+    n_launches = len(batches)
     kernels = {}
     for k in KN:
         ms, nl = kt[k]
         if nl == 0:
             continue
-        # per-step time from the per-launch average: the event recorder keeps at most 8192 regions, so on long
-        # runs (--steps > ~180) only the first launches are timed - their average is still the launch duration
-        per_step = (ms / nl) * len(batches)
+        # per-step time from the per-launch average: the event recorder keeps a bounded number of regions, so on long
+        # runs only the first launches are timed - their average is still the launch duration
+        per_step = (ms / nl) * n_launches
         ent = {"ms_per_step": per_step, "launches": nl, "avg_ms": ms / nl}
         if k in work:
             kind, w = work[k]
@@ -225,34 +277,146 @@ def main():
             ent["note"] = "runs on the side stream next to te_wgrad / te_gemm_dx: its span overlaps them and is not part of the serial sum"
         kernels[k] = ent
     dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
-    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs, gfx950 correction applied - profiles/r01f_pmc_traffic.json); only valid for the profiled workload
+    # HBM traffic per launch from the COMMITTED PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # separate runs, gfx950 correction applied): static numbers, valid only for the profiled workload - not measured in this run
     traffic = {}
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")))
-        if a.shape == "gowalla" and B == 12500 and world == 1:
-            traffic = {k: v["hbm_bytes_per_launch"] for k, v in pj["kernels"].items()}
-    except Exception:
-        pass
+    traffic_src = None
+    for tag in (PROFILE_TAG, "r01f"):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
+            if a.shape == "gowalla" and B == 12500 and world == 1:
+                traffic = {k: v["hbm_bytes_per_launch"] for k, v in pj["kernels"].items()}
+                traffic_src = "static: profiles/%s_pmc_traffic.json (rocprofv3 PMC passes of this command, not measured in this run)" % tag
+            break
+        except Exception:
+            continue
     for k in kernels:
         if k in traffic:
             kernels[k]["traffic_bytes_per_launch"] = traffic[k]
-    roofline = dict(kernel=dom, traffic=traffic.get(dom), **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
+    roofline = dict(kernel=dom, traffic=traffic.get(dom), traffic_source=traffic_src,
+                    **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
     roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
+    # ---- gather / scatter against the HBM roofline: three accountings over the SAME kernel time --------------------
     GS = ("te_gather", "te_dsum", "te_scatter", "rows_apply")
     gs_ms = sum(kernels[k]["ms_per_step"] for k in GS if k in kernels)
-    gs_bytes = sum(work[k][1] for k in GS if k in kernels)
-    hbm = {"kernels": [k for k in GS if k in kernels], "bound": "hbm",
-           "achieved": gs_bytes * a.steps / (gs_ms * a.steps * 1e-3) / 1e9 if gs_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "traffic": sum(traffic.get(k, 0) for k in GS) or None}
-    hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
+    gs_impl = sum(work[k][1] for k in GS if k in kernels)
+    e = 4.0
+    survey_bytes = 3.0 * pos * D * e + 16.0 * pos + uniq_seq * D * e if uniq_seq else None      # SURVEY.md 8(d) bytes_seq, summed
+    rows_only = 2.0 * steps_per_epoch * D * e + 2.0 * uniq * D * e          # E's two table rows per step + touched rows r/w
+    acc = lambda b: {"bytes_per_epoch": b, "achieved_GBps": b / (gs_ms * 1e-3) / 1e9, "frac": b / (gs_ms * 1e-3) / 1e9 / PEAK_HBM_GBS} if b and gs_ms > 0 else None
+    hbm = {"kernels": [k for k in GS if k in kernels], "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "ms_per_epoch": gs_ms,
+           "survey_8d": acc(survey_bytes), "implementation": acc(gs_impl), "embedding_rows_only": acc(rows_only),
+           "traffic": sum(traffic.get(k, 0) for k in GS) * n_launches or None, "traffic_source": traffic_src,
+           "definitions": {
+               "survey_8d": "SURVEY.md 8(d) / BASELINE.md 4: per sequence 3*L*D*e + 16*L gathered + (n_unique(p U q) + n_unique(dp))*D*e written, summed over "
+                            "the epoch's sequences - the contract figure.  NOTE the gather of the step input [lt[p] | di[dp]] is fused into the MFMA-bound "
+                            "te_gemm_ax / te_wgrad (rows go straight into their LDS tiles) and its time is NOT in ms_per_epoch",
+               "implementation": "bytes the HBM-bound kernels have to move in this decomposition, intermediates included (E rows out, dx / h rows in, DA rows "
+                                 "for the per-bin sums, touched rows read + written)",
+               "embedding_rows_only": "table rows only: the two rows of E per step + every touched row read and written once per launch"}}
+    hbm["achieved"] = (hbm["survey_8d"] or hbm["implementation"])["achieved_GBps"]
+    hbm["frac"] = (hbm["survey_8d"] or hbm["implementation"])["frac"]
     total_flops = step_flops(D, NB) * steps_per_epoch
     executed_flops = sum(w for k, (kind, w) in work.items() if kind == "flop" and k in kernels and k != "seq_train") or total_flops
     train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels if k != "te_finalize")
 
+    solo = rank == 0 and world == 1 and not a.emulate_world
+    # ---- the reference's own schedule on the GPU + learning quality at equal wall time --------------------------------
+    reference_schedule = None
+    quality = None
+    if solo and not a.no_quality:
+        pop = np.bincount(tab.p, minlength=n_item)
+        top = np.argsort(-pop)[:20]
+
+        def timed_training(run_epoch, seconds, users_per_epoch):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter(); n = 0
+            while time.perf_counter() - t0 < seconds:
+                n += run_epoch()
+                torch.cuda.synchronize(dev)
+            return n, time.perf_counter() - t0
+
+        # (1) reference schedule: model.train(uidx), one SGD step per user in shuffled order (prog_bpr_gru_spatial.py:249-250)
+        ctx.set_batch_cap(1.0)
+        mref = new_model(tab, n_local, seed=11)
+        pr = np.random.default_rng(5).permutation(n_local).astype(np.int32)
+        cursor = [0]
+
+        def ref_chunk():
+            c0 = cursor[0]
+            for u in pr[c0:c0 + 500]:
+                mref.train(np.int32(u))
+            cursor[0] = (c0 + 500) % max(n_local - 500, 1)
+            return 500
+        n_ref, t_ref = timed_training(ref_chunk, a.reference_seconds, n_local)
+        rec_ref, auc_ref = evaluate_model(mref, tab, n_local, dev)
+        reference_schedule = {"seq_per_s": n_ref / t_ref, "ms_per_step": 1e3 * t_ref / n_ref, "users_trained": n_ref, "train_seconds": t_ref,
+                              "note": "model.train(uidx) one user per step through the per-sequence engine (host call + 3 kernel launches per user): "
+                                      "the reference's execution model on the GPU, bound by the 49-step latency chain of ONE sequence"}
+        del mref
+
+        # (2) batched modes from the same initial parameters for --quality-seconds of training each
+        def batched(Bq, cap, seconds):
+            ctx.set_batch_cap(cap)
+            m = new_model(tab, n_local, seed=11)
+            _, Bq_, bt = make_batches(n_local, lens_local, Bq, seed=321)
+            od = torch.as_tensor(np.concatenate(bt).astype(np.int32)).to(dev)
+            ep = [0]
+
+            def one():
+                if ep[0] > 0:
+                    m.resample_negatives_device(99 * 1000003 + ep[0])          # fresh negatives every epoch, as the driver does (:221-228)
+                train_epoch(m, od, Bq_, n_local); ep[0] += 1
+                return n_local
+            n, t = timed_training(one, seconds, n_local)
+            rec, auc = evaluate_model(m, tab, n_local, dev)
+            return {"batch_users_per_launch": Bq_, "batch_cap": cap, "train_seconds": t, "epochs": ep[0], "seq_per_s": n / t,
+                    "recall_at_20": rec, "auc": auc}
+        modes = {"headline": batched(a.batch_users, a.batch_cap, a.quality_seconds),
+                 "headline_mean_rule": batched(a.batch_users, 1.0, a.quality_seconds),
+                 "small_launches": batched(256, 16.0, a.quality_seconds)}
+        ctx.set_batch_cap(a.batch_cap)
+        quality = {"data": "synthetic with a next-POI signal: %.0f %% of the transitions go to one of the 32 nearest POIs" % (100 * a.local),
+                   "random_recall_at_20": 20.0 / n_item, "popularity_recall_at_20": float(np.isin(tab.tes_p.reshape(-1), top).mean()),
+                   "reference_schedule": {"train_seconds": t_ref, "users_trained": n_ref, "epochs": n_ref / float(n_local),
+                                          "recall_at_20": rec_ref, "auc": auc_ref},
+                   "modes": modes,
+                   "headline_vs_reference": {"recall_ratio": modes["headline"]["recall_at_20"] / max(rec_ref, 1e-9),
+                                             "wall_time_ratio": modes["headline"]["train_seconds"] / t_ref,
+                                             "statement": "headline mode (B = %d, cap = %g) after %.1f s of training vs the reference schedule after %.1f s"
+                                                          % (B, a.batch_cap, modes["headline"]["train_seconds"], t_ref)}}
+
+    # ---- secondary shape: BASELINE.json configs[1] (Foursquare shape, D = 64, the two-table path) ------------------------
+    secondary = None
+    if solo and not a.no_secondary and a.shape != "foursquare":
+        ni2, nu2, ml2, D2_ = pdata.SHAPES["foursquare"]
+        ds2 = pdata.make_synthetic(nu2, ni2, ml2, seed=20260928 + 1, local=a.local)
+        tab2 = ds2.shard(0, nu2)
+        m2 = poi_amd.models.OboSpatialGru(train=tab2, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=nu2, n_item=ni2,
+                                          n_dists=[ds2.dist_num, ds2.dd / 1000.0], n_in=D2_, n_hidden=D2_, device=dev, seed=7, coords=ds2.coords)
+        l2 = np.diff(tab2.off.astype(np.int64))
+        _, B2, bt2 = make_batches(nu2, l2, nu2)
+        od2 = torch.as_tensor(np.concatenate(bt2).astype(np.int32)).to(dev)
+        for _ in range(5):
+            train_epoch(m2, od2, B2, nu2)
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(400):
+            train_epoch(m2, od2, B2, nu2)
+        torch.cuda.synchronize(dev); t2 = time.perf_counter() - t0
+        evaluate_model(m2, tab2, nu2, dev)
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(20):
+            rec2, auc2 = evaluate_model(m2, tab2, nu2, dev)
+        torch.cuda.synchronize(dev); te2 = time.perf_counter() - t0
+        secondary = {"workload": "synthetic foursquare-shape: %d POIs, %d users, seq<=%d, dim=%d (BASELINE.json configs[1]); one %d-user launch per epoch"
+                                 % (ni2, nu2, ml2, D2_, B2),
+                     "train_seq_per_s": nu2 * 400 / t2, "ms_per_epoch": 1e3 * t2 / 400, "eval_users_per_s": nu2 * 20 / te2,
+                     "recall_at_20_after_405_epochs": rec2, "auc": auc2}
+        del m2
+
     # ---- CPU baseline: plain-C float64 port of the same per-sequence algorithm, 1 thread -------------
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if solo and not a.no_cpu_baseline:
         from oracle import c_oracle as C
         from oracle import poi_oracle as O
         rng = np.random.default_rng(7)
@@ -278,11 +442,11 @@ def main():
             Sc = max(16, min(S, n_local // ncore))
             reps = [{k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in P.items()} for _ in range(ncore)]
 
-            def work(i):
+            def work_fn(i):
                 C.spatial_epoch(reps[i], tab.off, tab.p, tab.q, tab.dp, tab.dq, ordr[i * Sc:(i + 1) * Sc], tab.len_max, 0.01, 0.001)
             t0 = time.perf_counter()
             with ThreadPoolExecutor(ncore) as ex:
-                list(ex.map(work, range(ncore)))
+                list(ex.map(work_fn, range(ncore)))
             ta = time.perf_counter() - t0
             all_cores = {"value": ncore * Sc / ta, "unit": "sequences/s", "cores": ncore,
                          "sample": "%d user-sharded replicas x %d sequences" % (ncore, Sc)}
@@ -299,15 +463,21 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic %s-shape: %d POIs, %d users, seq<=%d, dim=%d, %d distance bins; one step = one "
                                    "Distance2Pre training epoch over all users" % (a.shape, n_item, n_user, max_len, D, ds.dist_num),
-                       "batch_users_per_launch": B, "parallelism": "user-shard x%d, per-epoch delta all-reduce" % world,
+                       "batch_users_per_launch": B, "batch_rule": "capped sum: a row touched by k sequences of a launch moves by min(k, %g)/k x the sum of "
+                                                                  "their reference updates (include/poi_hip.h); see `quality` for what it learns" % a.batch_cap,
+                       "batch_cap": a.batch_cap, "local_transition_fraction": a.local,
+                       "parallelism": "user-shard x%d, per-epoch delta all-reduce" % world,
                        "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence"},
+            "timed_window_s": dt,
             "eval_users_per_s": eval_users_per_s, "eval": eval_detail,
             "roofline": roofline, "roofline_gather_scatter": hbm, "kernels": kernels,
             "train_step_tflops": executed_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "train_step_tflops_reference_formulation": total_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
+            "reference_schedule": reference_schedule, "quality": quality, "multi_gpu": multi, "secondary": secondary,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    sync.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

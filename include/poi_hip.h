@@ -25,6 +25,10 @@
  *    every sequence's reference update is evaluated at the launch-entry parameter values; each
  *    parameter row then moves by the MEAN of the updates of the sequences that touch it (dense
  *    tensors are touched by all n_seq sequences).  See DESIGN.md "Batch semantics".
+ *    poi_ctx_set_batch_cap(cap) generalises the rule: a row touched by k sequences moves by
+ *    min(k, cap) / k times the SUM of their updates - cap = 1 (default) is the mean, cap = infinity the plain sum,
+ *    i.e. to first order in alpha what k sequential reference steps would do; in between, up to `cap` updates
+ *    count in full and hot rows (popular POIs, distance bins, the dense tensors) are averaged down to `cap`.
  */
 #ifndef POI_HIP_H
 #define POI_HIP_H
@@ -79,6 +83,9 @@ int poi_ctx_num_cu(const poi_ctx* ctx);
  * 1 = per-sequence engine, 2 = tile engine whenever supported.  Both implement the same arithmetic
  * (only the f32 summation order differs).  Also settable with POI_ENGINE=seq|tile. */
 int poi_ctx_set_engine(poi_ctx* ctx, int engine);
+/* Batch rule cap (>= 1, see "Batch semantics" above); applies to poi_spatial_step / poi_gru_step / poi_bpr_step
+ * (snapshot mode) launches with more than one sequence.  n_seq == 1 is the reference step for every cap. */
+int poi_ctx_set_batch_cap(poi_ctx* ctx, float cap);
 
 /* ---- a5: BPR-MF step - OboBpr.bpr_train(uidx, [p, q]), public/BPR.py:201-241 ----------------
  * n independent (user, positive, negative) triples.  ux (n_user, D), lt (n_item+1, D).

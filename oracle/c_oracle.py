@@ -52,10 +52,11 @@ def score_topk(users, items, k):
     return out
 
 
-def spatial_batch_mean(P, off, p, q, dp, dq, ids, len_max, alpha, lam, threads=None):
+def spatial_batch_mean(P, off, p, q, dp, dq, ids, len_max, alpha, lam, threads=None, cap=1.0):
     """Oracle side of the batch rule (include/poi_hip.h): every sequence's reference update evaluated at P, each
     table row moved by the MEAN of the deltas of the sequences touching it, dense tensors by the mean over all
-    sequences.  The launch is cut into `threads` slices run concurrently (ctypes releases the GIL); the slices'
+    sequences; with cap > 1, min(k, cap) / k times the SUM of the k touching sequences' deltas
+    (poi_ctx_set_batch_cap).  The launch is cut into `threads` slices run concurrently (ctypes releases the GIL); the slices'
     float64 accumulators are added in slice order.  Returns (P_new, out (n, 5), touched) with touched = dict of the
     boolean row masks of lt / di.  P is not modified."""
     import concurrent.futures as cf
@@ -92,12 +93,13 @@ def spatial_batch_mean(P, off, p, q, dp, dq, ids, len_max, alpha, lam, threads=N
     for i, x in enumerate(parts):
         out[bounds[i]:bounds[i + 1]] = x[5]
     N = dict(P)
-    N["lt"] = A["lt"] + acc_lt / np.maximum(c_lt, 1)[:, None]
-    N["di"] = A["di"] + acc_di / np.maximum(c_di, 1)[:, None]
+    sc = lambda c: np.minimum(np.maximum(c, 1), cap) / np.maximum(c, 1)
+    N["lt"] = A["lt"] + acc_lt * sc(c_lt)[:, None]
+    N["di"] = A["di"] + acc_di * sc(c_di)[:, None]
     o = 0
     for k in ("ui", "wh", "bi", "vs", "bs"):
-        N[k] = A[k] + acc_d[o:o + A[k].size].reshape(A[k].shape) / n
+        N[k] = A[k] + acc_d[o:o + A[k].size].reshape(A[k].shape) * (min(n, cap) / n)
         o += A[k].size
-    N["wd"] = float(wd[0] + acc_d[o] / n)
-    N["loss_weight"] = A["loss_weight"] + acc_d[o + 1:o + 3] / n
+    N["wd"] = float(wd[0] + acc_d[o] * (min(n, cap) / n))
+    N["loss_weight"] = A["loss_weight"] + acc_d[o + 1:o + 3] * (min(n, cap) / n)
     return N, out, dict(lt=c_lt > 0, di=c_di > 0)

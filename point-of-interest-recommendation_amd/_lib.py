@@ -40,6 +40,7 @@ SIGNATURES = {
     "poi_last_error": (c_char_p, [c_void_p]),
     "poi_ctx_num_cu": (c_int, [c_void_p]),
     "poi_ctx_set_engine": (c_int, [c_void_p, c_int]),
+    "poi_ctx_set_batch_cap": (c_int, [c_void_p, c_float]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                              c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
     "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
@@ -140,6 +141,10 @@ class Context:
     def set_engine(self, name):
         """'auto' | 'seq' | 'tile' (see poi_ctx_set_engine)."""
         self.check(self.lib.poi_ctx_set_engine(self.handle, {"auto": 0, "seq": 1, "tile": 2}[name]))
+
+    def set_batch_cap(self, cap):
+        """Batch rule cap (include/poi_hip.h, poi_ctx_set_batch_cap): 1 = mean rule."""
+        self.check(self.lib.poi_ctx_set_batch_cap(self.handle, float(cap)))
 
     def timing(self, on=True):
         self.check(self.lib.poi_timing_reset(self.handle))

@@ -26,6 +26,7 @@ struct poi_ctx {
   // per-sequence engine
   DevBuf ws, slab, te_ws, hslab;
   int engine = 0;   // 0 auto, 1 per-sequence, 2 tile
+  float batch_cap = 1.0f;   // poi_ctx_set_batch_cap
   int wgrad_rounds = 2;
   int head_rounds = 3;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
   int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1 (tuning only)
@@ -145,6 +146,7 @@ static void fill_args(poi::SeqArgs& A, const poi_gru_params* P, const poi_seq_ta
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq;
   A.len_max = T->len_max; A.cap = T->max_len;
   A.uidx = uidx; A.n_seq = n;
+  A.bcap = 1.0f;
 }
 
 // Carve the tile engine's packed-row workspace out of one grow-only buffer.
@@ -249,7 +251,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   }
   poi::SeqArgs A;
   fill_args(A, P, T, uidx, n);
-  A.out = out;
+  A.out = out; A.bcap = c->batch_cap;
   A.ws = (float*)c->ws.p; A.ws_stride = wsf;
   A.slab = (float*)c->slab.p;
   A.g_lt = (float*)c->g_lt.p; A.mult_lt = (int*)c->mult_lt.p; A.nseq_lt = (int*)c->nseq_lt.p;
@@ -257,7 +259,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (tile) {
     poi::TeArgs E;
     if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
-    E.out = out; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
+    E.out = out; E.bcap = c->batch_cap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
@@ -318,7 +320,7 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
   poi::BprArgs A;
   memset(&A, 0, sizeof A);
   A.ux = ux; A.lt = lt; A.n_user = n_user; A.n_item = n_item; A.dim = dim;
-  A.uidx = uidx; A.p = p; A.q = q; A.n = n; A.alpha = alpha; A.lambda = lambda; A.loss = loss_out;
+  A.uidx = uidx; A.p = p; A.q = q; A.n = n; A.alpha = alpha; A.lambda = lambda; A.loss = loss_out; A.bcap = c->batch_cap;
   if (mode == POI_BPR_SNAPSHOT) {
     int rc;
     if ((rc = ensure(c, c->g_ux, sizeof(float) * (size_t)n_user * dim, st))) return rc;
@@ -525,6 +527,12 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
 int poi_ctx_set_engine(poi_ctx* c, int engine) {
   if (!c || engine < 0 || engine > 2) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence) or 2 (tile)");
   c->engine = engine;
+  return POI_OK;
+}
+
+int poi_ctx_set_batch_cap(poi_ctx* c, float cap) {
+  if (!c || !(cap >= 1.0f)) return fail(c, POI_EINVAL, "batch cap must be >= 1 (1 = mean rule)");
+  c->batch_cap = cap;
   return POI_OK;
 }
 

@@ -94,12 +94,13 @@ __global__ __launch_bounds__(POI_BLOCK) void bpr_grad_kernel(BprArgs A) {
 }
 
 template <int LPT>
-__device__ __forceinline__ void bpr_claim(float* T, float* G, int* cnt, int row, int D, int gl, float al, float lm) {
+__device__ __forceinline__ void bpr_claim(float* T, float* G, int* cnt, int row, int D, int gl, float al, float lm, float cap) {
   int got = 0;
   if (gl == 0) got = atomicExch(&cnt[row], 0);
   got = __shfl(got, 0, LPT);
   if (got <= 0) return;
   const float inv = 1.0f / (float)got;
+  al *= fminf((float)got, cap);            // batch rule: min(got, cap) of the touching triples' updates count
   float* t = T + (size_t)row * D;
   float* g = G + (size_t)row * D;
   for (int j = gl * 4; j < D; j += LPT * 4) {
@@ -119,9 +120,9 @@ __global__ __launch_bounds__(POI_BLOCK) void bpr_apply_kernel(BprArgs A) {
   const int gl = threadIdx.x % LPT;
   const int gpb = POI_BLOCK / LPT;
   for (int i = blockIdx.x * gpb + threadIdx.x / LPT; i < A.n; i += gridDim.x * gpb) {
-    bpr_claim<LPT>(A.ux, A.g_ux, A.cnt_ux, A.uidx[i], D, gl, A.alpha, A.lambda);
-    bpr_claim<LPT>(A.lt, A.g_lt, A.cnt_lt, A.p[i], D, gl, A.alpha, A.lambda);
-    bpr_claim<LPT>(A.lt, A.g_lt, A.cnt_lt, A.q[i], D, gl, A.alpha, A.lambda);
+    bpr_claim<LPT>(A.ux, A.g_ux, A.cnt_ux, A.uidx[i], D, gl, A.alpha, A.lambda, A.bcap);
+    bpr_claim<LPT>(A.lt, A.g_lt, A.cnt_lt, A.p[i], D, gl, A.alpha, A.lambda, A.bcap);
+    bpr_claim<LPT>(A.lt, A.g_lt, A.cnt_lt, A.q[i], D, gl, A.alpha, A.lambda, A.bcap);
   }
 }
 

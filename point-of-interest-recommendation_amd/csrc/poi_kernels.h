@@ -15,7 +15,7 @@ struct Timing {
   struct Rec { std::string name; hipEvent_t a, b; };
   bool on = false;
   std::vector<Rec> recs;
-  size_t limit = 8192;
+  size_t limit = 32768;
   void begin(const char* name, hipStream_t st) {
     if (!on || recs.size() >= limit) { open_ = false; return; }
     Rec r; r.name = name;
@@ -49,6 +49,7 @@ struct SeqArgs {
   int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
   // predict outputs
   float *hts, *sts;
+  float bcap;        // batch rule: at most `bcap` of the touching sequences' updates count (1 = mean rule), include/poi_hip.h
 };
 
 // Layout of one dense-gradient slab (offsets in floats).
@@ -112,6 +113,7 @@ struct TeArgs {
   float* hot_part;                    // (hot chunks, D) partial sums
   int* hot_nf;                        // per hot chunk: distinct-sequence count
   float* gcoef;                       // per packed row: d loss / d (h . e) (te_head)
+  float bcap;                         // batch rule cap (see SeqArgs)
 };
 // entry code: packed-row index of the position (28 bits) + what the position contributes
 #define TE_ENT_ROW 0x0FFFFFFF
@@ -149,6 +151,7 @@ struct BprArgs {
   float* loss;
   float *g_ux, *g_lt;
   int *cnt_ux, *cnt_lt;   // touches per row in this launch (== multiplicity == distinct triples)
+  float bcap;             // batch rule cap (see SeqArgs)
 };
 hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st, Timing* tm);
 

@@ -416,11 +416,11 @@ __global__ __launch_bounds__(POI_BLOCK) void seq_predict_kernel(SeqArgs A) {
 // nseq are re-zeroed.  No atomics (each row has exactly one owner), deterministic, and the scan of
 // the counters costs 4 bytes per table row.
 __device__ __forceinline__ void apply_row(float* __restrict__ T, float* __restrict__ G, int* __restrict__ mult,
-                                          int* __restrict__ nseq, int row, int D, float alpha, float lambda) {
+                                          int* __restrict__ nseq, int row, int D, float alpha, float lambda, float cap) {
   const int got = nseq[row];
   if (got <= 0) return;
   const int m = mult[row];
-  const float sc = alpha / (float)got, lm = lambda * (float)m;
+  const float sc = alpha * fminf((float)got, cap) / (float)got, lm = lambda * (float)m;
   float* t = T + (size_t)row * D;
   float* g = G + (size_t)row * D;
   for (int j = lane_id() * 4; j < D; j += 256) {
@@ -439,8 +439,8 @@ __global__ __launch_bounds__(POI_BLOCK) void rows_apply_kernel(SeqArgs A, float 
   const int D = A.dim;
   const int n_lt = A.n_item + 1, n_di = SPATIAL ? A.n_dist + 1 : 0;
   for (int r = blockIdx.x * POI_NWAVE + wave_id(); r < n_lt + n_di; r += gridDim.x * POI_NWAVE) {
-    if (r < n_lt) apply_row(A.lt, A.g_lt, A.mult_lt, A.nseq_lt, r, D, alpha, lambda);
-    else apply_row(A.di, A.g_di, A.mult_di, A.nseq_di, r - n_lt, D, alpha, lambda);
+    if (r < n_lt) apply_row(A.lt, A.g_lt, A.mult_lt, A.nseq_lt, r, D, alpha, lambda, A.bcap);
+    else apply_row(A.di, A.g_di, A.mult_di, A.nseq_di, r - n_lt, D, alpha, lambda, A.bcap);
   }
 }
 
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(POI_BLOCK) void dense_apply_kernel(SeqArgs A, int n
   const int D = A.dim, XW = SPATIAL ? 2 * D : D, NB = SPATIAL ? A.n_dist + 1 : 0;
   const DenseLayout dl = dense_layout(D, XW, NB);
   const float inv_n = 1.0f / (float)A.n_seq;
+  alpha *= fminf((float)A.n_seq, A.bcap);      // batch rule: min(n, cap) of the n sequences' updates count (cap = 1: their mean)
   const int i = blockIdx.x * POI_BLOCK + threadIdx.x;
   if (i >= dl.total) return;
   if (SPATIAL && i == dl.upq) return;   // consumed together with dl.sur by one thread (below)

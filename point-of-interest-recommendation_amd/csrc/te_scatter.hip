@@ -202,13 +202,13 @@ __device__ __forceinline__ float4 seg_sum(const TeArgs& A, int s, int cnt, int d
   return acc;
 }
 
-// row <- row - alpha * (G + lambda * mult * row) / nseq      (batch rule, include/poi_hip.h)
+// row <- row - alpha * min(nseq, cap) / nseq * (G + lambda * mult * row)      (batch rule, include/poi_hip.h)
 template <int D>
-__device__ __forceinline__ void apply_sum(float* __restrict__ trow, float4 g, int mult, int nseq, float alpha, float lambda) {
+__device__ __forceinline__ void apply_sum(float* __restrict__ trow, float4 g, int mult, int nseq, float alpha, float lambda, float cap) {
   constexpr int LPR = D / 4;
   const int lane = lane_id();
   if (lane >= LPR) return;
-  const float sc = alpha / (float)nseq, lm = lambda * (float)mult;
+  const float sc = alpha * fminf((float)nseq, cap) / (float)nseq, lm = lambda * (float)mult;
   float4 tv = *reinterpret_cast<float4*>(trow + lane * 4);
   tv.x -= sc * (g.x + lm * tv.x); tv.y -= sc * (g.y + lm * tv.y);
   tv.z -= sc * (g.z + lm * tv.z); tv.w -= sc * (g.w + lm * tv.w);
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
     int nf = 0;
     float4 g = seg_sum<D>(A, start, cnt, ri.doff, &nf);
     if (A.bintab && ri.doff) g = *reinterpret_cast<const float4*>(A.dgd + (size_t)(row - A.n_item - 1) * D + (lane % (D / 4)) * 4);
-    apply_sum<D>(ri.trow, g, cnt + am, ri.pn ? an : nf, alpha, lambda);
+    apply_sum<D>(ri.trow, g, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
 }
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) nf += __shfl_xor(nf, o, 64);
     if (A.bintab && ri.doff) acc = *reinterpret_cast<const float4*>(A.dgd + (size_t)(row - A.n_item - 1) * D + c);
-    apply_sum<D>(ri.trow, acc, cnt + am, ri.pn ? an : nf, alpha, lambda);
+    apply_sum<D>(ri.trow, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
 }

@@ -89,6 +89,41 @@ def test_tile_batch_matches_mean_rule_and_seq_engine(pa, dim, n_dist, n_user):
     pa._lib.context(0).set_engine("auto")
 
 
+@pytest.mark.parametrize("cap", [4.0, 1e9])
+def test_batch_cap_generalises_the_mean_rule(pa, cap):
+    """poi_ctx_set_batch_cap: a row touched by k sequences moves by min(k, cap) / k times the SUM of their reference
+    updates (cap = 1: the mean; huge cap: the plain sum), dense tensors with k = n_seq - both engines, against the
+    float64 oracle of the same rule."""
+    from oracle import c_oracle as C
+    from poi_amd.data import padded_to_csr
+    T = toy_problem(170, n_user=120, n_item=150, n_dist=23, dim=64, len_max=11, hot=20)
+    P = spatial_params(170, T)
+    lens = T["lens"]
+    off, p = padded_to_csr(T["train"][0], lens); _, q = padded_to_csr(T["train"][2], lens)
+    _, dp = padded_to_csr(T["dist"][0], lens); _, dq = padded_to_csr(T["dist"][2], lens)
+    users = np.random.default_rng(2).permutation(120)[:100].astype(np.int32)
+    exp, eout, _ = C.spatial_batch_mean(P, off, p, q, dp, dq, users, T["len_max"], 0.001, 0.001, cap=cap)
+    ctx = pa._lib.context(0)
+    try:
+        ctx.set_batch_cap(cap)
+        for eng in ("tile", "seq"):
+            model = pa.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.001, 0.001], n_user=T["n_user"],
+                                            n_item=T["n_item"], n_dists=[T["n_dist"], 0.2], n_in=T["dim"], n_hidden=T["dim"], init=P)
+            ctx.set_engine(eng)
+            out = model.train_batch(users)
+            assert_close(np.asarray(out)[:, :3], eout[:, :3], eng + " losses", rtol=2e-5)
+            assert_step_close(_get(model), exp, P, SP_NAMES, "%s cap %g" % (eng, cap))
+            # a single sequence is the reference step whatever the cap
+            u = int(users[0])
+            Pn, _ = O.spatial_step(P, T["train"][0][u], T["train"][2][u], T["dist"][0][u], T["dist"][2][u], T["train"][1][u], 0.001, 0.001)
+            m1 = pa.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.001, 0.001], n_user=T["n_user"],
+                                         n_item=T["n_item"], n_dists=[T["n_dist"], 0.2], n_in=T["dim"], n_hidden=T["dim"], init=P)
+            m1.train(np.int32(u))
+            assert_step_close(_get(m1), Pn, P, SP_NAMES, "%s single sequence under cap %g" % (eng, cap))
+    finally:
+        ctx.set_batch_cap(1.0); ctx.set_engine("auto")
+
+
 @pytest.mark.parametrize("dim,n_dist", [(64, 23), (128, 200)])
 def test_tile_predict_matches_oracle(pa, dim, n_dist):
     T = toy_problem(80 + dim, n_user=75, n_item=200, n_dist=n_dist, dim=dim, len_max=13)

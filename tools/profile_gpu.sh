@@ -7,11 +7,11 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 2 --warmup 1 --eval-steps 2 --no-cpu-baseline --no-quality --no-secondary"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o k -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
   -f csv -d $OUT/sq -o s -- $CMD > $OUT/sq.log 2>&1
-python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls -R $OUT | head -30
