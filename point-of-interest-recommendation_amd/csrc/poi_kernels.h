@@ -81,7 +81,8 @@ struct TeArgs {
   int spatial, xw;                    // 1 / 2D: Distance2Pre (POI + distance-bin input); 0 / D: plain GRU + BPR (n_dist == -1)
   int bintab;                         // spatial && D >= 128: distance-bin half through per-bin tables (te_ztab / te_dsum)
   float *ztab, *dpart, *dsum, *dgd;   // (n_dist+1) x 3D table; per-chunk partial sums of DA; per-bin sums; per-bin d di sums
-  int* dch0;                          // first 64-entry chunk of each bin (+ total)
+  int *dch0, *dch1;                   // first 64-entry chunk / first super-chunk of each bin (+ total)
+  float* dpart2; int *dnf, *dnf2, *dbn;   // super-chunk partial sums; distinct-sequence counts per chunk / super-chunk / bin
   int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_p, *row_dp, *row_ab;   // packed row -> CSR position, step index, input table rows (lt, di)
@@ -114,6 +115,7 @@ struct TeArgs {
   int* hot_nf;                        // per hot chunk: distinct-sequence count
   float* gcoef;                       // per packed row: d loss / d (h . e) (te_head)
   float bcap;                         // batch rule cap (see SeqArgs)
+  const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
 };
 // entry code: packed-row index of the position (28 bits) + what the position contributes
 #define TE_ENT_ROW 0x0FFFFFFF

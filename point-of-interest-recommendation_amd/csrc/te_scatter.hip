@@ -232,34 +232,76 @@ __device__ __forceinline__ RowInfo row_info(const TeArgs& A, int row) {
   return r;
 }
 
+// Cold rows (<= TE_COLD_MAX entries; the bulk: ~5 entries per touched POI row).  The kernel is bound by the number of
+// loads in flight, not by bytes: a row's update is a chain seg_end -> seg_start -> entry codes -> dx / h rows -> table row.
+// So a wavefront works on 64 / (D/4) rows at once (D/4 lanes x float4 = one row), takes a row's entries EIGHT at a time, and
+// every load of a batch is issued unconditionally before the first use: an entry without a dx (or g*h) term reads a
+// resident all-zero row instead of branching around the load (a branch would make the waitcnt pass drain the queue).
+// Entries are added in batch order ((e0+e1)+(e2+e3))+((e4+e5)+(e6+e7)), batches in order: reproducible.
 template <int D>
 __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, float lambda) {
-  const int R = A.n_item + 1 + A.n_dist + 1;
-  const int lane = lane_id();
-  for (int row = blockIdx.x * 4 + wave_id(); row < R; row += gridDim.x * 4) {
-    const int end = A.seg_end[row];
+  constexpr int LPR = D / 4, RPW = 64 / LPR;
+  const int R = A.bintab ? A.n_item + 1 : A.n_item + 1 + A.n_dist + 1;      // bintab: the distance-bin rows are written by te_dapply
+  const int lane = lane_id(), sub = lane / LPR, c = (lane % LPR) * 4, lead = sub * LPR;
+  const float* __restrict__ zrow = A.zrow;
+  const int nw = gridDim.x * 4;
+  for (int row0 = (blockIdx.x * 4 + wave_id()) * RPW; row0 < R; row0 += nw * RPW) {
+    const int row = min(row0 + sub, R - 1);
+    const bool in = row0 + sub < R;
+    const int end = in ? A.seg_end[row] : 0;
     const RowInfo ri = row_info(A, row);
     // padding rows: analytic multiplicity / sequence count from te_rowmap
-    const int am = ri.pm ? *ri.pm : 0, an = ri.pn ? *ri.pn : 0;
-    if (end == 0 && an == 0) continue;
+    const int am = (in && ri.pm) ? *ri.pm : 0, an = (in && ri.pn) ? *ri.pn : 0;
     const int start = end ? A.seg_start[row] : 0, cnt = end - start;
-    if (cnt > TE_COLD_MAX) {
+    const bool hot = cnt > TE_COLD_MAX;
+    if (hot) {
       const int nch = (cnt + TE_HOT_CHUNK - 1) / TE_HOT_CHUNK;
       int h = 0, c0 = 0;
-      if (lane == 0) {
+      if (lane == lead) {
         h = atomicAdd(&A.cnt[1], 1);
         c0 = atomicAdd(&A.cnt[2], nch);
         A.hot_rows[h] = make_int4(row, start, cnt, c0);
       }
-      h = __shfl(h, 0, 64); c0 = __shfl(c0, 0, 64);
-      for (int c = lane; c < nch; c += 64) A.hot_chunks[c0 + c] = make_int2(h, c);
-      continue;
+      h = __shfl(h, lead, 64); c0 = __shfl(c0, lead, 64);
+      for (int k = lane - lead; k < nch; k += LPR) A.hot_chunks[c0 + k] = make_int2(h, k);
     }
+    const int n_e = hot ? 0 : cnt;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int nf = 0;
-    float4 g = seg_sum<D>(A, start, cnt, ri.doff, &nf);
-    if (A.bintab && ri.doff) g = *reinterpret_cast<const float4*>(A.dgd + (size_t)(row - A.n_item - 1) * D + (lane % (D / 4)) * 4);
-    apply_sum<D>(ri.trow, g, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
-    if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
+    for (int i0 = 0; i0 < n_e; i0 += 8) {
+      int e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int v = A.ent[start + min(i0 + u, n_e - 1)]; e[u] = i0 + u < n_e ? v : 0; }
+      float4 x[8], hh[8]; float g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t rr = (size_t)(e[u] & TE_ENT_ROW);
+        const bool dx = (e[u] & TE_ENT_DX) != 0, gh = (e[u] & TE_ENT_GH) != 0;
+        const float* px = dx ? A.X + rr * A.xw + ri.doff + c : zrow + c;
+        const float* ph = gh ? A.H + (rr - 1) * D + c : zrow + c;
+        const float* pg = gh ? A.gcoef + (rr - 1) : zrow;
+        x[u] = *reinterpret_cast<const float4*>(px);
+        hh[u] = *reinterpret_cast<const float4*>(ph);
+        g[u] = *pg;
+      }
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float gg = (e[u] & TE_ENT_NEG) ? -g[u] : g[u];
+        v[u] = make_float4(fmaf(gg, hh[u].x, x[u].x), fmaf(gg, hh[u].y, x[u].y), fmaf(gg, hh[u].z, x[u].z), fmaf(gg, hh[u].w, x[u].w));
+        nf += e[u] < 0 ? 1 : 0;
+      }
+      acc = f4_add(acc, f4_add(f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])), f4_add(f4_add(v[4], v[5]), f4_add(v[6], v[7]))));
+    }
+    if (in && !hot && (end != 0 || an != 0)) {
+      const int nseq = ri.pn ? an : nf, mult = cnt + am;
+      const float sc = alpha * fminf((float)nseq, A.bcap) / (float)max(nseq, 1), lm = lambda * (float)mult;
+      float4 tv = *reinterpret_cast<float4*>(ri.trow + c);
+      tv.x -= sc * (acc.x + lm * tv.x); tv.y -= sc * (acc.y + lm * tv.y);
+      tv.z -= sc * (acc.z + lm * tv.z); tv.w -= sc * (acc.w + lm * tv.w);
+      *reinterpret_cast<float4*>(ri.trow + c) = tv;
+      if (lane == lead) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
+    }
   }
 }
 
@@ -320,7 +362,6 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
     for (int i = lane; i < nch; i += 64) nf += A.hot_nf[c0 + i];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) nf += __shfl_xor(nf, o, 64);
-    if (A.bintab && ri.doff) acc = *reinterpret_cast<const float4*>(A.dgd + (size_t)(row - A.n_item - 1) * D + c);
     apply_sum<D>(ri.trow, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
@@ -336,20 +377,32 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
 // The rows of a bin are the DX entries of its segment in the sorted entry list, cut into 64-entry chunks (one
 // workgroup iteration each; the bins are very uneven), whose partial sums are added in chunk order: reproducible.
 // -------------------------------------------------------------------------------------------------
-// chunk table: dch0[b] = first 64-entry chunk of bin b (exclusive scan of the bins' chunk counts), dch0[NB] = total
+// chunk tables: dch0[b] = first 64-entry chunk of bin b (exclusive scan of the bins' chunk counts), dch0[NB] = total;
+// dch1[b] = first SUPER-chunk (TE_DSUPER consecutive chunks of one bin) of bin b, dch1[NB] = total.  The bins are very
+// uneven on real check-in data (most hops are short: a few bins hold almost every step), so the per-bin sum is a
+// three-level tree - 64-entry chunks (te_dsum), TE_DSUPER-chunk groups (te_dred), groups of a bin (te_dfin) - every level
+// added in index order: reproducible, and no level walks more than a few dozen partials serially.
+#define TE_DSUPER 32
 __global__ __launch_bounds__(256) void te_dprep_kernel(TeArgs A) {
-  __shared__ int s[256];
+  __shared__ int s[256], s2[256];
   const int NB = A.n_dist + 1, t = threadIdx.x;
   int n = 0;
   if (t < NB) { const int row = A.n_item + 1 + t, end = A.seg_end[row]; n = end ? (end - A.seg_start[row] + 63) / 64 : 0; }
-  s[t] = n;
+  const int n2 = (n + TE_DSUPER - 1) / TE_DSUPER;
+  s[t] = n; s2[t] = n2;
   __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) { const int v = t >= o ? s[t - o] : 0; __syncthreads(); s[t] += v; __syncthreads(); }
-  if (t < NB) A.dch0[t] = s[t] - n;
-  if (t == 255) A.dch0[NB] = s[255];
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = t >= o ? s[t - o] : 0, v2 = t >= o ? s2[t - o] : 0;
+    __syncthreads();
+    s[t] += v; s2[t] += v2;
+    __syncthreads();
+  }
+  if (t < NB) { A.dch0[t] = s[t] - n; A.dch1[t] = s2[t] - n2; }
+  if (t == 255) { A.dch0[NB] = s[255]; A.dch1[NB] = s2[255]; }
 }
 
-// one 64-entry chunk of one bin per workgroup iteration, thread = column of DA
+// one 64-entry chunk of one bin per workgroup iteration, thread = column of DA; thread 0 also counts the chunk's
+// TE_ENT_FIRST flags (= distinct sequences of the batch rule: a sequence's entries are contiguous in a row segment)
 template <int D>
 __global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
   const int NB = A.n_dist + 1, col = threadIdx.x;
@@ -360,6 +413,7 @@ __global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
     const int row = A.n_item + 1 + lo;
     const int c0 = A.seg_start[row] + 64 * (ci - A.dch0[lo]), ce = min(A.seg_end[row], c0 + 64);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int nf = 0;
     for (int i = c0; i < ce; i += 16) {
       int e[16];
 #pragma unroll
@@ -368,31 +422,58 @@ __global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) v[u] = A.G[(size_t)(e[u] & TE_ENT_ROW) * 3 * D + col];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (i + u < ce && (e[u] & TE_ENT_DX)) ? v[u] : 0.f;
+      for (int u = 0; u < 16; ++u) { v[u] = (i + u < ce && (e[u] & TE_ENT_DX)) ? v[u] : 0.f; nf += (i + u < ce && e[u] < 0) ? 1 : 0; }
       s0 += (v[0] + v[4]) + (v[8] + v[12]); s1 += (v[1] + v[5]) + (v[9] + v[13]);
       s2 += (v[2] + v[6]) + (v[10] + v[14]); s3 += (v[3] + v[7]) + (v[11] + v[15]);
     }
     A.dpart[(size_t)ci * 3 * D + col] = (s0 + s1) + (s2 + s3);
+    if (col == 0) A.dnf[ci] = nf;
   }
 }
 
-// S[b] = sum of the bin's chunk partials (in chunk order); dgd[b] = S[b] . ui[:, D:2D]
+// one super-chunk (<= TE_DSUPER consecutive chunk partials of one bin) per workgroup iteration
+template <int D>
+__global__ __launch_bounds__(3 * D) void te_dred_kernel(TeArgs A) {
+  const int NB = A.n_dist + 1, col = threadIdx.x;
+  const int total = A.dch1[NB];
+  for (int si = blockIdx.x; si < total; si += gridDim.x) {
+    int lo = 0, hi = NB - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.dch1[mid] <= si) lo = mid; else hi = mid - 1; }
+    const int c0 = A.dch0[lo] + TE_DSUPER * (si - A.dch1[lo]), c1 = min(A.dch0[lo + 1], c0 + TE_DSUPER);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int nf = 0;
+#pragma unroll
+    for (int g = 0; g < TE_DSUPER / 8; ++g)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + 8 * g + u;
+        const float v = A.dpart[(size_t)min(c, c1 - 1) * 3 * D + col];
+        a[u] += c < c1 ? v : 0.f;
+      }
+    if (col == 0) for (int c = c0; c < c1; ++c) nf += A.dnf[c];
+    A.dpart2[(size_t)si * 3 * D + col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    if (col == 0) A.dnf2[si] = nf;
+  }
+}
+
+// S[b] = sum of the bin's super-chunk partials (in order); dgd[b] = S[b] . ui[:, D:2D]; dbn[b] = distinct sequences
 template <int D>
 __global__ __launch_bounds__(3 * D) void te_dfin_kernel(TeArgs A) {
   __shared__ float S[3 * D];
   __shared__ float gp[3][D];
   const int b = blockIdx.x, col = threadIdx.x;
-  const int c0 = A.dch0[b], c1 = A.dch0[b + 1];
+  const int c0 = A.dch1[b], c1 = A.dch1[b + 1];
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int c = c0;
   for (; c + 7 < c1; c += 8) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += A.dpart[(size_t)(c + u) * 3 * D + col];
+    for (int u = 0; u < 8; ++u) a[u] += A.dpart2[(size_t)(c + u) * 3 * D + col];
   }
-  for (; c < c1; ++c) a[0] += A.dpart[(size_t)c * 3 * D + col];
+  for (; c < c1; ++c) a[0] += A.dpart2[(size_t)c * 3 * D + col];
   const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   S[col] = s;
   A.dsum[(size_t)b * 3 * D + col] = s;
+  if (col == 0) { int nf = 0; for (int k = c0; k < c1; ++k) nf += A.dnf2[k]; A.dbn[b] = nf; }
   __syncthreads();
   {   // matvec: thread (part, cc) sums k in [part*D, (part+1)*D), three parts added in order
     const int part = col / D, cc = col % D;
@@ -406,6 +487,26 @@ __global__ __launch_bounds__(3 * D) void te_dfin_kernel(TeArgs A) {
   }
   __syncthreads();
   if (col < D) A.dgd[(size_t)b * D + col] = (gp[0][col] + gp[1][col]) + gp[2][col];
+}
+
+// write-back of the distance-bin rows (bintab): di[b] <- di[b] - alpha * min(n, cap) / n * (dgd[b] + lambda * mult * di[b]) with
+// mult = the row's entries (+ the padding row's analytic multiplicity) and n = its distinct sequences (te_dfin; padding row:
+// te_rowmap's counter).  Runs AFTER te_dui, which needs the old di.  Re-zeroes the row's segment / padding bookkeeping.
+template <int D>
+__global__ __launch_bounds__(D) void te_dapply_kernel(TeArgs A, float alpha, float lambda) {
+  const int b = blockIdx.x, c = threadIdx.x, row = A.n_item + 1 + b;
+  const int end = A.seg_end[row], cnt = end ? end - A.seg_start[row] : 0;
+  const bool pad = b == A.n_dist;
+  const int am = pad ? A.mult_di[A.n_dist] : 0, an = pad ? A.nseq_di[A.n_dist] : 0;
+  const int nseq = pad ? an : A.dbn[b];
+  __syncthreads();                              // every thread has read the counters before thread 0 clears them
+  if (end != 0 || an != 0) {
+    const float sc = alpha * fminf((float)nseq, A.bcap) / (float)max(nseq, 1), lm = lambda * (float)(cnt + am);
+    float* t = A.di + (size_t)b * D + c;
+    const float v = *t;
+    *t = v - sc * (A.dgd[(size_t)b * D + c] + lm * v);
+  }
+  if (c == 0) { A.seg_end[row] = 0; if (pad) { A.mult_di[A.n_dist] = 0; A.nseq_di[A.n_dist] = 0; } }
 }
 
 // d ui[k][D + c] = sum_b S[b][k] * di[b][c]  (di BEFORE this launch's write-back) -> slab 0 (zero on entry: plain store).
@@ -441,8 +542,10 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
     hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, st, A);
     tm->end(st);
     tm->begin("te_bin_gemm", st);
+    hipLaunchKernelGGL(te_dred_kernel<D>, dim3(num_cu * 2), dim3(3 * D), 0, st, A);
     hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A);
     hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(4 * D), 0, st, A);
+    hipLaunchKernelGGL(te_dapply_kernel<D>, dim3(A.n_dist + 1), dim3(D), 0, st, A, alpha, lambda);
     tm->end(st);
   }
   tm->begin("te_scatter", st);
