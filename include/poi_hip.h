@@ -111,6 +111,26 @@ int poi_gru_step(poi_ctx* ctx, const poi_gru_params* prm, const poi_seq_tables* 
                  const int32_t* uidx, int32_t n_seq, float alpha, float lambda,
                  float* out, void* stream);
 
+/* ---- f4: CA-RNN (flag 3) - OboCARNN, public/CA_RNN.py:46-227 ----------------------------------
+ * lt (n_item+1, D), wd (n_dist+1, H, D) interval-specific transition matrices, M (H, D); H == D (the driver passes
+ * n_in == n_hidden, prog_bpr_gru_spatial.py:148-149).  h0 is the zero vector (never trained).
+ * poi_carnn_step: seq_train(uidx), :105-170 - out[k] = los = -sum_t log sigmoid(yp_t - yq_t); sparse write-back of the
+ *   unique rows of p U q (lt) and of the unique interval MATRICES of dp U dq (wd), dense update of M; batch rule as above.
+ * poi_carnn_predict: seq_predict(start_end), :172-217, literally (the predict graph adds-then-sums, :191:
+ *   h_t = sigmoid(M p_t + rowsum(wd[d_t]) + sum(h_{t-1}))); prm->lt / prm->wd must point at the snapshots.
+ * poi_carnn_score_all: compute_sub_all_scores(start_end), :91-101, literally:
+ *   score[u][j] = -( sum(wd[bin(u, j)]) + H * sum(users[u]) + sum(M . items[j]) ),  bin(u, j) = the reference's
+ *   usrs_last_poi_to_all_intervals entry, computed on the fly from coords / cphi / thr (as poi_dist_prob) - the U x N
+ *   matrix is never materialised.  scores_out (n, n_item). */
+typedef struct poi_carnn_params { float* lt; float* wd; float* M; int32_t n_item; int32_t n_dist; int32_t dim; } poi_carnn_params;
+int poi_carnn_step(poi_ctx* ctx, const poi_carnn_params* prm, const poi_seq_tables* tab, const int32_t* uidx, int32_t n_seq,
+                   float alpha, float lambda, float* out, void* stream);
+int poi_carnn_predict(poi_ctx* ctx, const poi_carnn_params* prm, const poi_seq_tables* tab, const int32_t* uidx, int32_t n,
+                      float* hts, void* stream);
+int poi_carnn_score_all(poi_ctx* ctx, const float* users, const float* items, const float* M, const float* dists, const double* coords,
+                        const double* cphi, const double* thr, const int32_t* last_poi, int32_t n, int32_t n_item, int32_t n_dist,
+                        int32_t dim, double dd, float* scores_out, void* stream);
+
 /* ---- a6: predict - seq_predict(start_end), public/GRU_Spatial.py:231-288, public/GRU.py:154-205
  * prm->lt / prm->di must point at the SNAPSHOTS trained_items / trained_dists.
  * hts (n, D) = hidden state after the user's whole train sequence; sts (n, n_dist+1) =
@@ -252,7 +272,7 @@ int poi_checksum(poi_ctx* ctx, const float* x, int64_t n, uint64_t* out_dev, voi
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's live roofline figures).
  * Kernel names: "seq_train", "rows_apply", "dense_apply", "seq_predict", "bpr_hogwild", "bpr_grad",
- * "bpr_apply", "score_topk", "score_all", "dist_prob", "sample_neg", "neg_dist", and for the tile engine "te_prep", "te_gather", "te_gemm_ax",
+ * "bpr_apply", "score_topk", "score_all", "dist_prob", "sample_neg", "neg_dist", "carnn_train", "carnn_predict", "carnn_score", and for the tile engine "te_prep", "te_gather", "te_gemm_ax",
  * "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx", "te_finalize", "te_predict".  poi_timing_get synchronises the device. */
 int poi_timing_enable(poi_ctx* ctx, int on);
 int poi_timing_reset(poi_ctx* ctx);

@@ -281,6 +281,114 @@ def gru_step(P, p, q, mask, alpha, lam):
 
 
 # ----------------------------------------------------------------------------------------------
+# f4: CA-RNN step / predict / scoring  (public/CA_RNN.py:46-227; flag 3 of prog_bpr_gru_spatial.py:141-151)
+# ----------------------------------------------------------------------------------------------
+def init_carnn_params(rng, n_item, n_dist, d):
+    """public/GRU.py:58-63 (lt, h0) + public/CA_RNN.py:55-62 (M (H, D), wd (n_dist+1, H, D)); n_in == n_hidden."""
+    u = lambda *s: rng.uniform(-0.5, 0.5, s)
+    return dict(lt=u(n_item + 1, d), M=u(d, d), wd=u(n_dist + 1, d, d), h0=np.zeros(d))
+
+
+def carnn_forward_cost(P, p, q, dp, dq, mask, lam):
+    """Forward only: (cost, los) of public/CA_RNN.py:128-150.  Used by the autograd / finite-difference tests."""
+    lt, M, wd = P['lt'], P['M'], P['wd']
+    L = int(np.sum(mask))
+    xps, xqs, wdps, wdqs = lt[p], lt[q], wd[dp], wd[dq]      # :117-121 (all LM rows / matrices)
+    h = P['h0'].copy()
+    tot = 0.0
+    for t in range(L - 1):                                   # :138-142, n_steps = L-1
+        h = sigmoid(M @ xps[t] + wdps[t] @ h)                # :131
+        yp = (wdps[t + 1] @ h) @ (M @ xps[t + 1])            # :132
+        yq = (wdqs[t + 1] @ h) @ (M @ xqs[t + 1])            # :133
+        tot += log_sigmoid(yp - yq)                          # :134
+    los = -tot                                               # :148
+    l2 = sum(np.sum(v * v) for v in (xps, xqs, M, wdps, wdqs))   # :147
+    return los + 0.5 * lam * l2, los
+
+
+def carnn_step(P, p, q, dp, dq, mask, alpha, lam):
+    """One ``OboCARNN.seq_train(uidx)`` (public/CA_RNN.py:105-170).  Returns (P_new, los); P is not modified
+    (Theano `updates`: everything evaluated at the old values).  Backward hand-derived, checked against an independent
+    float64 autograd of carnn_forward_cost (tests/test_oracle_autograd.py)."""
+    p, q, dp, dq = (np.asarray(v, np.int64) for v in (p, q, dp, dq))
+    lt, M, wd = P['lt'], P['M'], P['wd']
+    D = lt.shape[1]
+    L = int(np.sum(mask))
+    ns = max(L - 1, 0)
+    xps, xqs = lt[p], lt[q]
+    hs = np.zeros((ns + 1, D)); hs[0] = P['h0']
+    mp = np.zeros((ns, D)); mq = np.zeros((ns, D)); vp = np.zeros((ns, D)); vq = np.zeros((ns, D)); ys = np.zeros(ns)
+    tot = 0.0
+    for t in range(ns):
+        hs[t + 1] = sigmoid(M @ xps[t] + wd[dp[t]] @ hs[t])
+        h = hs[t + 1]
+        mp[t], mq[t] = M @ xps[t + 1], M @ xqs[t + 1]
+        vp[t], vq[t] = wd[dp[t + 1]] @ h, wd[dq[t + 1]] @ h
+        ys[t] = vp[t] @ mp[t] - vq[t] @ mq[t]
+        tot += log_sigmoid(ys[t])
+    los = -tot
+    g_M = np.zeros_like(M); g_lt = np.zeros_like(lt); g_wd = np.zeros_like(wd)
+    dh_next = np.zeros(D)
+    for t in range(ns - 1, -1, -1):
+        h, hp = hs[t + 1], hs[t]
+        a, b = dp[t + 1], dq[t + 1]
+        g = -sigmoid(-ys[t])                                 # d cost / d (yp - yq)
+        dh = dh_next + g * (wd[a].T @ mp[t] - wd[b].T @ mq[t])
+        g_wd[a] += g * np.outer(mp[t], h)
+        g_wd[b] -= g * np.outer(mq[t], h)
+        g_M += g * (np.outer(vp[t], xps[t + 1]) - np.outer(vq[t], xqs[t + 1]))
+        g_lt[p[t + 1]] += g * (M.T @ vp[t])
+        g_lt[q[t + 1]] -= g * (M.T @ vq[t])
+        da = dh * h * (1.0 - h)
+        g_M += np.outer(da, xps[t])
+        g_lt[p[t]] += M.T @ da
+        g_wd[dp[t]] += np.outer(da, hp)
+        dh_next = wd[dp[t]].T @ da
+    # L2 over ALL LM gathered rows / matrices, multiplicity-weighted (:147)
+    np.add.at(g_lt, p, lam * xps)
+    np.add.at(g_lt, q, lam * xqs)
+    np.add.at(g_wd, dp, lam * wd[dp])
+    np.add.at(g_wd, dq, lam * wd[dq])
+    N = dict(P)
+    N['M'] = M - alpha * (g_M + lam * M)                     # :151-152
+    R = np.unique(np.concatenate((p, q)))                    # :123-125
+    S = np.unique(np.concatenate((dp, dq)))                  # :127-129
+    lt_new = lt.copy(); lt_new[R] = lt[R] - alpha * g_lt[R]  # :153,155
+    wd_new = wd.copy(); wd_new[S] = wd[S] - alpha * g_wd[S]  # :154,156
+    N['lt'], N['wd'] = lt_new, wd_new
+    return N, los                                            # :163
+
+
+def carnn_predict(P, items, dists, p_rows, d_rows, masks):
+    """public/CA_RNN.py:172-217, literally: h_t = sigmoid(p_t . M^T + sum(wd_t + h_{t-1}[None, :], axis = 2)), i.e. the
+    ROW SUMS of the interval matrix plus the SUM of the previous state (the broadcast-add-then-sum of :191 - not the
+    matrix-vector product of the training graph).  items / dists are the snapshots.  Returns hts (n, D)."""
+    M = P['M']
+    n = len(p_rows)
+    H = M.shape[0]
+    hts = np.zeros((n, H))
+    for k in range(n):
+        L = int(np.sum(masks[k]))
+        h = P['h0'].copy()
+        for t in range(L):
+            wd_t = dists[d_rows[k][t]]                        # (H, D)
+            h = sigmoid(items[p_rows[k][t]] @ M.T + np.sum(wd_t + h[None, :], axis=1))
+        hts[k] = h
+    return hts
+
+
+def carnn_score_all(users, items, M, dists, ulptai_rows):
+    """OboCARNN.compute_sub_all_scores (public/CA_RNN.py:91-101), literally:
+    h_W[u, j, i] = sum_k (dists[ulptai[u, j]][i, k] + users[u, k]);  r_M[j, i] = (items[j] . M^T)[i];
+    score[u, j] = - sum_i (h_W[u, j, i] + r_M[j, i]).  items includes the padding row (dropped)."""
+    users = np.asarray(users, F64); it = np.asarray(items, F64)[:-1]
+    Wsum = np.asarray(dists, F64).sum(axis=(1, 2))           # (n_dist + 1,)
+    H = M.shape[0]
+    m = (it @ M.T).sum(axis=1)                               # (N,)
+    return -(Wsum[np.asarray(ulptai_rows)] + H * users.sum(axis=1)[:, None] + m[None, :])
+
+
+# ----------------------------------------------------------------------------------------------
 # a5: BPR-MF step  (public/BPR.py:201-237)
 # ----------------------------------------------------------------------------------------------
 def bpr_step(P, uidx, pi, qi, alpha, lam):

@@ -20,6 +20,10 @@ class GruParams(ctypes.Structure):
                [("n_item", c_int32), ("n_dist", c_int32), ("dim", c_int32)]
 
 
+class CarnnParams(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("lt", "wd", "M")] + [("n_item", c_int32), ("n_dist", c_int32), ("dim", c_int32)]
+
+
 class SyncSeg(ctypes.Structure):
     _fields_ = [("cur", c_void_p), ("rows", c_int64), ("width", c_int64), ("rule", c_int32)]
 
@@ -49,6 +53,10 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "poi_gru_predict": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_void_p, c_void_p,
                                 c_void_p]),
+    "poi_carnn_step": (c_int, [c_void_p, POINTER(CarnnParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float, c_void_p, c_void_p]),
+    "poi_carnn_predict": (c_int, [c_void_p, POINTER(CarnnParams), POINTER(SeqTables), c_void_p, c_int32, c_void_p, c_void_p]),
+    "poi_carnn_score_all": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                    c_int32, c_int32, c_double, c_void_p, c_void_p]),
     "poi_score_all": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "poi_score_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,

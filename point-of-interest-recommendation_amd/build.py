@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpoi_hip.so")
-SOURCES = ["abi.hip", "seq_engine.hip", "tile_engine.hip", "te_scatter.hip", "bpr.hip", "score_topk.hip", "misc.hip", "sync.hip"]
-HEADERS = ["poi_common.h", "poi_kernels.h", os.path.join("..", "..", "include", "poi_hip.h")]
+SOURCES = ["abi.hip", "seq_engine.hip", "tile_engine.hip", "te_scatter.hip", "bpr.hip", "score_topk.hip", "misc.hip", "sync.hip", "carnn.hip"]
+HEADERS = ["poi_common.h", "poi_kernels.h", "seq_common.h", os.path.join("..", "..", "include", "poi_hip.h")]
 
 
 def _hipcc():

@@ -31,6 +31,7 @@ struct poi_ctx {
   int head_rounds = 3;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
   int score_variant = -1;   // -1 auto; POI_SCORE_VARIANT=0|1 (tuning only)
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
+  DevBuf g_wd, mult_wd, nseq_wd, ca_ws, ca_slab, ca_scr;      // CA-RNN
   hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
   // BPR
@@ -115,7 +116,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
   DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e,
-                   &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
+                   &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
   if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); }
@@ -307,6 +308,89 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   int grid = c->num_cu * c->wg_per_cu;
   if (grid > n) grid = n;
   HIPCHK(c, poi::launch_seq_predict(A, spatial, grid, (hipStream_t)stream, &c->tm));
+  return POI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_carnn(poi_ctx* c, const poi_carnn_params* P, const poi_seq_tables* T, bool need_q) {
+  if (!c || !P || !T) return fail(c, POI_EINVAL, "NULL ctx/params/tables");
+  if (P->dim <= 0 || P->dim % 4 != 0 || P->dim > 256) return fail(c, POI_ENOTSUP, "dim must be a multiple of 4 in [4, 256] (got %d)", P->dim);
+  if (!P->lt || !P->wd || !P->M || P->n_dist <= 0 || P->n_item <= 0) return fail(c, POI_EINVAL, "CA-RNN needs lt / wd / M, n_item > 0 and n_dist > 0");
+  if (!T->off || !T->p || !T->dp) return fail(c, POI_EINVAL, "tables: off/p/dp must be non-NULL");
+  if (need_q && (!T->q || !T->dq)) return fail(c, POI_EINVAL, "tables: q/dq must be non-NULL");
+  if (T->max_len <= 0 || T->len_max < T->max_len) return fail(c, POI_EINVAL, "tables: need 0 < max_len <= len_max");
+  return POI_OK;
+}
+
+static void fill_carnn(poi::CaArgs& A, const poi_carnn_params* P, const poi_seq_tables* T, const int32_t* uidx, int n) {
+  memset(&A, 0, sizeof A);
+  A.lt = P->lt; A.wd = P->wd; A.M = P->M; A.n_item = P->n_item; A.n_dist = P->n_dist; A.dim = P->dim;
+  A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max; A.cap = T->max_len;
+  A.uidx = uidx; A.n_seq = n; A.bcap = 1.0f;
+}
+
+int poi_carnn_step(poi_ctx* c, const poi_carnn_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
+                   float alpha, float lambda, float* out, void* stream) {
+  int rc = check_carnn(c, P, T, true);
+  if (rc) return rc;
+  if (!uidx || !out || n < 0) return fail(c, POI_EINVAL, "uidx/out NULL or n < 0");
+  if (n == 0) return POI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int D = P->dim;
+  int grid = c->num_cu * c->wg_per_cu;
+  if (grid > n) grid = n;
+  const size_t wsf = poi::carnn_ws_floats(D, T->max_len);
+  if ((rc = ensure(c, c->ca_ws, sizeof(float) * wsf * grid, st))) return rc;
+  if ((rc = ensure(c, c->ca_slab, sizeof(float) * (size_t)D * D * grid, st))) return rc;
+  if ((rc = ensure(c, c->g_lt, sizeof(float) * (size_t)(P->n_item + 1) * D, st))) return rc;
+  if ((rc = ensure(c, c->mult_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
+  if ((rc = ensure(c, c->nseq_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
+  if ((rc = ensure(c, c->g_wd, sizeof(float) * (size_t)(P->n_dist + 1) * D * D, st))) return rc;
+  if ((rc = ensure(c, c->mult_wd, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
+  if ((rc = ensure(c, c->nseq_wd, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
+  poi::CaArgs A;
+  fill_carnn(A, P, T, uidx, n);
+  A.out = out; A.bcap = c->batch_cap;
+  A.ws = (float*)c->ca_ws.p; A.ws_stride = wsf; A.slab = (float*)c->ca_slab.p;
+  A.g_lt = (float*)c->g_lt.p; A.mult_lt = (int*)c->mult_lt.p; A.nseq_lt = (int*)c->nseq_lt.p;
+  A.g_wd = (float*)c->g_wd.p; A.mult_wd = (int*)c->mult_wd.p; A.nseq_wd = (int*)c->nseq_wd.p;
+  HIPCHK(c, poi::launch_carnn_train(A, grid, alpha, lambda, st, &c->tm));
+  return POI_OK;
+}
+
+int poi_carnn_predict(poi_ctx* c, const poi_carnn_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n, float* hts, void* stream) {
+  int rc = check_carnn(c, P, T, false);
+  if (rc) return rc;
+  if (!uidx || !hts || n < 0) return fail(c, POI_EINVAL, "uidx/hts NULL or n < 0");
+  if (n == 0) return POI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = ensure(c, c->ca_scr, sizeof(float) * ((size_t)(P->n_dist + 1) * P->dim + (size_t)P->n_item + 2048), st))) return rc;
+  poi::CaArgs A;
+  fill_carnn(A, P, T, uidx, n);
+  A.hts = hts;
+  int grid = c->num_cu * 4;
+  if (grid > n) grid = n;
+  HIPCHK(c, poi::launch_carnn_predict(A, grid, (float*)c->ca_scr.p, st, &c->tm));
+  return POI_OK;
+}
+
+int poi_carnn_score_all(poi_ctx* c, const float* users, const float* items, const float* M, const float* dists, const double* coords,
+                        const double* cphi, const double* thr, const int32_t* last_poi, int32_t n, int32_t n_item, int32_t n_dist, int32_t dim,
+                        double dd, float* scores_out, void* stream) {
+  if (!c || !users || !items || !M || !dists || !coords || !cphi || !thr || !last_poi || !scores_out) return fail(c, POI_EINVAL, "poi_carnn_score_all: NULL argument");
+  if (n < 0 || n_item <= 0 || n_dist <= 0 || dim <= 0 || !(dd > 0)) return fail(c, POI_EINVAL, "bad sizes");
+  if (n == 0) return POI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->ca_scr, sizeof(float) * ((size_t)(n_dist + 1) * dim + (size_t)n_item + 2048), st))) return rc;
+  for (int32_t o = 0; o < n; o += 32768) {
+    const int32_t m = n - o < 32768 ? n - o : 32768;
+    HIPCHK(c, poi::launch_carnn_score(users + (size_t)o * dim, items, M, dists, coords, cphi, thr, last_poi + o, m, n_item, n_dist, dim, dd,
+                                      (float*)c->ca_scr.p, scores_out + (size_t)o * n_item, st, &c->tm));
+  }
   return POI_OK;
 }
 

@@ -143,6 +143,29 @@ size_t seq_ws_floats(int D, int NB, int cap);
 hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
 hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st, Timing* tm);
 
+// CA-RNN (carnn.hip)
+struct CaArgs {
+  float *lt, *wd, *M;                 // POI table (n_item+1, D), interval matrices (n_dist+1, H, D), input matrix (H, D); H == D
+  int n_item, n_dist, dim;
+  const int *off, *p, *q, *dp, *dq;
+  int len_max, cap;
+  const int* uidx;
+  int n_seq;
+  float* out;                         // train: loss per sequence
+  float* ws; size_t ws_stride;        // per-workgroup activations
+  float* slab;                        // per-workgroup d M
+  float *g_lt, *g_wd;                 // zero-initialised gradient tables
+  int *mult_lt, *nseq_lt, *mult_wd, *nseq_wd;
+  float* hts;                         // predict output
+  float bcap;
+};
+size_t carnn_ws_floats(int D, int cap);
+hipError_t launch_carnn_train(const CaArgs& A, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
+hipError_t launch_carnn_predict(const CaArgs& A, int grid, float* wrs, hipStream_t st, Timing* tm);
+hipError_t launch_carnn_score(const float* users, const float* items, const float* M, const float* dists, const double* coords, const double* cphi,
+                              const double* thr, const int* last_poi, int n, int N, int n_dist, int D, double dd, float* scratch, float* out,
+                              hipStream_t st, Timing* tm);
+
 // BPR-MF
 struct BprArgs {
   float *ux, *lt;

@@ -37,6 +37,9 @@ def build_model(ds, p, device="cuda:0", seed=None):
     if p["gru"] == 1:
         return models.OboGru(train=tab, test=None, alpha_lambda=al, n_user=ds.n_user, n_item=ds.n_item, n_in=size, n_hidden=size,
                              device=device, seed=seed)
+    if p["gru"] == 3:                                                   # prog_bpr_gru_spatial.py:141-151
+        return models.OboCARNN(train=tab, test=None, dist=None, alpha_lambda=al, n_user=ds.n_user, n_item=ds.n_item,
+                               n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=size, n_hidden=size, device=device, seed=seed, coords=ds.coords)
     return models.OboSpatialGru(train=tab, test=None, dist=None, alpha_lambda=al, n_user=ds.n_user, n_item=ds.n_item,
                                 n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=size, n_hidden=size, device=device, seed=seed,
                                 coords=ds.coords)
@@ -120,7 +123,7 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
                 model.resample_negatives_device(p.get("seed", 0) * 1000003 + epoch)
             else:
                 ds.resample_negatives(rng_neg)
-                model.set_negatives_csr(ds.tra_q, ds.tes_q, ds.tra_dq if p["gru"] == 2 else None)
+                model.set_negatives_csr(ds.tra_q, ds.tes_q, ds.tra_dq if p["gru"] in (2, 3) else None)
         t0 = time.time()
         order = np.random.default_rng(123 + epoch).permutation(U).astype(np.int32)      # :236-238
         loss = 0.0
@@ -152,6 +155,9 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
         if p["gru"] == 0:
             model.update_trained_users()
         elif p["gru"] == 1:
+            model.update_trained_users(torch.cat([model.predict_device(se) for se in ses_tes]))
+        elif p["gru"] == 3:                                         # :293-300
+            model.update_trained_dists()
             model.update_trained_users(torch.cat([model.predict_device(se) for se in ses_tes]))
         else:
             model.update_trained_dists()

@@ -524,6 +524,119 @@ class OboSpatialGru(GruBasic):
 
 
 # =================================================================================================
+class OboCARNN(GruBasic):
+    """public/CA_RNN.py:46-227 - CA-RNN (flag 3 of prog_bpr_gru_spatial.py:141-151): interval-specific transition
+    matrices wd[(n_dist+1), H, D], input matrix M (H, D), sigmoid RNN, BPR.  Same ctor as the reference; `ulptai` (the
+    reference's U x N usrs_last_poi_to_all_intervals matrix) is accepted for signature compatibility but never
+    uploaded: with coords= the scoring kernel computes those bins on the fly (bit-identical, tested)."""
+
+    spatial = True          # has distance-bin tables (negatives refresh computes dq)
+
+    def __init__(self, train, test, dist, alpha_lambda, n_user, n_item, n_dists, n_in, n_hidden, ulptai=None,
+                 device="cuda:0", init=None, seed=None, coords=None):
+        n_dist, dd = n_dists
+        self.n_dist, self.dd = int(n_dist), float(dd)
+        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device=device, init=init, seed=seed)
+        if self._csr is not None:
+            dp, dq, tes_dist_masks = (np.ascontiguousarray(v, np.int32) for v in (self._csr.dp, self._csr.dq, self._csr.tes_dp))
+        else:
+            tra_dist_masks, tes_dist_masks, tra_dist_neg_masks = dist
+            _, dp = padded_to_csr(tra_dist_masks, self._lens)
+            _, dq = padded_to_csr(tra_dist_neg_masks, self._lens)
+        self._check_ids("train distance bins", dp, self.n_dist); self._check_ids("negative distance bins", dq, self.n_dist)
+        self.dp, self.dq = torch.as_tensor(dp).to(self.device), torch.as_tensor(dq).to(self.device)
+        self.tes_dist_masks = self._dev(tes_dist_masks, torch.int32)
+        rng = np.random.default_rng(seed + 1) if seed is not None else np.random
+        u = lambda *s: rng.uniform(-0.5, 0.5, s)
+        D, NB = self.dim, self.n_dist + 1
+        init = init or {}
+        g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
+        self.M = Shared(self._dev(g("M", lambda: u(D, D))))                                # CA_RNN.py:55-56
+        self.wd = Shared(self._dev(g("wd", lambda: u(NB, D, D))))                          # :61-62
+        self.trained_dists = Shared(self._dev(u(NB, D, D)))                                # :66-67
+        self.coords = None if coords is None else self._dev(np.asarray(coords, np.float64), torch.float64)
+        self._cphi = None if coords is None else self._dev(cos_lat(coords), torch.float64)
+        self._binthr = None if coords is None else self._dev(bin_thresholds(self.dd * 1000.0, self.n_dist), torch.float64)
+        self.params = [self.M]
+        self.l2 = _L2(self, ["lt", "wd", "M"])                                             # :70-76
+
+    def s_update_neg_masks(self, tra_buys_neg_masks, tes_buys_neg_masks, tra_dist_neg_masks):
+        """public/CA_RNN.py:80-84."""
+        self.update_neg_masks(tra_buys_neg_masks, tes_buys_neg_masks)
+        _, dq = padded_to_csr(tra_dist_neg_masks, self._lens)
+        self.dq = torch.as_tensor(dq).to(self.device)
+
+    def update_trained_dists(self):
+        """public/CA_RNN.py:86-89."""
+        self.trained_dists.t.copy_(self.wd.t)
+
+    def _cparams(self, snapshot=False):
+        P = _lib.CarnnParams()
+        P.lt = (self.trained_items if snapshot else self.lt).t.data_ptr()
+        P.wd = (self.trained_dists if snapshot else self.wd).t.data_ptr()
+        P.M = self.M.t.data_ptr()
+        P.n_item, P.n_dist, P.dim = self.n_item, self.n_dist, self.dim
+        return P
+
+    def _tables(self):
+        T = super()._tables()
+        T.dp, T.dq = self.dp.data_ptr(), self.dq.data_ptr()
+        return T
+
+    def train(self, idx):
+        """seq_train(uidx) -> los (public/CA_RNN.py:160-170,219-221)."""
+        return float(self.train_batch(np.atleast_1d(idx))[0])
+
+    def train_batch(self, idxs, sync=True):
+        ids, _ = self._ids(idxs)
+        n = ids.numel()
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        P, T = self._cparams(), self._tables()
+        self.ctx.check(self.lib.poi_carnn_step(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n,
+                                               self.alpha_lambda[0], self.alpha_lambda[1], _ptr(out), self._stream()))
+        return out.cpu().numpy() if sync else out
+
+    def predict_device(self, idxs):
+        ids, _ = self._ids(idxs)
+        n = ids.numel()
+        hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        P, T = self._cparams(snapshot=True), self._tables()
+        self.ctx.check(self.lib.poi_carnn_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n, _ptr(hts), self._stream()))
+        return hts
+
+    def compute_sub_all_scores_device(self, start_end):
+        """public/CA_RNN.py:91-101 -> (n, n_item) device tensor."""
+        if self.coords is None:
+            raise _lib.PoiError("OboCARNN scoring needs coords= at construction (the interval of (last train POI, POI) is computed on the device)")
+        ids, users, lo = self._users_rows(start_end)
+        n = ids.numel()
+        if getattr(self, "_last_poi", None) is None:
+            lens = torch.as_tensor(self._off_host[1:].astype(np.int64) - 1).to(self.device)
+            self._last_poi = self.p.index_select(0, lens).contiguous()
+        lp = self._rows(self._last_poi, ids, lo)
+        out = torch.empty((n, self.n_item), dtype=torch.float32, device=self.device)
+        self.ctx.check(self.lib.poi_carnn_score_all(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), _ptr(self.M.t), _ptr(self.trained_dists.t),
+                                                    _ptr(self.coords), _ptr(self._cphi), _ptr(self._binthr), _ptr(lp), n, self.n_item, self.n_dist,
+                                                    self.dim, self.dd * 1000.0, _ptr(out), self._stream()))
+        return out
+
+    def compute_sub_topk(self, start_end, k, return_scores=False):
+        """Valuate.py:132-146 on the CA-RNN scores: the (n, n_item) rows stay on the device, poi_topk selects."""
+        ids, _ = self._ids(start_end)
+        n = ids.numel()
+        idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
+        step = max(1, min(n, (1 << 28) // max(self.n_item, 1)))           # <= 1 GiB of scores at a time
+        a = np.atleast_1d(np.asarray(start_end)) if not isinstance(start_end, torch.Tensor) else start_end
+        for o in range(0, n, step):
+            full = self.compute_sub_all_scores_device(a[o:o + step])
+            m = full.shape[0]
+            self.ctx.check(self.lib.poi_topk(self.ctx.handle, _ptr(full), m, self.n_item, int(k), ctypes.c_void_p(idx.data_ptr() + 4 * o * k),
+                                             ctypes.c_void_p(sc.data_ptr() + 4 * o * k) if sc is not None else None, self._stream()))
+        return (idx, sc) if return_scores else idx
+
+
+# =================================================================================================
 class MfBasic(_Base):
     """public/BPR.py:28-134."""
 

@@ -139,3 +139,74 @@ def test_bpr_step_matches_autograd():
     assert np.isclose(loss, -upq.item(), rtol=1e-13)
     assert np.allclose(Pn['ux'], P['ux'] - alpha * T['ux'].grad.numpy(), rtol=1e-12, atol=1e-15)
     assert np.allclose(Pn['lt'], P['lt'] - alpha * T['lt'].grad.numpy(), rtol=1e-12, atol=1e-15)
+
+
+# ---- CA-RNN (public/CA_RNN.py:105-170) ---------------------------------------------------------------------------------
+def _toy_carnn(seed, N=19, B=6, D=5, LM=9, L=6):
+    rng = np.random.default_rng(seed)
+    P = O.init_carnn_params(rng, N, B, D)
+    p = np.full(LM, N); q = np.full(LM, N); dp = np.full(LM, B); dq = np.full(LM, B)
+    p[:L] = rng.integers(0, 6, L); q[:L] = rng.integers(4, N, L)                  # repeated POIs on purpose
+    dp[1:L] = rng.integers(0, B + 1, L - 1); dq[1:L] = rng.integers(0, B + 1, L - 1)      # shared interval matrices
+    mask = np.array([1] * L + [0] * (LM - L))
+    return P, p, q, dp, dq, mask
+
+
+def _torch_carnn_cost(T, p, q, dp, dq, L, lam):
+    lt, M, wd = T['lt'], T['M'], T['wd']
+    xps, xqs, wdps, wdqs = lt[p], lt[q], wd[dp], wd[dq]
+    h = torch.zeros(lt.shape[1], dtype=F64)
+    tot = 0.0
+    for t in range(L - 1):
+        h = torch.sigmoid(M @ xps[t] + wdps[t] @ h)
+        yp = (wdps[t + 1] @ h) @ (M @ xps[t + 1])
+        yq = (wdqs[t + 1] @ h) @ (M @ xqs[t + 1])
+        tot = tot + torch.log(torch.sigmoid(yp - yq))
+    los = -tot
+    l2 = sum((v ** 2).sum() for v in (xps, xqs, M, wdps, wdqs))
+    return los + 0.5 * lam * l2, los
+
+
+@pytest.mark.parametrize("seed,L", [(0, 6), (1, 4), (2, 9)])
+def test_carnn_step_matches_autograd(seed, L):
+    alpha, lam = 0.01, 0.001
+    P, p, q, dp, dq, mask = _toy_carnn(seed, L=L)
+    T = {k: torch.tensor(np.asarray(v, float), dtype=F64, requires_grad=True) for k, v in P.items() if k != 'h0'}
+    cost, los = _torch_carnn_cost(T, p, q, dp, dq, L, lam)
+    cost.backward()
+    Pn, out = O.carnn_step(P, p, q, dp, dq, mask, alpha, lam)
+    assert np.isclose(out, los.item(), rtol=1e-13)
+    c0, l0 = O.carnn_forward_cost(P, p, q, dp, dq, mask, lam)
+    assert np.isclose(c0, cost.item(), rtol=1e-13) and np.isclose(l0, los.item(), rtol=1e-13)
+    assert np.allclose(Pn['M'], P['M'] - alpha * T['M'].grad.numpy(), rtol=1e-11, atol=1e-14)
+    R = np.unique(np.concatenate((p, q))); S = np.unique(np.concatenate((dp, dq)))
+    lt_exp = P['lt'].copy(); lt_exp[R] -= alpha * T['lt'].grad.numpy()[R]
+    wd_exp = P['wd'].copy(); wd_exp[S] -= alpha * T['wd'].grad.numpy()[S]
+    assert np.allclose(Pn['lt'], lt_exp, rtol=1e-11, atol=1e-14)
+    assert np.allclose(Pn['wd'], wd_exp, rtol=1e-11, atol=1e-14)
+    assert np.array_equal(Pn['wd'][np.setdiff1d(np.arange(P['wd'].shape[0]), S)], P['wd'][np.setdiff1d(np.arange(P['wd'].shape[0]), S)])
+
+
+def test_carnn_predict_and_scores_follow_the_literal_broadcast_sums():
+    """The predict / scoring graphs of CA-RNN add-then-sum (public/CA_RNN.py:97-100,191): restated independently with
+    explicit broadcasting in torch."""
+    rng = np.random.default_rng(3)
+    N, B, D, n, LM = 17, 5, 4, 3, 6
+    P = O.init_carnn_params(rng, N, B, D)
+    lens = [6, 4, 5]
+    p_rows = rng.integers(0, N, (n, LM)); d_rows = rng.integers(0, B + 1, (n, LM))
+    masks = np.array([[1] * L + [0] * (LM - L) for L in lens])
+    hts = O.carnn_predict(P, P['lt'], P['wd'], p_rows, d_rows, masks)
+    M, wd, lt = (torch.tensor(P[k], dtype=F64) for k in ('M', 'wd', 'lt'))
+    for k in range(n):
+        h = torch.zeros(1, D, dtype=F64)
+        for t in range(lens[k]):
+            p_t = lt[p_rows[k, t]][None, :]; wd_t = wd[d_rows[k, t]][None]
+            h = torch.sigmoid(p_t @ M.T + torch.sum(wd_t + h.reshape(1, 1, D), 2))
+        assert np.allclose(hts[k], h[0].numpy(), rtol=1e-13)
+    ul = rng.integers(0, B + 1, (n, N))
+    sc = O.carnn_score_all(hts, P['lt'], P['M'], P['wd'], ul)
+    users = torch.tensor(hts, dtype=F64)
+    h_W = torch.sum(wd[torch.tensor(ul)] + users.reshape(n, 1, 1, D), 3)
+    r_M = (lt[:-1] @ M.T).reshape(1, N, D)
+    assert np.allclose(sc, (-torch.sum(h_W + r_M, 2)).numpy(), rtol=1e-12)
