@@ -26,11 +26,14 @@ import torch.distributed as dist
 from . import _lib
 
 RULES = {"sum": _lib.SYNC_SUM, "mean": _lib.SYNC_MEAN, "mean_touched": _lib.SYNC_MEAN_TOUCHED}
-# the embedding tables: every replica's sparse updates count in full (a row touched by one replica only keeps its whole
-# update, as inside a launch); the dense weights and the 201 distance-bin rows, which EVERY replica moves in every
-# launch, are averaged - a sum would multiply their step (and their L2 decay) by the world size.
-DEFAULT_RULES = {"lt": "sum", "ux": "sum", "di": "mean", "ui": "mean", "wh": "mean", "bi": "mean", "vs": "mean", "bs": "mean",
-                 "wd": "mean", "loss_weight": "mean"}
+# Evidence (tools/quality.py --world 8, N replicas emulated on one GPU, Gowalla shape, cap 64, 120 epochs; DESIGN.md "Multi-GPU"):
+# "sum" on everything diverges (a hot row already moved by up to `cap` updates inside every replica's launch moves 8 x that),
+# lt "sum" + dense "mean" learns slowest (recall@20 0.27), "mean" on everything 0.45, against 0.55 for one GPU with four launches
+# per epoch.  So: the POI table takes the mean over the replicas that MOVED the row (a row only one shard's users visit keeps
+# its whole update, hot rows are averaged - the launch-level batch rule one level up), everything every replica moves in
+# every launch (distance-bin rows, dense weights) is averaged (model averaging, as in local SGD).
+DEFAULT_RULES = {"lt": "mean_touched", "ux": "mean_touched", "wd_table": "mean_touched", "di": "mean", "ui": "mean", "wh": "mean", "bi": "mean",
+                 "vs": "mean", "bs": "mean", "wd": "mean", "loss_weight": "mean", "M": "mean"}
 
 
 class _DevArray:
@@ -126,8 +129,9 @@ class ReplicaSync:
                       torch.distributed.all_reduce on the same buffer (default: when the backend is nccl)
     force           : run the whole delta / all-reduce / apply path even at world size 1 (self-check)"""
 
-    def __init__(self, tensors, rules=None, group=None, backend=None, ctx=None, force=False, own_comm=None):
+    def __init__(self, tensors, rules=None, group=None, backend=None, ctx=None, force=False, own_comm=None, names=None):
         self.tensors = list(tensors)
+        self.names = list(names) if names is not None else ["t%d" % i for i in range(len(self.tensors))]
         rules = list(rules) if rules is not None else ["sum"] * len(self.tensors)
         if len(rules) != len(self.tensors) or any(r not in RULES for r in rules):
             raise ValueError("one rule of %s per tensor" % sorted(RULES))
@@ -167,7 +171,7 @@ class ReplicaSync:
 
     def report(self):
         """Self-validation block for bench.py: what the collective saw and whether the replicas agree bit for bit."""
-        out = {"world_size": self.world, "rules": dict(zip(("t%d" % i for i in range(len(self.rules))), self.rules)),
+        out = {"world_size": self.world, "rules": dict(zip(self.names, self.rules)),
                "collective": "rccl (library communicator, poi_allreduce_tables)" if self.own_comm else
                ("torch.distributed.all_reduce" if self.active else "none (world size 1)"), "epochs_synced": self.epochs}
         if isinstance(self.backend, HipSyncBackend):
@@ -198,4 +202,4 @@ def model_sync(model, names=None, rules=None, **kw):
     """ReplicaSync over a model's parameters with DEFAULT_RULES (override per name with rules={...})."""
     names = names or [n for n in ("lt", "di", "ux", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight") if hasattr(model, n)]
     r = dict(DEFAULT_RULES); r.update(rules or {})
-    return ReplicaSync([getattr(model, n).t for n in names], rules=[r[n] for n in names], ctx=model.ctx, **kw)
+    return ReplicaSync([getattr(model, n).t for n in names], rules=[r[n] for n in names], ctx=model.ctx, names=names, **kw)

@@ -151,3 +151,16 @@ def test_rccl_entry_points_world_size_1(pa):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_emulated_replicas_converge_like_one_gpu(pa):
+    """Convergence of the per-epoch reconciliation with DEFAULT_RULES: 4 replicas emulated on one GPU (each trains its user
+    shard from the epoch-start snapshot in two launches, deltas combined by poi_sync_*) against one GPU making the same
+    number of sequential launches per epoch, on data with a next-POI signal.  Same epochs -> recall@20 within 15 %, and
+    far above the popularity baseline's neighbourhood (measured at the Gowalla shape: DESIGN.md "Multi-GPU")."""
+    from tools import quality
+    common = ["--shape", "foursquare", "--users", "4000", "--cap", "16", "--epochs", "40", "--eval-every", "40"]
+    one = quality.main(common + ["--batch", "2000"])[-1]
+    four = quality.main(common + ["--batch", "500", "--world", "4"])[-1]
+    assert one["recall"] > 0.25 and four["recall"] > 0.25, (one, four)
+    assert four["recall"] >= 0.85 * one["recall"], (one, four)

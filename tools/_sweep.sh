@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_carnn.py -m gpu -q --timeout 900 -x > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error|assert" gpurun_out/t.log | tail -12
+python -m pytest tests/test_gpu_multi.py -m gpu -q --timeout 900 -x -k emulated > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error|assert|recall" gpurun_out/t.log | tail -12

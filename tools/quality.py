@@ -24,7 +24,9 @@ def evaluate(model, ds, p, ses_tes, ses_auc):
     return m["at"][20]["recall"], m["auc"]
 
 
-def main():
+def main(argv=None):
+    """Runs the experiment; returns the list of per-evaluation records (also printed as JSON lines)."""
+    records = []
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="foursquare")
     ap.add_argument("--batch", type=int, default=1)
@@ -34,12 +36,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.0)
     ap.add_argument("--world", type=int, default=1)
     ap.add_argument("--rules", default="default", help="default | sum | mean | mean_touched (all tensors)")
+    ap.add_argument("--shard-batch", type=int, default=0, help="users per launch inside a replica (default: --batch)")
     ap.add_argument("--local", type=float, default=0.8)
     ap.add_argument("--users", type=int, default=0)
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--eval-every", type=int, default=1)
     ap.add_argument("--limit", type=int, default=0, help="train only the first LIMIT users of each epoch's shuffled order (time-boxed B=1 runs)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
     n_user = a.users or n_user; D = a.dim or D
     ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928, local=a.local)
@@ -95,10 +98,15 @@ def main():
         if (epoch + 1) % a.eval_every and not last:
             continue
         rec, auc = evaluate(model, ds, p, ses_tes, ses_auc)
+        records.append({"epoch": epoch, "recall": rec, "auc": auc, "train_s": t_train})
         print(json.dumps({"epoch": epoch, "train_s": round(t_train, 3), "seq_per_s": round((a.limit or n_user) * (epoch + 1) / t_train, 1),
                           "recall@20": round(rec, 4), "auc": round(auc, 4), "batch": a.batch, "cap": a.cap, "alpha": a.alpha, "world": a.world}), flush=True)
         if a.seconds and t_train >= a.seconds:
             break
+    model.ctx.set_batch_cap(1.0)
+    if sync is not None:
+        sync.close()
+    return records
 
 
 if __name__ == "__main__":
