@@ -134,9 +134,12 @@ int poi_carnn_score_all(poi_ctx* ctx, const float* users, const float* items, co
 /* ---- a6: predict - seq_predict(start_end), public/GRU_Spatial.py:231-288, public/GRU.py:154-205
  * prm->lt / prm->di must point at the SNAPSHOTS trained_items / trained_dists.
  * hts (n, D) = hidden state after the user's whole train sequence; sts (n, n_dist+1) =
- * softmax(vs.h + bs) (spatial only; pass NULL for OboGru). */
+ * softmax(vs.h + bs) (spatial only; pass NULL for OboGru).
+ * out_row (n, device) or NULL: the result of uidx[k] is written to output row out_row[k] instead of k - the caller
+ * can hand the users over sorted by descending length (a 16-sequence recurrent tile runs for its longest member) and
+ * still receive the rows in its own order, with no gather / scatter pass of its own. */
 int poi_gru_predict(poi_ctx* ctx, const poi_gru_params* prm, const poi_seq_tables* tab,
-                    const int32_t* uidx, int32_t n, float* hts, float* sts, void* stream);
+                    const int32_t* uidx, const int32_t* out_row, int32_t n, float* hts, float* sts, void* stream);
 
 /* ---- a8: all-POI scoring - compute_sub_all_scores(start_end) --------------------------------
  * public/GRU.py:93-96, public/BPR.py:76-79; spatial variant adds wd*prob, public/GRU_Spatial.py:117-125.

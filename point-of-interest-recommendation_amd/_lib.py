@@ -51,7 +51,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p]),
     "poi_gru_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
                              c_void_p, c_void_p]),
-    "poi_gru_predict": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_void_p, c_void_p,
+    "poi_gru_predict": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                 c_void_p]),
     "poi_carnn_step": (c_int, [c_void_p, POINTER(CarnnParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float, c_void_p, c_void_p]),
     "poi_carnn_predict": (c_int, [c_void_p, POINTER(CarnnParams), POINTER(SeqTables), c_void_p, c_int32, c_void_p, c_void_p]),

@@ -287,7 +287,7 @@ int poi_gru_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, c
   return seq_step(c, P, T, uidx, n, alpha, lambda, out, stream, false);
 }
 
-int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
+int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, const int32_t* out_row, int32_t n,
                     float* hts, float* sts, void* stream) {
   const bool spatial = P && P->di != nullptr;
   int rc = check_gru(c, P, T, spatial, false);
@@ -298,13 +298,13 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (use_tile(c, P, spatial, n)) {
     poi::TeArgs E;
     if ((rc = te_setup(c, E, P, T, uidx, n, true, spatial, (hipStream_t)stream))) return rc;
-    E.hts = hts; E.sts = sts;
+    E.hts = hts; E.sts = sts; E.out_row = out_row;
     HIPCHK(c, poi::launch_te_predict(E, c->num_cu, (hipStream_t)stream, &c->tm));
     return POI_OK;
   }
   poi::SeqArgs A;
   fill_args(A, P, T, uidx, n);
-  A.hts = hts; A.sts = sts;
+  A.hts = hts; A.sts = sts; A.out_row = out_row;
   int grid = c->num_cu * c->wg_per_cu;
   if (grid > n) grid = n;
   HIPCHK(c, poi::launch_seq_predict(A, spatial, grid, (hipStream_t)stream, &c->tm));

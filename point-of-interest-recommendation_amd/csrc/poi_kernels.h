@@ -47,8 +47,8 @@ struct SeqArgs {
   float* slab;                      // per-workgroup dense-gradient slabs
   float *g_lt, *g_di;               // zero-initialised gradient tables
   int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
-  // predict outputs
-  float *hts, *sts;
+  // predict outputs (row k of the launch goes to output row out_row[k], or k when out_row is null)
+  float *hts, *sts; const int* out_row;
   float bcap;        // batch rule: at most `bcap` of the touching sequences' updates count (1 = mean rule), include/poi_hip.h
 };
 
@@ -99,7 +99,7 @@ struct TeArgs {
   float* hslab; int hstride;          // te_head's per-workgroup d bs | d wd partials (n_head x hstride)
   DenseLayout dl;
   int *mult_lt, *nseq_lt, *mult_di, *nseq_di;    // only the padding rows' entries are used (analytic touches)
-  float *hts, *sts;
+  float *hts, *sts; const int* out_row;     // predict: row k of the launch -> output row out_row[k] (null: k)
   // sorted segmented scatter (te_scatter.hip): every table touch of the launch becomes one (row key,
   // entry) pair; a stable radix sort groups them by row, and each row's update is a plain ordered sum
   int key_bits;                       // bits of the largest key (= sentinel = number of table rows)

@@ -364,10 +364,11 @@ __global__ __launch_bounds__(POI_BLOCK) void seq_predict_kernel(SeqArgs A) {
       __syncthreads();
       cell_forward(A, S, D, XW, nullptr, nullptr, nullptr, nullptr);
     }
-    for (int j = tid; j < D; j += POI_BLOCK) A.hts[(size_t)k * D + j] = S.hcur[j];
+    const int ko = A.out_row ? A.out_row[k] : k;
+    for (int j = tid; j < D; j += POI_BLOCK) A.hts[(size_t)ko * D + j] = S.hcur[j];
     if (SPATIAL && A.sts) {
       head_softmax(A, S, D, NB);
-      for (int kk = tid; kk < NB; kk += POI_BLOCK) A.sts[(size_t)k * NB + kk] = S.os[kk];
+      for (int kk = tid; kk < NB; kk += POI_BLOCK) A.sts[(size_t)ko * NB + kk] = S.os[kk];
     }
     __syncthreads();
   }

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r, k = tile * 16 + i;
-      if (k < A.n_seq) A.hts[(size_t)k * D + col] = hcur[r];
+      if (k < A.n_seq) A.hts[(size_t)(A.out_row ? A.out_row[k] : k) * D + col] = hcur[r];
     }
   }
 }

@@ -101,16 +101,27 @@ class _Base:
         n = ids.numel()
         return table[lo:lo + n] if lo is not None else table.index_select(0, ids.long()).contiguous()
 
-    def _by_length(self, ids):
-        """(ids sorted by descending sequence length, order) for the recurrent kernels: a 16-sequence tile runs for
-        its longest member, so homogeneous tiles halve the forward pass of a full evaluation.  `order` maps the
-        sorted position back: out[order] = out_sorted.  None when the launch is too small to matter."""
-        if ids.numel() < 64:
+    def _by_length(self, idxs):
+        """(ids sorted by descending sequence length, out_row) for the recurrent kernels: a 16-sequence tile runs for
+        its longest member, so homogeneous tiles halve the forward pass of a full evaluation.  out_row[k] = position of
+        the k-th sorted id in the caller's order: poi_gru_predict writes its result there, so nothing is permuted
+        afterwards.  The order is computed on the host from the host-side lengths (once per distinct id list: cached for
+        the common "all users" / contiguous-range calls).  Device tensors and small launches are taken as they come."""
+        if isinstance(idxs, torch.Tensor):
+            return self._ids(idxs)[0], None
+        a = np.atleast_1d(np.asarray(idxs)).astype(np.int64)
+        ids, lo = self._ids(a)
+        if len(a) < 64:
             return ids, None
-        if getattr(self, "_lens_dev", None) is None:
-            self._lens_dev = torch.as_tensor(np.asarray(self._lens, np.int32)).to(self.device)
-        order = torch.argsort(self._lens_dev.index_select(0, ids.long()), descending=True, stable=True)
-        return ids.index_select(0, order).contiguous(), order
+        key = (int(a[0]), len(a)) if lo is not None else None
+        cache = self.__dict__.setdefault("_order_cache", {})
+        if key is not None and key in cache:
+            return cache[key]
+        order = np.argsort(-np.asarray(self._lens)[a], kind="stable").astype(np.int32)
+        out = (torch.as_tensor(a[order].astype(np.int32)).to(self.device), torch.as_tensor(order).to(self.device))
+        if key is not None and len(cache) < 64:
+            cache[key] = out
+        return out
 
     # ---- tables -------------------------------------------------------------------------------
     @staticmethod
@@ -294,14 +305,13 @@ class GruBasic(_Base):
         return self.predict_device(idxs).cpu().numpy()
 
     def predict_device(self, idxs):
-        ids, _ = self._ids(idxs)
-        ids, order = self._by_length(ids)
+        ids, out_row = self._by_length(idxs)
         n = ids.numel()
         hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         P, T = self._params(snapshot=True), self._tables()
-        self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n, _ptr(hts), None,
+        self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), _ptr(out_row), n, _ptr(hts), None,
                                                 self._stream()))
-        return hts if order is None else torch.empty_like(hts).index_copy_(0, order, hts)
+        return hts
 
 
 class OboGru(GruBasic):
@@ -510,17 +520,14 @@ class OboSpatialGru(GruBasic):
         return [h.cpu().numpy(), s.cpu().numpy()]
 
     def predict_device(self, idxs):
-        ids, _ = self._ids(idxs)
-        ids, order = self._by_length(ids)
+        ids, out_row = self._by_length(idxs)
         n = ids.numel()
         hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         sts = torch.empty((n, self.n_dist + 1), dtype=torch.float32, device=self.device)
         P, T = self._params(snapshot=True), self._tables()
-        self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), n, _ptr(hts), _ptr(sts),
+        self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), _ptr(out_row), n, _ptr(hts), _ptr(sts),
                                                 self._stream()))
-        if order is None:
-            return hts, sts
-        return torch.empty_like(hts).index_copy_(0, order, hts), torch.empty_like(sts).index_copy_(0, order, sts)
+        return hts, sts
 
 
 # =================================================================================================
