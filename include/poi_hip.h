@@ -156,7 +156,8 @@ int poi_score_topk(poi_ctx* ctx, const float* users, const float* items, int32_t
                    int32_t dim, const float* wd, const float* prob, int32_t k,
                    int32_t* idx_out, float* score_out, void* stream);
 
-/* ---- a9 alone: top-K of a given score matrix (checks the selection independently of the GEMM) */
+/* ---- a9 alone: top-K of a given score matrix, k <= 64 (checks the selection independently of the GEMM; also the path for
+ * cut-offs beyond the fused kernels' k <= 32, e.g. at_nums = [5, 10, 15, 20, 30, 50] of public/Valuate.py:126) */
 int poi_topk(poi_ctx* ctx, const float* scores, int32_t n, int32_t n_item, int32_t k,
              int32_t* idx_out, float* score_out, void* stream);
 

@@ -521,7 +521,7 @@ int poi_score_topk_ulptai(poi_ctx* c, const float* users, const float* items, in
 int poi_topk(poi_ctx* c, const float* scores, int32_t n, int32_t n_item, int32_t k, int32_t* idx_out, float* score_out,
              void* stream) {
   if (!c || !scores || !idx_out) return fail(c, POI_EINVAL, "poi_topk: NULL argument");
-  if (k <= 0 || k > 32 || k > n_item) return fail(c, POI_ENOTSUP, "top-K supports 1 <= k <= min(32, n_item) (got %d)", k);
+  if (k <= 0 || k > 64 || k > n_item) return fail(c, POI_ENOTSUP, "poi_topk supports 1 <= k <= min(64, n_item) (got %d)", k);
   if (n < 0) return fail(c, POI_EINVAL, "n < 0");
   if (n == 0) return POI_OK;
   HIPCHK(c, hipSetDevice(c->device));

@@ -486,15 +486,16 @@ __global__ __launch_bounds__(POI_BLOCK) void topk_rows_kernel(const float* __res
   int cnt = 0;
   float thr = -INFINITY;
   auto compact = [&]() {
-    // best K of up to 128 pending candidates: sort each half, then the 2K survivors
+    // best K (<= 64) of up to 128 pending candidates: sort each half best-first; max(a[i], b[63 - i]) then holds the 64
+    // best of the 128 (bitonic partition), one more sort orders them
     float s0 = lane < cnt ? cs[w][lane] : -INFINITY; int i0 = lane < cnt ? ci[w][lane] : INT_MAX;
     float s1 = lane + 64 < cnt ? cs[w][lane + 64] : -INFINITY; int i1 = lane + 64 < cnt ? ci[w][lane + 64] : INT_MAX;
     wave_sort_desc(s0, i0);
     wave_sort_desc(s1, i1);
-    // lanes [0,K) <- first list, lanes [K,2K) <- second list (2K <= 64)
-    const float t1 = __shfl(s1, (lane - K) & 63, 64); const int j1 = __shfl(i1, (lane - K) & 63, 64);
-    float s = lane < K ? s0 : (lane < 2 * K ? t1 : -INFINITY);
-    int idx = lane < K ? i0 : (lane < 2 * K ? j1 : INT_MAX);
+    const float t1 = __shfl(s1, 63 - lane, 64); const int j1 = __shfl(i1, 63 - lane, 64);
+    const bool take0 = better(s0, i0, t1, j1) || (s0 == t1 && i0 == j1);
+    float s = take0 ? s0 : t1;
+    int idx = take0 ? i0 : j1;
     wave_sort_desc(s, idx);
     wave_fence();
     if (lane < K) { cs[w][lane] = s; ci[w][lane] = idx; }

@@ -68,6 +68,9 @@ def device_rank_metrics(model, starts_ends_tes, at_nums):
     """Fused top-K + metric accumulation on the device: only (len(at_nums), 3) doubles reach the host."""
     import ctypes
     import torch
+    at_nums = list(at_nums)
+    if not at_nums or len(at_nums) > 8 or any(b <= a for a, b in zip(at_nums, at_nums[1:])) or at_nums[0] <= 0 or at_nums[-1] > 64:
+        raise ValueError("at_nums must be 1..8 strictly ascending cut-offs <= 64 (got %r)" % (at_nums,))
     kmax = at_nums[-1]
     acc = torch.zeros((len(at_nums), 3), dtype=torch.float64, device=model.device)
     at = torch.as_tensor(np.asarray(at_nums, np.int32)).to(model.device)

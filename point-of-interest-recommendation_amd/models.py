@@ -239,6 +239,8 @@ class _Base:
     def compute_sub_topk(self, start_end, k, return_scores=False):
         """Fused a8+a9: (n, k) int32 indices sorted by descending score (public/Valuate.py:132-146)
         without materialising the (n, n_item) score matrix."""
+        if k > 32:
+            return self._topk_from_scores(start_end, k, return_scores)
         ids, users, lo = self._users_rows(start_end)
         n = ids.numel()
         wd, prob = self._prob_rows(ids, lo)
@@ -246,6 +248,23 @@ class _Base:
         sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
         self.ctx.check(self.lib.poi_score_topk(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim,
                                                _ptr(wd), _ptr(prob), int(k), _ptr(idx), _ptr(sc), self._stream()))
+        return (idx, sc) if return_scores else idx
+
+
+    def _topk_from_scores(self, start_end, k, return_scores=False):
+        """Cut-offs beyond the fused kernels' k <= 32 (e.g. at_nums = [5, 10, 15, 20, 30, 50], public/Valuate.py:126):
+        explicit score rows (compute_sub_all_scores_device, <= 1 GiB at a time) + poi_topk (k <= 64)."""
+        if k > 64:
+            raise _lib.PoiError("top-K supports k <= 64 (got %d)" % k)
+        a = start_end if isinstance(start_end, torch.Tensor) else np.atleast_1d(np.asarray(start_end))
+        n = len(a)
+        idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
+        step = max(1, min(n, (1 << 28) // max(self.n_item, 1)))
+        for o in range(0, n, step):
+            full = self.compute_sub_all_scores_device(a[o:o + step])
+            self.ctx.check(self.lib.poi_topk(self.ctx.handle, _ptr(full), full.shape[0], self.n_item, int(k), ctypes.c_void_p(idx.data_ptr() + 4 * o * k),
+                                             ctypes.c_void_p(sc.data_ptr() + 4 * o * k) if sc is not None else None, self._stream()))
         return (idx, sc) if return_scores else idx
 
 
@@ -453,6 +472,8 @@ class OboSpatialGru(GruBasic):
         """Fused scoring + top-K.  With bin probabilities (update_trained_sus) and coordinates, contiguous
         user ranges starting at a multiple of 32 take the distance term from the resident bin matrix
         (poi_score_topk_ulptai); anything else falls back to the dense prob rows."""
+        if k > 32:
+            return self._topk_from_scores(start_end, k, return_scores)
         ids, lo = self._ids(start_end)
         if self.prob is None and self.trained_sus is not None and self.coords is not None and lo is not None and lo % 32 == 0 \
                 and self.dim <= 128:
@@ -629,18 +650,7 @@ class OboCARNN(GruBasic):
 
     def compute_sub_topk(self, start_end, k, return_scores=False):
         """Valuate.py:132-146 on the CA-RNN scores: the (n, n_item) rows stay on the device, poi_topk selects."""
-        ids, _ = self._ids(start_end)
-        n = ids.numel()
-        idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
-        sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
-        step = max(1, min(n, (1 << 28) // max(self.n_item, 1)))           # <= 1 GiB of scores at a time
-        a = np.atleast_1d(np.asarray(start_end)) if not isinstance(start_end, torch.Tensor) else start_end
-        for o in range(0, n, step):
-            full = self.compute_sub_all_scores_device(a[o:o + step])
-            m = full.shape[0]
-            self.ctx.check(self.lib.poi_topk(self.ctx.handle, _ptr(full), m, self.n_item, int(k), ctypes.c_void_p(idx.data_ptr() + 4 * o * k),
-                                             ctypes.c_void_p(sc.data_ptr() + 4 * o * k) if sc is not None else None, self._stream()))
-        return (idx, sc) if return_scores else idx
+        return self._topk_from_scores(start_end, k, return_scores)
 
 
 # =================================================================================================

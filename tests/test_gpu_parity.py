@@ -276,6 +276,34 @@ def test_score_topk_fused_bit_exact_ranks(pa, n, n_item, dim, k):
     assert np.array_equal(got, O.topk_desc(fsc, k))
 
 
+def test_topk_cutoffs_beyond_32(pa):
+    """at_nums such as [5, 10, 15, 20, 30, 50] (public/Valuate.py:126): k > 32 goes through explicit score rows + poi_topk
+    (k <= 64); ranks bit-exact against the float64 oracle on gap-checked rows; metrics accept the cut-offs; k > 64 is loud."""
+    from poi_amd.evaluate import device_rank_metrics
+    T = toy_problem(77, n_user=40, n_item=700, n_dist=11, dim=32)
+    P = spatial_params(77, T)
+    model = _spatial_model(pa, T, P)
+    model.update_trained_items()
+    rng = np.random.default_rng(3)
+    users = rng.uniform(-0.5, 0.5, (40, 32)).astype(np.float32)
+    model.update_trained_users(users)
+    ids = np.arange(40, dtype=np.int32)
+    for k in (33, 50, 64):
+        idx = model.compute_sub_topk(ids, k).cpu().numpy()
+        full = users.astype(np.float64) @ np.asarray(P["lt"][:-1], np.float64).T
+        top = O.topk_desc(full, k + 1)
+        tv = np.take_along_axis(full, top, axis=1)
+        ok = (tv[:, :-1] - tv[:, 1:]).min(axis=1) > 2e-6 * np.abs(tv).max()
+        assert ok.sum() >= 10
+        assert np.array_equal(idx[ok], top[ok][:, :k])
+    m = device_rank_metrics(model, [ids], [5, 10, 15, 20, 30, 50])
+    assert set(m) == {5, 10, 15, 20, 30, 50} and all(0.0 <= m[k]["recall"] <= 1.0 for k in m)
+    with pytest.raises(pa._lib.PoiError):
+        model.compute_sub_topk(ids, 65)
+    with pytest.raises(ValueError):
+        device_rank_metrics(model, [ids], [20, 10])
+
+
 def test_topk_with_ties_uses_index_order(pa):
     import torch
     sc = np.zeros((4, 300), np.float32)
