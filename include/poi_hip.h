@@ -78,8 +78,8 @@ const char* poi_last_error(const poi_ctx* ctx);   /* also valid with ctx == NULL
 /* number of CUs / name of the device the ctx is bound to (host-side queries) */
 int poi_ctx_num_cu(const poi_ctx* ctx);
 
-/* Engine used by poi_spatial_step / poi_gru_predict (spatial): 0 = auto (tile engine for launches of
- * >= 64 sequences when dim is 64 or 128 and n_dist+1 <= 256, per-sequence engine otherwise),
+/* Engine used by poi_spatial_step / poi_gru_step / poi_gru_predict: 0 = auto (tile engine whenever dim is 64 or 128 and
+ * n_dist+1 <= 256 - also for a single sequence, where it is ~5x faster -, per-sequence engine otherwise),
  * 1 = per-sequence engine, 2 = tile engine whenever supported.  Both implement the same arithmetic
  * (only the f32 summation order differs).  Also settable with POI_ENGINE=seq|tile. */
 int poi_ctx_set_engine(poi_ctx* ctx, int engine);

@@ -45,14 +45,18 @@ def test_selftest_primitives(pa):
     ctx.check(ctx.lib.poi_selftest(ctx.handle, None))
 
 
+@pytest.mark.parametrize("engine", ["auto", "seq"])
 @pytest.mark.parametrize("seed,dim,n_dist,n_item", [(0, 8, 11, 50), (1, 20, 37, 80), (4, 32, 200, 600), (2, 64, 200, 400), (3, 128, 200, 300)])
-def test_spatial_step_parity_sequential(pa, seed, dim, n_dist, n_item):
+def test_spatial_step_parity_sequential(pa, seed, dim, n_dist, n_item, engine):
     """model.train(uidx) one user after another == the reference's hot loop #1
     (prog_bpr_gru_spatial.py:249-250): every step must match, and the state carried between steps
     (gradient tables re-zeroed, slabs consumed) must stay consistent."""
+    if engine == "seq" and dim < 64:
+        pytest.skip("auto already is the per-sequence engine at this dim")
     T = toy_problem(seed, n_user=5, n_item=n_item, n_dist=n_dist, dim=dim, len_max=9 if dim > 32 else 10)
     P = spatial_params(seed, T)
     model = _spatial_model(pa, T, P)
+    model.ctx.set_engine(engine)
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     worst = 0.0
     for u in [3, 0, 4, 1, 0]:
@@ -65,6 +69,7 @@ def test_spatial_step_parity_sequential(pa, seed, dim, n_dist, n_item):
         worst = max(worst, assert_step_close(got, P, old, SP_NAMES, "after user %d" % u))
         # continue BOTH sides from the device's float32 state so errors do not compound across steps
         P = round_f32({**P, **{k: got[k] for k in SP_NAMES}})
+    model.ctx.set_engine("auto")
     print("spatial sequential worst rel err %.2e" % worst)
 
 
