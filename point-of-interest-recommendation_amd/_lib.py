@@ -147,8 +147,8 @@ class Context:
         return self.lib.poi_ctx_num_cu(self.handle)
 
     def set_engine(self, name):
-        """'auto' | 'seq' | 'tile' (see poi_ctx_set_engine)."""
-        self.check(self.lib.poi_ctx_set_engine(self.handle, {"auto": 0, "seq": 1, "tile": 2}[name]))
+        """'auto' | 'seq' | 'tile' | 'tile32' (see poi_ctx_set_engine)."""
+        self.check(self.lib.poi_ctx_set_engine(self.handle, {"auto": 0, "seq": 1, "tile": 2, "tile32": 3}[name]))
 
     def set_batch_cap(self, cap):
         """Batch rule cap (include/poi_hip.h, poi_ctx_set_batch_cap): 1 = mean rule."""

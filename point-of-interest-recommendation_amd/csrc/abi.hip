@@ -160,6 +160,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.n_item = P->n_item; A.n_dist = n_dist; A.dim = D;
   A.spatial = spatial ? 1 : 0; A.xw = spatial ? 2 * D : D;
   A.bintab = poi::te_bintab(D, spatial) ? 1 : 0;
+  A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
@@ -240,7 +241,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   const bool tile = use_tile(c, P, spatial, n);
   int n_head = 0, n_kc = 0, n_slab = grid;
   if (tile) {
-    n_head = c->num_cu * c->head_rounds;
+    n_head = c->num_cu * (D >= 256 && c->head_rounds > 2 ? 2 : c->head_rounds);      // D = 256: 62 KB of LDS per te_head workgroup, two per CU
     // te_wgrad launches (output-tile jobs) x n_kc K-chunks: fill the CUs exactly (no ragged second round)
     n_kc = (c->num_cu * c->wgrad_rounds) / poi::te_wgrad_jobs(D, spatial ? P->n_dist : -1, spatial);
     if (n_kc < 1) n_kc = 1;
@@ -617,7 +618,7 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
 }
 
 int poi_ctx_set_engine(poi_ctx* c, int engine) {
-  if (!c || engine < 0 || engine > 2) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence) or 2 (tile)");
+  if (!c || engine < 0 || engine > 3) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence), 2 (tile) or 3 (tile, streaming recurrent kernels)");
   c->engine = engine;
   return POI_OK;
 }

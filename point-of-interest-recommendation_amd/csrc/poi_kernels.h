@@ -79,6 +79,7 @@ struct TeArgs {
   float* out;
   int predict;                        // 1: forward over all L positions, no bookkeeping
   int spatial, xw;                    // 1 / 2D: Distance2Pre (POI + distance-bin input); 0 / D: plain GRU + BPR (n_dist == -1)
+  int rec32;                          // streaming recurrent kernels on 32-sequence tiles (D = 256; D = 128 on request)
   int bintab;                         // spatial && D >= 128: distance-bin half through per-bin tables (te_ztab / te_dsum)
   float *ztab, *dpart, *dsum, *dgd;   // (n_dist+1) x 3D table; per-chunk partial sums of DA; per-bin sums; per-bin d di sums
   int *dch0, *dch1;                   // first 64-entry chunk / first super-chunk of each bin (+ total)

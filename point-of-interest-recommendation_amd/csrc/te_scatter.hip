@@ -559,6 +559,7 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm) {
   if (A.dim == 64) return te_scatter_t<64>(A, alpha, lambda, num_cu, st, tm);
   if (A.dim == 128) return te_scatter_t<128>(A, alpha, lambda, num_cu, st, tm);
+  if (A.dim == 256) return te_scatter_t<256>(A, alpha, lambda, num_cu, st, tm);
   return hipErrorInvalidValue;
 }
 

@@ -25,11 +25,15 @@
 #include "poi_common.h"
 #include "poi_kernels.h"
 
+#include <stdlib.h>
+
 namespace poi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TE_BLOCK 256
+// D >= 256: the recurrent weights no longer fit the register file of one workgroup - streaming kernels (te_rec_fwd32 / bwd32);
+// TeArgs.rec32 also selects them at D = 128 (engine 3 of poi_ctx_set_engine: same arithmetic, different tiling - tests).
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -868,6 +872,210 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// te_rec_fwd32 / te_rec_bwd32: the recurrent kernels for D = 256 (config X; also instantiable at D = 128).  At D = 256 the
+// recurrent weights are 786 KB: the register-resident scheme of the 16-sequence kernels would need 192 registers per wave
+// with four waves per SIMD.  Here a workgroup (4 waves) owns a tile of 32 sequences, keeps h_{t-1} / r*h_{t-1} in LDS and
+// STREAMS the weights from L2 in MFMA B-fragment order every step (mma_lds_packed, one k-group of prefetch): a step of a
+// 32-row tile is 12.6 MFLOP = ~20 us of the CU's matrix pipe against ~5 us to pull 786 KB at 64 B/clk, so the stream
+// hides behind the 32x32x2 MFMAs.  Wave w owns hidden columns [D/4 * w, D/4 * (w + 1)) of all three gates, i.e.
+// TPW = D/128 n-tiles per gate: the state update is lane-local in the MFMA C layout.  Two barriers per step.
+// -------------------------------------------------------------------------------------------------
+template <int D, bool predict>
+__global__ __launch_bounds__(TE_BLOCK) void te_rec_fwd32_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int K8 = D / 8, LDA = D + 4, TPW = D / 128, NTG = D / 32;       // NTG: n-tiles per gate
+  float* Hb = lds;                       // h_{t-1}, overwritten by h_t   32 x LDA
+  float* RHb = Hb + 32 * LDA;            // r * h_{t-1}
+  __shared__ int s_r0[32], s_ns[32];
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  if (tid < 32) {
+    const int k = tile * 32 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  for (int e = tid; e < 32 * LDA; e += TE_BLOCK) Hb[e] = 0.f;
+  lds_barrier();
+  int ns_max = 0;
+  for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
+  const int Tsp = A.soff[A.n_seq];       // spare packed row: finished sequences read / write it unconditionally
+  int ntzr[2 * TPW], ntc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) { ntzr[i] = w * TPW + i; ntzr[TPW + i] = NTG + w * TPW + i; ntc[i] = 2 * NTG + w * TPW + i; }
+  float hcur[TPW][16];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hcur[i][r] = 0.f;
+  for (int t = 0; t < ns_max; ++t) {
+    size_t grow[16];
+    bool on[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); on[r] = t < s_ns[i]; grow[r] = (size_t)(on[r] ? s_r0[i] + t : Tsp); }
+    // pre-activations X.ui^T + bi of this step (te_gemm_ax): fetched now, added after the MFMA loop
+    float gz[TPW][16], gr[TPW][16];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* g = A.G + grow[r] * 3 * D + (w * TPW + i) * 32 + li;
+        gz[i][r] = g[0]; gr[i][r] = g[D];
+      }
+    f32x16 azr[1][2 * TPW];
+#pragma unroll
+    for (int j = 0; j < 2 * TPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) azr[0][j][r] = 0.f;
+    mma_lds_packed<1, 2 * TPW, K8>(azr, Hb, LDA, A.pWhT16, ntzr);
+    float zv[TPW][16];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = (w * TPW + i) * 32 + li;
+        zv[i][r] = fast_sigmoid(azr[0][i][r] + gz[i][r]);
+        const float rv = fast_sigmoid(azr[0][TPW + i][r] + gr[i][r]);
+        const float rh = rv * hcur[i][r];
+        RHb[c_row(r, lane) * LDA + col] = rh;
+        if (!predict) { A.G[grow[r] * 3 * D + D + col] = rv; A.RH[grow[r] * D + col] = rh; }
+      }
+    float gc[TPW][16];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gc[i][r] = A.G[grow[r] * 3 * D + 2 * D + (w * TPW + i) * 32 + li];
+    lds_barrier();
+    f32x16 ac[1][TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ac[0][j][r] = 0.f;
+    mma_lds_packed<1, TPW, K8>(ac, RHb, LDA, A.pWhT16, ntc);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = (w * TPW + i) * 32 + li;
+        const float c = fast_tanh(ac[0][i][r] + gc[i][r]);
+        const float hn = on[r] ? (1.0f - zv[i][r]) * hcur[i][r] + zv[i][r] * c : hcur[i][r];
+        Hb[c_row(r, lane) * LDA + col] = hn;          // nobody reads Hb between the two barriers of a step
+        hcur[i][r] = hn;
+        if (!predict) { A.G[grow[r] * 3 * D + col] = zv[i][r]; A.G[grow[r] * 3 * D + 2 * D + col] = c; A.H[grow[r] * D + col] = hn; }
+      }
+    lds_barrier();
+  }
+  if (predict) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = tile * 32 + c_row(r, lane);
+        if (k < A.n_seq) A.hts[(size_t)(A.out_row ? A.out_row[k] : k) * D + (w * TPW + i) * 32 + li] = hcur[i][r];
+      }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_rec_bwd32_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int K8 = D / 8, LDA = D + 4, LDB = 2 * D + 4, TPW = D / 128;
+  float* Ac = lds;                       // da_c           32 x LDA
+  float* Azr = Ac + 32 * LDA;            // da_z | da_r    32 x LDB
+  __shared__ int s_r0[32], s_ns[32];
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  if (tid < 32) {
+    const int k = tile * 32 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  lds_barrier();
+  int ns_max = 0;
+  for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
+  const int Tsp = A.soff[A.n_seq];
+  int ntw[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) ntw[i] = w * TPW + i;
+  float dhn[TPW][16], sbz[TPW], sbr[TPW], sbc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    sbz[i] = sbr[i] = sbc[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dhn[i][r] = 0.f;
+  }
+  for (int t = ns_max - 1; t >= 0; --t) {
+    size_t grow[16];
+    bool on[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int i = c_row(r, lane); on[r] = t < s_ns[i]; grow[r] = (size_t)(on[r] ? s_r0[i] + t : Tsp); }
+    float daz[TPW][16], rv[TPW][16], hp[TPW][16], dhp[TPW][16], dacv[TPW][16];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = (w * TPW + i) * 32 + li;
+        const float* g = A.G + grow[r] * 3 * D + col;
+        // the spare row holds arbitrary bits: select, do not multiply by zero
+        const float z = on[r] ? g[0] : 0.f, rr = on[r] ? g[D] : 0.f, c = on[r] ? g[2 * D] : 0.f;
+        const float hraw = A.H[(on[r] && t > 0 ? grow[r] - 1 : (size_t)Tsp) * D + col];
+        const float h = (on[r] && t > 0) ? hraw : 0.f;
+        const float draw = A.DH[grow[r] * D + col];
+        const float dh = on[r] ? dhn[i][r] + draw : 0.f;
+        rv[i][r] = rr; hp[i][r] = h;
+        daz[i][r] = dh * (c - h) * z * (1.0f - z);
+        dhp[i][r] = dh * (1.0f - z);
+        dacv[i][r] = dh * z * (1.0f - c * c);
+        Ac[c_row(r, lane) * LDA + col] = dacv[i][r];
+      }
+    lds_barrier();
+    f32x16 m[1][TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m[0][j][r] = 0.f;
+    mma_lds_packed<1, TPW, K8>(m, Ac, LDA, A.pWhc16, ntw);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = (w * TPW + i) * 32 + li, ri = c_row(r, lane);
+        const float mv = m[0][i][r];
+        const float dr = mv * hp[i][r];
+        dhp[i][r] += mv * rv[i][r];
+        const float dar = dr * rv[i][r] * (1.0f - rv[i][r]);
+        Azr[ri * LDB + col] = daz[i][r];
+        Azr[ri * LDB + D + col] = dar;
+        float* g = A.G + grow[r] * 3 * D + col;
+        g[0] = daz[i][r]; g[D] = dar; g[2 * D] = dacv[i][r];
+        sbz[i] += daz[i][r]; sbr[i] += dar; sbc[i] += dacv[i][r];        // zero for inactive steps (dh == 0)
+      }
+    lds_barrier();
+    f32x16 acc[1][TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    mma_lds_packed<1, TPW, 2 * K8>(acc, Azr, LDB, A.pWhzr16, ntw);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dhn[i][r] = on[r] ? dhp[i][r] + acc[0][i][r] : 0.f;
+    // (no third barrier: Ac is rewritten only after every wave passed the second barrier, Azr only after the next first one)
+  }
+  // d bi partials of this tile: a lane holds 16 rows of its columns, the two half-waves the other 16
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    sbz[i] += __shfl_xor(sbz[i], 32, 64); sbr[i] += __shfl_xor(sbr[i], 32, 64); sbc[i] += __shfl_xor(sbc[i], 32, 64);
+    if (lane < 32) {
+      float* bp = A.bi_part + (size_t)tile * 3 * D + (w * TPW + i) * 32 + li;
+      bp[0] = sbz[i]; bp[D] = sbr[i]; bp[2 * D] = sbc[i];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // te_head: 32 packed rows per iteration (persistent grid).  NBT = number of 32-bin tiles (bins padded).
 // mode 0: training - losses, d logits (stored to DL for the d vs job of te_wgrad), DH = d logits . vs
 // + g * E, g (for the sorted scatter), d bs / d wd partials; mode 1: predict (sts only, rows =
@@ -875,7 +1083,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
 // three workgroups per CU, whose MFMA / softmax / staging phases overlap.
 // -------------------------------------------------------------------------------------------------
 template <int D, int NBT, int MODE>
-__global__ __launch_bounds__(TE_BLOCK, 3) void te_head_kernel(TeArgs A) {
+__global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int K8 = D / 8, LDH = D + 4, NBP = NBT * 32, LDO = NBP + 4, NTW = (NBT + 3) / 4, NTD = D / 32;
   constexpr int KB8 = NBP / 8, DTW = (NTD + 3) / 4, LPR = D / 4;
@@ -1274,7 +1482,7 @@ int te_wgrad_jobs(int D, int n_dist, bool spatial) {
 // Distance2Pre at D >= 128: the distance-bin half of the input goes through per-bin tables (te_ztab / te_dsum)
 bool te_bintab(int D, bool spatial) { return spatial && D >= 128; }
 
-bool te_supported(int D, int n_dist) { return (D == 64 || D == 128) && n_dist + 1 <= 256; }   // plain GRU: n_dist == -1
+bool te_supported(int D, int n_dist) { return (D == 64 || D == 128 || D == 256) && n_dist + 1 <= 256; }   // plain GRU: n_dist == -1
 
 int te_nbp(int n_dist);
 static int nbt_for(int nb) { const int t = (nb + 31) / 32; return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8; }
@@ -1310,11 +1518,17 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     if (A.spatial) J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
     // 16-column fragments of the recurrent kernels (16x16x4 MFMA): B[k][n] = wh[2][k][n] (K = D, N = D) and
     // B[k][n] = wh_flat[k][n], k < 2D (K = 2D, N = D)
-    J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 16, D / 16, A.pWhc16, 1};
-    J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 16, D / 16, A.pWhzr16, 1};
+    if (A.rec32) {      // 32-column fragments of the streaming recurrent kernels (same buffers)
+      J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 8, D / 32, A.pWhc16, 0};
+      J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 8, D / 32, A.pWhzr16, 0};
+    } else {
+      J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 16, D / 16, A.pWhc16, 1};
+      J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 16, D / 16, A.pWhzr16, 1};
+    }
   }
-  // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments
-  J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
+  // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments (32-column ones for the streaming kernels)
+  if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
+  else J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
   J.n = n;
 }
 
@@ -1369,7 +1583,12 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
   }
   tm->begin("te_rec_fwd", st);
-  hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+  if constexpr (D >= 128) {
+    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false>), dim3((n + 31) / 32), dim3(TE_BLOCK), sizeof(float) * 2 * 32 * (D + 4), st, A);
+  }
+  if constexpr (D <= 128) {
+    if (!A.rec32) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+  }
   tm->end(st);
   tm->begin("te_head", st);
   if (A.spatial) {
@@ -1380,7 +1599,12 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   tm->end(st);
   tm->begin("te_rec_bwd", st);
-  hipLaunchKernelGGL(te_rec_bwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
+  if constexpr (D >= 128) {
+    if (A.rec32) hipLaunchKernelGGL(te_rec_bwd32_kernel<D>, dim3((n + 31) / 32), dim3(TE_BLOCK), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
+  }
+  if constexpr (D <= 128) {
+    if (!A.rec32) hipLaunchKernelGGL(te_rec_bwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
+  }
   tm->end(st);
   // per-sequence losses and the fixed-order partial sums only need te_head / te_rec_bwd: two small kernels that
   // fit beside the GEMMs' workgroups (14 registers, no LDS) instead of two more serial launches at the end
@@ -1388,7 +1612,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   auto finalize = [&](hipStream_t s) {
     tm->begin("te_finalize", s);
     hipLaunchKernelGGL(te_finalize_kernel, dim3(n_fin), dim3(TE_BLOCK), 0, s, A);
-    hipLaunchKernelGGL(te_parts_kernel, dim3((n_out + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, s, A, (n + 15) / 16, n_fin);
+    hipLaunchKernelGGL(te_parts_kernel, dim3((n_out + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, s, A, A.rec32 ? (n + 31) / 32 : (n + 15) / 16, n_fin);
     tm->end(s);
   };
   if (A.side) {
@@ -1419,9 +1643,24 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   return hipGetLastError();
 }
 
+static hipError_t te_optin_lds() {
+  // the streaming recurrent kernels need more than the default 64 KB of dynamic LDS at D = 256 (99 KB backward)
+  static bool done = false;
+  if (done) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  done = e == hipSuccess;
+  return e;
+}
+
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
+  hipError_t e = te_optin_lds();
+  if (e != hipSuccess) return e;
   if (A.dim == 64) return te_train_t<64>(A, num_cu, st, tm);
   if (A.dim == 128) return te_train_t<128>(A, num_cu, st, tm);
+  if (A.dim == 256) return te_train_t<256>(A, num_cu, st, tm);
   return hipErrorInvalidValue;
 }
 
@@ -1435,7 +1674,12 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   te_launch_ax<D>(A, num_cu, st);
-  hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+  if constexpr (D >= 128) {
+    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true>), dim3((n + 31) / 32), dim3(TE_BLOCK), sizeof(float) * 2 * 32 * (D + 4), st, A);
+  }
+  if constexpr (D <= 128) {
+    if (!A.rec32) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+  }
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
   tm->end(st);
@@ -1443,8 +1687,11 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
 }
 
 hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
+  hipError_t e = te_optin_lds();
+  if (e != hipSuccess) return e;
   if (A.dim == 64) return te_predict_t<64>(A, num_cu, st, tm);
   if (A.dim == 128) return te_predict_t<128>(A, num_cu, st, tm);
+  if (A.dim == 256) return te_predict_t<256>(A, num_cu, st, tm);
   return hipErrorInvalidValue;
 }
 
