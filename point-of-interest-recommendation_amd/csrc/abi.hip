@@ -172,7 +172,9 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
   const size_t n_hot = Ncap / (TE_COLD_MAX + 1) + 2, n_chunk = Ncap / TE_HOT_CHUNK + n_hot + 2;
   const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)((n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
-  const size_t sin = sorted ? 7 * Ncap + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
+  const int Rrows = P->n_item + 1 + n_dist + 1;
+  const bool listed = sorted && (size_t)Rrows > 4 * Ncap;      // table much larger than the launch's footprint: touched-row list
+  const size_t sin = sorted ? 7 * Ncap + (listed ? Ncap : 0) + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
   // per-bin tables (bintab): ztab + per-bin sums + d di sums, and (training) the sliced partial sums of DA
   const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2;      // 64-entry chunks of the bins' entry segments
   const size_t n_dsuper = n_dchunk / 32 + NBt + 2;
@@ -208,6 +210,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.code = itake(Ncap); A.slot_seq = itake(Ncap); A.ent = itake(Ncap);
     A.hist = itake(RS_HIST_INTS + RS_MAXBIN);   // + per-digit totals
     A.cnt = itake(4);
+    A.urow = listed ? itake(Ncap) : nullptr;
     A.hot_rows = (int4*)itake(4 * n_hot); A.hot_chunks = (int2*)itake(2 * n_chunk); A.hot_nf = itake(n_chunk);
     A.seg_start = (int*)c->seg_s.p; A.seg_end = (int*)c->seg_e.p;
     A.dch0 = itake(260);
@@ -249,11 +252,11 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = ensure(c, c->hslab, sizeof(float) * (size_t)n_head * ((NB + 4) & ~3), st))) return rc;
   } else if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
   if ((rc = ensure(c, c->slab, sizeof(float) * (size_t)dl.total * n_slab, st))) return rc;
-  if ((rc = ensure(c, c->g_lt, sizeof(float) * (size_t)(P->n_item + 1) * D, st))) return rc;
+  if (!tile && (rc = ensure(c, c->g_lt, sizeof(float) * (size_t)(P->n_item + 1) * D, st))) return rc;      // (10 GB at 10 M POIs x 256)
   if ((rc = ensure(c, c->mult_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
   if ((rc = ensure(c, c->nseq_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
   if (spatial) {
-    if ((rc = ensure(c, c->g_di, sizeof(float) * (size_t)(P->n_dist + 1) * D, st))) return rc;
+    if (!tile && (rc = ensure(c, c->g_di, sizeof(float) * (size_t)(P->n_dist + 1) * D, st))) return rc;
     if ((rc = ensure(c, c->mult_di, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
     if ((rc = ensure(c, c->nseq_di, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
   }

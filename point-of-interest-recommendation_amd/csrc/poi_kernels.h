@@ -109,7 +109,8 @@ struct TeArgs {
   int *ent;                           // sorted entry codes (bit 31: first entry of its sequence in the row)
   int *seg_start, *seg_end;           // per unified row: [start, end) in `ent`; end == 0 <=> untouched (persistent, re-zeroed)
   int *hist;                          // radix histogram (bins x blocks)
-  int *cnt;                           // [0] number of slots, [1] hot rows, [2] hot chunks
+  int *cnt;                           // [0] number of slots, [1] hot rows, [2] hot chunks, [3] touched rows (urow)
+  int *urow;                          // list of touched table rows (null: te_reduce scans the tables), see te_segment
   int4* hot_rows;                     // {row, start, count, first chunk}
   int2* hot_chunks;                   // {hot row index, chunk index}
   float* hot_part;                    // (hot chunks, D) partial sums

@@ -129,7 +129,12 @@ __global__ __launch_bounds__(256) void te_segment_kernel(TeArgs A, const int* __
     const bool same = i > 0 && Ks[i - 1] == k;
     const bool first = !same || A.slot_seq[Vs[i - 1]] != A.slot_seq[v];
     A.ent[i] = A.code[v] | (first ? (int)TE_ENT_FIRST : 0);
-    if (!same) A.seg_start[k] = i;
+    if (!same) {
+      A.seg_start[k] = i;
+      // touched-row list for tables much larger than a launch's footprint (te_reduce then walks the touched rows instead of
+      // scanning every table row; the order of the list is irrelevant - each row is reduced on its own)
+      if (A.urow) A.urow[atomicAdd(&A.cnt[3], 1)] = k;
+    }
     if (i == N - 1 || Ks[i + 1] != k) A.seg_end[k] = i + 1;
   }
 }
@@ -241,13 +246,22 @@ __device__ __forceinline__ RowInfo row_info(const TeArgs& A, int row) {
 template <int D>
 __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, float lambda) {
   constexpr int LPR = D / 4, RPW = 64 / LPR;
-  const int R = A.bintab ? A.n_item + 1 : A.n_item + 1 + A.n_dist + 1;      // bintab: the distance-bin rows are written by te_dapply
+  const int RT = A.bintab ? A.n_item + 1 : A.n_item + 1 + A.n_dist + 1;     // bintab: the distance-bin rows are written by te_dapply
+  // scan mode: every table row; list mode (A.urow): the launch's touched rows + the padding rows (which may be touched only
+  // analytically, i.e. have no segment) - a padding row that does have a segment is in the list already and skipped at the tail
+  const int n_u = A.urow ? A.cnt[3] : 0, n_pad = A.urow ? (A.bintab || A.n_dist < 0 ? 1 : 2) : 0;
+  const int R = A.urow ? n_u + n_pad : RT;
   const int lane = lane_id(), sub = lane / LPR, c = (lane % LPR) * 4, lead = sub * LPR;
   const float* __restrict__ zrow = A.zrow;
   const int nw = gridDim.x * 4;
   for (int row0 = (blockIdx.x * 4 + wave_id()) * RPW; row0 < R; row0 += nw * RPW) {
-    const int row = min(row0 + sub, R - 1);
-    const bool in = row0 + sub < R;
+    const int idx = min(row0 + sub, R - 1);
+    bool in = row0 + sub < R;
+    int row = idx;
+    if (A.urow) {
+      if (idx < n_u) { row = A.urow[idx]; in = in && row < RT; row = min(row, RT - 1); }
+      else { row = idx == n_u ? A.n_item : A.n_item + 1 + A.n_dist; in = in && A.seg_end[row] == 0; }
+    }
     const int end = in ? A.seg_end[row] : 0;
     const RowInfo ri = row_info(A, row);
     // padding rows: analytic multiplicity / sequence count from te_rowmap

@@ -92,6 +92,34 @@ def test_tile_batch_matches_mean_rule_and_seq_engine(pa, dim, n_dist, n_user, ti
     pa._lib.context(0).set_engine("auto")
 
 
+@pytest.mark.parametrize("dim,n_seq", [(64, 1), (128, 7), (256, 3)])
+def test_tile_touched_row_list_for_tables_much_larger_than_the_launch(pa, dim, n_seq):
+    """A POI table far larger than the launch's footprint (config X: 10 M rows against < 1 M touches): te_reduce walks the
+    launch's touched-row list instead of scanning the table.  Same oracle bars; rows never touched stay bit-identical; the
+    padding rows (touched only analytically: no segment) still get their L2 decay."""
+    T = toy_problem(210 + dim, n_user=14, n_item=6000, n_dist=40, dim=dim, len_max=9, hot=3000)
+    P = spatial_params(210 + dim, T)
+    users = np.nonzero(T["lens"] < T["len_max"])[0][:n_seq].astype(np.int32)        # shorter than len_max: the padding rows are touched, analytically only
+    assert len(users) == n_seq
+    exp, outs = _oracle_batch(P, T, users)
+    model = _model(pa, T, P)
+    model.ctx.set_engine("tile")
+    got_out = model.train_batch(users)
+    for k, out in enumerate(outs):
+        assert_close(got_out[k][:3], out[:3], "losses[%d]" % k, rtol=2e-5)
+    got = _get(model)
+    assert_step_close(got, exp, P, SP_NAMES, "touched-row list")
+    same = (got["lt"] == np.asarray(P["lt"], np.float32)).all(axis=1)
+    touched = np.zeros(T["n_item"] + 1, bool)
+    for u in users:
+        touched[T["train"][0][u]] = True; touched[T["train"][2][u]] = True
+    touched[T["n_item"]] = True
+    assert np.array_equal(~same, touched), "rows changed != rows touched (incl. the analytically touched padding row)"
+    # second launch: segment bookkeeping was re-zeroed through the list as well
+    model.train_batch(users)
+    model.ctx.set_engine("auto")
+
+
 @pytest.mark.parametrize("cap", [4.0, 1e9])
 def test_batch_cap_generalises_the_mean_rule(pa, cap):
     """poi_ctx_set_batch_cap: a row touched by k sequences moves by min(k, cap) / k times the SUM of their reference
