@@ -194,6 +194,15 @@ int poi_score_topk_ulptai(poi_ctx* ctx, const float* users, const float* items, 
                           const float* wd, const float* sts, const void* ulptai, int32_t bin_bytes, int32_t n_dist,
                           int32_t k, int32_t* idx_out, float* score_out, void* stream);
 
+/* The same score with the bins computed ON THE FLY from the coordinates inside the scoring kernel (float64 Haversine `c` in the
+ * reference's operation order + the exact host thresholds of poi_dist_prob): neither the reference's U x N bin matrix nor a dense
+ * prob matrix is ever materialised - the form for tables where U x N bytes cannot exist (config X: 1 M users x 10 M POIs), any
+ * dim <= 256, any batch start.  last_poi (n) = the batch users' last train POI; sts as for poi_score_topk_ulptai (column n_dist
+ * zero, readable for whole 32-user tiles). */
+int poi_score_topk_geo(poi_ctx* ctx, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim, const float* wd,
+                       const float* sts, const double* coords, const double* cphi, const double* thr, const int32_t* last_poi,
+                       int32_t n_dist, double dd, int32_t k, int32_t* idx_out, float* score_out, void* stream);
+
 /* ---- last-train-POI -> all-POI distance-bin probability rows (8f rank 2) ---------------------
  * public/Load_Data_by_length.py:183-235 (fun_compute_distance + fun_acquire_prob) for a user batch:
  * prob_out[k][j] = sts[k][bin] * (bin < n_dist), bin = cal_dis(coord[last_poi[k]], coord[j]).

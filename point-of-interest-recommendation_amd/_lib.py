@@ -71,6 +71,8 @@ SIGNATURES = {
                                  c_void_p, c_int32, c_void_p]),
     "poi_score_topk_ulptai": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                       c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "poi_score_topk_geo": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int32, c_double, c_int32, c_void_p, c_void_p, c_void_p]),
     "poi_rank_metrics": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "poi_sample_negatives": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, ctypes.c_uint64,
                                      c_void_p, c_void_p, c_void_p]),

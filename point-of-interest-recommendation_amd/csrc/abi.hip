@@ -430,7 +430,7 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
 }
 
 // ---------------------------------------------------------------------------------------------
-struct UlptaiArg { const void* bins; int bin_bytes; const float* sts; int n_dist; };
+struct UlptaiArg { const void* bins; int bin_bytes; const float* sts; int n_dist; const double *coords, *cphi, *thr; const int* last_poi; double dd; };
 
 static int score_common(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
                         const float* wd, const float* prob, float* scores, int32_t k, int32_t* idx_out, float* score_out,
@@ -448,13 +448,15 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   A.users = users; A.items = items; A.n = n; A.n_item = n_item; A.dim = dim; A.wd = wd; A.prob = prob;
   A.scores = scores; A.k = k; A.idx_out = idx_out; A.score_out = score_out;
   if (U) { A.ulptai = U->bins; A.bin_bytes = U->bin_bytes; A.sts = U->sts; A.n_dist = U->n_dist; }
+  if (U && !U->bins) { A.geo = 1; A.coords = U->coords; A.cphi = U->cphi; A.thr = U->thr; A.last_poi = U->last_poi; A.dd = U->dd; }
   if (const char* e = getenv("POI_SCORE_DBG")) A.dbg = atoi(e);
   const int ntile = (n_item + 31) / 32;
   // variant: 0 = one item stream per wave (row-per-lane loads; small n or dim > 128), 1 = packed item
   // stream per wave with the user tile's A fragments in LDS (default for n >= 128)
   int variant = (n >= 128 && dim <= 128) ? 1 : 0;
   if (c->score_variant >= 0 && dim <= 128) variant = c->score_variant;
-  if (U) variant = 1;      // the bin matrix is laid out for the packed-stream kernel
+  if (U && U->bins) variant = 1;      // the bin matrix is laid out for the packed-stream kernel
+  if (U && !U->bins) variant = 0;     // bins on the fly: the row-per-lane kernel (any dim <= 256)
   const int n_utile = (n + 31) / 32;
   const int units = n_utile;
   // long item streams keep per-user thresholds high (few top-K compactions)
@@ -522,7 +524,17 @@ int poi_score_topk_ulptai(poi_ctx* c, const float* users, const float* items, in
   if (bin_bytes != 1 && bin_bytes != 2) return fail(c, POI_EINVAL, "bin_bytes must be 1 or 2");
   if (dim > 128) return fail(c, POI_ENOTSUP, "the bin-matrix path supports dim <= 128 (got %d)", dim);
   if (n_dist <= 0 || (int64_t)n * (n_dist + 1) >= (int64_t)1 << 31) return fail(c, POI_EINVAL, "n * (n_dist + 1) must stay below 2^31: score in batches");
-  const UlptaiArg U{ulptai, bin_bytes, sts, n_dist};
+  const UlptaiArg U{ulptai, bin_bytes, sts, n_dist, nullptr, nullptr, nullptr, nullptr, 0.0};
+  return score_common(c, users, items, n, n_item, dim, wd, nullptr, nullptr, k, idx_out, score_out, stream, &U);
+}
+
+int poi_score_topk_geo(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim, const float* wd, const float* sts,
+                       const double* coords, const double* cphi, const double* thr, const int32_t* last_poi, int32_t n_dist, double dd,
+                       int32_t k, int32_t* idx_out, float* score_out, void* stream) {
+  if (!idx_out || k <= 0) return fail(c, POI_EINVAL, "idx_out NULL or k <= 0");
+  if (!wd || !sts || !coords || !cphi || !thr || !last_poi) return fail(c, POI_EINVAL, "poi_score_topk_geo: NULL argument");
+  if (n_dist <= 0 || !(dd > 0)) return fail(c, POI_EINVAL, "bad n_dist / dd");
+  const UlptaiArg U{nullptr, 0, sts, n_dist, coords, cphi, thr, last_poi, dd};
   return score_common(c, users, items, n, n_item, dim, wd, nullptr, nullptr, k, idx_out, score_out, stream, &U);
 }
 

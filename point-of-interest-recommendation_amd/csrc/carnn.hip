@@ -212,16 +212,6 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_item_term_kernel(const float*
   }
 }
 
-__device__ __forceinline__ double ca_cos_small(double x) {
-  if (fabs(x) < 0.03125) {
-    const double z = x * x;
-    double p = -1.0 / 479001600.0;
-    p = fma(p, z, 1.0 / 3628800.0); p = fma(p, z, -1.0 / 40320.0); p = fma(p, z, 1.0 / 720.0); p = fma(p, z, -1.0 / 24.0); p = fma(p, z, 0.5);
-    return fma(-z, p, 1.0);
-  }
-  return cos(x);
-}
-
 // compute_sub_all_scores (public/CA_RNN.py:91-101), literally: score[u][j] = -(wsum[bin(u, j)] + H * sum(user_u) + m[j]) with
 // bin(u, j) = usrs_last_poi_to_all_intervals[u][j] computed on the fly from the coordinates with the exact host thresholds
 // (same arithmetic as dist_prob_kernel in misc.hip; the U x N bin matrix of the reference is never materialised)
@@ -247,12 +237,8 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_score_kernel(const float* __r
 #pragma clang fp contract(off)
       const double a = (lat1 - coords[2 * j]) * pr;
       const double b = (lon1 - coords[2 * j + 1]) * pr;
-      const double c = (1.0 - ca_cos_small(a)) / 2 + c1 * cphi[j] * (1.0 - ca_cos_small(b)) / 2;
-      int g = (int)(sqrtf((float)c) * scale);
-      g = g < 0 ? 0 : (g > n_dist ? n_dist : g);
-      while (g > 0 && c < s_thr[g - 1]) --g;
-      while (g < n_dist && c >= s_thr[g]) ++g;
-      bin = g;
+      const double c = (1.0 - cos_small(a)) / 2 + c1 * cphi[j] * (1.0 - cos_small(b)) / 2;
+      bin = bin_of_c(c, s_thr, n_dist, scale);
     }
     out[(size_t)k * N + j] = -((s_w[bin] + su) + m[j]);
   }

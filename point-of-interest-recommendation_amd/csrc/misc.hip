@@ -54,22 +54,6 @@ __device__ __forceinline__ int cal_dis_bin(double lat1, double lon1, double lat2
   return interval < dist_num ? interval : dist_num;
 }
 
-// cos(x) for the small angle differences of nearby POIs: a 6-term Taylor/Horner polynomial (error
-// < 1e-27 for |x| < 1/32, evaluation rounding <= 1 ulp); larger arguments take the library cos.
-__device__ __forceinline__ double cos_small(double x) {
-  if (fabs(x) < 0.03125) {
-    const double z = x * x;
-    double p = -1.0 / 479001600.0;
-    p = fma(p, z, 1.0 / 3628800.0);
-    p = fma(p, z, -1.0 / 40320.0);
-    p = fma(p, z, 1.0 / 720.0);
-    p = fma(p, z, -1.0 / 24.0);
-    p = fma(p, z, 0.5);
-    return fma(-z, p, 1.0);
-  }
-  return cos(x);
-}
-
 // fun_compute_distance + fun_acquire_prob (public/Load_Data_by_length.py:183-235) for a user batch.
 // With `cphi` (host cos(lat*pi/180) per POI) and `thr` (bin_thresholds of data.py: the smallest c at
 // which each bin starts, found with the reference's own libm) the per-pair work is two small-angle

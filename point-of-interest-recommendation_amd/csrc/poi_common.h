@@ -146,4 +146,32 @@ __device__ __forceinline__ void gemv_cols(const float* __restrict__ W, int rows,
   __syncthreads();
 }
 
+// cos(x) for the small angle differences of nearby POIs: a 6-term Taylor/Horner polynomial (error
+// < 1e-27 for |x| < 1/32, evaluation rounding <= 1 ulp); larger arguments take the library cos.
+__device__ __forceinline__ double cos_small(double x) {
+  if (fabs(x) < 0.03125) {
+    const double z = x * x;
+    double p = -1.0 / 479001600.0;
+    p = fma(p, z, 1.0 / 3628800.0);
+    p = fma(p, z, -1.0 / 40320.0);
+    p = fma(p, z, 1.0 / 720.0);
+    p = fma(p, z, -1.0 / 24.0);
+    p = fma(p, z, 0.5);
+    return fma(-z, p, 1.0);
+  }
+  return cos(x);
+}
+
+
+// Distance bin of a Haversine `c` (public/Load_Data_by_length.py:32-39) through the exact host thresholds (data.bin_thresholds):
+// bin = #{t : c >= thr[t]}, thr ascending (LDS or global).  asin(x) ~ x at these distances, so int(sqrt(c) * 12742e3 / dd) is within
+// one bin of the answer; the thresholds then decide.
+__device__ __forceinline__ int bin_of_c(double c, const double* thr, int n_dist, float scale) {
+  int g = (int)(sqrtf((float)c) * scale);
+  g = g < 0 ? 0 : (g > n_dist ? n_dist : g);
+  while (g > 0 && c < thr[g - 1]) --g;
+  while (g < n_dist && c >= thr[g]) ++g;
+  return g;
+}
+
 }  // namespace poi

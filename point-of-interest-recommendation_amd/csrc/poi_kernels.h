@@ -191,6 +191,8 @@ struct ScoreArgs {
   // distance term through the resident bin matrix (ulptai_kernel layout) instead of `prob`:
   // score += wd * (bin < n_dist ? sts[user][bin] : 0)
   const void* ulptai; int bin_bytes; const float* sts; int n_dist;
+  // ... or with the bins computed on the fly from the coordinates (no U x N matrix at all): geo != 0
+  int geo; const double *coords, *cphi, *thr; const int* last_poi; double dd;
   float* scores;            // (n, n_item) or null
   int k;                    // 0 = no top-K
   int n_split;              // item splits for the fused top-K

@@ -202,9 +202,14 @@ __device__ __forceinline__ void tile_epilogue(const ScoreArgs& A, WaveTopk& T, c
   }
 }
 
-template <int D8, bool DB>
+// GEO: the distance term wd * (bin < n_dist ? sts[user][bin] : 0) with bin = cal_dis(last train POI of the user, item) computed
+// HERE from the coordinates (float64 Haversine `c` in the reference's operation order + the exact host thresholds, as
+// dist_prob_kernel): neither the reference's U x N bin matrix nor a dense prob matrix exists - the only form that scales to
+// 1 M users x 10 M POIs.  A lane owns one item of the tile (its coordinates live in registers) and 16 users (LDS).
+template <int D8, bool DB, bool GEO>
 __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
   __shared__ WaveTopk tk[POI_NWAVE];
+  extern __shared__ __align__(16) double s_geo[];        // GEO: thr[n_dist] | user lat[32] | lon[32] | cos(lat)[32]
   const int lane = lane_id(), w = wave_id();
   const int li = lane & 31, h = lane >> 5;
   const int D = A.dim, N = A.n_item, K = A.k;
@@ -234,7 +239,18 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
       af[m] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float wd = (A.prob && A.wd) ? A.wd[0] : 0.f;
+  const float wd = ((A.prob || GEO) && A.wd) ? A.wd[0] : 0.f;
+  double* s_ulat = s_geo + A.n_dist; double* s_ulon = s_ulat + 32; double* s_ucp = s_ulon + 32;
+  const float gscale = GEO ? (float)(12742.0 * 1000.0 / A.dd) : 0.f;
+  const int NBg = A.n_dist + 1;
+  if (GEO) {
+    for (int i = threadIdx.x; i < A.n_dist; i += POI_BLOCK) s_geo[i] = A.thr[i];
+    if (threadIdx.x < 32) {
+      const int lp = A.last_poi[min(ut * 32 + (int)threadIdx.x, A.n - 1)];
+      s_ulat[threadIdx.x] = A.coords[2 * lp]; s_ulon[threadIdx.x] = A.coords[2 * lp + 1]; s_ucp[threadIdx.x] = A.cphi[lp];
+    }
+    __syncthreads();
+  }
 
   auto load_b = [&](float4 (&bf)[D8], int tile) {
     const int irow = min(tile * 32 + li, N - 1);
@@ -265,10 +281,30 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
       const int j = tile * 32 + li;
       const bool jvalid = j < N;
       float pv[16];
+      if constexpr (GEO) {
+        const int jc = min(j, N - 1);
+        const double jlat = A.coords[2 * jc], jlon = A.coords[2 * jc + 1], jcp = A.cphi[jc];
+        const double pr = 0.017453292519943295;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int ul = (r & 3) + 8 * (r >> 2) + 4 * h;
+          int bin;
+          {
+#pragma clang fp contract(off)
+            const double a = (s_ulat[ul] - jlat) * pr;
+            const double b = (s_ulon[ul] - jlon) * pr;
+            const double c = (1.0 - cos_small(a)) / 2 + s_ucp[ul] * jcp * (1.0 - cos_small(b)) / 2;
+            bin = bin_of_c(c, s_geo, A.n_dist, gscale);
+          }
+          // (the caller's table has a zero in column n_dist and is readable for whole 32-user tiles: as the BINS path)
+          pv[r] = A.sts[(size_t)(ut * 32 + ul) * NBg + bin];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          pv[r] = (A.prob && jvalid && urow < A.n) ? A.prob[(size_t)urow * N + j] : 0.f;
+        }
       }
       tile_epilogue(A, T, acc, pv, thr, wd, ut, j, j - t_begin * 32, jvalid, K, tile - t_begin);
     }
@@ -529,7 +565,17 @@ template <int D8, bool DB>
 static hipError_t launch_score_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   dim3 grid((A.n + 31) / 32, A.n_split / POI_NWAVE);
   tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
-  hipLaunchKernelGGL((score_kernel<D8, DB>), grid, dim3(POI_BLOCK), 0, st, A);
+  if (A.geo) {
+    // static candidate lists (62 KB) + the dynamic threshold / user-coordinate block exceed the default 64 KB of LDS per workgroup
+    static bool optin = false;
+    if (!optin) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<D8, DB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      if (e != hipSuccess) return e;
+      optin = true;
+    }
+    hipLaunchKernelGGL((score_kernel<D8, DB, true>), grid, dim3(POI_BLOCK), sizeof(double) * (A.n_dist + 96), st, A);
+  }
+  else hipLaunchKernelGGL((score_kernel<D8, DB, false>), grid, dim3(POI_BLOCK), 0, st, A);
   tm->end(st);
   return hipGetLastError();
 }

@@ -389,6 +389,7 @@ class OboSpatialGru(GruBasic):
         self.trained_dists = Shared(self._dev(u(NB, D)))                                   # :74
         self.prob = None                       # dense (n_user, n_item) only on request (update_prob)
         self.trained_sus = None                # (n_user, NB) - fused alternative to `prob`
+        self.use_bin_matrix = None             # None = auto: resident U x N bin matrix when it is <= 16 GiB, else bins on the fly
         self.coords = None if coords is None else self._dev(np.asarray(coords, np.float64), torch.float64)
         self._cphi = None if coords is None else self._dev(cos_lat(coords), torch.float64)
         self._binthr = None if coords is None else self._dev(bin_thresholds(self.dd * 1000.0, self.n_dist), torch.float64)
@@ -475,7 +476,10 @@ class OboSpatialGru(GruBasic):
         if k > 32:
             return self._topk_from_scores(start_end, k, return_scores)
         ids, lo = self._ids(start_end)
-        if self.prob is None and self.trained_sus is not None and self.coords is not None and lo is not None and lo % 32 == 0 \
+        ubm = self.use_bin_matrix
+        if ubm is None:
+            ubm = self.n_user * float(self.n_item) * (1 if self.n_dist <= 255 else 2) <= float(1 << 34)
+        if ubm and self.prob is None and self.trained_sus is not None and self.coords is not None and lo is not None and lo % 32 == 0 \
                 and self.dim <= 128:
             if getattr(self, "_ulptai", None) is None:
                 self.build_ulptai()
@@ -489,7 +493,28 @@ class OboSpatialGru(GruBasic):
                                                           _ptr(self.wd.t), _ptr(st), bins, self._ulptai_bytes, self.n_dist, int(k),
                                                           _ptr(idx), _ptr(sc), self._stream()))
             return (idx, sc) if return_scores else idx
+        if self.prob is None and self.trained_sus is not None and self.coords is not None:
+            # anything else (unaligned / arbitrary id lists, dim 256, tables whose U x N bin matrix cannot exist): the bins are
+            # computed on the fly inside the scoring kernel - no bin matrix, no dense prob rows
+            return self._topk_geo(ids, lo, k, return_scores)
         return super().compute_sub_topk(start_end, k, return_scores)
+
+    def _topk_geo(self, ids, lo, k, return_scores=False):
+        n = ids.numel()
+        users = self._rows(self.trained_users.t, ids, lo)
+        pad = ((n + 31) // 32) * 32
+        if lo is not None and lo + pad <= self._sus_masked.shape[0]:
+            st = self._sus_masked[lo:lo + pad]
+        else:                                   # whole 32-user tiles must be readable
+            st = torch.zeros((pad, self.n_dist + 1), dtype=torch.float32, device=self.device)
+            st[:n] = self._rows(self._sus_masked, ids, lo)
+        lp = self._rows(self._last_poi, ids, lo)
+        idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
+        self.ctx.check(self.lib.poi_score_topk_geo(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim, _ptr(self.wd.t),
+                                                   _ptr(st), _ptr(self.coords), _ptr(self._cphi), _ptr(self._binthr), _ptr(lp), self.n_dist,
+                                                   self.dd * 1000.0, int(k), _ptr(idx), _ptr(sc), self._stream()))
+        return (idx, sc) if return_scores else idx
 
     def _prob_rows(self, ids, lo):
         if self.prob is not None:

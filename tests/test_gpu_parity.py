@@ -447,6 +447,39 @@ def test_ulptai_matrix_and_fused_topk(pa, golden_dir):
         assert np.array_equal(got[sel], exp[lo:lo + n][sel])
 
 
+@pytest.mark.parametrize("dim", [64, 256])
+def test_geo_scoring_bins_on_the_fly_equal_the_bin_matrix_and_the_oracle(pa, dim):
+    """poi_score_topk_geo: the distance bins of (last train POI, POI) are computed inside the scoring kernel - ranks must equal
+    (a) the float64 oracle with the reference's usrs_last_poi_to_all_intervals (compute_distance) + fun_acquire_prob and
+    (b) for dim <= 128 the resident-bin-matrix path, for unaligned and arbitrary id lists and at dim 256."""
+    T = toy_problem(88, n_user=70, n_item=1500, n_dist=200, dim=dim, len_max=9)
+    rng = np.random.default_rng(8)
+    coords = np.stack([40.0 + rng.random(1500) * 0.3, -74.0 + rng.random(1500) * 0.3], 1)
+    P = spatial_params(88, T)
+    model = _spatial_model(pa, T, P, coords=coords)
+    model.update_trained_items(); model.update_trained_dists()
+    ids = np.arange(70, dtype=np.int32)
+    hts, sts = model.predict(ids)
+    model.update_trained_users(hts); model.update_trained_sus(sts)
+    ul = O.compute_distance(T["train"][0], T["train"][1], [tuple(c) for c in coords], 200.0, 200)
+    prob = O.acquire_prob(np.asarray(sts, np.float64), ul, 200)
+    full = O.score_all(np.asarray(hts, np.float64), np.asarray(P["lt"], np.float64), float(P["wd"]), prob)
+    top = O.topk_desc(full, 21)
+    tv = np.take_along_axis(full, top, axis=1)
+    ok = (tv[:, :-1] - tv[:, 1:]).min(axis=1) > (1e-5 if dim <= 128 else 6e-5) * np.abs(tv).max()
+    assert ok.sum() >= 30
+    model.use_bin_matrix = False
+    for sel in (ids, np.arange(5, 47, dtype=np.int32), np.array([3, 60, 17, 18, 44], np.int32)):
+        idx = model.compute_sub_topk(sel, 20).cpu().numpy()
+        assert np.array_equal(idx[ok[sel]], top[sel][ok[sel]][:, :20]), "geo ranks differ from the oracle's"
+    if dim <= 128:
+        model.use_bin_matrix = True
+        a = model.compute_sub_topk(ids, 20).cpu().numpy()
+        model.use_bin_matrix = False
+        b = model.compute_sub_topk(ids, 20).cpu().numpy()
+        assert np.array_equal(a, b), "bin-matrix path and on-the-fly path disagree"
+
+
 def test_l2_eval(pa):
     T = toy_problem(50, n_user=4, n_item=30, n_dist=7, dim=8)
     P = spatial_params(50, T)
