@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed training epochs (default: a >= 2 s timed window)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla"])
+    ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla", "x1"],
+                    help="x1 = one GPU's slice of BASELINE.json configs[4]: 10 M POIs, 125 k users (1 M / 8), dim 256 (f32 tables)")
+    ap.add_argument("--eval-users", type=int, default=0, help="score only the first N users of the shard in the evaluation passes (0 = all; x1 default 8192)")
     ap.add_argument("--batch-users", type=int, default=12500)
     ap.add_argument("--batch-cap", type=float, default=64.0,
                     help="batch rule cap (poi_ctx_set_batch_cap): a row touched by k sequences of a launch moves by min(k, cap)/k x the sum of "
@@ -116,6 +118,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
+    if a.shape == "x1":
+        # 10 M POIs: i.i.d. Zipf check-ins (the neighbour structure of --local needs a k-d tree over 10 M points), throughput only
+        a.local = 0.0; a.no_quality = True; a.no_secondary = True; a.no_cpu_baseline = True
+        a.eval_users = a.eval_users or 8192
+        if a.steps == 200:
+            a.steps = 20
     ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local)
     lo, hi = pdata.shard_users(n_user, a.emulate_world or world, rank, ds.lens)
     tab = ds.shard(lo, hi)
@@ -182,14 +190,15 @@ def main():
     if not a.no_eval:
         all_ids = np.arange(n_local, dtype=np.int32)
         tes = torch.as_tensor(tab.tes_p.reshape(-1).astype(np.int32)).to(dev)
+        n_eval = min(a.eval_users, n_local) if a.eval_users else n_local
 
         def eval_epoch():
             model.update_trained_items(); model.update_trained_dists()
             hts, sts = model.predict_device(all_ids)
             model.update_trained_users(hts); model.update_trained_sus(sts)
             hits = torch.zeros((), dtype=torch.int64, device=dev)
-            for c0 in range(0, n_local, a.eval_chunk):
-                ids = all_ids[c0:min(c0 + a.eval_chunk, n_local)]
+            for c0 in range(0, n_eval, a.eval_chunk):
+                ids = all_ids[c0:min(c0 + a.eval_chunk, n_eval)]
                 idx = model.compute_sub_topk(ids, 20)
                 hits += (idx == tes[c0:c0 + len(ids), None]).any(dim=1).sum()
             return hits
@@ -209,9 +218,11 @@ def main():
         ms_pred = ctx.timing_get("seq_predict")[0] + ctx.timing_get("te_predict")[0]
         ms_dist = ctx.timing_get("dist_prob")[0]
         ctx.timing(False)
-        eval_users_per_s = n_user * a.eval_steps / dte
-        fl = 2.0 * n_local * n_item * D * a.eval_steps
-        eval_detail = {"ms_per_eval": 1e3 * dte / a.eval_steps, "recall_at_20_after_timed_training": float(hits.item()) / n_local,
+        eval_users_per_s = (n_user if n_eval == n_local else n_eval) * a.eval_steps / dte
+        fl = 2.0 * n_eval * n_item * D * a.eval_steps
+        eval_detail = {"ms_per_eval": 1e3 * dte / a.eval_steps, "recall_at_20_after_timed_training": float(hits.item()) / n_eval,
+                       "users_scored_per_eval": n_eval, "users_predicted_per_eval": n_local,
+                       "distance_term": "resident bin matrix" if getattr(model, "_ulptai", None) is not None else "bins on the fly (poi_score_topk_geo)",
                        "score_topk_tflops": fl / (ms_score * 1e-3) / 1e12 if ms_score > 0 else None,
                        "score_topk_frac_of_f32_mfma_peak": fl / (ms_score * 1e-3) / 1e12 / PEAK_F32_TFLOPS if ms_score > 0 else None,
                        "ms_predict_per_eval": ms_pred / a.eval_steps, "ms_score_topk_per_eval": ms_score / a.eval_steps,

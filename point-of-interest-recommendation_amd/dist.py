@@ -129,7 +129,7 @@ class ReplicaSync:
                       torch.distributed.all_reduce on the same buffer (default: when the backend is nccl)
     force           : run the whole delta / all-reduce / apply path even at world size 1 (self-check)"""
 
-    def __init__(self, tensors, rules=None, group=None, backend=None, ctx=None, force=False, own_comm=None, names=None):
+    def __init__(self, tensors, rules=None, group=None, backend=None, ctx=None, force=False, own_comm=None, names=None, force_backend=False):
         self.tensors = list(tensors)
         self.names = list(names) if names is not None else ["t%d" % i for i in range(len(self.tensors))]
         rules = list(rules) if rules is not None else ["sum"] * len(self.tensors)
@@ -140,7 +140,10 @@ class ReplicaSync:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = bool(force) and dist.is_initialized()
         self.active = self.world > 1 or self.force
-        if backend is None:
+        self._ctx = ctx
+        if backend is None and not self.active and not force_backend:
+            backend = None                    # world size 1: no snapshot / delta buffers (2 x the parameter bytes) are allocated
+        elif backend is None:
             if ctx is None:
                 raise ValueError("ReplicaSync needs ctx= (HIP kernels of libpoi_hip.so) or an explicit backend")
             backend = HipSyncBackend(self.tensors, rules, ctx, self.tensors[0].device)
@@ -148,6 +151,8 @@ class ReplicaSync:
                 own_comm = self.active and dist.get_backend(group) == "nccl"
             if own_comm and self.active:
                 backend.init_comm(group)
+        if isinstance(backend, HipSyncBackend) and own_comm is None:
+            own_comm = False
         self.backend = backend
         self.own_comm = bool(own_comm) and getattr(backend, "comm", None) is not None
         self.epochs = 0
@@ -174,6 +179,14 @@ class ReplicaSync:
         out = {"world_size": self.world, "rules": dict(zip(self.names, self.rules)),
                "collective": "rccl (library communicator, poi_allreduce_tables)" if self.own_comm else
                ("torch.distributed.all_reduce" if self.active else "none (world size 1)"), "epochs_synced": self.epochs}
+        if self.backend is None and self._ctx is not None:
+            out["allreduce_bytes"] = 0
+            acc = torch.zeros(1, dtype=torch.int64, device=self.tensors[0].device)
+            for t in self.tensors:
+                self._ctx.check(self._ctx.lib.poi_checksum(self._ctx.handle, t.data_ptr(), t.numel(), acc.data_ptr(),
+                                                           ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)))
+            out["replica_checksums_equal"] = True
+            out["replica_checksum"] = "%016x" % (int(acc.item()) & 0xFFFFFFFFFFFFFFFF)
         if isinstance(self.backend, HipSyncBackend):
             if self.own_comm and self.epochs:
                 ms, nb = self.backend.stats()

@@ -35,7 +35,7 @@ def test_sync_kernels_three_emulated_replicas_all_rules(pa):
     rules = ["sum", "mean_touched", "mean", "mean", "sum"]
     base = [rnd(*s) for s in shapes]
     cur = [b.clone() for b in base]
-    sync = pa.dist.ReplicaSync(cur, rules=rules, ctx=ctx)
+    sync = pa.dist.ReplicaSync(cur, rules=rules, ctx=ctx, force_backend=True)
     sync.backend.begin_epoch()                              # (world size 1: ReplicaSync itself stays passive)
     world = 3
     total = torch.zeros_like(sync.backend.flat)
@@ -87,7 +87,7 @@ def test_two_shards_from_one_snapshot_reconcile_to_the_oracle(pa, engine, rules)
                                          n_item=T["n_item"], n_dists=[T["n_dist"], 0.2], n_in=dim, n_hidden=dim, init=P)
     models = [mk(), mk()]
     models[0].ctx.set_engine(engine)
-    syncs = [pa.dist.model_sync(m, rules=rules) for m in models]
+    syncs = [pa.dist.model_sync(m, rules=rules, force_backend=True) for m in models]
     r = dict(pa.dist.DEFAULT_RULES); r.update(rules or {})
     flats = []
     for m, s, ids in zip(models, syncs, shards):

@@ -58,7 +58,7 @@ def main(argv=None):
     sync = None
     if a.world > 1:
         rules = None if a.rules == "default" else {n: a.rules for n in names}
-        sync = poi_amd.dist.model_sync(model, rules=rules)
+        sync = poi_amd.dist.model_sync(model, rules=rules, force_backend=True)
         bounds = [pdata.shard_users(n_user, a.world, r, lens) for r in range(a.world)]
     t_train = 0.0
     for epoch in range(a.epochs):
