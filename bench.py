@@ -362,8 +362,8 @@ def main():
         n_ref, t_ref = timed_training(ref_chunk, a.reference_seconds, n_local)
         rec_ref, auc_ref = evaluate_model(mref, tab, n_local, dev)
         reference_schedule = {"seq_per_s": n_ref / t_ref, "ms_per_step": 1e3 * t_ref / n_ref, "users_trained": n_ref, "train_seconds": t_ref,
-                              "note": "model.train(uidx) one user per step through the per-sequence engine (host call + 3 kernel launches per user): "
-                                      "the reference's execution model on the GPU, bound by the 49-step latency chain of ONE sequence"}
+                              "note": "model.train(uidx), one SGD step per user in shuffled order: the reference's execution model on the GPU (tile engine at "
+                                      "one sequence per launch: ~40 kernel launches around the 49-step latency chain of ONE sequence, host-synchronous)"}
         del mref
 
         # (2) batched modes from the same initial parameters for --quality-seconds of training each

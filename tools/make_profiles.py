@@ -39,9 +39,9 @@ try:
 except Exception:
     pass
 with open(os.path.join(P, tag + "_kernel_stats.md"), "w") as f:
-    f.write("# %s - rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`\n\n" % tag)
-    f.write("Gowalla-shape synthetic (100 k POIs, 50 k users, L <= 50, D = 128, 200 bins), one MI355X; 3 training epochs of\n"
-            "4 launches (12500 users each) + 2 evaluation passes.  Full CSV: `%s_kernel_stats.csv`.\n\n" % tag)
+    f.write("# %s - rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --eval-steps 2 --no-cpu-baseline --no-quality --no-secondary`\n\n" % tag)
+    f.write("Gowalla-shape synthetic (100 k POIs, 50 k users, L <= 50, D = 128, 200 bins; 80 %% of the transitions local), one MI355X; 4 training\n"
+            "epochs of 4 launches (12500 users each) + 3 evaluation passes.  Full CSV: `%s_kernel_stats.csv`.\n\n" % tag)
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows:
         if float(r["Percentage"]) < 0.05:
@@ -49,7 +49,7 @@ with open(os.path.join(P, tag + "_kernel_stats.md"), "w") as f:
         f.write("| `%s` | %s | %.3f | %.1f | %.2f |\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                          float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
     if bench:
-        f.write("\nLive HIP-event timings of the same build (`bench.py --steps 5 --warmup 2`): %.0f seq/s, %.2f ms/epoch, eval %.0f users/s.\n\n"
+        f.write("\nLive HIP-event timings of the same build (`bench.py`, defaults): %.0f seq/s, %.2f ms/epoch, eval %.0f users/s.\n\n"
                 % (bench["value"], bench["ms_per_step"], bench.get("eval_users_per_s") or 0))
         f.write("| timed region | ms/epoch | achieved | of peak |\n|---|---|---|---|\n")
         for k, v in bench["kernels"].items():
@@ -74,7 +74,7 @@ wa, wc = counters("write")
 # timed regions of bench.py -> kernels
 REGION = {"te_gather": ["te_gather_kernel"], "te_gemm_ax": ["te_gemm_nt_kernel<true", "te_gemm_ntk_kernel<true", "te_gemm_ntk_kernel<false, true", "te_ztab_kernel"], "te_gemm_dx": ["te_gemm_nt_kernel<false", "te_gemm_ntk_kernel<false, false"],
           "te_rec_fwd": ["te_rec_fwd16_kernel"], "te_rec_bwd": ["te_rec_bwd16_kernel"], "te_head": ["te_head_kernel", "te_bpr_head_kernel"],
-          "te_wgrad": ["te_wgrad_kernel"], "te_scatter": ["te_reduce_kernel", "te_hot_reduce_kernel", "te_hot_apply_kernel"], "te_dsum": ["te_dprep_kernel", "te_dsum_kernel"], "te_bin_gemm": ["te_dfin_kernel", "te_dui_kernel"],
+          "te_wgrad": ["te_wgrad_kernel"], "te_scatter": ["te_reduce_kernel", "te_hot_reduce_kernel", "te_hot_apply_kernel"], "te_dsum": ["te_dprep_kernel", "te_dsum_kernel"], "te_bin_gemm": ["te_dred_kernel", "te_dfin_kernel", "te_dui_kernel", "te_dapply_kernel"],
           "dense_apply": ["dense_apply_kernel"], "te_finalize": ["te_finalize_kernel", "te_parts_kernel"],
           "te_prep": ["te_len_kernel", "te_scan_kernel", "te_rowmap_kernel", "te_pack_kernel", "te_transpose_kernel", "rs_hist_kernel",
                       "rs_digit_scan_kernel", "rs_scatter_kernel", "te_segment_kernel"],
