@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200, help="timed training epochs (default: a >= 2 s timed window)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla", "x1"],
-                    help="x1 = one GPU's slice of BASELINE.json configs[4]: 10 M POIs, 125 k users (1 M / 8), dim 256 (f32 tables)")
+                    help="x1 = one GPU's slice of BASELINE.json configs[4]: 10 M POIs, 125 k users (1 M / 8), dim 256, fp16 POI table")
+    ap.add_argument("--table-dtype", default=None, choices=["f32", "f16"],
+                    help="storage type of the POI table (arithmetic is float32 either way); default f32, x1: f16 as BASELINE.json configs[4] says")
     ap.add_argument("--eval-users", type=int, default=0, help="score only the first N users of the shard in the evaluation passes (0 = all; x1 default 8192)")
     ap.add_argument("--batch-users", type=int, default=12500)
     ap.add_argument("--batch-cap", type=float, default=64.0,
@@ -122,8 +124,10 @@ def main():
         # 10 M POIs: i.i.d. Zipf check-ins (the neighbour structure of --local needs a k-d tree over 10 M points), throughput only
         a.local = 0.0; a.no_quality = True; a.no_secondary = True; a.no_cpu_baseline = True
         a.eval_users = a.eval_users or 8192
+        a.table_dtype = a.table_dtype or "f16"
         if a.steps == 200:
             a.steps = 20
+    a.table_dtype = a.table_dtype or "f32"
     ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local)
     lo, hi = pdata.shard_users(n_user, a.emulate_world or world, rank, ds.lens)
     tab = ds.shard(lo, hi)
@@ -133,7 +137,7 @@ def main():
     def new_model(tab_, n_users, dim=D, seed=7):
         return poi_amd.models.OboSpatialGru(train=tab_, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=n_users,
                                             n_item=len(ds.coords), n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=dim, n_hidden=dim,
-                                            device=dev, seed=seed, coords=ds.coords)
+                                            device=dev, seed=seed, coords=ds.coords, table_dtype=a.table_dtype)
     model = new_model(tab, n_local)
     ctx = model.ctx
     ctx.set_batch_cap(a.batch_cap)
@@ -471,7 +475,7 @@ def main():
             "metric": "check-in sequences/sec training (Distance2Pre) + all-POI top-K eval users/sec",
             "value": seq_per_s, "unit": "sequences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "table_storage": a.table_dtype, "data": "synthetic",
             "config": {"workload": "synthetic %s-shape: %d POIs, %d users, seq<=%d, dim=%d, %d distance bins; one step = one "
                                    "Distance2Pre training epoch over all users" % (a.shape, n_item, n_user, max_len, D, ds.dist_num),
                        "batch_users_per_launch": B, "batch_rule": "capped sum: a row touched by k sequences of a launch moves by min(k, %g)/k x the sum of "

@@ -19,7 +19,8 @@
  *    len_max (public/Load_Data_by_length.py:115-124); the only arithmetic effect of the padding -
  *    the L2 decay of the padding rows lt[n_item] / di[n_dist] (public/GRU_Spatial.py:202-203) - is
  *    reproduced analytically from `len_max`.
- *  - Table element type: float32 (POI_F32).  All arithmetic is float32 (reference: float64).
+ *  - Table element type: float32; the POI table may be stored as IEEE half (poi_ctx_register_f16).  All arithmetic is float32
+ *    (reference: float64).
  *
  * Batch semantics (n_seq > 1, "throughput mode"; n_seq == 1 is exactly the reference step):
  *    every sequence's reference update is evaluated at the launch-entry parameter values; each
@@ -49,6 +50,11 @@ enum {
   POI_EHIP = -3,     /* a HIP runtime call failed */
   POI_ENOTSUP = -4   /* configuration not supported by this build */
 };
+
+/* Table element types.  Every table is float32 unless its buffer has been registered as IEEE half with
+ * poi_ctx_register_f16 (config X: "fp16 embeddings"): storage only - all arithmetic stays float32, rows are converted when they are
+ * gathered and rounded to nearest-even when they are written back. */
+enum { POI_F32 = 0, POI_F16 = 1 };
 
 typedef struct poi_ctx poi_ctx;
 
@@ -84,6 +90,14 @@ int poi_ctx_num_cu(const poi_ctx* ctx);
  * dim 256 (32-sequence tiles, weights streamed from L2) also at dim 128 - a testing aid.  Both implement the same arithmetic
  * (only the f32 summation order differs).  Also settable with POI_ENGINE=seq|tile. */
 int poi_ctx_set_engine(poi_ctx* ctx, int engine);
+/* fp16 POI tables: declare that the device buffer [ptr, ptr + bytes) holds IEEE half elements.  From then on every entry point that is
+ * handed a pointer INSIDE a registered buffer as its POI table (`lt` of poi_gru_params for poi_spatial_step / poi_gru_step /
+ * poi_gru_predict; `items` of poi_score_all / poi_score_topk* / poi_auc_preference; `x` of poi_sumsq) reads / writes it as half.
+ * Supported by the tile engine (dim 64 / 128 / 256) and the scoring / AUC / L2 kernels; the per-sequence engine, BPR-MF and CA-RNN
+ * return POI_ENOTSUP for a half table.  poi_ctx_unregister_f16(ptr) forgets the buffer (call it before freeing). */
+int poi_ctx_register_f16(poi_ctx* ctx, const void* ptr, int64_t bytes);
+int poi_ctx_unregister_f16(poi_ctx* ctx, const void* ptr);
+
 /* Batch rule cap (>= 1, see "Batch semantics" above); applies to poi_spatial_step / poi_gru_step / poi_bpr_step
  * (snapshot mode) launches with more than one sequence.  n_seq == 1 is the reference step for every cap. */
 int poi_ctx_set_batch_cap(poi_ctx* ctx, float cap);
@@ -269,7 +283,7 @@ int poi_allreduce_tables(poi_ctx* ctx, poi_comm* comm, float* buf, int64_t n, vo
  * is also the next epoch's theta_start); the three steps are exported separately so that a host can run the
  * collective elsewhere (tests: gloo on CPU copies; single-GPU emulation of N replicas). */
 enum { POI_SYNC_SUM = 0, POI_SYNC_MEAN = 1, POI_SYNC_MEAN_TOUCHED = 2 };
-typedef struct poi_sync_seg { float* cur; int64_t rows; int64_t width; int32_t rule; } poi_sync_seg;
+typedef struct poi_sync_seg { float* cur; int64_t rows; int64_t width; int32_t rule; int32_t dtype; /* POI_F32 | POI_F16 (cur holds IEEE half) */ } poi_sync_seg;
 typedef struct poi_sync poi_sync;
 int poi_sync_create(poi_ctx* ctx, int device, const poi_sync_seg* segs_host, int32_t n_seg, poi_sync** out);
 int poi_sync_destroy(poi_sync* s);

@@ -25,7 +25,7 @@ class CarnnParams(ctypes.Structure):
 
 
 class SyncSeg(ctypes.Structure):
-    _fields_ = [("cur", c_void_p), ("rows", c_int64), ("width", c_int64), ("rule", c_int32)]
+    _fields_ = [("cur", c_void_p), ("rows", c_int64), ("width", c_int64), ("rule", c_int32), ("dtype", c_int32)]
 
 
 SYNC_SUM, SYNC_MEAN, SYNC_MEAN_TOUCHED = 0, 1, 2
@@ -45,6 +45,8 @@ SIGNATURES = {
     "poi_ctx_num_cu": (c_int, [c_void_p]),
     "poi_ctx_set_engine": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_batch_cap": (c_int, [c_void_p, c_float]),
+    "poi_ctx_register_f16": (c_int, [c_void_p, c_void_p, c_int64]),
+    "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                              c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
     "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
@@ -155,6 +157,13 @@ class Context:
     def set_batch_cap(self, cap):
         """Batch rule cap (include/poi_hip.h, poi_ctx_set_batch_cap): 1 = mean rule."""
         self.check(self.lib.poi_ctx_set_batch_cap(self.handle, float(cap)))
+
+    def register_f16(self, tensor):
+        """Declare a torch.float16 device tensor as an IEEE-half POI table (poi_ctx_register_f16)."""
+        self.check(self.lib.poi_ctx_register_f16(self.handle, tensor.data_ptr(), tensor.numel() * 2))
+
+    def unregister_f16(self, tensor):
+        self.check(self.lib.poi_ctx_unregister_f16(self.handle, tensor.data_ptr()))
 
     def timing(self, on=True):
         self.check(self.lib.poi_timing_reset(self.handle))

@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <utility>
+#include <vector>
 
 namespace {
 thread_local std::string g_err;
@@ -41,7 +43,14 @@ struct poi_ctx {
   // selftest
   DevBuf st;
   poi::Timing tm;
+  std::vector<std::pair<const char*, size_t>> f16;      // registered IEEE-half table buffers (poi_ctx_register_f16)
 };
+
+static int is_f16(const poi_ctx* c, const void* p) {
+  if (!c || !p) return 0;
+  for (auto& r : c->f16) if ((const char*)p >= r.first && (const char*)p < r.first + r.second) return 1;
+  return 0;
+}
 
 static int fail(poi_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -159,6 +168,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.lt = P->lt; A.di = P->di; A.ui = P->ui; A.wh = P->wh; A.bi = P->bi; A.vs = P->vs; A.bs = P->bs; A.wd = P->wd; A.lw = P->lw;
   A.n_item = P->n_item; A.n_dist = n_dist; A.dim = D;
   A.spatial = spatial ? 1 : 0; A.xw = spatial ? 2 * D : D;
+  A.lt_f16 = is_f16(c, P->lt);
   A.bintab = poi::te_bintab(D, spatial) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
@@ -242,6 +252,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   const poi::DenseLayout dl = poi::dense_layout(D, XW, NB);
   const size_t wsf = poi::seq_ws_floats(D, NB, T->max_len);
   const bool tile = use_tile(c, P, spatial, n);
+  if (!tile && is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 256 bins)");
   int n_head = 0, n_kc = 0, n_slab = grid;
   if (tile) {
     n_head = c->num_cu * (D >= 256 && c->head_rounds > 2 ? 2 : c->head_rounds);      // D = 256: 62 KB of LDS per te_head workgroup, two per CU
@@ -310,6 +321,7 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     HIPCHK(c, poi::launch_te_predict(E, c->num_cu, (hipStream_t)stream, &c->tm));
     return POI_OK;
   }
+  if (is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 256 bins)");
   poi::SeqArgs A;
   fill_args(A, P, T, uidx, n);
   A.hts = hts; A.sts = sts; A.out_row = out_row;
@@ -341,6 +353,7 @@ int poi_carnn_step(poi_ctx* c, const poi_carnn_params* P, const poi_seq_tables* 
                    float alpha, float lambda, float* out, void* stream) {
   int rc = check_carnn(c, P, T, true);
   if (rc) return rc;
+  if (is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "CA-RNN supports float32 tables only");
   if (!uidx || !out || n < 0) return fail(c, POI_EINVAL, "uidx/out NULL or n < 0");
   if (n == 0) return POI_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -407,6 +420,7 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
                  const int32_t* uidx, const int32_t* p, const int32_t* q, int32_t n,
                  float alpha, float lambda, float* loss_out, int mode, void* stream) {
   if (!c || !ux || !lt || !uidx || !p || !q || !loss_out) return fail(c, POI_EINVAL, "poi_bpr_step: NULL argument");
+  if (is_f16(c, lt) || is_f16(c, ux)) return fail(c, POI_ENOTSUP, "BPR-MF supports float32 tables only");
   if (dim <= 0 || dim % 4 != 0) return fail(c, POI_ENOTSUP, "dim must be a positive multiple of 4 (got %d)", dim);
   if (n < 0 || n_user <= 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
   if (mode != POI_BPR_SNAPSHOT && mode != POI_BPR_HOGWILD) return fail(c, POI_EINVAL, "unknown mode %d", mode);
@@ -445,7 +459,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   HIPCHK(c, hipSetDevice(c->device));
   poi::ScoreArgs A;
   memset(&A, 0, sizeof A);
-  A.users = users; A.items = items; A.n = n; A.n_item = n_item; A.dim = dim; A.wd = wd; A.prob = prob;
+  A.users = users; A.items = items; A.items_f16 = is_f16(c, items); A.n = n; A.n_item = n_item; A.dim = dim; A.wd = wd; A.prob = prob;
   A.scores = scores; A.k = k; A.idx_out = idx_out; A.score_out = score_out;
   if (U) { A.ulptai = U->bins; A.bin_bytes = U->bin_bytes; A.sts = U->sts; A.n_dist = U->n_dist; }
   if (U && !U->bins) { A.geo = 1; A.coords = U->coords; A.cphi = U->cphi; A.thr = U->thr; A.last_poi = U->last_poi; A.dd = U->dd; }
@@ -555,7 +569,7 @@ int poi_auc_preference(poi_ctx* c, const float* users, const float* items, int32
   if (dim <= 0 || dim % 4 != 0) return fail(c, POI_ENOTSUP, "dim must be a positive multiple of 4");
   if (n < 0 || len < 0) return fail(c, POI_EINVAL, "bad sizes");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, poi::launch_auc(users, items, n, dim, tp, tq, tm, len, out, (hipStream_t)stream));
+  HIPCHK(c, poi::launch_auc(users, items, is_f16(c, items), n, dim, tp, tq, tm, len, out, (hipStream_t)stream));
   return POI_OK;
 }
 
@@ -563,7 +577,8 @@ int poi_sumsq(poi_ctx* c, const float* x, int64_t n, double* out, void* stream) 
   if (!c || !x || !out || n < 0) return fail(c, POI_EINVAL, "poi_sumsq: bad argument");
   if (n == 0) return POI_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, poi::launch_sumsq(x, n, out, (hipStream_t)stream));
+  if (is_f16(c, x)) HIPCHK(c, poi::launch_sumsq_f16(x, n, out, (hipStream_t)stream));
+  else HIPCHK(c, poi::launch_sumsq(x, n, out, (hipStream_t)stream));
   return POI_OK;
 }
 
@@ -635,6 +650,19 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
 int poi_ctx_set_engine(poi_ctx* c, int engine) {
   if (!c || engine < 0 || engine > 3) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence), 2 (tile) or 3 (tile, streaming recurrent kernels)");
   c->engine = engine;
+  return POI_OK;
+}
+
+int poi_ctx_register_f16(poi_ctx* c, const void* ptr, int64_t bytes) {
+  if (!c || !ptr || bytes <= 0) return fail(c, POI_EINVAL, "poi_ctx_register_f16: bad argument");
+  for (auto& r : c->f16) if (r.first == (const char*)ptr) { r.second = (size_t)bytes; return POI_OK; }
+  c->f16.emplace_back((const char*)ptr, (size_t)bytes);
+  return POI_OK;
+}
+
+int poi_ctx_unregister_f16(poi_ctx* c, const void* ptr) {
+  if (!c) return fail(c, POI_EINVAL, "NULL ctx");
+  for (size_t i = 0; i < c->f16.size(); ++i) if (c->f16[i].first == (const char*)ptr) { c->f16.erase(c->f16.begin() + i); return POI_OK; }
   return POI_OK;
 }
 

@@ -6,20 +6,18 @@
 namespace poi {
 
 // compute_sub_auc_preference (public/GRU.py:98-110): one wavefront per (user, test position).
-__global__ __launch_bounds__(POI_BLOCK) void auc_kernel(const float* __restrict__ users, const float* __restrict__ items,
+__global__ __launch_bounds__(POI_BLOCK) void auc_kernel(const float* __restrict__ users, const float* __restrict__ items, int items_f16,
                                                          int n, int D, const int* __restrict__ tp, const int* __restrict__ tq,
                                                          const int* __restrict__ tm, int len, uint8_t* __restrict__ out) {
   const int e = blockIdx.x * POI_NWAVE + wave_id();
   if (e >= n * len) return;
   const int u = e / len;
   const float* ur = users + (size_t)u * D;
-  const float* pr = items + (size_t)tp[e] * D;
-  const float* qr = items + (size_t)tq[e] * D;
   float acc = 0.f;
   for (int j = lane_id() * 4; j < D; j += 256) {
     const float4 a = *reinterpret_cast<const float4*>(ur + j);
-    const float4 b = *reinterpret_cast<const float4*>(pr + j);
-    const float4 c = *reinterpret_cast<const float4*>(qr + j);
+    const float4 b = ld4t(items, (size_t)tp[e] * D + j, items_f16);
+    const float4 c = ld4t(items, (size_t)tq[e] * D + j, items_f16);
     acc += a.x * (b.x - c.x) + a.y * (b.y - c.y) + a.z * (b.z - c.z) + a.w * (b.w - c.w);
   }
   acc = wave_sum(acc);
@@ -31,6 +29,19 @@ __global__ __launch_bounds__(POI_BLOCK) void sumsq_kernel(const float* __restric
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * POI_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * POI_BLOCK) {
     const double v = (double)x[i];
+    acc += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane_id() == 0) red[wave_id()] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(POI_BLOCK) void sumsq_f16_kernel(const __half* __restrict__ x, int64_t n, double* out) {
+  __shared__ double red[POI_NWAVE];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * POI_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * POI_BLOCK) {
+    const double v = (double)__half2float(x[i]);
     acc += v * v;
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -348,11 +359,18 @@ __global__ __launch_bounds__(POI_BLOCK) void selftest_kernel(float* buf, int* fa
   }
 }
 
-hipError_t launch_auc(const float* users, const float* items, int n, int dim, const int* tp, const int* tq,
+hipError_t launch_auc(const float* users, const float* items, int items_f16, int n, int dim, const int* tp, const int* tq,
                       const int* tm, int len, uint8_t* out, hipStream_t st) {
   const int e = n * len;
   if (e <= 0) return hipSuccess;
-  hipLaunchKernelGGL(auc_kernel, dim3((e + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, users, items, n, dim, tp, tq, tm, len, out);
+  hipLaunchKernelGGL(auc_kernel, dim3((e + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, users, items, items_f16, n, dim, tp, tq, tm, len, out);
+  return hipGetLastError();
+}
+hipError_t launch_sumsq_f16(const void* x, int64_t n, double* out, hipStream_t st) {
+  int64_t g = (n + POI_BLOCK * 8 - 1) / (POI_BLOCK * 8);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(sumsq_f16_kernel, dim3((unsigned)g), dim3(POI_BLOCK), 0, st, (const __half*)x, n, out);
   return hipGetLastError();
 }
 hipError_t launch_sumsq(const float* x, int64_t n, double* out, hipStream_t st) {

@@ -2,6 +2,7 @@
 // reductions through LDS, and the two GEMV shapes the per-sequence engine uses.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #define POI_WAVE 64
@@ -58,6 +59,29 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   if (lane_id() == 0) red[wave_id()] = v;
   __syncthreads();
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---- table element access: float32 or IEEE half storage, float32 arithmetic (config X: fp16 embedding tables) ----------------
+// Offsets are in ELEMENTS.  A half row of 4 elements is one 8-byte load / store; conversion is round-to-nearest-even.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __half* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+  const float2 fa = __half22float2(a), fb = __half22float2(b);
+  return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__half* p, float4 v) {
+  const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+  uint2 u; u.x = *reinterpret_cast<const unsigned*>(&a); u.y = *reinterpret_cast<const unsigned*>(&b);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+// runtime-typed (f16 is wave-uniform)
+__device__ __forceinline__ float4 ld4t(const void* base, size_t off, int f16) {
+  return f16 ? ld4(reinterpret_cast<const __half*>(base) + off) : ld4(reinterpret_cast<const float*>(base) + off);
+}
+__device__ __forceinline__ void st4t(void* base, size_t off, int f16, float4 v) {
+  if (f16) st4(reinterpret_cast<__half*>(base) + off, v); else st4(reinterpret_cast<float*>(base) + off, v);
 }
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) {

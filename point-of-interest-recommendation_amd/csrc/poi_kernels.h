@@ -79,6 +79,7 @@ struct TeArgs {
   float* out;
   int predict;                        // 1: forward over all L positions, no bookkeeping
   int spatial, xw;                    // 1 / 2D: Distance2Pre (POI + distance-bin input); 0 / D: plain GRU + BPR (n_dist == -1)
+  int lt_f16;                         // the POI table `lt` is stored as IEEE half (float32 arithmetic): config X
   int rec32;                          // streaming recurrent kernels on 32-sequence tiles (D = 256; D = 128 on request)
   int bintab;                         // spatial && D >= 128: distance-bin half through per-bin tables (te_ztab / te_dsum)
   float *ztab, *dpart, *dsum, *dgd;   // (n_dist+1) x 3D table; per-chunk partial sums of DA; per-bin sums; per-bin d di sums
@@ -184,7 +185,7 @@ hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st, Timing* tm);
 
 // scoring / top-K
 struct ScoreArgs {
-  const float *users, *items;
+  const float *users, *items; int items_f16;      // items: float32, or IEEE half when items_f16
   float4* items_packed;     // MFMA B-fragment order (large-n kernel), ctx scratch
   int n, n_item, dim;
   const float *wd, *prob;
@@ -209,8 +210,9 @@ hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, int n_pad, hipStre
 hipError_t launch_topk_rows(const float* scores, int n, int n_item, int k, int* idx_out, float* score_out, hipStream_t st);
 
 // misc
-hipError_t launch_auc(const float* users, const float* items, int n, int dim, const int* tp, const int* tq,
+hipError_t launch_auc(const float* users, const float* items, int items_f16, int n, int dim, const int* tp, const int* tq,
                       const int* tm, int len, uint8_t* out, hipStream_t st);
+hipError_t launch_sumsq_f16(const void* x, int64_t n, double* out, hipStream_t st);
 hipError_t launch_sumsq(const float* x, int64_t n, double* out, hipStream_t st);
 hipError_t launch_dist_prob(const double* coords, const double* cphi, const double* thr, const int* last_poi, const float* sts,
                             int n, int n_item, int n_dist, double dd, float* prob, hipStream_t st);

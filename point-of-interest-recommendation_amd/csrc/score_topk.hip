@@ -254,11 +254,10 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
 
   auto load_b = [&](float4 (&bf)[D8], int tile) {
     const int irow = min(tile * 32 + li, N - 1);
-    const float* ip = A.items + (size_t)irow * D;
 #pragma unroll
     for (int m = 0; m < D8; ++m) {
       const int k0 = 8 * m + 4 * h;
-      bf[m] = k0 < D ? *reinterpret_cast<const float4*>(ip + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bf[m] = k0 < D ? ld4t(A.items, (size_t)irow * D + k0, A.items_f16) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
 
@@ -333,7 +332,7 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
 // Pack the item table into MFMA B-fragment order (see tile_engine.hip):
 //   P[(tile * D8 + m) * 64 + lane] = float4{ items[32 tile + j][8m + 4h + c], c = 0..3 }, lane = 32h + j
 // so that a wave's B loads are contiguous 1-KiB streams.  Rows >= n_item and k >= D are zero.
-__global__ __launch_bounds__(POI_BLOCK) void pack_items_kernel(const float* __restrict__ items, int n_item, int D, int D8,
+__global__ __launch_bounds__(POI_BLOCK) void pack_items_kernel(const float* __restrict__ items, int items_f16, int n_item, int D, int D8,
                                                                float4* __restrict__ out, size_t total) {
   for (size_t e = (size_t)blockIdx.x * POI_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * POI_BLOCK) {
     const int lane = (int)(e & 63);
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(POI_BLOCK) void pack_items_kernel(const float* __re
     const size_t row = tile * 32 + (lane & 31);
     const int k0 = 8 * m + 4 * (lane >> 5);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < (size_t)n_item && k0 < D) v = *reinterpret_cast<const float4*>(items + row * D + k0);
+    if (row < (size_t)n_item && k0 < D) v = ld4t(items, row * D + k0, items_f16);
     out[e] = v;
   }
 }
@@ -584,7 +583,7 @@ template <int D8>
 static hipError_t launch_score_packed_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   const size_t total = (size_t)((A.n_item + 31) / 32) * D8 * 64;
   tm->begin("pack_items", st);
-  hipLaunchKernelGGL(pack_items_kernel, dim3(2048), dim3(POI_BLOCK), 0, st, A.items, A.n_item, A.dim, D8, A.items_packed, total);
+  hipLaunchKernelGGL(pack_items_kernel, dim3(2048), dim3(POI_BLOCK), 0, st, A.items, A.items_f16, A.n_item, A.dim, D8, A.items_packed, total);
   tm->end(st);
   dim3 grid((A.n + 31) / 32, A.n_split / POI_NWAVE);
   tm->begin(A.k > 0 ? "score_topk" : "score_all", st);

@@ -55,33 +55,42 @@ static Rccl* rccl() {
 // ---------------------------------------------------------------------------------------------------------------
 // kernels: one wavefront per row of a segment (rows x width floats, width % 4 == 0 or handled by the scalar tail)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sync_delta_kernel(const float* __restrict__ cur, const float* __restrict__ base,
+// (f16: `cur` holds IEEE half - config X's fp16 tables; snapshot, deltas and the all-reduce stay float32, the combined value is
+// rounded to half once, and the snapshot keeps exactly that rounded value so that replicas stay bit-identical)
+__device__ __forceinline__ float ldc(const float* cur, long long i, int f16) { return f16 ? __half2float(reinterpret_cast<const __half*>(cur)[i]) : cur[i]; }
+
+__global__ __launch_bounds__(256) void sync_delta_kernel(const float* __restrict__ cur, int f16, const float* __restrict__ base,
                                                          float* __restrict__ delta, float* __restrict__ touched,
                                                          long long rows, long long width) {
   const int lane = lane_id();
   for (long long r = (long long)blockIdx.x * 4 + wave_id(); r < rows; r += (long long)gridDim.x * 4) {
-    const float* c = cur + r * width; const float* b = base + r * width; float* d = delta + r * width;
+    const float* b = base + r * width; float* d = delta + r * width;
     bool any = false;
-    for (long long j = lane; j < width; j += 64) { const float v = c[j] - b[j]; d[j] = v; any |= (v != 0.f); }
+    for (long long j = lane; j < width; j += 64) { const float v = ldc(cur, r * width + j, f16) - b[j]; d[j] = v; any |= (v != 0.f); }
     if (touched) { const bool t = __ballot(any) != 0ull; if (lane == 0) touched[r] = t ? 1.f : 0.f; }
   }
 }
 
 // cur <- base + scale * dsum ; base <- cur.   rule 0: scale 1, 1: 1 / world, 2: 1 / max(count[row], 1)
-__global__ __launch_bounds__(256) void sync_apply_kernel(float* __restrict__ cur, float* __restrict__ base,
+__global__ __launch_bounds__(256) void sync_apply_kernel(float* __restrict__ cur, int f16, float* __restrict__ base,
                                                          const float* __restrict__ dsum, const float* __restrict__ count,
                                                          long long rows, long long width, int rule, float inv_world) {
   const int lane = lane_id();
   for (long long r = (long long)blockIdx.x * 4 + wave_id(); r < rows; r += (long long)gridDim.x * 4) {
     float sc = rule == 1 ? inv_world : 1.f;
     if (rule == 2) { const float n = count[r]; sc = 1.f / fmaxf(n, 1.f); }
-    float* c = cur + r * width; float* b = base + r * width; const float* d = dsum + r * width;
-    for (long long j = lane; j < width; j += 64) { const float v = fmaf(sc, d[j], b[j]); c[j] = v; b[j] = v; }
+    float* b = base + r * width; const float* d = dsum + r * width;
+    for (long long j = lane; j < width; j += 64) {
+      float v = fmaf(sc, d[j], b[j]);
+      if (f16) { const __half hv = __float2half_rn(v); reinterpret_cast<__half*>(cur)[r * width + j] = hv; v = __half2float(hv); }
+      else cur[r * width + j] = v;
+      b[j] = v;
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void sync_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+__global__ __launch_bounds__(256) void sync_copy_kernel(const float* __restrict__ src, int f16, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = ldc(src, i, f16);
 }
 
 // order-independent checksum of a float buffer: 64-bit sum of the 32-bit patterns (equal buffers <=> equal sums,
@@ -180,7 +189,7 @@ int poi_sync_create(poi_ctx* ctx, int device, const poi_sync_seg* segs_host, int
   long long o = 0;
   for (int i = 0; i < n_seg; ++i) {
     const poi_sync_seg& g = segs_host[i];
-    if (!g.cur || g.rows <= 0 || g.width <= 0 || g.rule < POI_SYNC_SUM || g.rule > POI_SYNC_MEAN_TOUCHED) { delete s; return sfail(nullptr, POI_EINVAL, "poi_sync_create: bad segment"); }
+    if (!g.cur || g.rows <= 0 || g.width <= 0 || g.rule < POI_SYNC_SUM || g.rule > POI_SYNC_MEAN_TOUCHED || (g.dtype != POI_F32 && g.dtype != POI_F16)) { delete s; return sfail(nullptr, POI_EINVAL, "poi_sync_create: bad segment"); }
     s->segs.push_back(g); s->off.push_back(o);
     o += g.rows * g.width;
     o = (o + 3) & ~3ll;
@@ -221,7 +230,7 @@ int poi_sync_begin_epoch(poi_sync* s, void* stream) {
   for (size_t i = 0; i < s->segs.size(); ++i) {
     const long long n = s->segs[i].rows * s->segs[i].width;
     hipLaunchKernelGGL(poi::sync_copy_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       s->segs[i].cur, s->base + s->off[i], n);
+                       s->segs[i].cur, (int)s->segs[i].dtype, s->base + s->off[i], n);
   }
   return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_begin_epoch: launch failed");
 }
@@ -231,7 +240,7 @@ int poi_sync_make_delta(poi_sync* s, void* stream) {
   if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
   for (size_t i = 0; i < s->segs.size(); ++i) {
     const poi_sync_seg& g = s->segs[i];
-    hipLaunchKernelGGL(poi::sync_delta_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base + s->off[i],
+    hipLaunchKernelGGL(poi::sync_delta_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, (int)g.dtype, s->base + s->off[i],
                        s->delta + s->off[i], s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr, (long long)g.rows, (long long)g.width);
   }
   return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_make_delta: launch failed");
@@ -248,7 +257,7 @@ int poi_sync_apply(poi_sync* s, int32_t world, void* stream) {
   if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
   for (size_t i = 0; i < s->segs.size(); ++i) {
     const poi_sync_seg& g = s->segs[i];
-    hipLaunchKernelGGL(poi::sync_apply_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base + s->off[i],
+    hipLaunchKernelGGL(poi::sync_apply_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, (int)g.dtype, s->base + s->off[i],
                        s->delta + s->off[i], s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr, (long long)g.rows, (long long)g.width,
                        (int)g.rule, 1.0f / (float)world);
   }

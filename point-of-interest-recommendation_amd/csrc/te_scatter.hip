@@ -209,27 +209,29 @@ __device__ __forceinline__ float4 seg_sum(const TeArgs& A, int s, int cnt, int d
 
 // row <- row - alpha * min(nseq, cap) / nseq * (G + lambda * mult * row)      (batch rule, include/poi_hip.h)
 template <int D>
-__device__ __forceinline__ void apply_sum(float* __restrict__ trow, float4 g, int mult, int nseq, float alpha, float lambda, float cap) {
+__device__ __forceinline__ void apply_sum(float* __restrict__ trow, int f16, float4 g, int mult, int nseq, float alpha, float lambda, float cap) {
   constexpr int LPR = D / 4;
   const int lane = lane_id();
   if (lane >= LPR) return;
   const float sc = alpha * fminf((float)nseq, cap) / (float)nseq, lm = lambda * (float)mult;
-  float4 tv = *reinterpret_cast<float4*>(trow + lane * 4);
+  float4 tv = ld4t(trow, (size_t)lane * 4, f16);
   tv.x -= sc * (g.x + lm * tv.x); tv.y -= sc * (g.y + lm * tv.y);
   tv.z -= sc * (g.z + lm * tv.z); tv.w -= sc * (g.w + lm * tv.w);
-  *reinterpret_cast<float4*>(trow + lane * 4) = tv;
+  st4t(trow, (size_t)lane * 4, f16, tv);
 }
 
-struct RowInfo { float* trow; int* pm; int* pn; int doff; };
+struct RowInfo { float* trow; int* pm; int* pn; int doff; int f16; };      // f16: trow addresses IEEE half elements
 __device__ __forceinline__ RowInfo row_info(const TeArgs& A, int row) {
   RowInfo r;
   const int D = A.dim;
   if (row <= A.n_item) {
-    r.trow = A.lt + (size_t)row * D; r.doff = 0;
+    r.f16 = A.lt_f16;
+    r.trow = A.lt_f16 ? reinterpret_cast<float*>(reinterpret_cast<__half*>(A.lt) + (size_t)row * D) : A.lt + (size_t)row * D; r.doff = 0;
     r.pm = row == A.n_item ? A.mult_lt + A.n_item : nullptr;
     r.pn = row == A.n_item ? A.nseq_lt + A.n_item : nullptr;
   } else {
     const int b = row - A.n_item - 1;
+    r.f16 = 0;
     r.trow = A.di + (size_t)b * D; r.doff = D;
     r.pm = b == A.n_dist ? A.mult_di + A.n_dist : nullptr;
     r.pn = b == A.n_dist ? A.nseq_di + A.n_dist : nullptr;
@@ -310,10 +312,10 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
     if (in && !hot && (end != 0 || an != 0)) {
       const int nseq = ri.pn ? an : nf, mult = cnt + am;
       const float sc = alpha * fminf((float)nseq, A.bcap) / (float)max(nseq, 1), lm = lambda * (float)mult;
-      float4 tv = *reinterpret_cast<float4*>(ri.trow + c);
+      float4 tv = ld4t(ri.trow, (size_t)c, ri.f16);
       tv.x -= sc * (acc.x + lm * tv.x); tv.y -= sc * (acc.y + lm * tv.y);
       tv.z -= sc * (acc.z + lm * tv.z); tv.w -= sc * (acc.w + lm * tv.w);
-      *reinterpret_cast<float4*>(ri.trow + c) = tv;
+      st4t(ri.trow, (size_t)c, ri.f16, tv);
       if (lane == lead) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
     }
   }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
     for (int i = lane; i < nch; i += 64) nf += A.hot_nf[c0 + i];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) nf += __shfl_xor(nf, o, 64);
-    apply_sum<D>(ri.trow, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
+    apply_sum<D>(ri.trow, ri.f16, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
 }

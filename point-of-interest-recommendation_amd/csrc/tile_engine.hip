@@ -276,8 +276,8 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A) {
   const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
   for (int r = blockIdx.x * RPB + sub; r < T; r += gridDim.x * RPB) {
     const int s = A.row_src[r];
-    const float4 a = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[s + 1] * D + c);
-    const float4 b = *reinterpret_cast<const float4*>(A.lt + (size_t)A.q[s + 1] * D + c);
+    const float4 a = ld4t(A.lt, (size_t)A.p[s + 1] * D + c, A.lt_f16);
+    const float4 b = ld4t(A.lt, (size_t)A.q[s + 1] * D + c, A.lt_f16);
     *reinterpret_cast<float4*>(A.E + (size_t)r * D + c) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
   }
 }
@@ -322,7 +322,7 @@ struct NtArgs {
   const float* B; int ldb; float* C; int ldc; const float* bias; const int* Tptr; int N, K;
   const float* ztab; const int* zidx;         // ZADD: C[r][:] += ztab[zidx[r]][:]   (ztab rows of N floats)
 };
-template <bool BIAS, bool GATHER>
+template <bool BIAS, bool GATHER, bool F16 = false>      // F16: tab0 (the POI table) holds IEEE half
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
   __shared__ __align__(16) float As[2][128][NT_LDK];
   __shared__ __align__(16) float Bs[2][128][NT_LDK];
@@ -365,7 +365,10 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
-        if (GATHER) ra[s] = *reinterpret_cast<const float4*>(tab + (size_t)s_idx[half][row] * P.Dg + coff + c);
+        if (GATHER) {
+          if (F16 && !half) ra[s] = ld4(reinterpret_cast<const __half*>(P.tab0) + (size_t)s_idx[0][row] * P.Dg + coff + c);
+          else ra[s] = *reinterpret_cast<const float4*>(tab + (size_t)s_idx[half][row] * P.Dg + coff + c);
+        }
         else ra[s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(r0 + row, T - 1) * lda + kc * 32 + c);
         rb[s] = *reinterpret_cast<const float4*>(Bg + (size_t)min(n0 + row, N - 1) * ldb + kc * 32 + c);
       }
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
 //  * the epilogue is branch-free: columns beyond N (N % 128 != 0) go to the spare row T.
 //  * ZADD: the epilogue adds row zidx[r] of a small table instead of a bias (te_gemm_ax: the distance-bin half
 //    of the step input only takes n_dist + 1 values, so its product with ui is a table, see te_ztab_kernel).
-template <bool BIAS, bool GATHER, int K, int DG, int N, int LDB = K, int LDC = N, bool ZADD = false>
+template <bool BIAS, bool GATHER, int K, int DG, int N, int LDB = K, int LDC = N, bool ZADD = false, bool F16 = false>
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
   constexpr int NCH = K / 32, ldb = LDB, ldc = LDC;       // B is N x K (row pitch LDB), C is T x N (row pitch LDC)
   static_assert(K % 64 == 0 && NCH >= 4, "te_gemm_ntk: K must be a multiple of 64, >= 128");
@@ -487,7 +490,10 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
-      if (GATHER) ra[set][s] = *reinterpret_cast<const float4*>(tab + (size_t)s_idx[ONE_TAB ? tp : half][row] * DG + coff + c);
+      if (GATHER) {
+        if (F16 && !half) ra[set][s] = ld4(reinterpret_cast<const __half*>(P.tab0) + (size_t)s_idx[ONE_TAB ? tp : 0][row] * DG + coff + c);
+        else ra[set][s] = *reinterpret_cast<const float4*>(tab + (size_t)s_idx[ONE_TAB ? tp : half][row] * DG + coff + c);
+      }
       else ra[set][s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(tr0 + row, T - 1) * lda + kc * 32 + c);
       rb[set][s] = *reinterpret_cast<const float4*>(Bg + (size_t)min(tn0 + row, N - 1) * ldb + kc * 32 + c);
     }
@@ -1282,7 +1288,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 // -------------------------------------------------------------------------------------------------
 __host__ __device__ inline int te_nbp_dev(int n_dist) { const int t = (n_dist + 1 + 31) / 32; return 32 * (t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8); }
 
-template <int D, int T>
+template <int D, int T, bool F16 = false>       // F16: the POI table (gather source of the d ui jobs) holds IEEE half
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc) {
   constexpr int LDT = T + 4, Q = T / 64;         // Q x Q accumulators per wave
   const int XW = A.xw;
@@ -1326,7 +1332,8 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   // through row_p / row_dp (no packed copy of X exists).  The row indices of a stage are loaded one gload
   // call earlier (`ni`), so the gather is not a dependent load inside the pipeline.
   const bool gdi = n0 >= D;
-  const float* gtab = (gdi ? A.di : A.lt) + (n0 - (gdi ? D : 0));
+  const int goff = n0 - (gdi ? D : 0);
+  const float* gtab = (gdi ? A.di : A.lt) + goff;        // (F16 and !gdi: A.lt is re-read as half below, offsets in elements)
   const int* gidx = bsel == 0 ? (gdi ? A.row_dp : A.row_p) : A.row_t;
   float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
   int rt0[F4], rt1[F4];
@@ -1341,8 +1348,18 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
       const int gr = min(r0 + r, rmax);
       rt[s] = A.row_t[gr];                                      // h_{t-1} operand (bsel 1): none at the first step
       ra[s] = *reinterpret_cast<const float4*>(Ap + (size_t)gr * lda + (c < acols ? c : 0));
-      const float* bptr = bsel == 0 ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
-      rbv[s] = *reinterpret_cast<const float4*>(bptr);
+      if constexpr (F16) {
+        // branch-free (a branch around a load drains the queue): both typed loads are always issued from valid addresses - the
+        // half one from row 0 of the table when this job does not gather it, the float one from H when it does - and selected
+        const bool hb = bsel == 0 && !gdi;
+        const float* bptr = (bsel == 0 && gdi) ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
+        const float4 fv = *reinterpret_cast<const float4*>(bptr);
+        const float4 hv = ld4(reinterpret_cast<const __half*>(A.lt) + (hb ? goff + (size_t)ni[s] * D + c : (size_t)c));
+        rbv[s] = make_float4(hb ? hv.x : fv.x, hb ? hv.y : fv.y, hb ? hv.z : fv.z, hb ? hv.w : fv.w);
+      } else {
+        const float* bptr = bsel == 0 ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
+        rbv[s] = *reinterpret_cast<const float4*>(bptr);
+      }
       ni[s] = gidx[min(r0 + 32 + r, rmax)];                // indices of the next stage
     }
   };
@@ -1534,24 +1551,32 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
 
 // ax = x . ui^T + bi.  Spatial: POI half through the GEMM (K = D, B = the first D columns of ui), distance-bin
 // half + bias from the per-bin table (te_ztab_kernel).  Plain GRU: one table, bias in the epilogue.
-template <int D>
-static void te_launch_ax(const TeArgs& A, int num_cu, hipStream_t st) {
+template <int D, bool F16>
+static void te_launch_ax_t(const TeArgs& A, int num_cu, hipStream_t st) {
   const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
   const int n = A.n_seq;
   if (A.bintab) {
     if constexpr (D >= 128) {
       hipLaunchKernelGGL(te_ztab_kernel, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A, A.ztab);
       NtArgs P{nullptr, 0, A.lt, nullptr, A.row_p, nullptr, D, A.ui, 2 * D, A.G, 3 * D, nullptr, A.soff + n, 3 * D, D, A.ztab, A.row_dp};
-      hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true>), grid, block, 0, st, P);
+      hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true, F16>), grid, block, 0, st, P);
     }
   } else if (A.spatial) {
     NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.row_dp, D, A.ui, 2 * D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, 2 * D, nullptr, nullptr};
-    hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, 2 * D, D, 3 * D>), grid, block, 0, st, P);
+    hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, 2 * D, D, 3 * D, 2 * D, 3 * D, false, F16>), grid, block, 0, st, P);
   } else {
     NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, nullptr, D, A.ui, D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, D, nullptr, nullptr};
-    if constexpr (D >= 128) hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, D, D, 3 * D>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((te_gemm_nt_kernel<true, true>), grid, block, 0, st, P);
+    if constexpr (D >= 128) hipLaunchKernelGGL((te_gemm_ntk_kernel<true, true, D, D, 3 * D, D, 3 * D, false, F16>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((te_gemm_nt_kernel<true, true, F16>), grid, block, 0, st, P);
   }
+}
+
+// ax = x . ui^T + bi.  Spatial: POI half through the GEMM (K = D, B = the first D columns of ui), distance-bin
+// half + bias from the per-bin table (te_ztab_kernel).  Plain GRU: one table, bias in the epilogue.
+template <int D>
+static void te_launch_ax(const TeArgs& A, int num_cu, hipStream_t st) {
+  if (A.lt_f16) te_launch_ax_t<D, true>(A, num_cu, st);
+  else te_launch_ax_t<D, false>(A, num_cu, st);
 }
 
 template <int D>
@@ -1624,7 +1649,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
     const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0);
-    hipLaunchKernelGGL((te_wgrad_kernel<D, T>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
+    if (A.lt_f16) hipLaunchKernelGGL((te_wgrad_kernel<D, T, true>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
+    else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
   tm->begin("te_gemm_dx", st);

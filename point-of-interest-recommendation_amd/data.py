@@ -251,7 +251,7 @@ SHAPES = {
     "tiny": (300, 64, 12, 16),
     "foursquare": (10_000, 5_000, 20, 64),
     "gowalla": (100_000, 50_000, 50, 128),
-    # one GPU's slice of BASELINE.json configs[4] (10 M POIs / 1 M users over 8 GPUs, dim 256): all POIs, 1/8 of the users
+    # one GPU's slice of BASELINE.json configs[4] (10 M POIs / 1 M users over 8 GPUs, dim 256, fp16 table): all POIs, 1/8 of the users
     "x1": (10_000_000, 125_000, 50, 256),
 }
 

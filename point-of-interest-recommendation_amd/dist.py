@@ -50,12 +50,13 @@ class HipSyncBackend:
         self.ctx, self.lib, self.device = ctx, ctx.lib, device
         self.tensors = list(tensors)              # keep them alive: the library holds raw pointers
         for t in self.tensors:
-            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
-                raise TypeError("ReplicaSync needs contiguous float32 tensors on %s" % device)
+            if t.dtype not in (torch.float32, torch.float16) or not t.is_contiguous() or t.device != device:
+                raise TypeError("ReplicaSync needs contiguous float32 (or float16-stored table) tensors on %s" % device)
         segs = (_lib.SyncSeg * len(self.tensors))()
         for s, t, r in zip(segs, self.tensors, rules):
             width = t.shape[-1] if t.dim() >= 1 and t.shape[-1] > 0 else 1
             s.cur, s.rows, s.width, s.rule = t.data_ptr(), t.numel() // width, width, RULES[r]
+            s.dtype = 1 if t.dtype == torch.float16 else 0
         h = ctypes.c_void_p()
         self._check(self.lib.poi_sync_create(ctx.handle, device.index, segs, len(self.tensors), ctypes.byref(h)))
         self.handle = h
@@ -108,7 +109,7 @@ class HipSyncBackend:
         """64-bit checksum over all synchronised tensors (bit-identical replicas <=> equal checksums)."""
         acc = torch.zeros(1, dtype=torch.int64, device=self.device)
         for t in self.tensors:
-            self._check(self.lib.poi_checksum(self.ctx.handle, t.data_ptr(), t.numel(), acc.data_ptr(), self._stream()))
+            self._check(self.lib.poi_checksum(self.ctx.handle, t.data_ptr(), t.numel() * t.element_size() // 4, acc.data_ptr(), self._stream()))
         return int(acc.item())
 
     def close(self):
@@ -183,7 +184,7 @@ class ReplicaSync:
             out["allreduce_bytes"] = 0
             acc = torch.zeros(1, dtype=torch.int64, device=self.tensors[0].device)
             for t in self.tensors:
-                self._ctx.check(self._ctx.lib.poi_checksum(self._ctx.handle, t.data_ptr(), t.numel(), acc.data_ptr(),
+                self._ctx.check(self._ctx.lib.poi_checksum(self._ctx.handle, t.data_ptr(), t.numel() * t.element_size() // 4, acc.data_ptr(),
                                                            ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)))
             out["replica_checksums_equal"] = True
             out["replica_checksum"] = "%016x" % (int(acc.item()) & 0xFFFFFFFFFFFFFFFF)

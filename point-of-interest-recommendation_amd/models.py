@@ -274,9 +274,17 @@ class GruBasic(_Base):
 
     spatial = False
 
-    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None):
+    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None, table_dtype="f32"):
+        """table_dtype="f16": the POI table `lt` and its evaluation snapshot are STORED as IEEE half (config X of BASELINE.json:
+        "fp16 embeddings"); all arithmetic stays float32 - rows are converted when gathered and rounded to nearest-even when
+        written back.  Tile engine only (dim 64 / 128 / 256).  NOTE: an update smaller than half an fp16 ulp of the element
+        (2.4e-4 at 0.5) is lost to the rounding; with alpha 0.01 that is most single-sequence updates - use launches with a
+        batch cap, whose summed updates are larger."""
         if n_in != n_hidden:
             raise ValueError("the reference drivers always pass n_in == n_hidden (prog_bpr_gru_spatial.py:138-139)")
+        if table_dtype not in ("f32", "f16"):
+            raise ValueError("table_dtype must be 'f32' or 'f16'")
+        self.table_dtype = table_dtype
         self._setup(device, alpha_lambda)
         self.n_user, self.n_item, self.dim = int(n_user), int(n_item), int(n_in)
         self._load_tables(train, test)
@@ -285,13 +293,23 @@ class GruBasic(_Base):
         D = self.dim
         init = init or {}
         g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
-        self.lt = Shared(self._dev(g("lt", lambda: u(n_item + 1, D))))                     # GRU.py:60
+        tdt = torch.float16 if table_dtype == "f16" else torch.float32
+        self.lt = Shared(self._dev(g("lt", lambda: u(n_item + 1, D)), tdt))                # GRU.py:60
         self.ui = Shared(self._dev(g("ui", lambda: u(3, D, self._xw()))))                  # :61 / GRU_Spatial.py:51
         self.wh = Shared(self._dev(g("wh", lambda: u(3, D, D))))                           # :62
         self.bi = Shared(self._dev(g("bi", lambda: np.zeros((3, D)))))                     # :64
         self.h0 = Shared(torch.zeros(D, dtype=torch.float32, device=self.device))                               # :63 never trained
-        self.trained_items = Shared(self._dev(u(n_item + 1, D)))                           # :71
+        self.trained_items = Shared(self._dev(u(n_item + 1, D), tdt))                      # :71
         self.trained_users = Shared(self._dev(u(n_user, D)))                               # :72
+        if table_dtype == "f16":
+            self.ctx.register_f16(self.lt.t); self.ctx.register_f16(self.trained_items.t)
+
+    def __del__(self):
+        try:
+            if getattr(self, "table_dtype", "f32") == "f16":
+                self.ctx.unregister_f16(self.lt.t); self.ctx.unregister_f16(self.trained_items.t)
+        except Exception:
+            pass
 
     def _xw(self):
         return self.dim
@@ -362,10 +380,10 @@ class OboSpatialGru(GruBasic):
     spatial = True
 
     def __init__(self, train, test, dist, alpha_lambda, n_user, n_item, n_dists, n_in, n_hidden,
-                 device="cuda:0", init=None, seed=None, coords=None):
+                 device="cuda:0", init=None, seed=None, coords=None, table_dtype="f32"):
         n_dist, dd = n_dists
         self.n_dist, self.dd = int(n_dist), float(dd)                                      # dd in km (ref passes dd/1000)
-        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device=device, init=init, seed=seed)
+        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device=device, init=init, seed=seed, table_dtype=table_dtype)
         if self._csr is not None:
             dp, dq, tes_dist_masks = (np.ascontiguousarray(v, np.int32) for v in (self._csr.dp, self._csr.dq, self._csr.tes_dp))
         else:

@@ -337,3 +337,65 @@ def test_tile_plain_gru_multi_tile_workgroups_match_seq_engine(pa, dim):
     assert_close(losses["tile"], losses["seq"], "losses", rtol=2e-5)
     for k in GRU_NAMES:
         assert_close(res["tile"][k], res["seq"][k], "tile vs seq " + k, rtol=2e-5)
+
+
+def _f16(a):
+    return np.asarray(a, np.float16).astype(np.float64)
+
+
+@pytest.mark.parametrize("dim,n_user", [(64, 60), (128, 60), (256, 40)])
+def test_fp16_poi_table_float32_math(pa, dim, n_user):
+    """Config X's "fp16 embeddings": lt stored as IEEE half, arithmetic float32.  Oracle: the float64 batch rule run from the
+    HALF-rounded table; expectation for lt = that result rounded to half (the device rounds once, at the write-back) - allowed to
+    differ by one half ulp where float32 lands on the other side of a rounding boundary; the float32 tensors keep the usual bars;
+    untouched rows stay bit-identical; predict + top-K read the half snapshot."""
+    T = toy_problem(300 + dim, n_user=n_user, n_item=400, n_dist=40, dim=dim, len_max=10, hot=100)
+    P = spatial_params(300 + dim, T)
+    P["lt"] = _f16(P["lt"])
+    users = np.random.default_rng(4).permutation(n_user)[: n_user - 3].astype(np.int32)
+    exp, outs = _oracle_batch(P, T, users)
+    model = pa.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=T["n_user"],
+                                    n_item=T["n_item"], n_dists=[T["n_dist"], 0.2], n_in=dim, n_hidden=dim, init=P, table_dtype="f16")
+    import torch
+    assert model.lt.t.dtype == torch.float16 and model.trained_items.t.dtype == torch.float16
+    got_out = model.train_batch(users)
+    for k, out in enumerate(outs):
+        assert_close(got_out[k][:3], out[:3], "losses[%d]" % k, rtol=2e-5)
+    got = _get(model)
+    dense = [k for k in SP_NAMES if k != "lt"]
+    assert_step_close(got, exp, P, dense, "fp16 table")
+    lt = np.asarray(got["lt"], np.float64)
+    want = _f16(exp["lt"])
+    ulp = np.spacing(np.abs(want).astype(np.float16)).astype(np.float64)
+    # + the float32-vs-float64 noise of the update itself (elements near zero have a tiny half ulp): the weight bar of the float32 tests
+    noise = (6e-5 if dim >= 256 else 1e-5) * np.abs(want).max()
+    assert (np.abs(lt - want) <= ulp + noise).all(), "lt differs from half(oracle) by more than one half ulp"
+    assert (lt == want).mean() > 0.98, "more than 2 % of the half elements rounded the other way"
+    touched = np.zeros(T["n_item"] + 1, bool)
+    for u in users:
+        touched[T["train"][0][u]] = True; touched[T["train"][2][u]] = True
+    assert np.array_equal(lt[~touched], P["lt"][~touched])
+    # evaluation path on the half snapshot
+    model.update_trained_items(); model.update_trained_dists()
+    ids = np.arange(n_user, dtype=np.int32)
+    hts, sts = model.predict(ids)
+    Pn = {**exp, "lt": lt, "h0": np.zeros(dim)}
+    for k in dense:
+        Pn[k] = np.asarray(got[k], np.float64) if k != "wd" else float(got[k])
+    eh, es = O.spatial_predict(Pn, lt, Pn["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
+    rt = 6e-5 if dim >= 256 else 1e-5
+    assert_close(hts, eh, "hts", rtol=rt); assert_close(sts, es, "sts", rtol=rt)
+    model.update_trained_users(hts)
+    idx = super(pa.models.OboSpatialGru, model).compute_sub_topk(ids, 10).cpu().numpy()          # no distance term: users . items
+    full = np.asarray(hts, np.float64) @ lt[:-1].T
+    top = O.topk_desc(full, 11)
+    tv = np.take_along_axis(full, top, axis=1)
+    ok = (tv[:, :-1] - tv[:, 1:]).min(axis=1) > 1e-5 * np.abs(tv).max()
+    assert ok.sum() >= n_user // 2
+    assert np.array_equal(idx[ok], top[ok][:, :10])
+    # the per-sequence engine refuses a half table
+    model.ctx.set_engine("seq")
+    with pytest.raises(pa._lib.PoiError):
+        model.train(np.int32(1))
+    model.ctx.set_engine("auto")
+    assert abs(model.l2.eval() - O.l2_value({**Pn, "loss_weight": got["loss_weight"]}, 0.001, SP_NAMES)) <= 1e-5 * model.l2.eval()
