@@ -181,7 +181,7 @@ def main():
         train_epoch()
     barrier()
     dt = rank_max(time.perf_counter() - t0)
-    KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx",
+    KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_psum", "te_wgrad", "te_gemm_dx",
           "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "rows_apply", "dense_apply"]
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)

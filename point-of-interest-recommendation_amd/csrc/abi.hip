@@ -36,6 +36,9 @@ struct poi_ctx {
   DevBuf g_wd, mult_wd, nseq_wd, ca_ws, ca_slab, ca_scr;      // CA-RNN
   hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
+  DevBuf pmark, seg_pidx;   // per-POI regrouping: per lt row "is a step input in this launch" (all-zero between launches), row -> S row
+  int ppoi = 1;             // POI_TE_PPOI=0 disables the regrouping (A/B)
+  float ppoi_rho = 0.2f;    // expected S rows / steps: balances te_wgrad's d ui jobs against the others (POI_PPOI_RHO)
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
@@ -105,6 +108,8 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_HEAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->head_rounds = v; }
   if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
+  if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
+  if (const char* e = getenv("POI_PPOI_RHO")) { const float v = (float)atof(e); if (v > 0.01f && v <= 1.f) c->ppoi_rho = v; }
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   const char* sd = getenv("POI_TE_SIDE");
@@ -124,7 +129,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e,
+  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->seg_pidx,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
@@ -171,6 +176,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.lt_f16 = is_f16(c, P->lt);
   A.bintab = poi::te_bintab(D, spatial) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
+  A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
@@ -189,12 +195,15 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2;      // 64-entry chunks of the bins' entry segments
   const size_t n_dsuper = n_dchunk / 32 + NBt + 2;
   const size_t bfl = A.bintab ? NBt * (size_t)(3 * D) * 2 + NBt * D + (sorted ? (n_dchunk + n_dsuper) * (size_t)(3 * D) : 0) + 64 : 0;
-  const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl;
-  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 2 * NBt + 64 : 0);
+  const size_t n_pch = Tcap / 32 + 4, n_phot = Tcap / 64 + 4;
+  const size_t pfl = A.ppoi ? Tcap * (size_t)(3 * D) + n_pch * (size_t)(3 * D) + 64 : 0;
+  const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl + pfl;
+  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 2 * NBt + 64 : 0) + (A.ppoi ? Tcap + 512 + 4 * n_phot + 2 * n_pch + 64 : 0);
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
   if (sorted && ((rc = ensure(c, c->seg_s, sizeof(int) * (size_t)(R + 1), st)) || (rc = ensure(c, c->seg_e, sizeof(int) * (size_t)(R + 1), st)))) return rc;
+  if (A.ppoi && ((rc = ensure(c, c->pmark, sizeof(int) * (size_t)(P->n_item + 2), st)) || (rc = ensure(c, c->seg_pidx, sizeof(int) * (size_t)(P->n_item + 2), st)))) return rc;
   float* f = (float*)c->te_ws.p;
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
   A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
@@ -206,6 +215,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.ztab = take(NBt * 3 * D); A.dsum = take(NBt * 3 * D); A.dgd = take(NBt * D);
     if (sorted) { A.dpart = take(n_dchunk * (size_t)(3 * D)); A.dpart2 = take(n_dsuper * (size_t)(3 * D)); }
   }
+  if (A.ppoi) { A.S = take(Tcap * (size_t)(3 * D)); A.ppart = take(n_pch * (size_t)(3 * D)); }
   if (sorted) {
     A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP);
     A.bi_part = take((size_t)((n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);
@@ -219,11 +229,15 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.keys0 = itake(Ncap); A.keys1 = itake(Ncap); A.vals0 = itake(Ncap); A.vals1 = itake(Ncap);
     A.code = itake(Ncap); A.slot_seq = itake(Ncap); A.ent = itake(Ncap);
     A.hist = itake(RS_HIST_INTS + RS_MAXBIN);   // + per-digit totals
-    A.cnt = itake(4);
+    A.cnt = itake(8);
     A.urow = listed ? itake(Ncap) : nullptr;
     A.hot_rows = (int4*)itake(4 * n_hot); A.hot_chunks = (int2*)itake(2 * n_chunk); A.hot_nf = itake(n_chunk);
     A.seg_start = (int*)c->seg_s.p; A.seg_end = (int*)c->seg_e.p;
     A.dch0 = itake(260);
+    if (A.ppoi) {
+      A.urow_p = itake(Tcap); A.pblk = itake(256); A.ph_rows = (int4*)itake(4 * n_phot); A.ph_chunks = (int2*)itake(2 * n_pch);
+      A.pmark = (int*)c->pmark.p; A.seg_pidx = (int*)c->seg_pidx.p;
+    }
     if (A.bintab) { A.dch1 = itake(260); A.dnf = itake(n_dchunk); A.dnf2 = itake(n_dsuper); A.dbn = itake(NBt + 4); }
   }
   return POI_OK;
@@ -253,13 +267,23 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   const size_t wsf = poi::seq_ws_floats(D, NB, T->max_len);
   const bool tile = use_tile(c, P, spatial, n);
   if (!tile && is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 256 bins)");
-  int n_head = 0, n_kc = 0, n_slab = grid;
+  int n_head = 0, n_kc = 0, n_kc_ui = 0, n_slab = grid;
   if (tile) {
     n_head = c->num_cu * (D >= 256 && c->head_rounds > 2 ? 2 : c->head_rounds);      // D = 256: 62 KB of LDS per te_head workgroup, two per CU
     // te_wgrad launches (output-tile jobs) x n_kc K-chunks: fill the CUs exactly (no ragged second round)
-    n_kc = (c->num_cu * c->wgrad_rounds) / poi::te_wgrad_jobs(D, spatial ? P->n_dist : -1, spatial);
+    const int jobs = poi::te_wgrad_jobs(D, spatial ? P->n_dist : -1, spatial), nui = poi::te_wgrad_ui_jobs(D, spatial ? P->n_dist : -1, spatial);
+    n_kc = (c->num_cu * c->wgrad_rounds) / jobs;
     if (n_kc < 1) n_kc = 1;
-    n_slab = n_kc;
+    n_kc_ui = n_kc;
+    if (poi::te_bintab(D, spatial) && c->ppoi) {
+      // per-POI regrouping: the d ui jobs contract over S rows (~rho x the steps): give them rho x the K-chunks of the others so
+      // that every workgroup of the (job, chunk) grid has the same amount of work and the grid still fills the chip exactly
+      n_kc = (int)((float)(c->num_cu * c->wgrad_rounds) / ((float)nui * c->ppoi_rho + (float)(jobs - nui)));
+      if (n_kc < 1) n_kc = 1;
+      n_kc_ui = (int)((float)n_kc * c->ppoi_rho + 0.5f);
+      if (n_kc_ui < 1) n_kc_ui = 1;
+    }
+    n_slab = n_kc > n_kc_ui ? n_kc : n_kc_ui;
     if ((rc = ensure(c, c->hslab, sizeof(float) * (size_t)n_head * ((NB + 4) & ~3), st))) return rc;
   } else if ((rc = ensure(c, c->ws, sizeof(float) * wsf * grid, st))) return rc;
   if ((rc = ensure(c, c->slab, sizeof(float) * (size_t)dl.total * n_slab, st))) return rc;
@@ -283,13 +307,14 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
     if ((rc = ensure(c, c->zrow, sizeof(float) * 1024, st))) return rc;
     E.zrow = (const float*)c->zrow.p;
-    E.out = out; E.bcap = c->batch_cap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc;
+    E.out = out; E.bcap = c->batch_cap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.n_kc_ui = n_kc_ui;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
     HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));
-    HIPCHK(c, poi::launch_dense_apply(A, spatial, n_kc, n_kc, alpha, lambda, st, &c->tm));
+    A.n_slab_ui = n_kc_ui;               // (number of slabs the d ui region was written to, see dense_apply_kernel)
+    HIPCHK(c, poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, st, &c->tm));
     return POI_OK;
   }
   HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st, &c->tm));

@@ -49,6 +49,7 @@ struct SeqArgs {
   int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
   // predict outputs (row k of the launch goes to output row out_row[k], or k when out_row is null)
   float *hts, *sts; const int* out_row;
+  int n_slab_ui;     // tile launches: slabs the d ui region was written to (0: as the other regions)
   float bcap;        // batch rule: at most `bcap` of the touching sequences' updates count (1 = mean rule), include/poi_hip.h
 };
 
@@ -110,7 +111,7 @@ struct TeArgs {
   int *ent;                           // sorted entry codes (bit 31: first entry of its sequence in the row)
   int *seg_start, *seg_end;           // per unified row: [start, end) in `ent`; end == 0 <=> untouched (persistent, re-zeroed)
   int *hist;                          // radix histogram (bins x blocks)
-  int *cnt;                           // [0] number of slots, [1] hot rows, [2] hot chunks, [3] touched rows (urow)
+  int *cnt;                           // [0] number of slots, [1] hot rows, [2] hot chunks, [3] touched rows (urow), [4] S rows, [5] / [6] S hot chunks / rows
   int *urow;                          // list of touched table rows (null: te_reduce scans the tables), see te_segment
   int4* hot_rows;                     // {row, start, count, first chunk}
   int2* hot_chunks;                   // {hot row index, chunk index}
@@ -118,6 +119,17 @@ struct TeArgs {
   int* hot_nf;                        // per hot chunk: distinct-sequence count
   float* gcoef;                       // per packed row: d loss / d (h . e) (te_head)
   float bcap;                         // batch rule cap (see SeqArgs)
+  // per-POI regrouping (ppoi; bintab only): the step input lt[p_t] takes far fewer distinct values than there are steps (231 k steps hit
+  // ~45 k POIs per launch), and everything the backward pass needs from it is linear in S[p] = sum over the steps with p_t = p of DA_t:
+  //   d lt[p] (dx part) = S[p] . ui[:, :D]   (te_gemm_dx over S rows)      d ui[:, :D] = S^T . lt[rows of S]   (te_wgrad, K = S rows)
+  int ppoi;
+  int *pmark;                         // per lt row: has a dx entry in this launch (zero between launches; te_slots sets, the write-back clears)
+  int *seg_pidx, *urow_p;             // lt row -> S row, S row -> lt row
+  int *pblk;                          // per-block counts of the S-row assignment
+  const int *ks;                      // sorted keys (set by launch_te_sort)
+  float *S, *ppart;                   // S (rows x 3D); 64-entry chunk partials of the hot S rows
+  int4 *ph_rows; int2 *ph_chunks;     // hot S rows {S row, start, count, first chunk}; chunk -> {hot row, chunk index}
+  int n_kc_ui;                        // te_wgrad: K-chunks of the d ui jobs (their K is the S-row count, ~T/5)
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
 };
 // entry code: packed-row index of the position (28 bits) + what the position contributes
@@ -135,6 +147,8 @@ bool te_supported(int D, int n_dist);
 bool te_bintab(int D, bool spatial);
 int te_wgrad_jobs(int D, int n_dist, bool spatial);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
+hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st);
+int te_wgrad_ui_jobs(int D, int n_dist, bool spatial);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 int te_nbp(int n_dist);
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);

@@ -408,8 +408,9 @@ __global__ __launch_bounds__(POI_BLOCK) void dense_apply_kernel(SeqArgs A, int n
   const int i = blockIdx.x * POI_BLOCK + threadIdx.x;
   if (i >= dl.total) return;
   if (SPATIAL && i == dl.upq) return;   // consumed together with dl.sur by one thread (below)
-  // regions vs | bs | wd are written by up to n_slab_head workgroups, everything else by n_slab
-  const int ns = (i >= dl.vs && i <= dl.wd) ? n_slab_head : n_slab;
+  // regions vs | bs | wd are written by up to n_slab_head workgroups, ui by A.n_slab_ui when set (tile launches: te_wgrad's d ui
+  // jobs use fewer K-chunks under the per-POI regrouping), everything else by n_slab
+  const int ns = (i >= dl.vs && i <= dl.wd) ? n_slab_head : (i < dl.wh && A.n_slab_ui > 0) ? A.n_slab_ui : n_slab;
   float g = 0.f;
   {
     float* base = A.slab + i;

@@ -18,6 +18,8 @@ namespace poi {
 
 #define RS_BLOCK 256
 
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
 // -------------------------------------------------------------------------------------------------
 // stable LSD radix sort of (key, value) pairs, element count read from device memory
 // -------------------------------------------------------------------------------------------------
@@ -139,6 +141,202 @@ __global__ __launch_bounds__(256) void te_segment_kernel(TeArgs A, const int* __
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// per-POI regrouping (TeArgs.ppoi): S rows.  A POI row with at least one dx entry (pmark, set by te_slots) becomes a row of S; its
+// index is its rank among such rows in sorted-key order - an exclusive scan over the sorted slots in two kernels (per-block counts,
+// then block prefix + in-block scan), so the order of the S rows (= the summation order of the d ui jobs of te_wgrad) does not depend
+// on scheduling.  Rows with more than 64 entries are cut into 64-entry chunks (te_psum_hot) whose partials are added in order.
+// -------------------------------------------------------------------------------------------------
+#define TE_PBLK 1024
+__device__ __forceinline__ bool te_pflag(const TeArgs& A, int i, int N) {
+  if (i >= N) return false;
+  const int k = A.ks[i];
+  return k <= A.n_item && (i == 0 || A.ks[i - 1] != k) && A.pmark[k] != 0;
+}
+__device__ __forceinline__ int te_pper(int N) { return (((N + TE_PBLK - 1) / TE_PBLK) + 255) & ~255; }
+__global__ __launch_bounds__(256) void te_pcount_kernel(TeArgs A) {
+  __shared__ int red[4];
+  const int N = A.cnt[0], per = te_pper(N);
+  const int b0 = blockIdx.x * per;
+  int c = 0;
+  for (int i = b0 + threadIdx.x; i < min(N, b0 + per); i += 256) c += te_pflag(A, i, N) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane_id() == 0) red[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) A.pblk[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// positions are taken in 256-wide strips (coalesced), ranks inside a strip from ballots: idx = rows before the block + rows in
+// earlier strips + rows in earlier waves of the strip + flagged lanes below this one.  pmark[row] <- idx + 1 (te_reduce reads the S
+// row index from the mark itself).
+__global__ __launch_bounds__(256) void te_passign_kernel(TeArgs A) {
+  __shared__ int s_w[4];
+  __shared__ int s_base;
+  const int N = A.cnt[0], per = te_pper(N), tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int b0 = blockIdx.x * per;
+  {
+    int v = 0;
+    for (int j = tid; j < (int)blockIdx.x; j += 256) v += A.pblk[j];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_w[w] = v;
+    __syncthreads();
+    if (tid == 0) s_base = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __syncthreads();
+  }
+  int base = s_base;
+  for (int i0 = b0; i0 < min(N, b0 + per); i0 += 256) {
+    const int i = i0 + tid;
+    const bool f = te_pflag(A, i, N);
+    const unsigned long long m = __ballot(f);
+    __syncthreads();
+    if (lane == 0) s_w[w] = __builtin_popcountll(m);
+    __syncthreads();
+    int before = 0;
+    for (int j = 0; j < w; ++j) before += s_w[j];
+    const int tot = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (f) {
+      const int idx = base + before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      const int row = A.ks[i], cnt = A.seg_end[row] - i;          // (te_segment: seg_start[row] == i)
+      A.pmark[row] = idx + 1; A.urow_p[idx] = row;
+      if (cnt > TE_COLD_MAX) {
+        const int nch = (cnt + 63) / 64;
+        const int h = atomicAdd(&A.cnt[6], 1), c0 = atomicAdd(&A.cnt[5], nch);
+        A.ph_rows[h] = make_int4(idx, i, cnt, c0);
+        for (int k = 0; k < nch; ++k) A.ph_chunks[c0 + k] = make_int2(h, k);
+      }
+    }
+    base += tot;
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) A.cnt[4] = base;          // total number of S rows
+}
+
+// S[idx] = sum of DA over the dx entries of the row (cold rows: one wavefront per row, eight entries in flight; every load
+// unconditional - entries without a dx term read the resident zero row).  A lane owns 3D / 128 float2 columns.
+template <int D>
+__device__ __forceinline__ void te_psum_range(const TeArgs& A, int s0, int n_e, float2 (&acc)[3 * D / 128]) {
+  constexpr int NF2 = 3 * D / 128;
+  const int lane = lane_id();
+#pragma unroll
+  for (int q = 0; q < NF2; ++q) acc[q] = make_float2(0.f, 0.f);
+  for (int i0 = 0; i0 < n_e; i0 += 8) {
+    int e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int v = A.ent[s0 + min(i0 + u, n_e - 1)]; e[u] = i0 + u < n_e ? v : 0; }
+    float2 v[8][NF2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* src = (e[u] & TE_ENT_DX) ? A.G + (size_t)(e[u] & TE_ENT_ROW) * 3 * D : A.zrow;
+#pragma unroll
+      for (int q = 0; q < NF2; ++q) v[u][q] = *reinterpret_cast<const float2*>(src + ((e[u] & TE_ENT_DX) ? 2 * (lane + 64 * q) : 2 * lane));
+    }
+#pragma unroll
+    for (int q = 0; q < NF2; ++q) {
+      const float x = ((v[0][q].x + v[1][q].x) + (v[2][q].x + v[3][q].x)) + ((v[4][q].x + v[5][q].x) + (v[6][q].x + v[7][q].x));
+      const float y = ((v[0][q].y + v[1][q].y) + (v[2][q].y + v[3][q].y)) + ((v[4][q].y + v[5][q].y) + (v[6][q].y + v[7][q].y));
+      acc[q].x += x; acc[q].y += y;
+    }
+  }
+}
+// cold rows (<= 64 entries; ~5 on average, half of them dx entries): the chain row -> segment -> entry codes -> DA rows is latency,
+// not bytes, so a wavefront works on FOUR rows at once - 16 lanes per row, a lane owns 3D/64 float4 columns (coalesced 256-byte
+// pieces of the 1.5 KB DA row) - with four entries of each row in flight.
+template <int D>
+__global__ __launch_bounds__(256) void te_psum_cold_kernel(TeArgs A) {
+  constexpr int NF4 = 3 * D / 64;                    // float4 per lane per DA row (16 lanes per row)
+  const int P = A.cnt[4], lane = lane_id(), sub = lane >> 4, l16 = lane & 15;
+  for (int i0 = (blockIdx.x * 4 + wave_id()) * 4; i0 < P; i0 += gridDim.x * 16) {
+    const int idx = min(i0 + sub, P - 1);
+    const bool in = i0 + sub < P;
+    const int row = A.urow_p[idx];
+    const int start = A.seg_start[row], cnt = A.seg_end[row] - start;
+    const int n_e = (in && cnt <= TE_COLD_MAX) ? cnt : 0;          // hot rows: te_psum_hot / te_psum_fin
+    float4 acc[NF4];
+#pragma unroll
+    for (int q = 0; q < NF4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e0 = 0; e0 < n_e; e0 += 4) {
+      int e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int v = A.ent[start + min(e0 + u, n_e - 1)]; e[u] = e0 + u < n_e ? v : 0; }
+      float4 v[4][NF4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool dx = (e[u] & TE_ENT_DX) != 0;
+        const float* src = dx ? A.G + (size_t)(e[u] & TE_ENT_ROW) * 3 * D : A.zrow;
+#pragma unroll
+        for (int q = 0; q < NF4; ++q) v[u][q] = *reinterpret_cast<const float4*>(src + (dx ? 4 * (l16 + 16 * q) : 4 * l16));
+      }
+#pragma unroll
+      for (int q = 0; q < NF4; ++q) acc[q] = f4_add(acc[q], f4_add(f4_add(v[0][q], v[1][q]), f4_add(v[2][q], v[3][q])));
+    }
+    if (n_e > 0) {
+#pragma unroll
+      for (int q = 0; q < NF4; ++q) *reinterpret_cast<float4*>(A.S + (size_t)idx * 3 * D + 4 * (l16 + 16 * q)) = acc[q];
+    }
+  }
+}
+template <int D>
+__global__ __launch_bounds__(256) void te_psum_hot_kernel(TeArgs A) {
+  constexpr int NF2 = 3 * D / 128;
+  const int NC = A.cnt[5], lane = lane_id();
+  for (int ci = blockIdx.x * 4 + wave_id(); ci < NC; ci += gridDim.x * 4) {
+    const int2 it = A.ph_chunks[ci];
+    const int4 hr = A.ph_rows[it.x];
+    const int s0 = hr.y + 64 * it.y, n_e = min(64, hr.z - 64 * it.y);
+    float2 acc[NF2];
+    te_psum_range<D>(A, s0, n_e, acc);
+#pragma unroll
+    for (int q = 0; q < NF2; ++q) *reinterpret_cast<float2*>(A.ppart + (size_t)ci * 3 * D + 2 * (lane + 64 * q)) = acc[q];
+  }
+}
+template <int D>
+__global__ __launch_bounds__(256) void te_psum_fin_kernel(TeArgs A) {
+  constexpr int NF2 = 3 * D / 128;
+  const int NH = A.cnt[6], lane = lane_id();
+  for (int h = blockIdx.x * 4 + wave_id(); h < NH; h += gridDim.x * 4) {
+    const int4 hr = A.ph_rows[h];
+    const int nch = (hr.z + 63) / 64;
+    float2 acc[NF2];
+#pragma unroll
+    for (int q = 0; q < NF2; ++q) acc[q] = make_float2(0.f, 0.f);
+    constexpr int UF = D <= 128 ? 16 : 8;            // chunk partials in flight (the hottest POI of a launch has ~170 chunks)
+    for (int k0 = 0; k0 < nch; k0 += UF) {
+      float2 v[UF][NF2];
+#pragma unroll
+      for (int u = 0; u < UF; ++u)
+#pragma unroll
+        for (int q = 0; q < NF2; ++q) {
+          const float2 t = *reinterpret_cast<const float2*>(A.ppart + (size_t)(hr.w + min(k0 + u, nch - 1)) * 3 * D + 2 * (lane + 64 * q));
+          v[u][q] = k0 + u < nch ? t : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+      for (int q = 0; q < NF2; ++q) {
+        float x = 0.f, y = 0.f;
+#pragma unroll
+        for (int u = 0; u < UF; ++u) { x += v[u][q].x; y += v[u][q].y; }
+        acc[q].x += x; acc[q].y += y;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NF2; ++q) *reinterpret_cast<float2*>(A.S + (size_t)hr.x * 3 * D + 2 * (lane + 64 * q)) = acc[q];
+  }
+}
+
+hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st) {
+  // S-row assignment: on the caller's stream, right before it is needed - next to te_head / te_wgrad (persistent grids sized to the
+  // CU count) a co-resident kernel costs them a workgroup slot (measured: te_head +30 us with these two on the side stream)
+  hipLaunchKernelGGL(te_pcount_kernel, dim3(TE_PBLK), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(te_passign_kernel, dim3(TE_PBLK), dim3(256), 0, st, A);
+  if (A.dim == 128) {
+    hipLaunchKernelGGL(te_psum_cold_kernel<128>, dim3(num_cu * 16), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_psum_hot_kernel<128>, dim3(num_cu * 8), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_psum_fin_kernel<128>, dim3(num_cu), dim3(256), 0, st, A);
+  } else if (A.dim == 256) {
+    hipLaunchKernelGGL(te_psum_cold_kernel<256>, dim3(num_cu * 16), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_psum_hot_kernel<256>, dim3(num_cu * 8), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_psum_fin_kernel<256>, dim3(num_cu), dim3(256), 0, st, A);
+  } else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st) {
   const int bits = A.key_bits;
   const int npass = bits <= 9 ? 1 : bits <= 18 ? 2 : bits <= 27 ? 3 : 4;
@@ -153,20 +351,19 @@ hipError_t launch_te_sort(TeArgs& A, hipStream_t st) {
     if (kout == A.keys1) { kout = A.keys0; vout = A.vals0; } else { kout = A.keys1; vout = A.vals1; }
   }
   hipLaunchKernelGGL(te_segment_kernel, dim3(1024), dim3(256), 0, st, A, kin, vin);
+  A.ks = kin;
   return hipGetLastError();
 }
 
 // -------------------------------------------------------------------------------------------------
 // reduction of a row's entries
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
 template <int D>
 __device__ __forceinline__ float4 ent_contrib(const TeArgs& A, int e, int doff, int c) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   const size_t rr = (size_t)(e & TE_ENT_ROW);
   // (bintab: a distance-bin row's dx sum comes from the per-bin sums of DA, see te_dsum below - no di half of X exists)
-  if ((e & TE_ENT_DX) && !(A.bintab && doff)) v = *reinterpret_cast<const float4*>(A.X + rr * A.xw + doff + c);
+  if ((e & TE_ENT_DX) && !(A.bintab && doff) && !A.ppoi) v = *reinterpret_cast<const float4*>(A.X + rr * A.xw + doff + c);
   if (e & TE_ENT_GH) {
     float g = A.gcoef[rr - 1];
     if (e & TE_ENT_NEG) g = -g;
@@ -292,7 +489,7 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const size_t rr = (size_t)(e[u] & TE_ENT_ROW);
-        const bool dx = (e[u] & TE_ENT_DX) != 0, gh = (e[u] & TE_ENT_GH) != 0;
+        const bool dx = (e[u] & TE_ENT_DX) != 0 && !A.ppoi, gh = (e[u] & TE_ENT_GH) != 0;      // (ppoi: the row's dx sum is ONE row of X)
         const float* px = dx ? A.X + rr * A.xw + ri.doff + c : zrow + c;
         const float* ph = gh ? A.H + (rr - 1) * D + c : zrow + c;
         const float* pg = gh ? A.gcoef + (rr - 1) : zrow;
@@ -308,6 +505,13 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
         nf += e[u] < 0 ? 1 : 0;
       }
       acc = f4_add(acc, f4_add(f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])), f4_add(f4_add(v[4], v[5]), f4_add(v[6], v[7]))));
+    }
+    // per-POI regrouping: the summed dx of the row's step inputs = S[row] . ui, row seg_pidx[row] of X (te_gemm_dx over S)
+    const int pmk = (A.ppoi && in && row <= A.n_item) ? A.pmark[row] : 0;          // S row + 1 (te_passign), 0: not a step input
+    if (pmk && !hot) {
+      const float4 xs = *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + c);
+      acc = f4_add(acc, xs);
+      if (lane == lead) A.pmark[row] = 0;
     }
     if (in && !hot && (end != 0 || an != 0)) {
       const int nseq = ri.pn ? an : nf, mult = cnt + am;
@@ -378,6 +582,11 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
     for (int i = lane; i < nch; i += 64) nf += A.hot_nf[c0 + i];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) nf += __shfl_xor(nf, o, 64);
+    const int pmk = (A.ppoi && row <= A.n_item) ? A.pmark[row] : 0;
+    if (pmk) {
+      acc = f4_add(acc, *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + c));
+      if (lane == 0) A.pmark[row] = 0;
+    }
     apply_sum<D>(ri.trow, ri.f16, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   for (int k = b; k < e; ++k) { const int v = A.soff[k]; A.soff[k] = run; run += v; }
   if (tid == 1023) {
     A.soff[n] = part[1023];
-    if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; }   // slots, hot rows, hot chunks, touched rows
+    if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; A.cnt[4] = 0; A.cnt[5] = 0; A.cnt[6] = 0; }   // slots, hot rows, hot chunks, touched rows, S rows, S hot chunks / rows
   }
 }
 
@@ -222,6 +222,7 @@ __device__ __forceinline__ void te_slots(const TeArgs& A, int k, int base, int L
       else { const int b = A.dp[base + j]; key = A.n_item + 1 + b; code |= (j < ns ? TE_ENT_DX : 0); is_pdi = b == A.n_dist; }
     }
     if (e < nslot) { A.keys0[S0 + e] = key; A.code[S0 + e] = code; A.slot_seq[S0 + e] = k; }
+    if (A.ppoi && e < L && e < ns) A.pmark[key] = 1;          // POI rows that are step inputs (dx entries): rows of S (te_passign: S row + 1)
     plt += __builtin_popcountll(__ballot(is_plt));
     pdi += __builtin_popcountll(__ballot(is_pdi));
   }
@@ -1298,16 +1299,25 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   constexpr int NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
   const int XWJ = A.bintab ? D : XW;                         // d ui columns that are GEMM jobs (bintab: POI half only)
   const int NB_UI = (3 * D / T) * (XWJ / T);
-  const int Trows = A.soff[A.n_seq], rmax = max(Trows - 1, 0);        // (loads are clamped to row rmax)
+  const int Tsteps = A.soff[A.n_seq];
   // (an XCD-aware (chunk, job) order - all jobs of a K-chunk on one XCD - measured 10 % slower than this plain
   // order: it needs a chunk count that is a multiple of 8, which leaves CU slots empty)
-  const int job = blockIdx.x, kc = blockIdx.y;
+  // grid: 1-D list of (job, K-chunk) pairs - the d ui jobs get A.n_kc_ui chunks each (ppoi: their K is the S-row count), the rest nkc
+  int job, kc;
+  {
+    const int b = blockIdx.x, nu = NB_UI * A.n_kc_ui;
+    if (b < nu) { job = b / A.n_kc_ui; kc = b % A.n_kc_ui; }
+    else { job = NB_UI + (b - nu) / nkc; kc = (b - nu) % nkc; }
+  }
+  const bool pp = A.ppoi && job < NB_UI;
+  if (pp) nkc = A.n_kc_ui;
   int m0, n0, ldo, bsel; size_t oo;
   if (job < NB_UI) { const int bn = XWJ / T; m0 = (job / bn) * T; n0 = (job % bn) * T; ldo = XW; oo = A.dl.ui; bsel = 0; }
   else if (job < NB_UI + NB_ZR) { const int j = job - NB_UI, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.wh; bsel = 1; }
   else if (job < NB_UI + NB_ZR + NB_C) { const int j = job - NB_UI - NB_ZR, bn = D / T; m0 = 2 * D + (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = (size_t)A.dl.wh + (size_t)2 * D * D; bsel = 2; }
   else { const int j = job - NB_UI - NB_ZR - NB_C, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.vs; bsel = 3; }   // d vs = DL^T . H
   const int NBP = te_nbp_dev(A.n_dist), NB = A.n_dist + 1;
+  const int Trows = pp ? A.cnt[4] : Tsteps, rmax = max(Trows - 1, 0);        // (loads are clamped to row rmax)
   const int chunk = (((Trows + nkc - 1) / nkc) + 63) & ~63;
   const int rb = kc * chunk, re = min(Trows, rb + chunk);
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, tid = threadIdx.x;
@@ -1322,7 +1332,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   // two register sets: the stage loaded during iteration i is written to LDS at the end of iteration
   // i+1 and consumed in iteration i+2, so a global load has two MFMA blocks to land.  Loads are
   // unconditional (clamped addresses) and masked when they are written to LDS: no branch, no wait.
-  const float* Ap = bsel != 3 ? A.G + m0 : A.DL + m0;
+  const float* Ap = pp ? A.S + m0 : bsel != 3 ? A.G + m0 : A.DL + m0;
   const int lda = bsel != 3 ? 3 * D : NBP;
   const float* Bp = bsel == 2 ? A.RH + n0 : A.H + n0;
   const int ldb = D;
@@ -1334,7 +1344,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   const bool gdi = n0 >= D;
   const int goff = n0 - (gdi ? D : 0);
   const float* gtab = (gdi ? A.di : A.lt) + goff;        // (F16 and !gdi: A.lt is re-read as half below, offsets in elements)
-  const int* gidx = bsel == 0 ? (gdi ? A.row_dp : A.row_p) : A.row_t;
+  const int* gidx = bsel == 0 ? (gdi ? A.row_dp : pp ? A.urow_p : A.row_p) : A.row_t;
   float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
   int rt0[F4], rt1[F4];
   unsigned ni[F4];      // unsigned: a signed index is sign-extended right behind its load, i.e. the wave waits for it there
@@ -1346,7 +1356,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
       const int e = tid + s * TE_BLOCK;
       const int r = e / (T / 4), c = (e % (T / 4)) * 4;
       const int gr = min(r0 + r, rmax);
-      rt[s] = A.row_t[gr];                                      // h_{t-1} operand (bsel 1): none at the first step
+      rt[s] = A.row_t[min(gr, Tsteps)];                         // h_{t-1} operand (bsel 1): none at the first step
       ra[s] = *reinterpret_cast<const float4*>(Ap + (size_t)gr * lda + (c < acols ? c : 0));
       if constexpr (F16) {
         // branch-free (a branch around a load drains the queue): both typed loads are always issued from valid addresses - the
@@ -1494,6 +1504,12 @@ __global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile
 int te_wgrad_jobs(int D, int n_dist, bool spatial) {
   const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial)) ? 2 * D : D;
   return (3 * D / T) * (XW / T) + (2 * D / T) * (D / T) + (D / T) * (D / T) + (spatial ? ((te_nbp_dev(n_dist) + T - 1) / T) * (D / T) : 0);
+}
+
+int te_wgrad_ui_jobs(int D, int n_dist, bool spatial) {
+  (void)n_dist;
+  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial)) ? 2 * D : D;
+  return (3 * D / T) * (XW / T);
 }
 
 // Distance2Pre at D >= 128: the distance-bin half of the input goes through per-bin tables (te_ztab / te_dsum)
@@ -1645,19 +1661,29 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     finalize(A.side);
     if (hipEventRecord(A.ev_fin, A.side) != hipSuccess) return hipGetLastError();
   }
+  if (A.ppoi) {
+    // per-POI sums of DA over the sorted entries (the sort ran on the side stream next to te_rec_fwd)
+    if (A.side && hipStreamWaitEvent(st, A.ev_sorted, 0) != hipSuccess) return hipGetLastError();
+    tm->begin("te_psum", st);
+    hipError_t pe = launch_te_psum(A, num_cu, st);
+    if (pe != hipSuccess) return pe;
+    tm->end(st);
+  }
   tm->begin("te_wgrad", st);
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
-    const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0);
-    if (A.lt_f16) hipLaunchKernelGGL((te_wgrad_kernel<D, T, true>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
-    else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), dim3(jobs, A.n_kc), dim3(TE_BLOCK), 0, st, A, A.n_kc);
+    const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0), nui = te_wgrad_ui_jobs(D, A.n_dist, A.spatial != 0);
+    const dim3 grid(nui * A.n_kc_ui + (jobs - nui) * A.n_kc);
+    if (A.lt_f16) hipLaunchKernelGGL((te_wgrad_kernel<D, T, true>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
+    else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
   tm->begin("te_gemm_dx", st);
   {
     // dx = DA . ui: K = 3D is always wide enough for the compile-time-K kernel.  With the per-bin table only the
     // POI half of dx is needed (N = D, written into the first D columns of the 2D-wide X rows).
-    NtArgs P{A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.soff + n, A.bintab ? D : XW, 3 * D, nullptr, nullptr};
+    // (ppoi: one row per distinct step-input POI - S . ui[:, :D] - instead of one per step)
+    NtArgs P{A.ppoi ? A.S : A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.ppoi ? A.cnt + 4 : A.soff + n, A.bintab ? D : XW, 3 * D, nullptr, nullptr};
     const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
     if (A.bintab) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D, 3 * D, 2 * D>), grid, block, 0, st, P);
     else if (A.spatial) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D>), grid, block, 0, st, P);

