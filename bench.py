@@ -239,9 +239,11 @@ def main():
     uniq = 0                       # table rows written per epoch: unique rows per LAUNCH (one write per row and launch)
     uniq_seq = 0                   # n_unique(p U q) + n_unique(dp) per SEQUENCE, summed
     pos = 0
+    s_rows = 0                     # per-POI regrouping: distinct step-input POIs per launch (rows of S), summed over the epoch's launches
     for b0 in range(0, n_local, B):
         ids = order_host[b0:b0 + B]
         sel = np.concatenate([np.arange(off64[u], off64[u + 1]) for u in ids])
+        s_rows += len(np.unique(np.concatenate([tab.p[off64[u]:off64[u + 1] - 1] for u in ids])))
         uniq += len(np.unique(np.concatenate((tab.p[sel], tab.q[sel])))) + 1 + len(np.unique(np.append(tab.dp[sel], ds.dist_num)))
         pos += len(sel)
     if n_local <= 60000:
@@ -257,18 +259,24 @@ def main():
     # reference formulation (step_flops)
     bintab = D >= 128
     xk = 6 if bintab else 12
+    # per-POI regrouping (bintab): te_gemm_dx and the d ui jobs of te_wgrad contract over the S rows (distinct step-input POIs of a
+    # launch) instead of over the steps - rho = S rows / steps
+    ppoi = bintab and os.environ.get("POI_TE_PPOI", "1") != "0"
+    rho = (s_rows / steps_per_epoch) if ppoi else 1.0
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
             "te_gemm_ax": ("flop", xk * D2 * steps_per_epoch), "te_rec_fwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_head": ("flop", 4.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
-            "te_wgrad": ("flop", ((6 + xk) * D2 + 2.0 * NB * D) * steps_per_epoch),     # d ui, d wh and d vs (split-K)
-            "te_gemm_dx": ("flop", xk * D2 * steps_per_epoch),
+            "te_wgrad": ("flop", ((6 + xk * rho) * D2 + 2.0 * NB * D) * steps_per_epoch),     # d ui (over S rows), d wh and d vs (split-K)
+            "te_gemm_dx": ("flop", xk * rho * D2 * steps_per_epoch),
+            # per-POI sums of DA: one read of the 3D-wide DA rows + the S rows written
+            "te_psum": ("byte", 3.0 * D * 4 * (1.0 + rho) * steps_per_epoch),
             # implementation bytes of the HBM-bound kernels (what each kernel has to move given the decomposition):
             # te_gather builds E = lt[p'] - lt[q'] (two table rows + two indices in, one packed row out per step)
             "te_gather": ("byte", (3.0 * D * 4 + 8) * steps_per_epoch),
             "rows_apply": ("byte", 2.0 * uniq * D * 4.0),      # read + write of every touched row
-            # sorted scatter: per step dx (D floats; two-table path: 2D) + h twice (the g*h term of the positive and of the
-            # negative row) in, every touched row read + written
-            "te_scatter": ("byte", (3.0 if bintab else 4.0) * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0),
+            # sorted scatter: h twice per step (the g*h term of the positive and of the negative row) + the dx sums (per-POI regrouping:
+            # one D-row per S row; otherwise D floats per step, two-table path 2D) in, every touched row read + written
+            "te_scatter": ("byte", ((2.0 + rho) if bintab else 4.0) * D * 4 * steps_per_epoch + 2.0 * uniq * D * 4.0),
             # per-bin sums of DA (bintab): one read of the 3D-wide DA rows
             "te_dsum": ("byte", 3.0 * D * 4 * steps_per_epoch)}
     n_launches = len(batches)
@@ -312,7 +320,7 @@ def main():
                     **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
     roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
     # ---- gather / scatter against the HBM roofline: three accountings over the SAME kernel time --------------------
-    GS = ("te_gather", "te_dsum", "te_scatter", "rows_apply")
+    GS = ("te_gather", "te_psum", "te_dsum", "te_scatter", "rows_apply")
     gs_ms = sum(kernels[k]["ms_per_step"] for k in GS if k in kernels)
     gs_impl = sum(work[k][1] for k in GS if k in kernels)
     e = 4.0
@@ -326,8 +334,8 @@ def main():
                "survey_8d": "SURVEY.md 8(d) / BASELINE.md 4: per sequence 3*L*D*e + 16*L gathered + (n_unique(p U q) + n_unique(dp))*D*e written, summed over "
                             "the epoch's sequences - the contract figure.  NOTE the gather of the step input [lt[p] | di[dp]] is fused into the MFMA-bound "
                             "te_gemm_ax / te_wgrad (rows go straight into their LDS tiles) and its time is NOT in ms_per_epoch",
-               "implementation": "bytes the HBM-bound kernels have to move in this decomposition, intermediates included (E rows out, dx / h rows in, DA rows "
-                                 "for the per-bin sums, touched rows read + written)",
+               "implementation": "bytes the HBM-bound kernels have to move in this decomposition, intermediates included (E rows out, h rows and the per-POI "
+                                 "dx sums in, DA rows read once for the per-bin and once for the per-POI sums, S rows out, touched rows read + written)",
                "embedding_rows_only": "table rows only: the two rows of E per step + every touched row read and written once per launch"}}
     hbm["achieved"] = (hbm["survey_8d"] or hbm["implementation"])["achieved_GBps"]
     hbm["frac"] = (hbm["survey_8d"] or hbm["implementation"])["frac"]
@@ -482,7 +490,8 @@ def main():
                                                                   "their reference updates (include/poi_hip.h); see `quality` for what it learns" % a.batch_cap,
                        "batch_cap": a.batch_cap, "local_transition_fraction": a.local,
                        "parallelism": "user-shard x%d, per-epoch delta all-reduce" % world,
-                       "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence"},
+                       "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence",
+                       "s_rows_per_step": rho},
             "timed_window_s": dt,
             "eval_users_per_s": eval_users_per_s, "eval": eval_detail,
             "roofline": roofline, "roofline_gather_scatter": hbm, "kernels": kernels,

@@ -195,15 +195,15 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2;      // 64-entry chunks of the bins' entry segments
   const size_t n_dsuper = n_dchunk / 32 + NBt + 2;
   const size_t bfl = A.bintab ? NBt * (size_t)(3 * D) * 2 + NBt * D + (sorted ? (n_dchunk + n_dsuper) * (size_t)(3 * D) : 0) + 64 : 0;
-  const size_t n_pch = Tcap / 32 + 4, n_phot = Tcap / 64 + 4;
-  const size_t pfl = A.ppoi ? Tcap * (size_t)(3 * D) + n_pch * (size_t)(3 * D) + 64 : 0;
+  const size_t n_prange = Tcap / 64 + 4;
+  const size_t pfl = A.ppoi ? Tcap * (size_t)(3 * D) + 2 * n_prange * (size_t)(3 * D) + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl + pfl;
-  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 2 * NBt + 64 : 0) + (A.ppoi ? Tcap + 512 + 4 * n_phot + 2 * n_pch + 64 : 0);
+  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 2 * NBt + 64 : 0) + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
   if (sorted && ((rc = ensure(c, c->seg_s, sizeof(int) * (size_t)(R + 1), st)) || (rc = ensure(c, c->seg_e, sizeof(int) * (size_t)(R + 1), st)))) return rc;
-  if (A.ppoi && ((rc = ensure(c, c->pmark, sizeof(int) * (size_t)(P->n_item + 2), st)) || (rc = ensure(c, c->seg_pidx, sizeof(int) * (size_t)(P->n_item + 2), st)))) return rc;
+  if (A.ppoi && (rc = ensure(c, c->pmark, sizeof(int) * (size_t)(P->n_item + 2), st))) return rc;
   float* f = (float*)c->te_ws.p;
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
   A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
@@ -215,7 +215,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.ztab = take(NBt * 3 * D); A.dsum = take(NBt * 3 * D); A.dgd = take(NBt * D);
     if (sorted) { A.dpart = take(n_dchunk * (size_t)(3 * D)); A.dpart2 = take(n_dsuper * (size_t)(3 * D)); }
   }
-  if (A.ppoi) { A.S = take(Tcap * (size_t)(3 * D)); A.ppart = take(n_pch * (size_t)(3 * D)); }
+  if (A.ppoi) { A.S = take(Tcap * (size_t)(3 * D)); A.pfirst = take(n_prange * (size_t)(3 * D)); A.plast = take(n_prange * (size_t)(3 * D)); }
   if (sorted) {
     A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP);
     A.bi_part = take((size_t)((n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);
@@ -235,8 +235,8 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.seg_start = (int*)c->seg_s.p; A.seg_end = (int*)c->seg_e.p;
     A.dch0 = itake(260);
     if (A.ppoi) {
-      A.urow_p = itake(Tcap); A.pblk = itake(256); A.ph_rows = (int4*)itake(4 * n_phot); A.ph_chunks = (int2*)itake(2 * n_pch);
-      A.pmark = (int*)c->pmark.p; A.seg_pidx = (int*)c->seg_pidx.p;
+      A.urow_p = itake(Tcap); A.pblk = itake(2 * 1024); A.dxe = itake(Tcap); A.dxs = itake(Tcap); A.dstart = itake(Tcap + 4);
+      A.pmark = (int*)c->pmark.p;
     }
     if (A.bintab) { A.dch1 = itake(260); A.dnf = itake(n_dchunk); A.dnf2 = itake(n_dsuper); A.dbn = itake(NBt + 4); }
   }

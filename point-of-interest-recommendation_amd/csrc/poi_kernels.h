@@ -111,7 +111,7 @@ struct TeArgs {
   int *ent;                           // sorted entry codes (bit 31: first entry of its sequence in the row)
   int *seg_start, *seg_end;           // per unified row: [start, end) in `ent`; end == 0 <=> untouched (persistent, re-zeroed)
   int *hist;                          // radix histogram (bins x blocks)
-  int *cnt;                           // [0] number of slots, [1] hot rows, [2] hot chunks, [3] touched rows (urow), [4] S rows, [5] / [6] S hot chunks / rows
+  int *cnt;                           // [0] number of slots, [1] hot rows, [2] hot chunks, [3] touched rows (urow), [4] S rows, [5] dx entries of the POI rows
   int *urow;                          // list of touched table rows (null: te_reduce scans the tables), see te_segment
   int4* hot_rows;                     // {row, start, count, first chunk}
   int2* hot_chunks;                   // {hot row index, chunk index}
@@ -124,11 +124,11 @@ struct TeArgs {
   //   d lt[p] (dx part) = S[p] . ui[:, :D]   (te_gemm_dx over S rows)      d ui[:, :D] = S^T . lt[rows of S]   (te_wgrad, K = S rows)
   int ppoi;
   int *pmark;                         // per lt row: has a dx entry in this launch (zero between launches; te_slots sets, the write-back clears)
-  int *seg_pidx, *urow_p;             // lt row -> S row, S row -> lt row
-  int *pblk;                          // per-block counts of the S-row assignment
+  int *urow_p;                        // S row -> lt row (lt row -> S row + 1 is pmark itself after te_passign)
+  int *pblk;                          // per-block counts of the scan (S rows | dx entries)
   const int *ks;                      // sorted keys (set by launch_te_sort)
-  float *S, *ppart;                   // S (rows x 3D); 64-entry chunk partials of the hot S rows
-  int4 *ph_rows; int2 *ph_chunks;     // hot S rows {S row, start, count, first chunk}; chunk -> {hot row, chunk index}
+  int *dxe, *dxs, *dstart;            // compacted dx entries of the POI rows: packed step row, S row; first list position of every S row (+ end)
+  float *S, *pfirst, *plast;          // S (rows x 3D); per 64-entry range: sum of its opening / closing run
   int n_kc_ui;                        // te_wgrad: K-chunks of the d ui jobs (their K is the S-row count, ~T/5)
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
 };

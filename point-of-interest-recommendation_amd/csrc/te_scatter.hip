@@ -142,10 +142,17 @@ __global__ __launch_bounds__(256) void te_segment_kernel(TeArgs A, const int* __
 }
 
 // -------------------------------------------------------------------------------------------------
-// per-POI regrouping (TeArgs.ppoi): S rows.  A POI row with at least one dx entry (pmark, set by te_slots) becomes a row of S; its
-// index is its rank among such rows in sorted-key order - an exclusive scan over the sorted slots in two kernels (per-block counts,
-// then block prefix + in-block scan), so the order of the S rows (= the summation order of the d ui jobs of te_wgrad) does not depend
-// on scheduling.  Rows with more than 64 entries are cut into 64-entry chunks (te_psum_hot) whose partials are added in order.
+// per-POI regrouping (TeArgs.ppoi): S[r] = sum of DA over the steps whose input POI is row r.
+//   te_pcount / te_passign  one exclusive scan over the sorted slots (per-block counts, then block prefix + ballot ranks inside
+//                           256-wide strips) ranks the POI rows that are step inputs (pmark, set by te_slots) in sorted-key order
+//                           -> S row index (pmark[row] <- index + 1, urow_p), AND compacts their dx entries into one list
+//                           (dxe = packed step row, dxs = S row, dstart = first list position of every S row).  The order of the S
+//                           rows - the summation order of te_wgrad's d ui jobs - does not depend on scheduling.
+//   te_psum                 streams the list like te_dsum streams the bins: one workgroup per 64 consecutive entries, thread =
+//                           column of DA, 16 rows in flight; a run of equal S rows inside the range is summed in order and flushed -
+//                           complete rows straight to S, the run that opens the range to pfirst[range], the one that closes it to
+//                           plast[range] (a hot POI spans many ranges)
+//   te_pfin                 stitches the rows that cross range boundaries: head fragment + whole ranges + tail fragment, in order
 // -------------------------------------------------------------------------------------------------
 #define TE_PBLK 1024
 __device__ __forceinline__ bool te_pflag(const TeArgs& A, int i, int N) {
@@ -153,170 +160,115 @@ __device__ __forceinline__ bool te_pflag(const TeArgs& A, int i, int N) {
   const int k = A.ks[i];
   return k <= A.n_item && (i == 0 || A.ks[i - 1] != k) && A.pmark[k] != 0;
 }
+__device__ __forceinline__ bool te_dxflag(const TeArgs& A, int i, int N) {
+  return i < N && A.ks[i] <= A.n_item && (A.ent[i] & TE_ENT_DX) != 0;
+}
 __device__ __forceinline__ int te_pper(int N) { return (((N + TE_PBLK - 1) / TE_PBLK) + 255) & ~255; }
 __global__ __launch_bounds__(256) void te_pcount_kernel(TeArgs A) {
-  __shared__ int red[4];
+  __shared__ int red[2][4];
   const int N = A.cnt[0], per = te_pper(N);
   const int b0 = blockIdx.x * per;
-  int c = 0;
-  for (int i = b0 + threadIdx.x; i < min(N, b0 + per); i += 256) c += te_pflag(A, i, N) ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if (lane_id() == 0) red[wave_id()] = c;
+  int c = 0, d = 0;
+  for (int i = b0 + threadIdx.x; i < min(N, b0 + per); i += 256) { c += te_pflag(A, i, N) ? 1 : 0; d += te_dxflag(A, i, N) ? 1 : 0; }
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+  if (lane_id() == 0) { red[0][wave_id()] = c; red[1][wave_id()] = d; }
   __syncthreads();
-  if (threadIdx.x == 0) A.pblk[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    A.pblk[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    A.pblk[TE_PBLK + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
 }
-// positions are taken in 256-wide strips (coalesced), ranks inside a strip from ballots: idx = rows before the block + rows in
-// earlier strips + rows in earlier waves of the strip + flagged lanes below this one.  pmark[row] <- idx + 1 (te_reduce reads the S
-// row index from the mark itself).
 __global__ __launch_bounds__(256) void te_passign_kernel(TeArgs A) {
-  __shared__ int s_w[4];
-  __shared__ int s_base;
+  __shared__ int s_w[2][4];
+  __shared__ int s_base[2];
   const int N = A.cnt[0], per = te_pper(N), tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int b0 = blockIdx.x * per;
   {
-    int v = 0;
-    for (int j = tid; j < (int)blockIdx.x; j += 256) v += A.pblk[j];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) s_w[w] = v;
+    int v = 0, v2 = 0;
+    for (int j = tid; j < (int)blockIdx.x; j += 256) { v += A.pblk[j]; v2 += A.pblk[TE_PBLK + j]; }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); v2 += __shfl_xor(v2, o, 64); }
+    if (lane == 0) { s_w[0][w] = v; s_w[1][w] = v2; }
     __syncthreads();
-    if (tid == 0) s_base = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (tid == 0) { s_base[0] = (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]); s_base[1] = (s_w[1][0] + s_w[1][1]) + (s_w[1][2] + s_w[1][3]); }
     __syncthreads();
   }
-  int base = s_base;
+  int rbase = s_base[0], dbase = s_base[1];
+  const unsigned long long below = (1ull << lane) - 1ull;
   for (int i0 = b0; i0 < min(N, b0 + per); i0 += 256) {
     const int i = i0 + tid;
-    const bool f = te_pflag(A, i, N);
-    const unsigned long long m = __ballot(f);
+    const bool f = te_pflag(A, i, N), dx = te_dxflag(A, i, N);
+    const unsigned long long m = __ballot(f), md = __ballot(dx);
     __syncthreads();
-    if (lane == 0) s_w[w] = __builtin_popcountll(m);
+    if (lane == 0) { s_w[0][w] = __builtin_popcountll(m); s_w[1][w] = __builtin_popcountll(md); }
     __syncthreads();
-    int before = 0;
-    for (int j = 0; j < w; ++j) before += s_w[j];
-    const int tot = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    int rb = 0, db = 0;
+    for (int j = 0; j < w; ++j) { rb += s_w[0][j]; db += s_w[1][j]; }
+    const int rinc = rbase + rb + __builtin_popcountll(m & below) + (f ? 1 : 0);     // row flags up to and including this position
+    const int dpos = dbase + db + __builtin_popcountll(md & below);                  // dx entries before this position
     if (f) {
-      const int idx = base + before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      const int row = A.ks[i], cnt = A.seg_end[row] - i;          // (te_segment: seg_start[row] == i)
-      A.pmark[row] = idx + 1; A.urow_p[idx] = row;
-      if (cnt > TE_COLD_MAX) {
-        const int nch = (cnt + 63) / 64;
-        const int h = atomicAdd(&A.cnt[6], 1), c0 = atomicAdd(&A.cnt[5], nch);
-        A.ph_rows[h] = make_int4(idx, i, cnt, c0);
-        for (int k = 0; k < nch; ++k) A.ph_chunks[c0 + k] = make_int2(h, k);
-      }
+      const int idx = rinc - 1, row = A.ks[i];
+      A.pmark[row] = idx + 1; A.urow_p[idx] = row; A.dstart[idx] = dpos;
     }
-    base += tot;
+    if (dx) { A.dxe[dpos] = A.ent[i] & TE_ENT_ROW; A.dxs[dpos] = rinc - 1; }           // (a dx entry's row is flagged at or before it)
+    rbase += (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]);
+    dbase += (s_w[1][0] + s_w[1][1]) + (s_w[1][2] + s_w[1][3]);
   }
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) A.cnt[4] = base;          // total number of S rows
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) { A.cnt[4] = rbase; A.cnt[5] = dbase; A.dstart[rbase] = dbase; }
 }
 
-// S[idx] = sum of DA over the dx entries of the row (cold rows: one wavefront per row, eight entries in flight; every load
-// unconditional - entries without a dx term read the resident zero row).  A lane owns 3D / 128 float2 columns.
 template <int D>
-__device__ __forceinline__ void te_psum_range(const TeArgs& A, int s0, int n_e, float2 (&acc)[3 * D / 128]) {
-  constexpr int NF2 = 3 * D / 128;
-  const int lane = lane_id();
+__global__ __launch_bounds__(3 * D) void te_psum_kernel(TeArgs A) {
+  const int Ndx = A.cnt[5], col = threadIdx.x;
+  const int nr = (Ndx + 63) / 64;
+  for (int r = blockIdx.x; r < nr; r += gridDim.x) {
+    const int j0 = 64 * r, j1 = min(Ndx, j0 + 64);
+    int cur = A.dxs[j0];
+    bool first = true;
+    float acc = 0.f;
+    for (int j = j0; j < j1; j += 16) {
+      int e[16], sr[16];
 #pragma unroll
-  for (int q = 0; q < NF2; ++q) acc[q] = make_float2(0.f, 0.f);
-  for (int i0 = 0; i0 < n_e; i0 += 8) {
-    int e[8];
+      for (int u = 0; u < 16; ++u) { e[u] = A.dxe[min(j + u, j1 - 1)]; sr[u] = A.dxs[min(j + u, j1 - 1)]; }
+      float v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int v = A.ent[s0 + min(i0 + u, n_e - 1)]; e[u] = i0 + u < n_e ? v : 0; }
-    float2 v[8][NF2];
+      for (int u = 0; u < 16; ++u) v[u] = A.G[(size_t)e[u] * 3 * D + col];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float* src = (e[u] & TE_ENT_DX) ? A.G + (size_t)(e[u] & TE_ENT_ROW) * 3 * D : A.zrow;
-#pragma unroll
-      for (int q = 0; q < NF2; ++q) v[u][q] = *reinterpret_cast<const float2*>(src + ((e[u] & TE_ENT_DX) ? 2 * (lane + 64 * q) : 2 * lane));
-    }
-#pragma unroll
-    for (int q = 0; q < NF2; ++q) {
-      const float x = ((v[0][q].x + v[1][q].x) + (v[2][q].x + v[3][q].x)) + ((v[4][q].x + v[5][q].x) + (v[6][q].x + v[7][q].x));
-      const float y = ((v[0][q].y + v[1][q].y) + (v[2][q].y + v[3][q].y)) + ((v[4][q].y + v[5][q].y) + (v[6][q].y + v[7][q].y));
-      acc[q].x += x; acc[q].y += y;
-    }
-  }
-}
-// cold rows (<= 64 entries; ~5 on average, half of them dx entries): the chain row -> segment -> entry codes -> DA rows is latency,
-// not bytes, so a wavefront works on FOUR rows at once - 16 lanes per row, a lane owns 3D/64 float4 columns (coalesced 256-byte
-// pieces of the 1.5 KB DA row) - with four entries of each row in flight.
-template <int D>
-__global__ __launch_bounds__(256) void te_psum_cold_kernel(TeArgs A) {
-  constexpr int NF4 = 3 * D / 64;                    // float4 per lane per DA row (16 lanes per row)
-  const int P = A.cnt[4], lane = lane_id(), sub = lane >> 4, l16 = lane & 15;
-  for (int i0 = (blockIdx.x * 4 + wave_id()) * 4; i0 < P; i0 += gridDim.x * 16) {
-    const int idx = min(i0 + sub, P - 1);
-    const bool in = i0 + sub < P;
-    const int row = A.urow_p[idx];
-    const int start = A.seg_start[row], cnt = A.seg_end[row] - start;
-    const int n_e = (in && cnt <= TE_COLD_MAX) ? cnt : 0;          // hot rows: te_psum_hot / te_psum_fin
-    float4 acc[NF4];
-#pragma unroll
-    for (int q = 0; q < NF4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e0 = 0; e0 < n_e; e0 += 4) {
-      int e[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int v = A.ent[start + min(e0 + u, n_e - 1)]; e[u] = e0 + u < n_e ? v : 0; }
-      float4 v[4][NF4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool dx = (e[u] & TE_ENT_DX) != 0;
-        const float* src = dx ? A.G + (size_t)(e[u] & TE_ENT_ROW) * 3 * D : A.zrow;
-#pragma unroll
-        for (int q = 0; q < NF4; ++q) v[u][q] = *reinterpret_cast<const float4*>(src + (dx ? 4 * (l16 + 16 * q) : 4 * l16));
-      }
-#pragma unroll
-      for (int q = 0; q < NF4; ++q) acc[q] = f4_add(acc[q], f4_add(f4_add(v[0][q], v[1][q]), f4_add(v[2][q], v[3][q])));
-    }
-    if (n_e > 0) {
-#pragma unroll
-      for (int q = 0; q < NF4; ++q) *reinterpret_cast<float4*>(A.S + (size_t)idx * 3 * D + 4 * (l16 + 16 * q)) = acc[q];
-    }
-  }
-}
-template <int D>
-__global__ __launch_bounds__(256) void te_psum_hot_kernel(TeArgs A) {
-  constexpr int NF2 = 3 * D / 128;
-  const int NC = A.cnt[5], lane = lane_id();
-  for (int ci = blockIdx.x * 4 + wave_id(); ci < NC; ci += gridDim.x * 4) {
-    const int2 it = A.ph_chunks[ci];
-    const int4 hr = A.ph_rows[it.x];
-    const int s0 = hr.y + 64 * it.y, n_e = min(64, hr.z - 64 * it.y);
-    float2 acc[NF2];
-    te_psum_range<D>(A, s0, n_e, acc);
-#pragma unroll
-    for (int q = 0; q < NF2; ++q) *reinterpret_cast<float2*>(A.ppart + (size_t)ci * 3 * D + 2 * (lane + 64 * q)) = acc[q];
-  }
-}
-template <int D>
-__global__ __launch_bounds__(256) void te_psum_fin_kernel(TeArgs A) {
-  constexpr int NF2 = 3 * D / 128;
-  const int NH = A.cnt[6], lane = lane_id();
-  for (int h = blockIdx.x * 4 + wave_id(); h < NH; h += gridDim.x * 4) {
-    const int4 hr = A.ph_rows[h];
-    const int nch = (hr.z + 63) / 64;
-    float2 acc[NF2];
-#pragma unroll
-    for (int q = 0; q < NF2; ++q) acc[q] = make_float2(0.f, 0.f);
-    constexpr int UF = D <= 128 ? 16 : 8;            // chunk partials in flight (the hottest POI of a launch has ~170 chunks)
-    for (int k0 = 0; k0 < nch; k0 += UF) {
-      float2 v[UF][NF2];
-#pragma unroll
-      for (int u = 0; u < UF; ++u)
-#pragma unroll
-        for (int q = 0; q < NF2; ++q) {
-          const float2 t = *reinterpret_cast<const float2*>(A.ppart + (size_t)(hr.w + min(k0 + u, nch - 1)) * 3 * D + 2 * (lane + 64 * q));
-          v[u][q] = k0 + u < nch ? t : make_float2(0.f, 0.f);
+      for (int u = 0; u < 16; ++u) {
+        if (j + u < j1) {                                  // (block-uniform control flow: every thread sees the same entries)
+          if (sr[u] != cur) {
+            if (first) A.pfirst[(size_t)r * 3 * D + col] = acc; else A.S[(size_t)cur * 3 * D + col] = acc;
+            first = false; cur = sr[u]; acc = 0.f;
+          }
+          acc += v[u];
         }
-#pragma unroll
-      for (int q = 0; q < NF2; ++q) {
-        float x = 0.f, y = 0.f;
-#pragma unroll
-        for (int u = 0; u < UF; ++u) { x += v[u][q].x; y += v[u][q].y; }
-        acc[q].x += x; acc[q].y += y;
       }
     }
+    if (first) A.pfirst[(size_t)r * 3 * D + col] = acc; else A.plast[(size_t)r * 3 * D + col] = acc;
+  }
+}
+
+// rows whose dx entries are not strictly inside one range: first / last run of a range, or spanning several ranges
+template <int D>
+__global__ __launch_bounds__(3 * D) void te_pfin_kernel(TeArgs A) {
+  const int P = A.cnt[4], Ndx = A.cnt[5], col = threadIdx.x;
+  for (int idx = blockIdx.x; idx < P; idx += gridDim.x) {
+    const int d0 = A.dstart[idx], d1 = A.dstart[idx + 1];
+    const int ra = d0 >> 6, rb = (d1 - 1) >> 6;
+    const bool first_a = (d0 & 63) == 0, closes_b = d1 == min(Ndx, 64 * (rb + 1));
+    if (ra == rb) {
+      if (first_a) A.S[(size_t)idx * 3 * D + col] = A.pfirst[(size_t)ra * 3 * D + col];
+      else if (closes_b) A.S[(size_t)idx * 3 * D + col] = A.plast[(size_t)ra * 3 * D + col];
+      continue;                                             // (strictly inside: te_psum wrote S)
+    }
+    float s = first_a ? A.pfirst[(size_t)ra * 3 * D + col] : A.plast[(size_t)ra * 3 * D + col];
+    for (int r0 = ra + 1; r0 <= rb; r0 += 16) {           // whole ranges and the tail fragment: all "first run of their range"
+      float v[16];
 #pragma unroll
-    for (int q = 0; q < NF2; ++q) *reinterpret_cast<float2*>(A.S + (size_t)hr.x * 3 * D + 2 * (lane + 64 * q)) = acc[q];
+      for (int u = 0; u < 16; ++u) v[u] = A.pfirst[(size_t)min(r0 + u, rb) * 3 * D + col];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += r0 + u <= rb ? v[u] : 0.f;
+    }
+    A.S[(size_t)idx * 3 * D + col] = s;
   }
 }
 
@@ -326,13 +278,11 @@ hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st) {
   hipLaunchKernelGGL(te_pcount_kernel, dim3(TE_PBLK), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_passign_kernel, dim3(TE_PBLK), dim3(256), 0, st, A);
   if (A.dim == 128) {
-    hipLaunchKernelGGL(te_psum_cold_kernel<128>, dim3(num_cu * 16), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(te_psum_hot_kernel<128>, dim3(num_cu * 8), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(te_psum_fin_kernel<128>, dim3(num_cu), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_psum_kernel<128>, dim3(num_cu * 8), dim3(384), 0, st, A);
+    hipLaunchKernelGGL(te_pfin_kernel<128>, dim3(num_cu * 16), dim3(384), 0, st, A);
   } else if (A.dim == 256) {
-    hipLaunchKernelGGL(te_psum_cold_kernel<256>, dim3(num_cu * 16), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(te_psum_hot_kernel<256>, dim3(num_cu * 8), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(te_psum_fin_kernel<256>, dim3(num_cu), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_psum_kernel<256>, dim3(num_cu * 8), dim3(768), 0, st, A);
+    hipLaunchKernelGGL(te_pfin_kernel<256>, dim3(num_cu * 16), dim3(768), 0, st, A);
   } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -442,7 +392,7 @@ __device__ __forceinline__ RowInfo row_info(const TeArgs& A, int row) {
 // every load of a batch is issued unconditionally before the first use: an entry without a dx (or g*h) term reads a
 // resident all-zero row instead of branching around the load (a branch would make the waitcnt pass drain the queue).
 // Entries are added in batch order ((e0+e1)+(e2+e3))+((e4+e5)+(e6+e7)), batches in order: reproducible.
-template <int D>
+template <int D, bool PPOI>       // PPOI: per-POI regrouping - a POI row's dx sum is ONE row of X (S . ui), no per-entry dx rows exist
 __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, float lambda) {
   constexpr int LPR = D / 4, RPW = 64 / LPR;
   const int RT = A.bintab ? A.n_item + 1 : A.n_item + 1 + A.n_dist + 1;     // bintab: the distance-bin rows are written by te_dapply
@@ -489,11 +439,11 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const size_t rr = (size_t)(e[u] & TE_ENT_ROW);
-        const bool dx = (e[u] & TE_ENT_DX) != 0 && !A.ppoi, gh = (e[u] & TE_ENT_GH) != 0;      // (ppoi: the row's dx sum is ONE row of X)
+        const bool dx = (e[u] & TE_ENT_DX) != 0, gh = (e[u] & TE_ENT_GH) != 0;
         const float* px = dx ? A.X + rr * A.xw + ri.doff + c : zrow + c;
         const float* ph = gh ? A.H + (rr - 1) * D + c : zrow + c;
         const float* pg = gh ? A.gcoef + (rr - 1) : zrow;
-        x[u] = *reinterpret_cast<const float4*>(px);
+        if (PPOI) x[u] = make_float4(0.f, 0.f, 0.f, 0.f); else x[u] = *reinterpret_cast<const float4*>(px);
         hh[u] = *reinterpret_cast<const float4*>(ph);
         g[u] = *pg;
       }
@@ -507,7 +457,7 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
       acc = f4_add(acc, f4_add(f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])), f4_add(f4_add(v[4], v[5]), f4_add(v[6], v[7]))));
     }
     // per-POI regrouping: the summed dx of the row's step inputs = S[row] . ui, row seg_pidx[row] of X (te_gemm_dx over S)
-    const int pmk = (A.ppoi && in && row <= A.n_item) ? A.pmark[row] : 0;          // S row + 1 (te_passign), 0: not a step input
+    const int pmk = (PPOI && in && row <= A.n_item) ? A.pmark[row] : 0;          // S row + 1 (te_passign), 0: not a step input
     if (pmk && !hot) {
       const float4 xs = *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + c);
       acc = f4_add(acc, xs);
@@ -774,7 +724,8 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
     tm->end(st);
   }
   tm->begin("te_scatter", st);
-  hipLaunchKernelGGL(te_reduce_kernel<D>, dim3(grid), dim3(256), 0, st, A, alpha, lambda);
+  if (A.ppoi) hipLaunchKernelGGL((te_reduce_kernel<D, true>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
+  else hipLaunchKernelGGL((te_reduce_kernel<D, false>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu), dim3(256), 0, st, A, alpha, lambda);
   tm->end(st);

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   for (int k = b; k < e; ++k) { const int v = A.soff[k]; A.soff[k] = run; run += v; }
   if (tid == 1023) {
     A.soff[n] = part[1023];
-    if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; A.cnt[4] = 0; A.cnt[5] = 0; A.cnt[6] = 0; }   // slots, hot rows, hot chunks, touched rows, S rows, S hot chunks / rows
+    if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; A.cnt[4] = 0; A.cnt[5] = 0; }   // slots, hot rows, hot chunks, touched rows, S rows, dx entries of the POI rows
   }
 }
 
