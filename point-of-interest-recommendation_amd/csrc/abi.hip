@@ -38,7 +38,7 @@ struct poi_ctx {
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
   DevBuf pmark, seg_pidx;   // per-POI regrouping: per lt row "is a step input in this launch" (all-zero between launches), row -> S row
   int ppoi = 1;             // POI_TE_PPOI=0 disables the regrouping (A/B)
-  float ppoi_rho = 0.2f;    // expected S rows / steps: balances te_wgrad's d ui jobs against the others (POI_PPOI_RHO)
+  DevBuf kc_dev;            // te_wgrad's K-chunk split, chosen on the device per launch
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
@@ -109,7 +109,6 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
-  if (const char* e = getenv("POI_PPOI_RHO")) { const float v = (float)atof(e); if (v > 0.01f && v <= 1.f) c->ppoi_rho = v; }
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   const char* sd = getenv("POI_TE_SIDE");
@@ -129,7 +128,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->seg_pidx,
+  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->seg_pidx, &c->kc_dev,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
@@ -276,12 +275,13 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if (n_kc < 1) n_kc = 1;
     n_kc_ui = n_kc;
     if (poi::te_bintab(D, spatial) && c->ppoi) {
-      // per-POI regrouping: the d ui jobs contract over S rows (~rho x the steps): give them rho x the K-chunks of the others so
-      // that every workgroup of the (job, chunk) grid has the same amount of work and the grid still fills the chip exactly
-      n_kc = (int)((float)(c->num_cu * c->wgrad_rounds) / ((float)nui * c->ppoi_rho + (float)(jobs - nui)));
-      if (n_kc < 1) n_kc = 1;
-      n_kc_ui = (int)((float)n_kc * c->ppoi_rho + 0.5f);
-      if (n_kc_ui < 1) n_kc_ui = 1;
+      // per-POI regrouping: te_wgrad picks the K-chunk split on the device from the launch's own S-row count; the slabs are sized for
+      // the extremes (no S rows: every slot goes to the T-row jobs; as many S rows as steps: the uniform split)
+      int a, b;
+      poi::te_wgrad_split(c->num_cu * c->wgrad_rounds, nui, jobs, 1, 1 << 20, &a, &b);
+      n_kc_ui = n_kc;
+      n_kc = a > n_kc ? a : n_kc;
+      if ((rc = ensure(c, c->kc_dev, 64, st))) return rc;
     }
     n_slab = n_kc > n_kc_ui ? n_kc : n_kc_ui;
     if ((rc = ensure(c, c->hslab, sizeof(float) * (size_t)n_head * ((NB + 4) & ~3), st))) return rc;
@@ -307,13 +307,14 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
     if ((rc = ensure(c, c->zrow, sizeof(float) * 1024, st))) return rc;
     E.zrow = (const float*)c->zrow.p;
-    E.out = out; E.bcap = c->batch_cap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.n_kc_ui = n_kc_ui;
+    E.out = out; E.bcap = c->batch_cap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
+    E.kc_dev = (poi::te_bintab(D, spatial) && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
     HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));
-    A.n_slab_ui = n_kc_ui;               // (number of slabs the d ui region was written to, see dense_apply_kernel)
+    A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)
     HIPCHK(c, poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, st, &c->tm));
     return POI_OK;
   }

@@ -49,9 +49,22 @@ struct SeqArgs {
   int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
   // predict outputs (row k of the launch goes to output row out_row[k], or k when out_row is null)
   float *hts, *sts; const int* out_row;
-  int n_slab_ui;     // tile launches: slabs the d ui region was written to (0: as the other regions)
+  const int* kc_dev; // tile launches: {slabs of the other regions, slabs of the d ui region}, written by te_wgrad (null: n_slab)
   float bcap;        // batch rule: at most `bcap` of the touching sequences' updates count (1 = mean rule), include/poi_hip.h
 };
+
+// te_wgrad's (job, K-chunk) grid: `slots` workgroups, nui d ui jobs contracting over P rows and (jobs - nui) jobs over T rows.  Every
+// workgroup should get the same number of rows: n_o chunks for the T-row jobs, n_u ~ n_o * P / T for the ui jobs, filling `slots`.
+__host__ __device__ inline void te_wgrad_split(int slots, int nui, int jobs, int P, int T, int* n_o, int* n_u) {
+  float rho = (T > 0 && P > 0) ? (float)P / (float)T : 1.f;
+  rho = rho < 0.02f ? 0.02f : rho > 1.f ? 1.f : rho;
+  int o = (int)((float)slots / ((float)nui * rho + (float)(jobs - nui)));
+  if (o < 1) o = 1;
+  int u = (int)((float)o * rho + 0.5f);
+  if (u < 1) u = 1;
+  while (o > 1 && nui * u + (jobs - nui) * o > slots) --o;
+  *n_o = o; *n_u = u;
+}
 
 // Layout of one dense-gradient slab (offsets in floats).
 struct DenseLayout { int ui, wh, bi, vs, bs, wd, sur, upq, total; };
@@ -129,7 +142,9 @@ struct TeArgs {
   const int *ks;                      // sorted keys (set by launch_te_sort)
   int *dxe, *dxs, *dstart;            // compacted dx entries of the POI rows: packed step row, S row; first list position of every S row (+ end)
   float *S, *pfirst, *plast;          // S (rows x 3D); per 64-entry range: sum of its opening / closing run
-  int n_kc_ui;                        // te_wgrad: K-chunks of the d ui jobs (their K is the S-row count, ~T/5)
+  int wg_slots;                       // te_wgrad: workgroups of the (job, K-chunk) grid (2 per CU)
+  int* kc_dev;                        // {K-chunks of the non-ui jobs, of the d ui jobs}: chosen ON THE DEVICE from the launch's own S-row / step counts
+                                      // (te_wgrad_split) - the split-K order is a function of the launch alone, not of its history
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
 };
 // entry code: packed-row index of the position (28 bits) + what the position contributes

@@ -408,9 +408,10 @@ __global__ __launch_bounds__(POI_BLOCK) void dense_apply_kernel(SeqArgs A, int n
   const int i = blockIdx.x * POI_BLOCK + threadIdx.x;
   if (i >= dl.total) return;
   if (SPATIAL && i == dl.upq) return;   // consumed together with dl.sur by one thread (below)
-  // regions vs | bs | wd are written by up to n_slab_head workgroups, ui by A.n_slab_ui when set (tile launches: te_wgrad's d ui
-  // jobs use fewer K-chunks under the per-POI regrouping), everything else by n_slab
-  const int ns = (i >= dl.vs && i <= dl.wd) ? n_slab_head : (i < dl.wh && A.n_slab_ui > 0) ? A.n_slab_ui : n_slab;
+  // regions vs | bs | wd are written by up to n_slab_head workgroups, everything else by n_slab - unless te_wgrad chose the K-chunk
+  // counts on the device (A.kc_dev = {chunks of the other jobs, chunks of the d ui jobs}: per-POI regrouping)
+  if (A.kc_dev) { n_slab = n_slab_head = A.kc_dev[0]; }
+  const int ns = (i >= dl.vs && i <= dl.wd) ? n_slab_head : (i < dl.wh && A.kc_dev) ? A.kc_dev[1] : n_slab;
   float g = 0.f;
   {
     float* base = A.slab + i;

@@ -1299,18 +1299,25 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   constexpr int NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
   const int XWJ = A.bintab ? D : XW;                         // d ui columns that are GEMM jobs (bintab: POI half only)
   const int NB_UI = (3 * D / T) * (XWJ / T);
-  const int Tsteps = A.soff[A.n_seq];
   // (an XCD-aware (chunk, job) order - all jobs of a K-chunk on one XCD - measured 10 % slower than this plain
   // order: it needs a chunk count that is a multiple of 8, which leaves CU slots empty)
-  // grid: 1-D list of (job, K-chunk) pairs - the d ui jobs get A.n_kc_ui chunks each (ppoi: their K is the S-row count), the rest nkc
+  // grid: A.wg_slots workgroups = a 1-D list of (job, K-chunk) pairs.  Under the per-POI regrouping the d ui jobs contract over the S
+  // rows (~T/5 of them), so they get proportionally fewer K-chunks - the split is computed HERE from the launch's own counts
+  // (te_wgrad_split), identically in every workgroup and in dense_apply, which reads it back from kc_dev
+  const int Tsteps = A.soff[A.n_seq];
+  const int NB_TOT = NB_UI + NB_ZR + NB_C + (A.spatial ? ((te_nbp_dev(A.n_dist) + T - 1) / T) * (D / T) : 0);
+  int n_o = nkc, n_u = nkc;
+  if (A.ppoi) te_wgrad_split(A.wg_slots, NB_UI, NB_TOT, A.cnt[4], Tsteps, &n_o, &n_u);
+  if (A.kc_dev && blockIdx.x == 0 && threadIdx.x == 0) { A.kc_dev[0] = n_o; A.kc_dev[1] = n_u; }
   int job, kc;
   {
-    const int b = blockIdx.x, nu = NB_UI * A.n_kc_ui;
-    if (b < nu) { job = b / A.n_kc_ui; kc = b % A.n_kc_ui; }
-    else { job = NB_UI + (b - nu) / nkc; kc = (b - nu) % nkc; }
+    const int b = blockIdx.x, nu = NB_UI * n_u;
+    if (b < nu) { job = b / n_u; kc = b % n_u; }
+    else { job = NB_UI + (b - nu) / n_o; kc = (b - nu) % n_o; }
+    if (job >= NB_TOT) return;                       // (the grid is sized for the worst case)
   }
   const bool pp = A.ppoi && job < NB_UI;
-  if (pp) nkc = A.n_kc_ui;
+  nkc = pp ? n_u : n_o;
   int m0, n0, ldo, bsel; size_t oo;
   if (job < NB_UI) { const int bn = XWJ / T; m0 = (job / bn) * T; n0 = (job % bn) * T; ldo = XW; oo = A.dl.ui; bsel = 0; }
   else if (job < NB_UI + NB_ZR) { const int j = job - NB_UI, bn = D / T; m0 = (j / bn) * T; n0 = (j % bn) * T; ldo = D; oo = A.dl.wh; bsel = 1; }
@@ -1672,8 +1679,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->begin("te_wgrad", st);
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
-    const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0), nui = te_wgrad_ui_jobs(D, A.n_dist, A.spatial != 0);
-    const dim3 grid(nui * A.n_kc_ui + (jobs - nui) * A.n_kc);
+    const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0);
+    const dim3 grid(A.ppoi ? A.wg_slots : jobs * A.n_kc);
     if (A.lt_f16) hipLaunchKernelGGL((te_wgrad_kernel<D, T, true>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
     else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
