@@ -887,10 +887,10 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
 // hides behind the 32x32x2 MFMAs.  Wave w owns hidden columns [D/4 * w, D/4 * (w + 1)) of all three gates, i.e.
 // TPW = D/128 n-tiles per gate: the state update is lane-local in the MFMA C layout.  Two barriers per step.
 // -------------------------------------------------------------------------------------------------
-template <int D, bool predict>
-__global__ __launch_bounds__(TE_BLOCK) void te_rec_fwd32_kernel(TeArgs A) {
+template <int D, bool predict, int NWV>      // NWV waves per workgroup: wave w owns hidden columns [D / NWV * w, D / NWV * (w + 1))
+__global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int K8 = D / 8, LDA = D + 4, TPW = D / 128, NTG = D / 32;       // NTG: n-tiles per gate
+  constexpr int K8 = D / 8, LDA = D + 4, TPW = D / 32 / NWV, NTG = D / 32;       // NTG: n-tiles per gate
   float* Hb = lds;                       // h_{t-1}, overwritten by h_t   32 x LDA
   float* RHb = Hb + 32 * LDA;            // r * h_{t-1}
   __shared__ int s_r0[32], s_ns[32];
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rec_fwd32_kernel(TeArgs A) {
     if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
   }
-  for (int e = tid; e < 32 * LDA; e += TE_BLOCK) Hb[e] = 0.f;
+  for (int e = tid; e < 32 * LDA; e += NWV * 64) Hb[e] = 0.f;
   lds_barrier();
   int ns_max = 0;
   for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
@@ -983,10 +983,10 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rec_fwd32_kernel(TeArgs A) {
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(TE_BLOCK) void te_rec_bwd32_kernel(TeArgs A) {
+template <int D, int NWV>
+__global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int K8 = D / 8, LDA = D + 4, LDB = 2 * D + 4, TPW = D / 128;
+  constexpr int K8 = D / 8, LDA = D + 4, LDB = 2 * D + 4, TPW = D / 32 / NWV;
   float* Ac = lds;                       // da_c           32 x LDA
   float* Azr = Ac + 32 * LDA;            // da_z | da_r    32 x LDB
   __shared__ int s_r0[32], s_ns[32];
@@ -1632,7 +1632,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   tm->begin("te_rec_fwd", st);
   if constexpr (D >= 128) {
-    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false>), dim3((n + 31) / 32), dim3(TE_BLOCK), sizeof(float) * 2 * 32 * (D + 4), st, A);
+    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
   }
   if constexpr (D <= 128) {
     if (!A.rec32) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
@@ -1648,7 +1648,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_rec_bwd", st);
   if constexpr (D >= 128) {
-    if (A.rec32) hipLaunchKernelGGL(te_rec_bwd32_kernel<D>, dim3((n + 31) / 32), dim3(TE_BLOCK), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
+    if (A.rec32) hipLaunchKernelGGL((te_rec_bwd32_kernel<D, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
   }
   if constexpr (D <= 128) {
     if (!A.rec32) hipLaunchKernelGGL(te_rec_bwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
@@ -1706,10 +1706,10 @@ static hipError_t te_optin_lds() {
   // the streaming recurrent kernels need more than the default 64 KB of dynamic LDS at D = 256 (99 KB backward)
   static bool done = false;
   if (done) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   done = e == hipSuccess;
   return e;
 }
@@ -1734,7 +1734,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   te_launch_ax<D>(A, num_cu, st);
   if constexpr (D >= 128) {
-    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true>), dim3((n + 31) / 32), dim3(TE_BLOCK), sizeof(float) * 2 * 32 * (D + 4), st, A);
+    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
   }
   if constexpr (D <= 128) {
     if (!A.rec32) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
