@@ -90,6 +90,15 @@ int poi_ctx_num_cu(const poi_ctx* ctx);
  * dim 256 (32-sequence tiles, weights streamed from L2) also at dim 128 - a testing aid.  Both implement the same arithmetic
  * (only the f32 summation order differs).  Also settable with POI_ENGINE=seq|tile. */
 int poi_ctx_set_engine(poi_ctx* ctx, int engine);
+/* hipGraph replay of the tile engine's training launch (poi_spatial_step / poi_gru_step): the ~40 kernels a launch enqueues on two
+ * streams are captured once per launch shape (second launch with the same parameters / tables / n / alpha / lambda) and replayed with
+ * ONE hipGraphLaunch; the caller's uidx / out pass through context-owned staging buffers, so any uidx / out pointer replays the same
+ * graph.  Same kernels, same order, same bits as the eager launch.  Off by default (POI_GRAPH=1 enables): on ROCm 7.0 / MI355X a
+ * replay takes exactly as long as the eager launch - the launch is bound by the dependent-dispatch chain on the GPU, not by the host
+ * (tools/bench_graph.py).  on = 1 replays launches of min_n <= n <= max_n sequences.  Kernel timing (poi_timing_enable) needs eager launches and switches replay off while it is on.
+ * poi_ctx_graph_replays: number of launches served by a replay so far. */
+int poi_ctx_set_graph(poi_ctx* ctx, int on, int min_n, int max_n);
+int64_t poi_ctx_graph_replays(const poi_ctx* ctx);
 /* fp16 POI tables: declare that the device buffer [ptr, ptr + bytes) holds IEEE half elements.  From then on every entry point that is
  * handed a pointer INSIDE a registered buffer as its POI table (`lt` of poi_gru_params for poi_spatial_step / poi_gru_step /
  * poi_gru_predict; `items` of poi_score_all / poi_score_topk* / poi_auc_preference; `x` of poi_sumsq) reads / writes it as half.

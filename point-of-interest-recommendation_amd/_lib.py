@@ -45,6 +45,8 @@ SIGNATURES = {
     "poi_ctx_num_cu": (c_int, [c_void_p]),
     "poi_ctx_set_engine": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_batch_cap": (c_int, [c_void_p, c_float]),
+    "poi_ctx_set_graph": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "poi_ctx_graph_replays": (c_int64, [c_void_p]),
     "poi_ctx_register_f16": (c_int, [c_void_p, c_void_p, c_int64]),
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
@@ -153,6 +155,13 @@ class Context:
     def set_engine(self, name):
         """'auto' | 'seq' | 'tile' | 'tile32' (see poi_ctx_set_engine)."""
         self.check(self.lib.poi_ctx_set_engine(self.handle, {"auto": 0, "seq": 1, "tile": 2, "tile32": 3}[name]))
+
+    def set_graph(self, on, min_n=0, max_n=1 << 30):
+        """hipGraph replay of the tile engine's training launches (poi_ctx_set_graph)."""
+        self.check(self.lib.poi_ctx_set_graph(self.handle, int(bool(on)), int(min_n), int(max_n)))
+
+    def graph_replays(self):
+        return int(self.lib.poi_ctx_graph_replays(self.handle))
 
     def set_batch_cap(self, cap):
         """Batch rule cap (include/poi_hip.h, poi_ctx_set_batch_cap): 1 = mean rule."""

@@ -39,6 +39,17 @@ struct poi_ctx {
   DevBuf pmark, seg_pidx;   // per-POI regrouping: per lt row "is a step input in this launch" (all-zero between launches), row -> S row
   int ppoi = 1;             // POI_TE_PPOI=0 disables the regrouping (A/B)
   DevBuf kc_dev;            // te_wgrad's K-chunk split, chosen on the device per launch
+  // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
+  // A launch is captured the second time its key (every pointer / size / scalar the kernels receive) is seen; the caller's uidx /
+  // out are staged through context buffers so that the key does not depend on them.
+  struct StepGraph { std::vector<uint64_t> key; hipGraph_t graph; hipGraphExec_t exec; uint64_t stamp; };
+  std::vector<StepGraph> graphs;
+  std::vector<uint64_t> seen_key;
+  int graph_mode = 0;       // off by default (no gain measured on ROCm 7.0: DESIGN.md section 5); POI_GRAPH=1 / poi_ctx_set_graph enable
+  int graph_min_n = 0, graph_max_n = 1 << 30;
+  uint64_t graph_stamp = 0, graph_replays = 0, graph_captures = 0;
+  hipStream_t cap = nullptr;   // capture stream (the caller's stream may be the null stream, which cannot capture)
+  DevBuf uidx_stage, out_stage;
   // BPR
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
@@ -109,6 +120,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
+  if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   const char* sd = getenv("POI_TE_SIDE");
@@ -122,16 +134,24 @@ int poi_ctx_create(poi_ctx** out, int device) {
       c->side = nullptr;                     // fall back to the inline sort
     }
   }
+  if (c->graph_mode && hipStreamCreateWithFlags(&c->cap, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->cap = nullptr; c->graph_mode = 0; }
   *out = c;
   return POI_OK;
 }
 
+static void drop_graphs(poi_ctx* c) {
+  for (auto& g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+  c->graphs.clear(); c->seen_key.clear();
+}
+
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->seg_pidx, &c->kc_dev,
+  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->seg_pidx, &c->kc_dev, &c->uidx_stage, &c->out_stage,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
+  drop_graphs(c);
+  if (c->cap) (void)hipStreamDestroy(c->cap);
   if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c;
@@ -312,10 +332,72 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
-    HIPCHK(c, poi::launch_te_train(E, c->num_cu, st, &c->tm));
-    HIPCHK(c, poi::launch_te_scatter(E, alpha, lambda, c->num_cu, st, &c->tm));
     A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)
-    HIPCHK(c, poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, st, &c->tm));
+    auto run = [&](hipStream_t s) -> hipError_t {
+      hipError_t e = poi::launch_te_train(E, c->num_cu, s, &c->tm);
+      if (e == hipSuccess) e = poi::launch_te_scatter(E, alpha, lambda, c->num_cu, s, &c->tm);
+      if (e == hipSuccess) e = poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, s, &c->tm);
+      return e;
+    };
+    const size_t out_bytes = sizeof(float) * (size_t)n * (spatial ? 5 : 1);
+    if (!c->graph_mode || c->tm.on || !c->side || n < c->graph_min_n || n > c->graph_max_n) { HIPCHK(c, run(st)); return POI_OK; }
+    // ---- graph replay ----
+    if ((rc = ensure(c, c->uidx_stage, sizeof(int32_t) * (size_t)n, st)) || (rc = ensure(c, c->out_stage, out_bytes, st))) return rc;
+    std::vector<uint64_t> key;
+    {
+      auto add = [&](const void* p, size_t bytes) { const size_t w = (bytes + 7) / 8, o = key.size(); key.resize(o + w, 0); memcpy(key.data() + o, p, bytes); };
+      add(P, sizeof *P); add(T, sizeof *T);
+      const uint64_t sc[] = {(uint64_t)n, (uint64_t)spatial, (uint64_t)c->engine, (uint64_t)c->ppoi, (uint64_t)n_head, (uint64_t)n_kc, (uint64_t)n_slab,
+                             (uint64_t)c->wgrad_rounds, (uint64_t)is_f16(c, P->lt)};
+      add(sc, sizeof sc);
+      const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
+      add(fs, sizeof fs);
+      const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p};
+      add(bufs, sizeof bufs);
+    }
+    poi_ctx::StepGraph* g = nullptr;
+    for (auto& e : c->graphs) if (e.key == key) { g = &e; break; }
+    if (!g && c->seen_key != key) {       // first sight: run eagerly (first-use initialisation happens outside any capture)
+      c->seen_key = key;
+      HIPCHK(c, run(st));
+      return POI_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->uidx_stage.p, uidx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (!g) {
+      E.uidx = (const int32_t*)c->uidx_stage.p; E.out = (float*)c->out_stage.p;
+      A.uidx = E.uidx; A.out = E.out;
+      hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+      hipError_t e = hipStreamBeginCapture(c->cap, hipStreamCaptureModeRelaxed);
+      if (e == hipSuccess) {
+        e = run(c->cap);
+        const hipError_t e2 = hipStreamEndCapture(c->cap, &graph);
+        if (e == hipSuccess) e = e2;
+      }
+      if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        c->graph_mode = 0;                 // this runtime cannot capture the launch: stay eager
+        E.uidx = uidx; E.out = out; A.uidx = uidx; A.out = out;
+        HIPCHK(c, run(st));
+        return POI_OK;
+      }
+      if (c->graphs.size() >= 8) {         // evict the least recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].stamp < c->graphs[lru].stamp) lru = i;
+        HIPCHK(c, hipStreamSynchronize(st));
+        (void)hipGraphExecDestroy(c->graphs[lru].exec); (void)hipGraphDestroy(c->graphs[lru].graph);
+        c->graphs.erase(c->graphs.begin() + lru);
+      }
+      c->graphs.push_back(poi_ctx::StepGraph{key, graph, exec, 0});
+      g = &c->graphs.back();
+      ++c->graph_captures;
+    }
+    g->stamp = ++c->graph_stamp;
+    HIPCHK(c, hipGraphLaunch(g->exec, st));
+    ++c->graph_replays;
+    HIPCHK(c, hipMemcpyAsync(out, c->out_stage.p, out_bytes, hipMemcpyDeviceToDevice, st));
     return POI_OK;
   }
   HIPCHK(c, poi::launch_seq_train(A, spatial, grid, alpha, lambda, st, &c->tm));
@@ -678,6 +760,18 @@ int poi_ctx_set_engine(poi_ctx* c, int engine) {
   c->engine = engine;
   return POI_OK;
 }
+
+int poi_ctx_set_graph(poi_ctx* c, int on, int min_n, int max_n) {
+  if (!c || on < 0 || on > 1 || min_n < 0 || max_n < min_n) return fail(c, POI_EINVAL, "poi_ctx_set_graph: on must be 0 / 1 and 0 <= min_n <= max_n");
+  if (on && !c->cap) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->cap, hipStreamNonBlocking));
+  }
+  c->graph_mode = on; c->graph_min_n = min_n; c->graph_max_n = max_n;
+  return POI_OK;
+}
+
+int64_t poi_ctx_graph_replays(const poi_ctx* c) { return c ? (int64_t)c->graph_replays : POI_EINVAL; }
 
 int poi_ctx_register_f16(poi_ctx* c, const void* ptr, int64_t bytes) {
   if (!c || !ptr || bytes <= 0) return fail(c, POI_EINVAL, "poi_ctx_register_f16: bad argument");

@@ -399,3 +399,32 @@ def test_fp16_poi_table_float32_math(pa, dim, n_user):
         model.train(np.int32(1))
     model.ctx.set_engine("auto")
     assert abs(model.l2.eval() - O.l2_value({**Pn, "loss_weight": got["loss_weight"]}, 0.001, SP_NAMES)) <= 1e-5 * model.l2.eval()
+
+
+@pytest.mark.parametrize("dim,n_user,batch", [(128, 96, 32), (64, 40, 1), (256, 48, 16)])
+def test_graph_replay_is_bitwise_the_eager_launch(pa, dim, n_user, batch):
+    """poi_ctx_set_graph: the captured launch replays the same kernels in the same order - parameters and per-sequence outputs are
+    bitwise those of eager launches, whatever uidx / out pointers the caller hands over (they are staged)."""
+    T = toy_problem(900 + dim, n_user=n_user, n_item=300, n_dist=200, dim=dim, len_max=12)
+    P = spatial_params(901 + dim, T)
+    rng = np.random.default_rng(5)
+    order = rng.permutation(n_user).astype(np.int32)
+    res = {}
+    for mode in ("eager", "graph"):
+        model = _model(pa, T, P)
+        model.ctx.set_engine("tile")
+        model.ctx.set_graph(mode == "graph")
+        r0 = model.ctx.graph_replays()
+        outs = []
+        for rep in range(2):
+            for b0 in range(0, n_user, batch):
+                outs.append(np.array(model.train_batch(order[b0:b0 + batch])))
+        res[mode] = (_get(model), outs, model.ctx.graph_replays() - r0)
+        model.ctx.set_graph(False)
+    n_launch = 2 * ((n_user + batch - 1) // batch)
+    assert res["eager"][2] == 0
+    assert res["graph"][2] >= n_launch - 3, res["graph"][2]          # first sight eager, second sight captures + replays
+    for k in SP_NAMES:
+        assert np.array_equal(np.asarray(res["eager"][0][k]), np.asarray(res["graph"][0][k])), k
+    for a, b in zip(res["eager"][1], res["graph"][1]):
+        assert np.array_equal(a, b)
