@@ -108,7 +108,11 @@ int poi_ctx_register_f16(poi_ctx* ctx, const void* ptr, int64_t bytes);
 int poi_ctx_unregister_f16(poi_ctx* ctx, const void* ptr);
 
 /* Batch rule cap (>= 1, see "Batch semantics" above); applies to poi_spatial_step / poi_gru_step / poi_bpr_step
- * (snapshot mode) launches with more than one sequence.  n_seq == 1 is the reference step for every cap. */
+ * (snapshot mode) launches with more than one sequence.  n_seq == 1 is the reference step for every cap.
+ * cap == 0 selects the MINI-BATCH rule of the reference's `Gru` class (public/GRU.py:395-498, cost :452-459): the launch is one
+ * mini-batch - loss gradients averaged over its n sequences, L2 terms of every gathered row (all len_max positions of every
+ * sequence, duplicates counted) summed: row -= alpha (G / n + lambda mult row); dense tensors: theta -= alpha (G / n + lambda theta).
+ * poi_gru_step / poi_spatial_step only (POI_ENOTSUP elsewhere). */
 int poi_ctx_set_batch_cap(poi_ctx* ctx, float cap);
 
 /* ---- a5: BPR-MF step - OboBpr.bpr_train(uidx, [p, q]), public/BPR.py:201-241 ----------------

@@ -244,8 +244,9 @@ def gru_forward_cost(P, p, q, mask, lam):
     return -tot + 0.5 * lam * l2, -tot
 
 
-def gru_step(P, p, q, mask, alpha, lam):
-    """One ``OboGru.seq_train(uidx)`` (public/GRU.py:313-385).  Returns (P_new, -upq)."""
+def _gru_seq_loss_grads(P, p, q, mask):
+    """Gradients of -sum_t log sigmoid(h_{t-1} . (x_p - x_q)) of ONE sequence (no L2 terms): (dense grads, g_lt, sum of log-sigmoids).
+    Shared by gru_step (public/GRU.py:313-385) and gru_minibatch_step (public/GRU.py:407-466): both scan the same recurrence."""
     p, q = np.asarray(p, np.int64), np.asarray(q, np.int64)
     lt, ui, wh, bi = P['lt'], P['ui'], P['wh'], P['bi']
     D = lt.shape[1]
@@ -268,8 +269,16 @@ def gru_step(P, p, q, mask, alpha, lam):
         g_lt[p[t]] += gu * hs[t]
         g_lt[q[t]] -= gu * hs[t]
         dh = dhp + gu * (xps[t] - xqs[t])                    # gradient wrt h_{t-1}
-    np.add.at(g_lt, p, lam * xps)                            # :365 all LM rows
-    np.add.at(g_lt, q, lam * xqs)
+    return g, g_lt, tot
+
+
+def gru_step(P, p, q, mask, alpha, lam):
+    """One ``OboGru.seq_train(uidx)`` (public/GRU.py:313-385).  Returns (P_new, -upq)."""
+    p, q = np.asarray(p, np.int64), np.asarray(q, np.int64)
+    lt, ui, wh, bi = P['lt'], P['ui'], P['wh'], P['bi']
+    g, g_lt, tot = _gru_seq_loss_grads(P, p, q, mask)
+    np.add.at(g_lt, p, lam * lt[p])                          # :365 all LM rows
+    np.add.at(g_lt, q, lam * lt[q])
     N = dict(P)
     N['ui'] = ui - alpha * (g['ui'] + lam * ui)
     N['wh'] = wh - alpha * (g['wh'] + lam * wh)
@@ -278,6 +287,60 @@ def gru_step(P, p, q, mask, alpha, lam):
     lt_new = lt.copy(); lt_new[R] = lt[R] - alpha * g_lt[R]  # :372-373
     N['lt'] = lt_new
     return N, -tot                                           # :380
+
+
+# ----------------------------------------------------------------------------------------------
+# f4: mini-batch ``Gru``  (public/GRU.py:395-498): a batch of users is ONE cost
+# ----------------------------------------------------------------------------------------------
+def gru_minibatch_forward_cost(P, p_rows, q_rows, masks, lam):
+    """Forward only: (cost, -upq) of public/GRU.py:412-459.  The scan runs over the batch for seq_length = the longest valid length
+    (:418, :450); the state is NOT masked, only the loss is (:446), so a shorter sequence keeps stepping on padding inputs without
+    contributing to the cost.  L2: every gathered row of xps / xqs (all len_max positions of every sequence), ui, wh, and bi once
+    (sum over the batch-broadcast bi divided by the batch size, :454-455).  Used by the autograd tests."""
+    p_rows, q_rows, masks = np.asarray(p_rows, np.int64), np.asarray(q_rows, np.int64), np.asarray(masks)
+    lt, ui, wh, bi = P['lt'], P['ui'], P['wh'], P['bi']
+    B = p_rows.shape[0]
+    seq_length = int(masks.sum(axis=1).max())
+    h = np.tile(P['h0'], (B, 1))
+    tot = 0.0
+    for t in range(seq_length):
+        xp, xq = lt[p_rows[:, t]], lt[q_rows[:, t]]
+        upq = np.sum(h * (xp - xq), axis=1)                                  # :444
+        tot += float(np.sum(np.array([log_sigmoid(u) for u in upq]) * masks[:, t]))      # :445-446
+        hn = np.empty_like(h)
+        for b in range(B):
+            _, _, _, hn[b] = _gru_cell(ui, wh, bi, xp[b], h[b])             # :438-443
+        h = hn
+    l2 = sum(np.sum(v * v) for v in (lt[p_rows], lt[q_rows], ui, wh)) + np.sum(bi * bi)      # :453-455
+    return -tot / B + 0.5 * lam * l2, -tot                                   # :457-459, :473
+
+
+def gru_minibatch_step(P, p_rows, q_rows, masks, alpha, lam):
+    """One ``Gru.seq_train(start_end)`` (public/GRU.py:407-485) on the padded rows of a batch of users.  Returns (P_new, -upq).
+    Loss gradients are the per-sequence ones (the unmasked tail of a shorter sequence carries no gradient) averaged over the batch;
+    the L2 term counts every gathered position; lt is written at the unique ids of the batch's padded rows (:429-431, :463)."""
+    p_rows, q_rows, masks = np.asarray(p_rows, np.int64), np.asarray(q_rows, np.int64), np.asarray(masks)
+    lt = P['lt']
+    B = p_rows.shape[0]
+    g = dict(ui=np.zeros_like(P['ui']), wh=np.zeros_like(P['wh']), bi=np.zeros_like(P['bi']))
+    g_lt = np.zeros_like(lt)
+    tot = 0.0
+    for b in range(B):
+        gb, glb, tb = _gru_seq_loss_grads(P, p_rows[b], q_rows[b], masks[b])
+        for k in g:
+            g[k] += gb[k] / B
+        g_lt += glb / B
+        tot += tb
+    pf, qf = p_rows.ravel(), q_rows.ravel()
+    np.add.at(g_lt, pf, lam * lt[pf])                        # :453 every gathered row, duplicates counted
+    np.add.at(g_lt, qf, lam * lt[qf])
+    N = dict(P)
+    for k in g:
+        N[k] = P[k] - alpha * (g[k] + lam * P[k])            # :460-461
+    R = np.unique(np.concatenate((pf, qf)))                  # :429-430
+    lt_new = lt.copy(); lt_new[R] = lt[R] - alpha * g_lt[R]  # :462-463
+    N['lt'] = lt_new
+    return N, -tot                                           # :473
 
 
 # ----------------------------------------------------------------------------------------------

@@ -7,12 +7,12 @@ Nothing here imports `oracle/` - that is test infrastructure.
 from . import _lib, build, data            # noqa: F401
 from ._lib import PoiError                  # noqa: F401
 
-__all__ = ["_lib", "build", "data", "models", "PoiError", "OboSpatialGru", "OboGru", "OboBpr"]
+__all__ = ["_lib", "build", "data", "models", "PoiError", "OboSpatialGru", "OboGru", "OboBpr", "OboCARNN", "Gru"]
 
 
 def __getattr__(name):
     # models needs torch; keep `import poi_amd` light for the build step
-    if name in ("models", "OboSpatialGru", "OboGru", "OboBpr", "GruBasic", "MfBasic", "evaluate", "harness", "dist"):
+    if name in ("models", "OboSpatialGru", "OboGru", "OboBpr", "OboCARNN", "Gru", "GruBasic", "MfBasic", "evaluate", "harness", "dist"):
         import importlib
         if name in ("models", "evaluate", "harness", "dist"):
             return importlib.import_module("." + name, __name__)

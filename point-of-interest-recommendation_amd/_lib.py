@@ -164,8 +164,9 @@ class Context:
         return int(self.lib.poi_ctx_graph_replays(self.handle))
 
     def set_batch_cap(self, cap):
-        """Batch rule cap (include/poi_hip.h, poi_ctx_set_batch_cap): 1 = mean rule."""
+        """Batch rule cap (include/poi_hip.h, poi_ctx_set_batch_cap): 1 = mean rule, 0 = the mini-batch rule of public/GRU.py:395-498."""
         self.check(self.lib.poi_ctx_set_batch_cap(self.handle, float(cap)))
+        self.batch_cap = float(cap)
 
     def register_f16(self, tensor):
         """Declare a torch.float16 device tensor as an IEEE-half POI table (poi_ctx_register_f16)."""

@@ -317,7 +317,8 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   }
   poi::SeqArgs A;
   fill_args(A, P, T, uidx, n);
-  A.out = out; A.bcap = c->batch_cap;
+  const float bcap = c->batch_cap == 0.0f ? -(float)n : c->batch_cap;      // 0: mini-batch rule, encoded as -n (rule_scales)
+  A.out = out; A.bcap = bcap;
   A.ws = (float*)c->ws.p; A.ws_stride = wsf;
   A.slab = (float*)c->slab.p;
   A.g_lt = (float*)c->g_lt.p; A.mult_lt = (int*)c->mult_lt.p; A.nseq_lt = (int*)c->nseq_lt.p;
@@ -327,7 +328,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
     if ((rc = ensure(c, c->zrow, sizeof(float) * 1024, st))) return rc;
     E.zrow = (const float*)c->zrow.p;
-    E.out = out; E.bcap = c->batch_cap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
+    E.out = out; E.bcap = bcap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
     E.kc_dev = (poi::te_bintab(D, spatial) && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
@@ -349,6 +350,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       add(P, sizeof *P); add(T, sizeof *T);
       const uint64_t sc[] = {(uint64_t)n, (uint64_t)spatial, (uint64_t)c->engine, (uint64_t)c->ppoi, (uint64_t)n_head, (uint64_t)n_kc, (uint64_t)n_slab,
                              (uint64_t)c->wgrad_rounds, (uint64_t)is_f16(c, P->lt)};
+      (void)bcap;
       add(sc, sizeof sc);
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
@@ -462,6 +464,7 @@ int poi_carnn_step(poi_ctx* c, const poi_carnn_params* P, const poi_seq_tables* 
   int rc = check_carnn(c, P, T, true);
   if (rc) return rc;
   if (is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "CA-RNN supports float32 tables only");
+  if (c->batch_cap == 0.0f) return fail(c, POI_ENOTSUP, "the mini-batch rule (batch cap 0) applies to poi_gru_step / poi_spatial_step only");
   if (!uidx || !out || n < 0) return fail(c, POI_EINVAL, "uidx/out NULL or n < 0");
   if (n == 0) return POI_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -532,6 +535,7 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
   if (dim <= 0 || dim % 4 != 0) return fail(c, POI_ENOTSUP, "dim must be a positive multiple of 4 (got %d)", dim);
   if (n < 0 || n_user <= 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
   if (mode != POI_BPR_SNAPSHOT && mode != POI_BPR_HOGWILD) return fail(c, POI_EINVAL, "unknown mode %d", mode);
+  if (c->batch_cap == 0.0f) return fail(c, POI_ENOTSUP, "the mini-batch rule (batch cap 0) applies to poi_gru_step / poi_spatial_step only");
   if (n == 0) return POI_OK;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(c, hipSetDevice(c->device));
@@ -787,7 +791,7 @@ int poi_ctx_unregister_f16(poi_ctx* c, const void* ptr) {
 }
 
 int poi_ctx_set_batch_cap(poi_ctx* c, float cap) {
-  if (!c || !(cap >= 1.0f)) return fail(c, POI_EINVAL, "batch cap must be >= 1 (1 = mean rule)");
+  if (!c || !(cap >= 1.0f || cap == 0.0f)) return fail(c, POI_EINVAL, "batch cap must be >= 1 (1 = mean rule) or 0 (mini-batch rule)");
   c->batch_cap = cap;
   return POI_OK;
 }

@@ -198,4 +198,14 @@ __device__ __forceinline__ int bin_of_c(double c, const double* thr, int n_dist,
   return g;
 }
 
+// Batch rule of a launch (include/poi_hip.h): a table row touched by `nseq` sequences with L2 multiplicity `mult` moves by
+//   row -= sc * (G + lm * row),   G = sum of the touching sequences' loss gradients.
+// cap >= 1: sc = alpha min(nseq, cap) / nseq, lm = lambda mult (capped sum; 1 = mean of the sequences' reference updates).
+// cap < 0 encodes the MINI-BATCH rule of public/GRU.py:452-466 for a launch of n = -cap sequences - cost = -sum(loss) / n + L2 over
+// every gathered row: row -= alpha (G / n + lambda mult row), i.e. sc = alpha / n, lm = lambda mult n.
+__device__ __forceinline__ void rule_scales(float alpha, float lambda, int nseq, int mult, float cap, float& sc, float& lm) {
+  if (cap < 0.f) { sc = alpha / -cap; lm = lambda * (float)mult * -cap; }
+  else { sc = alpha * fminf((float)nseq, cap) / (float)max(nseq, 1); lm = lambda * (float)mult; }
+}
+
 }  // namespace poi

@@ -39,14 +39,14 @@ __device__ __forceinline__ void count_rows(const int* __restrict__ a, const int*
 }
 
 
-// One wavefront per table row: row <- row - alpha * min(nseq, cap) / nseq * (G[row] + lambda * mult[row] * row); G / mult / nseq are
+// One wavefront per table row: row <- row - sc * (G[row] + lm * row) with the batch rule's scales (rule_scales); G / mult / nseq are
 // re-zeroed.  `D` is the row width in floats (a CA-RNN interval matrix is one row of H * D floats).
 __device__ __forceinline__ void apply_row(float* __restrict__ T, float* __restrict__ G, int* __restrict__ mult,
                                           int* __restrict__ nseq, int row, int D, float alpha, float lambda, float cap) {
   const int got = nseq[row];
   if (got <= 0) return;
   const int m = mult[row];
-  const float sc = alpha * fminf((float)got, cap) / (float)got, lm = lambda * (float)m;
+  float sc, lm; rule_scales(alpha, lambda, got, m, cap, sc, lm);
   float* t = T + (size_t)row * D;
   float* g = G + (size_t)row * D;
   for (int j = lane_id() * 4; j < D; j += 256) {

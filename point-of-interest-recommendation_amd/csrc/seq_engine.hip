@@ -404,7 +404,7 @@ __global__ __launch_bounds__(POI_BLOCK) void dense_apply_kernel(SeqArgs A, int n
   const int D = A.dim, XW = SPATIAL ? 2 * D : D, NB = SPATIAL ? A.n_dist + 1 : 0;
   const DenseLayout dl = dense_layout(D, XW, NB);
   const float inv_n = 1.0f / (float)A.n_seq;
-  alpha *= fminf((float)A.n_seq, A.bcap);      // batch rule: min(n, cap) of the n sequences' updates count (cap = 1: their mean)
+  alpha *= A.bcap < 0.f ? 1.0f : fminf((float)A.n_seq, A.bcap);      // batch rule: min(n, cap) of the n sequences' updates count (cap = 1: their mean == the mini-batch rule for dense tensors)
   const int i = blockIdx.x * POI_BLOCK + threadIdx.x;
   if (i >= dl.total) return;
   if (SPATIAL && i == dl.upq) return;   // consumed together with dl.sur by one thread (below)

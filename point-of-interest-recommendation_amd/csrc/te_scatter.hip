@@ -360,7 +360,7 @@ __device__ __forceinline__ void apply_sum(float* __restrict__ trow, int f16, flo
   constexpr int LPR = D / 4;
   const int lane = lane_id();
   if (lane >= LPR) return;
-  const float sc = alpha * fminf((float)nseq, cap) / (float)nseq, lm = lambda * (float)mult;
+  float sc, lm; rule_scales(alpha, lambda, nseq, mult, cap, sc, lm);
   float4 tv = ld4t(trow, (size_t)lane * 4, f16);
   tv.x -= sc * (g.x + lm * tv.x); tv.y -= sc * (g.y + lm * tv.y);
   tv.z -= sc * (g.z + lm * tv.z); tv.w -= sc * (g.w + lm * tv.w);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
     }
     if (in && !hot && (end != 0 || an != 0)) {
       const int nseq = ri.pn ? an : nf, mult = cnt + am;
-      const float sc = alpha * fminf((float)nseq, A.bcap) / (float)max(nseq, 1), lm = lambda * (float)mult;
+      float sc, lm; rule_scales(alpha, lambda, nseq, mult, A.bcap, sc, lm);
       float4 tv = ld4t(ri.trow, (size_t)c, ri.f16);
       tv.x -= sc * (acc.x + lm * tv.x); tv.y -= sc * (acc.y + lm * tv.y);
       tv.z -= sc * (acc.z + lm * tv.z); tv.w -= sc * (acc.w + lm * tv.w);
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(D) void te_dapply_kernel(TeArgs A, float alpha, flo
   const int nseq = pad ? an : A.dbn[b];
   __syncthreads();                              // every thread has read the counters before thread 0 clears them
   if (end != 0 || an != 0) {
-    const float sc = alpha * fminf((float)nseq, A.bcap) / (float)max(nseq, 1), lm = lambda * (float)(cnt + am);
+    float sc, lm; rule_scales(alpha, lambda, nseq, cnt + am, A.bcap, sc, lm);
     float* t = A.di + (size_t)b * D + c;
     const float v = *t;
     *t = v - sc * (A.dgd[(size_t)b * D + c] + lm * v);

@@ -374,6 +374,29 @@ class OboGru(GruBasic):
         return out.cpu().numpy() if sync else out
 
 
+class Gru(OboGru):
+    """public/GRU.py:395-498 - the mini-batch GRU: `train(idxs)` takes a LIST of users and makes ONE SGD step on the cost
+    -sum(loss) / batch + 0.5 lambda (every gathered row, ui, wh, bi) (:452-459).  Same kernels as OboGru with the launch as the
+    mini-batch (poi_ctx_set_batch_cap(0), include/poi_hip.h): loss gradients averaged over the launch, L2 terms summed; predict /
+    scoring / AUC are GruBasic's.  Returns -upq, the batch's summed loss (:473), like the reference."""
+
+    def train(self, idxs):
+        return float(np.sum(self.train_batch(idxs)))
+
+    def train_batch(self, idxs, sync=True):
+        prev = getattr(self.ctx, "batch_cap", 1.0)
+        self.ctx.set_batch_cap(0.0)
+        try:
+            return super().train_batch(idxs, sync=sync)
+        finally:
+            self.ctx.set_batch_cap(prev)
+
+    def normalize(self):
+        """public/GRU.py:476-481: lt rows scaled to unit L2 norm (never called by the reference's drivers)."""
+        t = self.lt.t.float()
+        self.lt.t.copy_((t / t.pow(2).sum(dim=1, keepdim=True).sqrt()).to(self.lt.t.dtype))
+
+
 class OboSpatialGru(GruBasic):
     """public/GRU_Spatial.py:42-292 - Distance2Pre."""
 

@@ -125,6 +125,54 @@ def test_gru_step_matches_autograd(seed, L):
     assert np.allclose(Pn['lt'], lt_exp, rtol=1e-11, atol=1e-14)
 
 
+def _torch_gru_minibatch_cost(T, p_rows, q_rows, masks, lam):
+    """Independent float64 autograd restatement of the batched scan (public/GRU.py:425-459): batched state, unmasked state update,
+    masked loss, mean over the batch, L2 over every gathered row."""
+    lt, ui, wh, bi = T['lt'], T['ui'], T['wh'], T['bi']
+    B = p_rows.shape[0]
+    xps, xqs = lt[torch.as_tensor(p_rows)], lt[torch.as_tensor(q_rows)]          # (B, LM, D)
+    m = torch.as_tensor(masks, dtype=F64)
+    n_steps = int(masks.sum(axis=1).max())
+    h = torch.zeros((B, lt.shape[1]), dtype=F64); tot = 0.0
+    for t in range(n_steps):
+        xp, xq = xps[:, t], xqs[:, t]
+        tot = tot + (torch.log(torch.sigmoid((h * (xp - xq)).sum(dim=1))) * m[:, t]).sum()
+        z = torch.sigmoid(xp @ ui[0].T + h @ wh[0].T + bi[0])
+        r = torch.sigmoid(xp @ ui[1].T + h @ wh[1].T + bi[1])
+        c = torch.tanh(xp @ ui[2].T + (r * h) @ wh[2].T + bi[2])
+        h = (1 - z) * h + z * c
+    l2 = sum((v ** 2).sum() for v in (xps, xqs, ui, wh)) + (bi.expand(B, 3, -1) ** 2).sum() / B
+    return -tot / B + 0.5 * lam * l2, -tot
+
+
+@pytest.mark.parametrize("seed,lens", [(0, (5, 2, 8)), (4, (1, 7, 7, 3, 6))])
+def test_gru_minibatch_step_matches_autograd(seed, lens):
+    """f4, mini-batch Gru (public/GRU.py:395-498): forward cost and hand-assembled update against autograd of the batched scan."""
+    alpha, lam = 0.01, 0.001
+    rng = np.random.default_rng(seed)
+    N, D, LM, B = 19, 6, 9, len(lens)
+    P = O.init_gru_params(rng, N, D); P['bi'] = rng.uniform(-0.2, 0.2, (3, D))
+    p_rows = np.full((B, LM), N); q_rows = np.full((B, LM), N); masks = np.zeros((B, LM), np.int64)
+    for b, L in enumerate(lens):
+        p_rows[b, :L] = rng.integers(0, 6, L); q_rows[b, :L] = rng.integers(3, N, L); masks[b, :L] = 1
+    T = {k: torch.tensor(v, dtype=F64, requires_grad=True) for k, v in P.items() if k != 'h0'}
+    cost, loss = _torch_gru_minibatch_cost(T, p_rows, q_rows, masks, lam)
+    cost.backward()
+    c_or, l_or = O.gru_minibatch_forward_cost(P, p_rows, q_rows, masks, lam)
+    assert np.isclose(c_or, cost.item(), rtol=1e-13) and np.isclose(l_or, loss.item(), rtol=1e-13)
+    Pn, out = O.gru_minibatch_step(P, p_rows, q_rows, masks, alpha, lam)
+    assert np.isclose(out, loss.item(), rtol=1e-13)
+    for k in ('ui', 'wh', 'bi'):
+        assert np.allclose(Pn[k], P[k] - alpha * T[k].grad.numpy(), rtol=1e-11, atol=1e-14), k
+    R = np.unique(np.concatenate((p_rows.ravel(), q_rows.ravel())))
+    lt_exp = P['lt'].copy(); lt_exp[R] -= alpha * T['lt'].grad.numpy()[R]
+    assert np.allclose(Pn['lt'], lt_exp, rtol=1e-11, atol=1e-14)
+    # a batch of one is the one-by-one step (public/GRU.py:313-385)
+    P1, o1 = O.gru_minibatch_step(P, p_rows[:1], q_rows[:1], masks[:1], alpha, lam)
+    P2, o2 = O.gru_step(P, p_rows[0], q_rows[0], masks[0], alpha, lam)
+    assert o1 == o2 and all(np.array_equal(P1[k], P2[k]) for k in ('lt', 'ui', 'wh', 'bi'))
+
+
 def test_bpr_step_matches_autograd():
     alpha, lam = 0.01, 0.001
     rng = np.random.default_rng(7)
