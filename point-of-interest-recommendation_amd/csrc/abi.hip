@@ -39,6 +39,9 @@ struct poi_ctx {
   DevBuf pmark, seg_pidx;   // per-POI regrouping: per lt row "is a step input in this launch" (all-zero between launches), row -> S row
   int ppoi = 1;             // POI_TE_PPOI=0 disables the regrouping (A/B)
   DevBuf kc_dev;            // te_wgrad's K-chunk split, chosen on the device per launch
+  DevBuf ptab, iota;        // forward table (te_rec_fwd16<FT>): lt . ui[:, :D]^T per table row; 0..n_item, n_item + 1
+  int iota_n = -1;          // rows the iota buffer currently describes
+  int fwd_tab = 1;          // POI_TE_FWDTAB=0 disables (A/B)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
   // A launch is captured the second time its key (every pointer / size / scalar the kernels receive) is seen; the caller's uidx /
   // out are staged through context buffers so that the key does not depend on them.
@@ -120,6 +123,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_WGRAD_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->wgrad_rounds = v; }
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
@@ -146,7 +150,7 @@ static void drop_graphs(poi_ctx* c) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->seg_pidx, &c->kc_dev, &c->uidx_stage, &c->out_stage,
+  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->seg_pidx, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
@@ -201,7 +205,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
   A.dl = poi::dense_layout(D, A.xw, n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 192;   // + spare rows: row T and the rest of the last 128-row tile
-  const size_t pk = (size_t)12 * D * D + (size_t)6 * D * D + (size_t)2 * NBP * D + (size_t)12 * D * D + 64;
+  const size_t pk = (size_t)12 * D * D + (size_t)9 * D * D + (size_t)2 * NBP * D + (size_t)12 * D * D + 64;
   // sorted scatter (training): 3 slots per sequence position
   const bool sorted = !predict;
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
@@ -223,11 +227,19 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const int R = P->n_item + 1 + n_dist + 1;
   if (sorted && ((rc = ensure(c, c->seg_s, sizeof(int) * (size_t)(R + 1), st)) || (rc = ensure(c, c->seg_e, sizeof(int) * (size_t)(R + 1), st)))) return rc;
   if (A.ppoi && (rc = ensure(c, c->pmark, sizeof(int) * (size_t)(P->n_item + 2), st))) return rc;
+  // forward table: worth it when the table has clearly fewer rows than the launch has steps (Tcap is the upper bound: sequences
+  // average ~40 % of the longest) - te_gemm_ax then multiplies n_item + 1 rows instead of one row per step
+  A.fwd_tab = (c->fwd_tab && A.bintab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap) ? 1 : 0;
+  if (A.fwd_tab) {
+    if ((rc = ensure(c, c->ptab, sizeof(float) * (size_t)(P->n_item + 2) * 3 * D, st)) || (rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
+    if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }
+    A.ptab = (float*)c->ptab.p; A.iota = (const int*)c->iota.p;
+  }
   float* f = (float*)c->te_ws.p;
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
   A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
   A.RH = take(Tcap * D); A.DH = take(Tcap * D); A.rowloss = take(Tcap * 2);
-  A.uiT = take((size_t)6 * D * D);
+  A.uiT = take((size_t)6 * D * D); A.uiP = take((size_t)3 * D * D);
   A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
   A.pWhT16 = (float4*)take((size_t)3 * D * D); A.pWhc16 = (float4*)take((size_t)D * D); A.pWhzr16 = (float4*)take((size_t)2 * D * D);
   if (A.bintab) {
@@ -355,7 +367,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
       const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
-                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p};
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)c->fwd_tab};
       add(bufs, sizeof bufs);
     }
     poi_ctx::StepGraph* g = nullptr;

@@ -104,6 +104,8 @@ struct TeArgs {
   int *soff, *row_src, *row_t, *row_p, *row_dp, *row_ab;   // packed row -> CSR position, step index, input table rows (lt, di)
   float *X, *E, *G, *H, *RH, *DH, *DL, *rowloss;   // DL: d logits (T x padded bins)
   float4 *pVsT, *pVs;
+  // forward table (te_rec_fwd16<FT>): ptab = lt . ui[:, :D]^T over all n_item + 1 table rows; iota = 0..n_item, then n_item + 1
+  float* ptab; const int* iota; int fwd_tab; float* uiP;       // uiP: ui's POI half with gate-interleaved rows
   float* uiT;                         // ui transposed (2D x 3D), K-contiguous B operand of te_gemm_dx
   float4 *pWhT16, *pWhc16, *pWhzr16;  // 16-column fragments (16x16x4 MFMA) for the recurrent kernels
   float* slab;
@@ -166,6 +168,7 @@ hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st);
 int te_wgrad_ui_jobs(int D, int n_dist, bool spatial);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 int te_nbp(int n_dist);
+void launch_te_iota(int* buf, int n, hipStream_t st);
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);

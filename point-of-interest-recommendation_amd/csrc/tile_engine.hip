@@ -648,8 +648,26 @@ __global__ __launch_bounds__(1024) void te_ztab_kernel(TeArgs A, float* __restri
     const float4 uv = *reinterpret_cast<const float4*>(u + c);
     z0 = fmaf(drow[c], uv.x, z0); z1 = fmaf(drow[c + 1], uv.y, z1); z2 = fmaf(drow[c + 2], uv.z, z2); z3 = fmaf(drow[c + 3], uv.w, z3);
   }
-  ztab[(size_t)b * 3 * D + n] = (z0 + z1) + (z2 + z3);
+  // forward-table mode: gate-interleaved columns ([c][gate]) - a lane of te_rec_fwd16 reads z | r | c of its column with one 12-byte load
+  const int o = A.fwd_tab ? 3 * (n % D) + n / D : n;
+  ztab[(size_t)b * 3 * D + o] = (z0 + z1) + (z2 + z3);
 }
+
+// uiP[3 c + g][k] = ui[g D + c][k], k < D: the POI half of ui with gate-interleaved rows, B operand of the forward table's product
+__global__ __launch_bounds__(256) void te_uiperm_kernel(TeArgs A) {
+  const int D = A.dim, XW = A.xw;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < 3 * D * D; e += gridDim.x * 256) {
+    const int n = e / D, k = e % D, g = n % 3, c = n / 3;
+    A.uiP[e] = A.ui[(size_t)(g * D + c) * XW + k];
+  }
+}
+
+// iota[i] = i for i < n, iota[n] = n (the row count te_gemm_ntk reads through its T pointer): the forward table's identity gather
+__global__ __launch_bounds__(256) void te_iota_kernel(int* __restrict__ buf, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i <= n) buf[i] = i;
+}
+void launch_te_iota(int* buf, int n, hipStream_t st) { hipLaunchKernelGGL(te_iota_kernel, dim3(n / 256 + 1), dim3(256), 0, st, buf, n); }
 
 // uiT[c][r] = ui[r][c]   (ui is 3D x 2D row-major): the K-contiguous B operand of dx = DA . ui
 __global__ __launch_bounds__(256) void te_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
@@ -668,7 +686,12 @@ __global__ __launch_bounds__(256) void te_transpose_kernel(const float* __restri
 // a 16-row step is half the matrix work of a 32-row step.  h_{t-1} / r*h_{t-1} cross waves through LDS
 // (two barriers per step).
 // -------------------------------------------------------------------------------------------------
-template <int D, bool predict>      // (compile-time: a runtime flag puts a branch around every store of the step)
+// FT (forward table): the pre-activations of a step are not read from G (filled by te_gemm_ax, one row per step) but assembled here
+// as ptab[p_t] + ztab[dp_t] - the step input takes far fewer distinct values than there are steps (231 k steps hit 100 k POIs),
+// so te_gemm_ax multiplies the TABLE once (te_launch_ax_t) and the recurrence gathers.  Same operands, same single addition as the
+// table epilogue of te_gemm_ax: bitwise the same pre-activations.  The row ids of step t+2 are fetched while step t computes
+// (a dependent load chain of two).
+template <int D, bool predict, bool FT = false>      // (compile-time: a runtime flag puts a branch around every store of the step)
 __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int KG = D / 16, LDA = D + 4, NW = D / 16;
@@ -697,22 +720,14 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
   load_bfrag<KG>(wc[0], A.pWhT16, 2 * NW + w);
   // pre-activations of the NEXT step are fetched while the current step computes (G still holds
   // X.ui^T + bi for rows not yet visited)
-  float cz[4], cr[4], cc[4], nz[4], nr[4], nc[4];
+  float cz[4], cr[4], cc[4];
   // Finished sequences read / write the spare packed row Tsp (= total rows; allocated, never
   // consumed): every access is unconditional, so no branch - and no conservative s_waitcnt vmcnt(0)
   // that would serialise the stores or turn the prefetch into a blocking load.
   const int Tsp = A.soff[A.n_seq];
-  auto fetch = [&](int t, float (&z)[4], float (&r)[4], float (&c)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* g = A.G + (size_t)(t < nsr[q] ? rowb[q] + t : Tsp) * 3 * D;
-      z[q] = g[col]; r[q] = g[D + col]; c[q] = g[2 * D + col];
-    }
-  };
-  fetch(0, cz, cr, cc);
   float hcur[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's elements of h_{t-1} (it wrote them itself)
-  for (int t = 0; t < ns_max; ++t) {
-    fetch(t + 1, nz, nr, nc);
+  // one step of the recurrence from the pre-activations cz / cr / cc
+  auto compute = [&](int t) {
     // r gate first: its sigmoid, the r*h exchange and the stores then overlap the z-gate MFMAs (of this
     // wave and of its SIMD partner) instead of sitting between the MFMA block and the barrier
     f32x4 ar[1], az[1], ac[1];
@@ -726,8 +741,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
       const float rh = rv * hcur[r];
       RHb[i * LDA + col] = rh;
       const size_t row = (size_t)(t < nsr[r] ? rowb[r] + t : Tsp);
-      A.G[row * 3 * D + D + col] = rv;
-      if (!predict) A.RH[row * D + col] = rh;
+      if (!predict) { A.G[row * 3 * D + D + col] = rv; A.RH[row * D + col] = rh; }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) az[0][r] = cz[r];
@@ -752,14 +766,77 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
       }
     }
     lds_barrier();
-    // Opaque use of the prefetched values HERE: the wait for them is then counted in straight-line code behind
-    // this step's stores (vmcnt(#stores)).  Left to the first use at the top of the next iteration, it merges
-    // with the loop-entry state and becomes a wait for most of the stores as well - a store round trip per step.
+  };
+  if constexpr (!FT) {
+    float nz[4], nr[4], nc[4];
+    auto fetch = [&](int t, float (&z)[4], float (&r)[4], float (&c)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      asm volatile("" : "+v"(nz[r]), "+v"(nr[r]), "+v"(nc[r]));
-      cz[r] = nz[r]; cr[r] = nr[r]; cc[r] = nc[r];
+      for (int q = 0; q < 4; ++q) {
+        const float* g = A.G + (size_t)(t < nsr[q] ? rowb[q] + t : Tsp) * 3 * D;
+        z[q] = g[col]; r[q] = g[D + col]; c[q] = g[2 * D + col];
+      }
+    };
+    fetch(0, cz, cr, cc);
+    for (int t = 0; t < ns_max; ++t) {
+      fetch(t + 1, nz, nr, nc);
+      compute(t);
+      // Opaque use of the prefetched values HERE: the wait for them is then counted in straight-line code behind
+      // this step's stores (vmcnt(#stores)).  Left to the first use at the top of the next iteration, it merges
+      // with the loop-entry state and becomes a wait for most of the stores as well - a store round trip per step.
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        asm volatile("" : "+v"(nz[r]), "+v"(nr[r]), "+v"(nc[r]));
+        cz[r] = nz[r]; cr[r] = nr[r]; cc[r] = nc[r];
+      }
     }
+  } else {
+    // Forward table, TWO steps of prefetch: the table rows of step t+2 are requested at the top of step t (random 1.5 KB rows: a
+    // longer latency than the sequential G rows of the plain path, and one workgroup per CU has nothing else to hide it), the
+    // row ids of step t+3 right after.  Two register sets alternate by step parity (the loop is unrolled by two, so they are
+    // renamed, not moved).  Row ids: lane (lane & 3) of every quad loads those of tile row g4 + (lane & 3); quad broadcasts hand
+    // them to the other three lanes when they are consumed, a step later.
+    struct f3 { float x, y, z; };
+    struct Pre { f3 g[4], y[4]; };
+    const int sub = lane & 3;
+    const int my_rowb = sub == 0 ? rowb[0] : sub == 1 ? rowb[1] : sub == 2 ? rowb[2] : rowb[3];
+    const int my_ns = sub == 0 ? nsr[0] : sub == 1 ? nsr[1] : sub == 2 ? nsr[2] : nsr[3];
+    int rp = 0, rz = 0;                        // raw row ids of this lane's row (in flight)
+    auto ids = [&](int t) {
+      const int rr = t < my_ns ? my_rowb + t : Tsp;              // (row Tsp holds whatever an earlier launch left: clamped on use)
+      rp = A.row_p[rr]; rz = A.row_dp[rr];
+    };
+    // consume rp / rz (row ids of step tn - 1), request the row ids of step tn, THEN the table rows: vmcnt retires in order, so the
+    // wait for the ids at the top of the next step covers only what is older than them - the table rows get two full steps
+    auto rows = [&](Pre& X, int tn) {
+      const int p1 = (int)min((unsigned)rp, (unsigned)A.n_item), z1 = (int)min((unsigned)rz, (unsigned)A.n_dist);
+      int pi[4], zi[4];
+      pi[0] = __builtin_amdgcn_mov_dpp(p1, 0x00, 0xF, 0xF, true); zi[0] = __builtin_amdgcn_mov_dpp(z1, 0x00, 0xF, 0xF, true);
+      pi[1] = __builtin_amdgcn_mov_dpp(p1, 0x55, 0xF, 0xF, true); zi[1] = __builtin_amdgcn_mov_dpp(z1, 0x55, 0xF, 0xF, true);
+      pi[2] = __builtin_amdgcn_mov_dpp(p1, 0xAA, 0xF, 0xF, true); zi[2] = __builtin_amdgcn_mov_dpp(z1, 0xAA, 0xF, 0xF, true);
+      pi[3] = __builtin_amdgcn_mov_dpp(p1, 0xFF, 0xF, 0xF, true); zi[3] = __builtin_amdgcn_mov_dpp(z1, 0xFF, 0xF, 0xF, true);
+      ids(tn);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        X.g[q] = *reinterpret_cast<const f3*>(A.ptab + (size_t)pi[q] * 3 * D + 3 * col);      // (gate-interleaved columns)
+        X.y[q] = *reinterpret_cast<const f3*>(A.ztab + (size_t)zi[q] * 3 * D + 3 * col);
+      }
+    };
+    auto take = [&](Pre& X) {                  // pre-activations of the next step <- a landed register set
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("" : "+v"(X.g[q].x), "+v"(X.g[q].y), "+v"(X.g[q].z), "+v"(X.y[q].x), "+v"(X.y[q].y), "+v"(X.y[q].z));
+        cz[q] = X.g[q].x + X.y[q].x; cr[q] = X.g[q].y + X.y[q].y; cc[q] = X.g[q].z + X.y[q].z;
+      }
+    };
+    Pre B0, B1;
+    ids(0); rows(B0, 1); take(B0);             // step 0
+    rows(B1, 2);                               // step 1 in flight, ids of step 2
+    int t = 0;
+    for (; t + 1 < ns_max; t += 2) {
+      rows(B0, t + 3); compute(t); take(B1);                 // B0 <- step t+2; step t+1 <- B1
+      rows(B1, t + 4); compute(t + 1); take(B0);             // B1 <- step t+3; step t+2 <- B0
+    }
+    if (t < ns_max) compute(t);                // odd length: the pre-activations of the last step are already in place
   }
   if (predict) {
 #pragma unroll
@@ -1178,6 +1255,9 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
       }
     }
     lds_barrier();
+    // next tile's staging rows: requested BEFORE the softmax phase (LDS + VALU only), so that they have landed when the second MFMA
+    // block starts waiting for its first B fragment - vmcnt is in order, that wait covers every older load (measured: -3 %)
+    prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
     {   // row-wise softmax + losses: 8 lanes per row
       const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
       float* o = Ot + row * LDO;
@@ -1227,8 +1307,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
     }
     lds_barrier();
     if (!MODE) {
-      // g * E of this lane's DH elements and the next tile's staging rows: issued now, consumed after the MFMAs
-      // and at the top of the next iteration
+      // g * E of this lane's DH elements: issued now, consumed after the MFMAs
       int ntd[DTW];
 #pragma unroll
       for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
@@ -1238,7 +1317,6 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           ge[j][r] = Esrc[(size_t)min(r0 + c_row(r, lane), T - 1) * D + ntd[j] * 32 + li];
-      prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
       // d logits -> DL (A operand of the d vs job of te_wgrad), d bs partials
       for (int e = tid; e < 32 * (NBP / 4); e += TE_BLOCK) {
         const int r = e / (NBP / 4), c = (e % (NBP / 4)) * 4;
@@ -1267,8 +1345,6 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
           A.DH[(size_t)min(r0 + i, T) * D + col] = acc[0][j][r] + s_g[i] * ge[j][r];
         }
       }
-    } else {
-      prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
     }
     stage();              // Ht / s_he / s_a / s_b were last read before the previous barrier
   }
@@ -1581,8 +1657,16 @@ static void te_launch_ax_t(const TeArgs& A, int num_cu, hipStream_t st) {
   if (A.bintab) {
     if constexpr (D >= 128) {
       hipLaunchKernelGGL(te_ztab_kernel, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A, A.ztab);
-      NtArgs P{nullptr, 0, A.lt, nullptr, A.row_p, nullptr, D, A.ui, 2 * D, A.G, 3 * D, nullptr, A.soff + n, 3 * D, D, A.ztab, A.row_dp};
-      hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true, F16>), grid, block, 0, st, P);
+      if (A.fwd_tab) {
+        // forward table: ptab = lt . ui[:, :D]^T over the n_item + 1 table rows (identity "gather": the same kernel reads the rows of a
+        // half table too), columns gate-interleaved like ztab's; te_rec_fwd16<FT> gathers ptab[p_t] + ztab[dp_t]
+        hipLaunchKernelGGL(te_uiperm_kernel, dim3(3 * D * D / 1024), dim3(256), 0, st, A);
+        NtArgs P{nullptr, 0, A.lt, nullptr, A.iota, nullptr, D, A.uiP, D, A.ptab, 3 * D, nullptr, A.iota + A.n_item + 1, 3 * D, D, nullptr, nullptr};
+        hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, D, 3 * D, false, F16>), grid, block, 0, st, P);
+      } else {
+        NtArgs P{nullptr, 0, A.lt, nullptr, A.row_p, nullptr, D, A.ui, 2 * D, A.G, 3 * D, nullptr, A.soff + n, 3 * D, D, A.ztab, A.row_dp};
+        hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true, F16>), grid, block, 0, st, P);
+      }
     }
   } else if (A.spatial) {
     NtArgs P{nullptr, 0, A.lt, A.di, A.row_p, A.row_dp, D, A.ui, 2 * D, A.G, 3 * D, A.bi, A.soff + n, 3 * D, 2 * D, nullptr, nullptr};
@@ -1635,7 +1719,10 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
   }
   if constexpr (D <= 128) {
-    if (!A.rec32) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+    if (!A.rec32) {
+      if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+      else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+    }
   }
   tm->end(st);
   tm->begin("te_head", st);
@@ -1737,7 +1824,10 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
     if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
   }
   if constexpr (D <= 128) {
-    if (!A.rec32) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+    if (!A.rec32) {
+      if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+      else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+    }
   }
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);
