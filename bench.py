@@ -263,8 +263,14 @@ def main():
     # launch) instead of over the steps - rho = S rows / steps
     ppoi = bintab and os.environ.get("POI_TE_PPOI", "1") != "0"
     rho = (s_rows / steps_per_epoch) if ppoi else 1.0
+    # forward table (bintab, 16-sequence recurrent tiles): te_gemm_ax multiplies the n_item + 1 table rows once per launch instead of one
+    # row per step (abi.hip te_setup: when the table has at most half as many rows as the launch's step capacity)
+    n_launches_ = len(batches)
+    fwd_tab = (bintab and D < 256 and os.environ.get("POI_TE_FWDTAB", "1") != "0"
+               and 2 * (n_item + 1) <= B * max(model.max_len - 1, 1) + 192)
+    ax_rows = (n_item + 1.0) * n_launches_ if fwd_tab else steps_per_epoch
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
-            "te_gemm_ax": ("flop", xk * D2 * steps_per_epoch), "te_rec_fwd": ("flop", 6 * D2 * steps_per_epoch),
+            "te_gemm_ax": ("flop", xk * D2 * ax_rows), "te_rec_fwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_head": ("flop", 4.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
             "te_wgrad": ("flop", ((6 + xk * rho) * D2 + 2.0 * NB * D) * steps_per_epoch),     # d ui (over S rows), d wh and d vs (split-K)
             "te_gemm_dx": ("flop", xk * rho * D2 * steps_per_epoch),

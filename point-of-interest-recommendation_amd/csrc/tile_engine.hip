@@ -879,32 +879,42 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
   float dhn[4], sbz = 0.f, sbr = 0.f, sbc = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) dhn[r] = 0.f;
-  // operands of step t-1 (z, r, c, h_{t-2}, DH) are fetched while step t computes
-  float fz[4], fr[4], fc[4], fh[4], fd[4], gz[4], gr_[4], gc[4], gh[4], gd[4];
+  // operands of step t-2 (z, r, c, h_{t-3}, DH) are fetched while step t computes: TWO steps of prefetch in two register sets that
+  // alternate by step parity (loop unrolled by two: renamed, not moved) - one workgroup per CU has nothing else to hide the HBM
+  // latency of the five rows a step reads, and a step is shorter than that latency under load (te_rec_fwd16<FT>: -7 %)
+  struct Ops { float z[4], r[4], c[4], h[4], d[4]; };
+  float fz[4], fr[4], fc[4], fh[4], fd[4];       // masked operands of the current step
   // unconditional accesses (inactive lanes use the spare packed row Tsp): see te_rec_fwd16
   const int Tsp = A.soff[A.n_seq];
-  auto fetch = [&](int t, float (&z)[4], float (&r)[4], float (&c)[4], float (&h)[4], float (&d)[4]) {
+  auto fetch = [&](int t, Ops& X) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool on = t >= 0 && t < nsr[q];
       const size_t row = (size_t)(on ? rowb[q] + t : Tsp);
       const float* g = A.G + row * 3 * D;
-      // raw values; the consumer masks them (a select here would wait for the load at once)
-      z[q] = g[col]; r[q] = g[D + col]; c[q] = g[2 * D + col];
-      h[q] = A.H[(on && t > 0 ? row - 1 : (size_t)Tsp) * D + col];
-      d[q] = A.DH[row * D + col];
+      // raw values; take() masks them (a select here would wait for the load at once)
+      X.z[q] = g[col]; X.r[q] = g[D + col]; X.c[q] = g[2 * D + col];
+      X.h[q] = A.H[(on && t > 0 ? row - 1 : (size_t)Tsp) * D + col];
+      X.d[q] = A.DH[row * D + col];
     }
   };
-  fetch(ns_max - 1, fz, fr, fc, fh, fd);
-  for (int t = ns_max - 1; t >= 0; --t) {
-    fetch(t - 1, gz, gr_, gc, gh, gd);
+  auto take = [&](Ops& X, int t) {               // operands of step t <- a landed register set
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      asm volatile("" : "+v"(X.z[r]), "+v"(X.r[r]), "+v"(X.c[r]), "+v"(X.h[r]), "+v"(X.d[r]));
+      const bool on = t >= 0 && t < nsr[r];
+      // the spare row holds arbitrary bits: select, do not multiply by zero
+      fz[r] = on ? X.z[r] : 0.f; fr[r] = on ? X.r[r] : 0.f; fc[r] = on ? X.c[r] : 0.f;
+      fh[r] = (on && t > 0) ? X.h[r] : 0.f; fd[r] = on ? X.d[r] : 0.f;
+    }
+  };
+  auto compute = [&](int t) {
     float zv[4], rv[4], hp[4], dz[4], dhp[4], dacv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r;
       const bool on = t < nsr[r];
-      // the spare row holds arbitrary bits: select, do not multiply by zero
-      const float z = on ? fz[r] : 0.f, rr = on ? fr[r] : 0.f, c = on ? fc[r] : 0.f, h = (on && t > 0) ? fh[r] : 0.f;
+      const float z = fz[r], rr = fr[r], c = fc[r], h = fh[r];
       const float dh = on ? dhn[r] + fd[r] : 0.f;
       zv[r] = z; rv[r] = rr; hp[r] = h;
       dz[r] = dh * (c - h);
@@ -937,14 +947,20 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
     for (int r = 0; r < 4; ++r) acc[0][r] = 0.f;
     mma16_regb<2 * KG, 1>(acc, Azr, LDB, wzrb);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][r] : 0.f;
-      fz[r] = gz[r]; fr[r] = gr_[r]; fc[r] = gc[r]; fh[r] = gh[r]; fd[r] = gd[r];
-    }
+    for (int r = 0; r < 4; ++r) dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][r] : 0.f;
     // No barrier here: Ac is free once every wave passed the second barrier (its readers ran before
     // it), and the next step's Azr writes come after the next first barrier, which every wave reaches
     // only after finishing this step's MFMA block on Azr.
+  };
+  Ops B0, B1;
+  int t = ns_max - 1;
+  fetch(t, B0); take(B0, t);
+  fetch(t - 1, B1);
+  for (; t >= 1; t -= 2) {
+    fetch(t - 2, B0); compute(t); take(B1, t - 1);
+    fetch(t - 3, B1); compute(t - 1); take(B0, t - 2);
   }
+  if (t == 0) compute(0);
   // d bi partial sums of this tile: the four 16-lane groups hold different sequences of the same column;
   // written per tile and summed in tile order by te_parts_kernel (no float atomics: reproducible)
   sbz += __shfl_xor(sbz, 16, 64); sbr += __shfl_xor(sbr, 16, 64); sbc += __shfl_xor(sbc, 16, 64);
