@@ -595,6 +595,8 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   if (c->score_variant >= 0 && dim <= 128) variant = c->score_variant;
   if (U && U->bins) variant = 1;      // the bin matrix is laid out for the packed-stream kernel
   if (U && !U->bins) variant = 0;     // bins on the fly: the row-per-lane kernel (any dim <= 256)
+  // ... or, for enough users to fill the chip with eight-wave workgroups and a wide model, the packed-stream GEO kernel
+  if (U && !U->bins && k > 0 && n >= 1024 && dim >= 128 && poi::score_geo_stream_lds(dim, U->n_dist) <= 160 * 1024 && c->score_variant != 0) variant = 2;
   const int n_utile = (n + 31) / 32;
   const int units = n_utile;
   // long item streams keep per-user thresholds high (few top-K compactions)
@@ -602,7 +604,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   if (want > ntile / 8) want = ntile / 8;      // >= 8 tiles per stream: amortise the per-wave top-K epilogue
   if (want < 1) want = 1;
   if (want < (ntile + 2046) / 2047) want = (ntile + 2046) / 2047;      // candidate lists hold 16-bit item offsets: < 65536 items per range
-  int n_split = ((want + 3) / 4) * 4;
+  int n_split = variant == 2 ? ((want + 7) / 8) * 8 : ((want + 3) / 4) * 4;
   A.n_split = n_split;
   const int n_pad = n_utile * 32;
   int rc;
@@ -617,7 +619,12 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
       A.gbound = (unsigned*)c->gbound.p;
     }
   }
-  if (variant == 1) {
+  if (variant == 2) {
+    const int d8 = dim <= 128 ? 16 : 32;
+    if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
+    A.items_packed = (float4*)c->items_pk.p;
+    HIPCHK(c, poi::launch_score_geo_stream(A, st, &c->tm));
+  } else if (variant == 1) {
     const int d8 = dim <= 32 ? 4 : dim <= 64 ? 8 : 16;
     if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
     A.items_packed = (float4*)c->items_pk.p;

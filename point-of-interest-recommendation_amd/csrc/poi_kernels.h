@@ -238,6 +238,8 @@ hipError_t launch_ulptai(const double* coords, const double* cphi, const double*
                          int n_dist, double dd, void* out, int bin_bytes, hipStream_t st);
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm);
 hipError_t launch_score_packed(const ScoreArgs& A, hipStream_t st, Timing* tm);
+hipError_t launch_score_geo_stream(const ScoreArgs& A, hipStream_t st, Timing* tm);
+size_t score_geo_stream_lds(int dim, int n_dist);
 hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, int n_pad, hipStream_t st);
 hipError_t launch_topk_rows(const float* scores, int n, int n_item, int k, int* idx_out, float* score_out, hipStream_t st);
 

@@ -482,6 +482,133 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// GEO on the packed item stream, for the 10 M-POI / dim-256 configuration (and any dim >= 128): the row-per-lane GEO kernel above
+// keeps the user tile's A fragments (128 registers at dim 256) AND a tile of B in registers - one wave per SIMD, every tile's item
+// rows fetched with nothing to hide the latency, and a float64 Haversine for every (user, item) pair: 19 % of the f32 matrix peak.
+// Here
+//  * a workgroup is EIGHT waves (two per SIMD) on one 32-user tile: A fragments in LDS (shared), eight item ranges;
+//  * the packed B stream runs a full tile ahead in ONE register set: the k-group that has just been multiplied is reloaded with the
+//    same k-group of the next tile (a ring: D8 loads in flight, 4 D8 registers instead of 8 D8);
+//  * the distance term is computed only where it can matter: score <= dot + ub[user], ub = max_b wd * sts[user][b] (>= 0: column
+//    n_dist of the table is zero), so a pair with dot + ub <= the user's K-th best so far can never enter the list and gets the
+//    term 0 - exactly the same candidates, ranks and scores as computing every bin.  Once the thresholds have risen (a few hundred
+//    items into a range) almost no pair passes: the float64 block runs for a handful of (tile, row) pairs.
+// LDS: 8 candidate-list blocks (124 KB) + A fragments (32 KB at dim 256) + thresholds / user coordinates: one workgroup per CU.
+// -------------------------------------------------------------------------------------------------
+#define SG_NW 8
+template <int D8>
+__global__ __launch_bounds__(SG_NW * 64) void score_kernel_geo_stream(ScoreArgs A) {
+  extern __shared__ __align__(16) float dyn[];
+  WaveTopk* tk = reinterpret_cast<WaveTopk*>(dyn);
+  float4* af = reinterpret_cast<float4*>(tk + SG_NW);
+  double* s_geo = reinterpret_cast<double*>(af + D8 * 64);       // thr[n_dist] | user lat[32] | lon[32] | cos(lat)[32]
+  double* s_ulat = s_geo + A.n_dist; double* s_ulon = s_ulat + 32; double* s_ucp = s_ulon + 32;
+  float* s_ub = reinterpret_cast<float*>(s_ucp + 32);             // 32 upper bounds of the distance term
+  const int lane = lane_id(), w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+  const int D = A.dim, N = A.n_item, K = A.k;
+  const int ut = blockIdx.x;
+  const int split = blockIdx.y * SG_NW + w;
+  const int ntile = (N + 31) / 32;
+  const int tps = (ntile + A.n_split - 1) / A.n_split;
+  const int t_begin = split * tps;
+  const int t_end = min(ntile, t_begin + tps);
+  WaveTopk& T = tk[w];
+  if (lane < 32) { T.cnt[lane] = 0; T.thr[lane] = -INFINITY; T.gseen[lane] = 0; }
+  const int NB = A.n_dist + 1;
+  const float wd = A.wd[0];
+  {
+    const int urow = min(ut * 32 + li, A.n - 1);
+    const float* up = A.users + (size_t)urow * D;
+    for (int m = w; m < D8; m += SG_NW) {
+      const int k0 = 8 * m + 4 * h;
+      af[m * 64 + lane] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = threadIdx.x; i < A.n_dist; i += SG_NW * 64) s_geo[i] = A.thr[i];
+    if (threadIdx.x < 32) {
+      const int lp = A.last_poi[min(ut * 32 + (int)threadIdx.x, A.n - 1)];
+      s_ulat[threadIdx.x] = A.coords[2 * lp]; s_ulon[threadIdx.x] = A.coords[2 * lp + 1]; s_ucp[threadIdx.x] = A.cphi[lp];
+    }
+    // ub[user] = max over the bins of wd * sts[user][bin] (the table is readable for whole 32-user tiles): wave w takes users 4w .. 4w+3
+    for (int q = 0; q < 4; ++q) {
+      const int u = 4 * w + q;
+      float mx = 0.f;
+      for (int b = lane; b < NB; b += 64) mx = fmaxf(mx, wd * A.sts[(size_t)(ut * 32 + u) * NB + b]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      if (lane == 0) s_ub[u] = mx;
+    }
+  }
+  __syncthreads();
+  float thr[16], ub[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { thr[r] = -INFINITY; ub[r] = s_ub[(r & 3) + 8 * (r >> 2) + 4 * h]; }
+  const float gscale = (float)(12742.0 * 1000.0 / A.dd);
+  const float4* bp = A.items_packed + lane;
+  const float4* ap = af + lane;
+  float4 b[D8];
+  if (t_begin < t_end) {
+#pragma unroll
+    for (int m = 0; m < D8; ++m) b[m] = bp[((size_t)t_begin * D8 + m) * 64];
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const size_t nb = (size_t)min(tile + 1, t_end - 1) * D8;        // (branch-free: the last tile reloads itself)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 a2[2];
+    a2[0] = ap[0];
+#pragma unroll
+    for (int m = 0; m < D8; ++m) {
+      if (m + 1 < D8) a2[(m + 1) & 1] = ap[(m + 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 a = a2[m & 1];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[m].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[m].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[m].w, acc, 0, 0, 0);
+      b[m] = bp[(nb + m) * 64];                                    // this k-group of the NEXT tile
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int j = tile * 32 + li;
+    const bool jvalid = j < N;
+    float pv[16];
+    bool cand = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pv[r] = 0.f; cand |= acc[r] + ub[r] > thr[r]; }
+    if (__any(cand && jvalid)) {
+      const int jc = min(j, N - 1);
+      const double jlat = A.coords[2 * jc], jlon = A.coords[2 * jc + 1], jcp = A.cphi[jc];
+      const double pr = 0.017453292519943295;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!__any(jvalid && acc[r] + ub[r] > thr[r])) continue;
+        const int ul = (r & 3) + 8 * (r >> 2) + 4 * h;
+        int bin;
+        {
+#pragma clang fp contract(off)
+          const double a = (s_ulat[ul] - jlat) * pr;
+          const double bb = (s_ulon[ul] - jlon) * pr;
+          const double c = (1.0 - cos_small(a)) / 2 + s_ucp[ul] * jcp * (1.0 - cos_small(bb)) / 2;
+          bin = bin_of_c(c, s_geo, A.n_dist, gscale);
+        }
+        pv[r] = A.sts[(size_t)(ut * 32 + ul) * NB + bin];
+      }
+    }
+    tile_epilogue(A, T, acc, pv, thr, wd, ut, j, j - t_begin * 32, jvalid, K, tile - t_begin);
+  }
+  const int n_pad = gridDim.x * 32;
+  for (int i = 0; i < 32; ++i) {
+    compact_user(T, i, K);
+    const int n = T.cnt[i];
+    if (lane < K) {
+      const size_t o = ((size_t)split * n_pad + ut * 32 + i) * K + lane;
+      A.cand_score[o] = lane < n ? T.cs[i][lane] : -INFINITY;
+      A.cand_idx[o] = lane < n ? t_begin * 32 + (int)T.ci[i][lane] : INT_MAX;
+    }
+  }
+}
+
 // Merge n_lists sorted K-lists per user into the final top-K (one wavefront per user).
 __global__ __launch_bounds__(POI_BLOCK) void topk_merge_kernel(ScoreArgs A, int n_lists, int n_pad) {
   const int lane = lane_id();
@@ -601,6 +728,38 @@ hipError_t launch_score_packed(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   return hipErrorInvalidValue;
 }
 
+
+size_t score_geo_stream_lds(int dim, int n_dist) {
+  const int d8 = dim <= 128 ? 16 : 32;
+  return sizeof(WaveTopk) * SG_NW + sizeof(float4) * d8 * 64 + sizeof(double) * (n_dist + 96) + sizeof(float) * 32;
+}
+
+template <int D8>
+static hipError_t launch_score_geo_stream_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
+  const size_t total = (size_t)((A.n_item + 31) / 32) * D8 * 64;
+  const size_t lds = score_geo_stream_lds(A.dim, A.n_dist);
+  static bool optin = false;
+  if (!optin) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel_geo_stream<D8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    optin = true;
+  }
+  tm->begin("pack_items", st);
+  hipLaunchKernelGGL(pack_items_kernel, dim3(2048), dim3(POI_BLOCK), 0, st, A.items, A.items_f16, A.n_item, A.dim, D8, A.items_packed, total);
+  tm->end(st);
+  dim3 grid((A.n + 31) / 32, A.n_split / SG_NW);
+  tm->begin("score_topk", st);
+  hipLaunchKernelGGL((score_kernel_geo_stream<D8>), grid, dim3(SG_NW * 64), lds, st, A);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+// GEO + top-K on the packed stream (n_split must be a multiple of 8; A.items_packed sized for d8 = 16 (dim <= 128) or 32)
+hipError_t launch_score_geo_stream(const ScoreArgs& A, hipStream_t st, Timing* tm) {
+  if (A.dim <= 128) return launch_score_geo_stream_t<16>(A, st, tm);
+  if (A.dim <= 256) return launch_score_geo_stream_t<32>(A, st, tm);
+  return hipErrorInvalidValue;
+}
 
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   if (A.dim <= 32) return launch_score_t<4, true>(A, st, tm);

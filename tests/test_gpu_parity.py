@@ -577,3 +577,51 @@ def test_device_rank_metrics_match_reference_golden(pa, golden_dir):
     # k = 20 equals the golden vectors produced by the reference helpers themselves
     assert got[3, 0] == g["zero_one"].sum()
     assert np.isclose(got[3, 1], g["map"].sum(), rtol=1e-12) and np.isclose(got[3, 2], g["ndcg"].sum(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("dim,f16", [(128, False), (256, False), (256, True)])
+def test_geo_stream_kernel_ranks_match_the_oracle(pa, dim, f16):
+    """poi_score_topk_geo with >= 1024 users and dim >= 128 runs the packed-stream GEO kernel (eight-wave workgroups, ring-buffered
+    item stream, distance term only where dot + max_b wd * sts[b] can beat the user's K-th best): ranks must equal the float64
+    oracle (cal_dis bins of (last POI, POI) -> fun_acquire_prob -> scores -> top-K), with a distance term large enough to decide
+    ranks, for a ragged user count and a half item table."""
+    import torch
+    from poi_amd.data import bin_thresholds, cal_dis_vec, cos_lat
+    ctx = pa._lib.context(0)
+    rng = np.random.default_rng(40 + dim)
+    n, N, B, dd, K = 1100, 4000, 200, 200.0, 20
+    coords = np.stack([40.0 + rng.random(N) * 0.25, -74.0 + rng.random(N) * 0.25], 1)
+    last = rng.integers(0, N, n).astype(np.int32)
+    users = (rng.standard_normal((n, dim)) * (0.06 if dim == 128 else 0.045)).astype(np.float32)
+    items = rng.standard_normal((N, dim)).astype(np.float16 if f16 else np.float32)
+    sus = rng.random((n, B + 1)).astype(np.float32); sus[:, B] = 0.0
+    wd = np.float32(0.9)
+    bins = np.stack([cal_dis_vec(coords[l, 0], coords[l, 1], coords[:, 0], coords[:, 1], dd, B) for l in last])
+    prob = np.take_along_axis(sus.astype(np.float64), bins, axis=1)
+    dot = users.astype(np.float64) @ items.astype(np.float64).T
+    full = dot + float(wd) * prob
+    exp = O.topk_desc(full, K)
+    assert (exp != O.topk_desc(dot, K)).mean() > 0.3, "the distance term must matter in this test"
+    srt = np.sort(full, axis=1)[:, ::-1][:, :K + 1]
+    ok = np.min(srt[:, :-1] - srt[:, 1:], axis=1) > 2e-5 * np.abs(srt).max()
+    assert ok.sum() > 600
+    pad = ((n + 31) // 32) * 32
+    sus_m = np.zeros((pad, B + 1), np.float32); sus_m[:n] = sus
+    du, dsus = torch.as_tensor(users).cuda(), torch.as_tensor(sus_m).cuda()
+    di = torch.as_tensor(items).cuda()
+    if f16:
+        ctx.register_f16(di)
+    try:
+        dco, dcp = torch.as_tensor(coords).cuda(), torch.as_tensor(cos_lat(coords)).cuda()
+        dth = torch.as_tensor(bin_thresholds(dd, B)).cuda()
+        dlast, dwd = torch.as_tensor(last).cuda(), torch.as_tensor(np.array([wd])).cuda()
+        idx = torch.empty((n, K), dtype=torch.int32, device="cuda")
+        sc = torch.empty((n, K), dtype=torch.float32, device="cuda")
+        ctx.check(ctx.lib.poi_score_topk_geo(ctx.handle, du.data_ptr(), di.data_ptr(), n, N, dim, dwd.data_ptr(), dsus.data_ptr(), dco.data_ptr(),
+                                             dcp.data_ptr(), dth.data_ptr(), dlast.data_ptr(), B, dd, K, idx.data_ptr(), sc.data_ptr(), None))
+        got, gsc = idx.cpu().numpy(), sc.cpu().numpy()
+    finally:
+        if f16:
+            ctx.unregister_f16(di)
+    assert np.array_equal(got[ok], exp[ok])
+    assert_close(gsc[ok], np.take_along_axis(full, exp, axis=1)[ok], "top-K scores", rtol=2e-5)
