@@ -127,6 +127,8 @@ def main():
         a.table_dtype = a.table_dtype or "f16"
         if a.steps == 200:
             a.steps = 20
+        if a.batch_users == 12500:
+            a.batch_users = 16384      # 512 recurrent tiles of 32 sequences: two full rounds of the 256 CUs (12500 -> 391 tiles: 1.5 rounds)
     a.table_dtype = a.table_dtype or "f32"
     ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local)
     lo, hi = pdata.shard_users(n_user, a.emulate_world or world, rank, ds.lens)
