@@ -50,6 +50,8 @@ def parse():
                     help="batch rule cap (poi_ctx_set_batch_cap): a row touched by k sequences of a launch moves by min(k, cap)/k x the sum of "
                          "their reference updates; 1 = mean rule.  64 is the setting whose recall matches the reference schedule (quality block)")
     ap.add_argument("--local", type=float, default=0.8, help="fraction of check-in transitions that go to one of the 32 nearest POIs (0: i.i.d. Zipf draws)")
+    ap.add_argument("--dd", type=float, default=200.0, help="distance-bin width in metres (the reference's other configuration: 25 with --ud-km 38 = 1520 bins)")
+    ap.add_argument("--ud-km", type=float, default=40.0, help="distance beyond which every POI falls into the last bin")
     ap.add_argument("--eval-steps", type=int, default=5)
     ap.add_argument("--eval-chunk", type=int, default=16384,
                     help="users per scoring call: 16384 = 512 user tiles = one workgroup per tile and two per CU with 4 item ranges each")
@@ -130,7 +132,7 @@ def main():
         if a.batch_users == 12500:
             a.batch_users = 16384      # 512 recurrent tiles of 32 sequences: two full rounds of the 256 CUs (12500 -> 391 tiles: 1.5 rounds)
     a.table_dtype = a.table_dtype or "f32"
-    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local)
+    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local, dd=a.dd, ud_km=a.ud_km)
     lo, hi = pdata.shard_users(n_user, a.emulate_world or world, rank, ds.lens)
     tab = ds.shard(lo, hi)
     n_local = hi - lo
@@ -259,7 +261,7 @@ def main():
     # half of the step input goes through per-bin tables: te_gemm_ax / te_gemm_dx / the d ui jobs of
     # te_wgrad only multiply the POI half, i.e. 36 D^2 + 6 NB D executed against the 54 D^2 + 6 NB D of the
     # reference formulation (step_flops)
-    bintab = D >= 128
+    bintab = D >= 128 and NB <= 256      # (beyond 256 bins the two-table path runs: te_bintab)
     xk = 6 if bintab else 12
     # per-POI regrouping (bintab): te_gemm_dx and the d ui jobs of te_wgrad contract over the S rows (distinct step-input POIs of a
     # launch) instead of over the steps - rho = S rows / steps

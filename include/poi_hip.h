@@ -85,7 +85,8 @@ const char* poi_last_error(const poi_ctx* ctx);   /* also valid with ctx == NULL
 int poi_ctx_num_cu(const poi_ctx* ctx);
 
 /* Engine used by poi_spatial_step / poi_gru_step / poi_gru_predict: 0 = auto (tile engine whenever dim is 64, 128 or 256 and
- * n_dist+1 <= 256 - also for a single sequence, where it is ~5x faster -, per-sequence engine otherwise),
+ * n_dist+1 <= 2048 - also for a single sequence, where it is ~5x faster -, per-sequence engine otherwise; beyond 256 bins the
+ * head runs bin-chunked with an online softmax and the distance-bin half of the input goes through the GEMMs again),
  * 1 = per-sequence engine, 2 = tile engine whenever supported, 3 = tile engine with the streaming recurrent kernels of
  * dim 256 (32-sequence tiles, weights streamed from L2) also at dim 128 - a testing aid.  Both implement the same arithmetic
  * (only the f32 summation order differs).  Also settable with POI_ENGINE=seq|tile. */

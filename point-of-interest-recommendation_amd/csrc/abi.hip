@@ -197,7 +197,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.n_item = P->n_item; A.n_dist = n_dist; A.dim = D;
   A.spatial = spatial ? 1 : 0; A.xw = spatial ? 2 * D : D;
   A.lt_f16 = is_f16(c, P->lt);
-  A.bintab = poi::te_bintab(D, spatial) ? 1 : 0;
+  A.bintab = poi::te_bintab(D, spatial, n_dist) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
   A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
@@ -297,7 +297,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   const poi::DenseLayout dl = poi::dense_layout(D, XW, NB);
   const size_t wsf = poi::seq_ws_floats(D, NB, T->max_len);
   const bool tile = use_tile(c, P, spatial, n);
-  if (!tile && is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 256 bins)");
+  if (!tile && is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 2048 bins)");
   int n_head = 0, n_kc = 0, n_kc_ui = 0, n_slab = grid;
   if (tile) {
     n_head = c->num_cu * (D >= 256 && c->head_rounds > 2 ? 2 : c->head_rounds);      // D = 256: 62 KB of LDS per te_head workgroup, two per CU
@@ -306,7 +306,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     n_kc = (c->num_cu * c->wgrad_rounds) / jobs;
     if (n_kc < 1) n_kc = 1;
     n_kc_ui = n_kc;
-    if (poi::te_bintab(D, spatial) && c->ppoi) {
+    if (poi::te_bintab(D, spatial, spatial ? P->n_dist : -1) && c->ppoi) {
       // per-POI regrouping: te_wgrad picks the K-chunk split on the device from the launch's own S-row count; the slabs are sized for
       // the extremes (no S rows: every slot goes to the T-row jobs; as many S rows as steps: the uniform split)
       int a, b;
@@ -341,7 +341,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = ensure(c, c->zrow, sizeof(float) * 1024, st))) return rc;
     E.zrow = (const float*)c->zrow.p;
     E.out = out; E.bcap = bcap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
-    E.kc_dev = (poi::te_bintab(D, spatial) && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
+    E.kc_dev = (poi::te_bintab(D, spatial, spatial ? P->n_dist : -1) && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
@@ -443,7 +443,7 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     HIPCHK(c, poi::launch_te_predict(E, c->num_cu, (hipStream_t)stream, &c->tm));
     return POI_OK;
   }
-  if (is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 256 bins)");
+  if (is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 2048 bins)");
   poi::SeqArgs A;
   fill_args(A, P, T, uidx, n);
   A.hts = hts; A.sts = sts; A.out_row = out_row;

@@ -161,7 +161,12 @@ struct TeArgs {
 #define RS_GRID 256
 #define RS_HIST_INTS (RS_MAXBIN * RS_GRID)   // radix histogram: bins x blocks
 bool te_supported(int D, int n_dist);
-bool te_bintab(int D, bool spatial);
+bool te_bintab(int D, bool spatial, int n_dist);
+// distance bins padded for the head / d vs tiles: 32 x {1, 2, 4, 7, 8} up to 256 bins, a multiple of 256 beyond (te_head_big's chunks)
+__host__ __device__ inline int te_nbp_dev(int n_dist) {
+  const int t = (n_dist + 1 + 31) / 32;
+  return t <= 8 ? 32 * (t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8) : 256 * ((n_dist + 1 + 255) / 256);
+}
 int te_wgrad_jobs(int D, int n_dist, bool spatial);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st);

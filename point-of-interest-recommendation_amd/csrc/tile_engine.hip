@@ -1373,13 +1373,257 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 }
 
 // -------------------------------------------------------------------------------------------------
+// te_head_big: the same head for MORE THAN 256 distance bins (the reference's dd = 25 m configuration has 1520,
+// public/GRU_Spatial.py:247): a 32 x (n_dist + 1) logits tile no longer fits LDS, so the bins go through it in chunks of 256 -
+//   pass A  logits chunk -> LDS -> per-lane running (max, sum of exp, sum of exp over bins <= a) + the two target logits:
+//           an online softmax, combined across the 8 lanes of a row after the last chunk;
+//   pass B  logits chunk again (recomputed: cheaper than an HBM round trip of the 32 x 1536 tile) -> probabilities ->
+//           d logits -> DL chunk, d bs, DH += d logits . vs[chunk]   (mode 1: probabilities -> sts).
+// Bins are padded to a multiple of 256 (te_nbp_dev); everything else as te_head_kernel.
+// -------------------------------------------------------------------------------------------------
+template <int MT, int NTW, int K8>
+__device__ __forceinline__ void mma_lds_packed_s(f32x16 (&acc)[MT][NTW], const float* __restrict__ ldsA, int lda,
+                                                 const float4* __restrict__ bp, const int (&nt)[NTW], int kstride) {
+  // mma_lds_packed over K8 k-groups of a packed operand whose n-tiles are `kstride` k-groups apart (a K-slice of a longer contraction)
+  const int lane = lane_id(), li = lane & 31, h = lane >> 5;
+  const float* arow = ldsA + li * lda + 4 * h;
+  const float4* bj[NTW];
+  float4 bc[NTW], bn[NTW], ac[MT], an[MT];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) { bj[j] = bp + ((size_t)nt[j] * kstride) * 64 + lane; bc[j] = *bj[j]; }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) ac[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda);
+#pragma unroll 2
+  for (int m = 0; m < K8; ++m) {
+    const int mn = m + 1 < K8 ? m + 1 : m;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bn[j] = bj[j][(size_t)mn * 64];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) an[i] = *reinterpret_cast<const float4*>(arow + (size_t)i * 32 * lda + 8 * mn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        acc[i][j] = mfma32(ac[i].x, bc[j].x, acc[i][j]);
+        acc[i][j] = mfma32(ac[i].y, bc[j].y, acc[i][j]);
+        acc[i][j] = mfma32(ac[i].z, bc[j].z, acc[i][j]);
+        acc[i][j] = mfma32(ac[i].w, bc[j].w, acc[i][j]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bc[j] = bn[j];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ac[i] = an[i];
+  }
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_big_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int K8 = D / 8, LDH = D + 4, CH = 256, LDO = CH + 4, NTD = D / 32, DTW = (NTD + 3) / 4, LPR = D / 4;
+  const int NB = A.n_dist + 1, NBP = te_nbp_dev(A.n_dist), NCH = NBP / CH, KB8 = NBP / 8;
+  float* Ht = lds;                  // 32 x LDH
+  float* Ot = Ht + 32 * LDH;        // 32 x LDO : one 256-bin chunk of logits -> d logits
+  float* s_dbs = Ot + 32 * LDO;     // NBP: d bs partial of this workgroup
+  __shared__ float s_g[32], s_he[32], s_red[8];
+  __shared__ int s_a[32], s_b[32];
+  const int T = MODE ? A.n_seq : A.soff[A.n_seq];
+  const float* __restrict__ Hsrc = MODE ? A.hts : A.H;
+  const float* __restrict__ Esrc = A.E;
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  if ((int)blockIdx.x * 32 >= T) return;
+  float ls0 = 0.f, ls1 = 1.f, wd = 0.f;
+  {
+    const float a = A.lw[0], b = A.lw[1], m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    ls0 = ea / (ea + eb); ls1 = eb / (ea + eb); wd = A.wd[0];
+  }
+  for (int e = tid; e < NBP; e += TE_BLOCK) s_dbs[e] = 0.f;
+  float dwd_acc = 0.f;
+  constexpr int SF4 = 32 * LPR / TE_BLOCK;
+  float4 ph[SF4], pe[SF4];
+  int pab = 0;
+  auto prefetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
+      const size_t gr = (size_t)min(r0 + r, T - 1);
+      ph[q] = *reinterpret_cast<const float4*>(Hsrc + gr * D + c);
+      if (!MODE) pe[q] = *reinterpret_cast<const float4*>(Esrc + gr * D + c);
+    }
+    if (!MODE) pab = A.row_ab[min(r0 + (tid & 31), T - 1)];
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
+      *reinterpret_cast<float4*>(Ht + r * LDH + c) = make_float4(ph[q].x, ph[q].y, ph[q].z, ph[q].w);
+      if (!MODE) {
+        float d = (ph[q].x * pe[q].x + ph[q].y * pe[q].y) + (ph[q].z * pe[q].z + ph[q].w * pe[q].w);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+        if ((tid % LPR) == 0) s_he[r] = d;
+      }
+    }
+    if (!MODE && tid < 32) { s_a[tid] = pab & 0xffff; s_b[tid] = (pab >> 16) & 0xffff; }
+  };
+  // logits of chunk c -> Ot (bias added; padding bins -inf)
+  auto logits = [&](int c) {
+    int nto[2];
+    float bsv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      nto[j] = c * 8 + w + 4 * j;
+      const int bin = nto[j] * 32 + li;
+      bsv[j] = A.bs[min(bin, NB - 1)];
+      bsv[j] = bin < NB ? bsv[j] : -INFINITY;
+    }
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    mma_lds_packed<1, 2, K8>(acc, Ht, LDH, A.pVsT, nto);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (w + 4 * j) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + col] = acc[0][j][r] + bsv[j];
+    }
+  };
+  prefetch(blockIdx.x * 32);
+  stage();
+  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    lds_barrier();
+    const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
+    const int a = MODE ? 0 : s_a[row], b = MODE ? 0 : s_b[row];
+    float* o = Ot + row * LDO;
+    // ---- pass A: online softmax statistics of this lane's bins (k = sub mod 8) ----
+    float m_l = -INFINITY, S_l = 0.f, C_l = 0.f, la = 0.f, lb = 0.f;
+    for (int c = 0; c < NCH; ++c) {
+      logits(c);
+      lds_barrier();
+      float mc = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < CH / 8; ++i) mc = fmaxf(mc, o[sub + 8 * i]);
+      const float mn = fmaxf(m_l, mc);
+      if (mn > -INFINITY) {                     // (a lane whose bins so far are all padding keeps its empty state)
+        const float sc = expf(m_l - mn);        // exp(-inf) = 0 on the first chunk
+        float s = 0.f, cs = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH / 8; ++i) {
+          const int k = c * CH + sub + 8 * i;
+          const float l = o[sub + 8 * i], e = expf(l - mn);
+          s += e; cs += k <= a ? e : 0.f;
+          la = k == a ? l : la; lb = k == b ? l : lb;
+        }
+        S_l = S_l * sc + s; C_l = C_l * sc + cs; m_l = mn;
+      }
+      lds_barrier();                            // Ot is rewritten by the next chunk / pass
+    }
+    float mx = m_l;
+    mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx));
+    const float rs = m_l > -INFINITY ? expf(m_l - mx) : 0.f;
+    float sum = S_l * rs, cum = C_l * rs;
+    sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
+    cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
+    la += dpp_f<0xB1>(la); la += dpp_f<0x4E>(la); la += dpp_f<0x141>(la);      // exactly one lane of the row captured each
+    lb += dpp_f<0xB1>(lb); lb += dpp_f<0x4E>(lb); lb += dpp_f<0x141>(lb);
+    const float inv = 1.0f / sum;
+    float g = 0.f, dot = 0.f, sa = 1.f;
+    const bool live = gr < T;
+    if (!MODE) {
+      cum *= inv;
+      sa = expf(la - mx) * inv;
+      const float sb = expf(lb - mx) * inv;
+      const float he = s_he[row];
+      const float u = he + wd * (sa - sb);
+      g = live ? -ls1 * sigmoidf_(-u) : 0.f;
+      dot = ls0 * cum - ls0 + g * wd * (sa - sb);
+      {
+        const size_t rsx = (size_t)min(gr, T);
+        A.rowloss[2 * rsx] = cum - logf(sa);
+        A.rowloss[2 * rsx + 1] = log_sigmoidf_(u);
+        A.gcoef[rsx] = g;
+      }
+      dwd_acc += sub == 0 ? g * (sa - sb) : 0.f;
+      if (sub == 0) s_g[row] = g;
+    }
+    // ---- pass B ----
+    int ntd[DTW];
+#pragma unroll
+    for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
+    prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
+    f32x16 dh[1][DTW];
+#pragma unroll
+    for (int j = 0; j < DTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[0][j][r] = 0.f;
+    for (int c = 0; c < NCH; ++c) {
+      logits(c);
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < CH / 8; ++i) {
+        const int k = c * CH + sub + 8 * i;
+        const float s = expf(o[sub + 8 * i] - mx) * inv;
+        if (MODE) {
+          if (live && k < NB) A.sts[(size_t)gr * NB + k] = s;
+        } else {
+          float ds = (k <= a ? ls0 : 0.f);
+          if (k == a) ds += g * wd - ls0 / sa;
+          if (k == b) ds -= g * wd;
+          o[sub + 8 * i] = (live && k < NB) ? s * (ds - dot) : 0.f;
+        }
+      }
+      lds_barrier();
+      if (!MODE) {
+        for (int e = tid; e < 32 * (CH / 4); e += TE_BLOCK) {
+          const int r = e / (CH / 4), cc = (e % (CH / 4)) * 4;
+          *reinterpret_cast<float4*>(A.DL + (size_t)min(r0 + r, T) * NBP + c * CH + cc) = *reinterpret_cast<const float4*>(Ot + r * LDO + cc);
+        }
+        {
+          float sd = 0.f;
+#pragma unroll
+          for (int r = 0; r < 32; ++r) sd += Ot[r * LDO + tid];
+          s_dbs[c * CH + tid] += sd;              // (thread tid owns bin c * 256 + tid)
+        }
+        mma_lds_packed_s<1, DTW, CH / 8>(dh, Ot, LDO, A.pVs + (size_t)c * (CH / 8) * 64, ntd, KB8);
+        lds_barrier();                            // the next chunk's logits overwrite Ot
+      }
+    }
+    if (!MODE) {
+#pragma unroll
+      for (int j = 0; j < DTW; ++j) {
+        if (w + 4 * j >= NTD) continue;
+        const int col = ntd[j] * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = c_row(r, lane);
+          // (g * E fetched here, after the chunk loop: registers; the kernel is MFMA-bound over 2 NCH + NCH products per tile)
+          const float ge = Esrc[(size_t)min(r0 + i, T - 1) * D + col];
+          A.DH[(size_t)min(r0 + i, T) * D + col] = dh[0][j][r] + s_g[i] * ge;
+        }
+      }
+    }
+    stage();
+  }
+  if (!MODE) {
+    __syncthreads();
+    float* hs = A.hslab + (size_t)blockIdx.x * A.hstride;
+    for (int e = tid; e < NB; e += TE_BLOCK) hs[e] += s_dbs[e];
+    const float dw = block_sum(dwd_acc, s_red);
+    if (tid == 0) hs[NB] += dw;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // te_wgrad: split-K transposed GEMMs  out[m][n] = sum_r DA[r][m0+m] * Bsrc[r][n0+n]  on TxT output
 // blocks (T = 128 when D % 128 == 0, else 64); K-chunk c covers packed rows [c*chunk, (c+1)*chunk).
 // job -> (A column block, B source).  Waves form a 2x2 grid, each owning (T/2)x(T/2) = Q x Q 32x32
 // accumulators; each 32-row stage is loaded from HBM/L2 into registers BEFORE the MFMA block of the
 // previous stage and written to the other LDS buffer after it (async-stage split, one barrier/stage).
 // -------------------------------------------------------------------------------------------------
-__host__ __device__ inline int te_nbp_dev(int n_dist) { const int t = (n_dist + 1 + 31) / 32; return 32 * (t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8); }
 
 template <int D, int T, bool F16 = false>       // F16: the POI table (gather source of the d ui jobs) holds IEEE half
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc) {
@@ -1601,25 +1845,25 @@ __global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile
 // host side
 // -------------------------------------------------------------------------------------------------
 int te_wgrad_jobs(int D, int n_dist, bool spatial) {
-  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial)) ? 2 * D : D;
+  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial, n_dist)) ? 2 * D : D;
   return (3 * D / T) * (XW / T) + (2 * D / T) * (D / T) + (D / T) * (D / T) + (spatial ? ((te_nbp_dev(n_dist) + T - 1) / T) * (D / T) : 0);
 }
 
 int te_wgrad_ui_jobs(int D, int n_dist, bool spatial) {
   (void)n_dist;
-  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial)) ? 2 * D : D;
+  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial, n_dist)) ? 2 * D : D;
   return (3 * D / T) * (XW / T);
 }
 
 // Distance2Pre at D >= 128: the distance-bin half of the input goes through per-bin tables (te_ztab / te_dsum)
-bool te_bintab(int D, bool spatial) { return spatial && D >= 128; }
+bool te_bintab(int D, bool spatial, int n_dist) { return spatial && D >= 128 && n_dist + 1 <= 256; }
 
-bool te_supported(int D, int n_dist) { return (D == 64 || D == 128 || D == 256) && n_dist + 1 <= 256; }   // plain GRU: n_dist == -1
+bool te_supported(int D, int n_dist) { return (D == 64 || D == 128 || D == 256) && n_dist + 1 <= 2048; }   // plain GRU: n_dist == -1
 
 int te_nbp(int n_dist);
-static int nbt_for(int nb) { const int t = (nb + 31) / 32; return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8; }
+static int nbt_for(int nb) { return te_nbp_dev(nb - 1) / 32; }
 
-int te_nbp(int n_dist) { return nbt_for(n_dist + 1) * 32; }
+int te_nbp(int n_dist) { return te_nbp_dev(n_dist); }
 
 template <int D, int NBT>
 static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_t st) {
@@ -1631,6 +1875,12 @@ static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_
 
 template <int D>
 static hipError_t te_head_dispatch(const TeArgs& A, int mode, int grid, hipStream_t st) {
+  if (A.n_dist + 1 > 256) {      // chunked head (te_head_big_kernel)
+    const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (256 + 4) + te_nbp_dev(A.n_dist));
+    if (mode) hipLaunchKernelGGL((te_head_big_kernel<D, 1>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
+    else hipLaunchKernelGGL((te_head_big_kernel<D, 0>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
+    return hipGetLastError();
+  }
   switch (nbt_for(A.n_dist + 1)) {
     case 1: return te_launch_head<D, 1>(A, mode, grid, st);
     case 2: return te_launch_head<D, 2>(A, mode, grid, st);

@@ -48,13 +48,15 @@ def _oracle_batch(P, T, users):
 
 
 @pytest.mark.parametrize("dim,n_dist,engine", [(64, 11, "tile"), (64, 200, "tile"), (128, 40, "tile"), (128, 200, "tile"), (128, 200, "tile32"),
-                                               (256, 40, "tile"), (256, 200, "tile")])
+                                               (256, 40, "tile"), (256, 200, "tile"),
+                                               (64, 1520, "tile"), (128, 1520, "tile"), (128, 300, "tile"), (256, 1520, "tile")])      # > 256 bins: chunked head
 def test_tile_single_sequence_is_the_reference_step(pa, dim, n_dist, engine):
     """(tile32 = the streaming recurrent kernels of dim 256 - 32-sequence tiles, weights streamed from L2 - at dim 128)"""
     T = toy_problem(60 + dim + n_dist, n_user=4, n_item=90, n_dist=n_dist, dim=dim, len_max=9)
     P = spatial_params(60 + dim, T)
     model = _model(pa, T, P)
     model.ctx.set_engine(engine)
+    model.ctx.timing(True)
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     for u in [2, 0, 2]:
         old = P
@@ -64,10 +66,13 @@ def test_tile_single_sequence_is_the_reference_step(pa, dim, n_dist, engine):
         got = _get(model)
         assert_step_close(got, P, old, SP_NAMES, "after user %d" % u)
         P = round_f32({**P, **got})
+    assert model.ctx.timing_get("te_head")[1] == 3, "the launches did not go through the tile engine"
+    model.ctx.timing(False)
     model.ctx.set_engine("auto")
 
 
 @pytest.mark.parametrize("dim,n_dist,n_user,tile_eng", [(64, 11, 45, "tile"), (64, 200, 70, "tile"), (128, 200, 37, "tile"), (128, 200, 70, "tile32"),
+                                                        (64, 1520, 45, "tile"), (128, 1520, 70, "tile"),
                                                        (256, 200, 70, "tile")])
 def test_tile_batch_matches_mean_rule_and_seq_engine(pa, dim, n_dist, n_user, tile_eng):
     T = toy_problem(70 + dim, n_user=n_user, n_item=120, n_dist=n_dist, dim=dim, len_max=11, hot=30)
@@ -155,7 +160,7 @@ def test_batch_cap_generalises_the_mean_rule(pa, cap):
         ctx.set_batch_cap(1.0); ctx.set_engine("auto")
 
 
-@pytest.mark.parametrize("dim,n_dist,engine", [(64, 23, "tile"), (128, 200, "tile"), (128, 200, "tile32"), (256, 200, "tile")])
+@pytest.mark.parametrize("dim,n_dist,engine", [(64, 23, "tile"), (128, 200, "tile"), (128, 200, "tile32"), (256, 200, "tile"), (64, 1520, "tile"), (128, 1520, "tile")])
 def test_tile_predict_matches_oracle(pa, dim, n_dist, engine):
     T = toy_problem(80 + dim, n_user=75, n_item=200, n_dist=n_dist, dim=dim, len_max=13)
     P = spatial_params(80 + dim, T)
