@@ -108,6 +108,14 @@ int64_t poi_ctx_graph_replays(const poi_ctx* ctx);
 int poi_ctx_register_f16(poi_ctx* ctx, const void* ptr, int64_t bytes);
 int poi_ctx_unregister_f16(poi_ctx* ctx, const void* ptr);
 
+/* Seeded top-K (optional, exact): seed_idx (n x k_seed int32, device) holds, for every user of the NEXT fused top-K call
+ * (poi_score_topk / _ulptai / _geo with the same n and user order), k_seed >= k distinct item ids - typically the user's top-K of the
+ * previous evaluation (public/Valuate.py runs after every epoch; the lists barely move).  The seed items' scores under the current
+ * model, minus a float32 rounding bound, are a lower bound of the user's K-th best score; the scoring kernels start from it instead
+ * of -inf and insert little more than the final top-K.  The result is the exact top-K whatever the seed holds (rows with an id
+ * outside [0, n_item) or a repeated id are simply not seeded).  Consumed by the next call; NULL clears. */
+int poi_ctx_set_topk_seed(poi_ctx* ctx, const int32_t* seed_idx, int32_t k_seed);
+
 /* Batch rule cap (>= 1, see "Batch semantics" above); applies to poi_spatial_step / poi_gru_step / poi_bpr_step
  * (snapshot mode) launches with more than one sequence.  n_seq == 1 is the reference step for every cap.
  * cap == 0 selects the MINI-BATCH rule of the reference's `Gru` class (public/GRU.py:395-498, cost :452-459): the launch is one

@@ -46,6 +46,7 @@ SIGNATURES = {
     "poi_ctx_set_engine": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_batch_cap": (c_int, [c_void_p, c_float]),
     "poi_ctx_set_graph": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "poi_ctx_set_topk_seed": (c_int, [c_void_p, c_void_p, c_int32]),
     "poi_ctx_graph_replays": (c_int64, [c_void_p]),
     "poi_ctx_register_f16": (c_int, [c_void_p, c_void_p, c_int64]),
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
@@ -159,6 +160,10 @@ class Context:
     def set_graph(self, on, min_n=0, max_n=1 << 30):
         """hipGraph replay of the tile engine's training launches (poi_ctx_set_graph)."""
         self.check(self.lib.poi_ctx_set_graph(self.handle, int(bool(on)), int(min_n), int(max_n)))
+
+    def set_topk_seed(self, seed, k_seed):
+        """Seed ids of the next fused top-K call (poi_ctx_set_topk_seed): an (n, k_seed) int32 device tensor or None."""
+        self.check(self.lib.poi_ctx_set_topk_seed(self.handle, None if seed is None else seed.data_ptr(), int(k_seed)))
 
     def graph_replays(self):
         return int(self.lib.poi_ctx_graph_replays(self.handle))

@@ -57,6 +57,7 @@ struct poi_ctx {
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
   DevBuf cand_s, cand_i, items_pk, gbound;
+  const int32_t* seed_idx = nullptr; int seed_k = 0;      // poi_ctx_set_topk_seed: consumed by the next fused top-K call
   // selftest
   DevBuf st;
   poi::Timing tm;
@@ -613,12 +614,20 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     if ((rc = ensure(c, c->cand_s, sizeof(float) * cand, st))) return rc;
     if ((rc = ensure(c, c->cand_i, sizeof(int) * cand, st))) return rc;
     A.cand_score = (float*)c->cand_s.p; A.cand_idx = (int*)c->cand_i.p;
-    if (n_split > 1) {
+    const bool seeded = c->seed_idx && c->seed_k >= k && c->seed_k <= 64;
+    if (n_split > 1 || seeded) {
       if ((rc = ensure(c, c->gbound, sizeof(unsigned) * (size_t)n_pad, st))) return rc;
       HIPCHK(c, hipMemsetAsync(c->gbound.p, 0, sizeof(unsigned) * (size_t)n_pad, st));
       A.gbound = (unsigned*)c->gbound.p;
     }
+    if (seeded) {
+      c->tm.begin("topk_seed", st);
+      HIPCHK(c, poi::launch_topk_seed(A, c->seed_idx, c->seed_k, st));
+      c->tm.end(st);
+      A.seeded = 1;
+    }
   }
+  c->seed_idx = nullptr; c->seed_k = 0;
   if (variant == 2) {
     const int d8 = dim <= 128 ? 16 : 32;
     if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
@@ -781,6 +790,12 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
 int poi_ctx_set_engine(poi_ctx* c, int engine) {
   if (!c || engine < 0 || engine > 3) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence), 2 (tile) or 3 (tile, streaming recurrent kernels)");
   c->engine = engine;
+  return POI_OK;
+}
+
+int poi_ctx_set_topk_seed(poi_ctx* c, const int32_t* seed_idx, int32_t k_seed) {
+  if (!c || (seed_idx && (k_seed <= 0 || k_seed > 64))) return fail(c, POI_EINVAL, "poi_ctx_set_topk_seed: k_seed must be in [1, 64]");
+  c->seed_idx = seed_idx; c->seed_k = seed_idx ? k_seed : 0;
   return POI_OK;
 }
 

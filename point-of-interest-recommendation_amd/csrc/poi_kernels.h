@@ -237,12 +237,14 @@ struct ScoreArgs {
   float* cand_score; int* cand_idx;   // (n_split, n_pad, k) partial top-K lists
   int dbg;                  // tuning switch (POI_SCORE_DBG), 0 in production
   unsigned* gbound;         // (n_pad) per-user lower bound of the K-th best score shared by all item ranges
+  int seeded;               // gbound starts from the caller's seed items' scores (topk_seed_kernel), not from zero
   int* idx_out; float* score_out;
 };
 hipError_t launch_ulptai(const double* coords, const double* cphi, const double* thr, const int* last_poi, int n, int n_item,
                          int n_dist, double dd, void* out, int bin_bytes, hipStream_t st);
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm);
 hipError_t launch_score_packed(const ScoreArgs& A, hipStream_t st, Timing* tm);
+hipError_t launch_topk_seed(const ScoreArgs& A, const int* seed, int k_seed, hipStream_t st);
 hipError_t launch_score_geo_stream(const ScoreArgs& A, hipStream_t st, Timing* tm);
 size_t score_geo_stream_lds(int dim, int n_dist);
 hipError_t launch_topk_merge(const ScoreArgs& A, int n_lists, int n_pad, hipStream_t st);

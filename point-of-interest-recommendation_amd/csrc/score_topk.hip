@@ -124,6 +124,118 @@ __device__ __forceinline__ void compact_user(WaveTopk& T, int i, int K, unsigned
   wave_fence();
 }
 
+// Initial thresholds of a wave from the seeded per-user bounds (topk_seed_kernel): the same fold as the periodic refresh in
+// tile_epilogue, once, before the first tile.
+__device__ __forceinline__ void seed_thresholds(const ScoreArgs& A, WaveTopk& T, float (&thr)[16], int ut, int h) {
+  if (!(A.k > 0 && A.gbound && A.seeded)) return;
+  const int lane = lane_id();
+  if (lane < 32) {
+    const unsigned g = __hip_atomic_load(A.gbound + ut * 32 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T.gtmp[lane] = g; T.gseen[lane] = g;
+  }
+  wave_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned g = T.gtmp[(r & 3) + 8 * (r >> 2) + 4 * h];
+    thr[r] = g ? fmaxf(thr[r], ord2f(g)) : thr[r];
+  }
+}
+
+// Seeded thresholds (poi_ctx_set_topk_seed): the caller hands over, per user, k_seed >= K DISTINCT item ids - in practice the user's
+// top-K of the previous evaluation.  Their scores under the CURRENT model bound the current K-th best score from below (any subset's
+// K-th best does), so the scoring kernels may start from that bound instead of -inf and append almost nothing but the final top-K:
+// the streaming top-K otherwise inserts ~K ln(items / K) records per user and item range.  Exactness does not depend on the seed's
+// quality: the bound is a true lower bound - each seed item's score is bounded below by
+//   fl(dot) - 4 D u sum|u_i v_i| - 4 u |score|  +  min_b wd sts[user][b]      (u = 2^-24; two float32 evaluations of the same dot
+// product differ by at most 2 gamma_D sum|u_i v_i|; the distance term is the one the scoring kernel will add - dense prob element, bin
+// matrix element or Haversine bin -, or at least its minimum over the bins) - and the K-th largest of those bounds is
+// published.  Out-of-range or repeated ids: no bound for that user (the kernels then start from -inf as before).  One wave per user.
+__global__ __launch_bounds__(POI_BLOCK) void topk_seed_kernel(ScoreArgs A, const int* __restrict__ seed, int k_seed) {
+  const int u = blockIdx.x * POI_NWAVE + wave_id(), lane = lane_id();
+  if (u >= A.n) return;
+  const int D = A.dim, K = A.k, N = A.n_item;
+  const int id = lane < k_seed ? seed[(size_t)u * k_seed + lane] : -1;
+  bool ok = lane >= k_seed || (id >= 0 && id < N);
+  for (int j = 0; j < k_seed; ++j) {           // distinct ids
+    const int oj = __builtin_amdgcn_readlane(id, j);
+    if (lane < k_seed && lane != j && id == oj) ok = false;
+  }
+  if (__ballot(!ok)) return;
+  const float wd = ((A.prob || A.sts) && A.wd) ? A.wd[0] : 0.f;
+  float dlb = 0.f, dmax = 0.f;                 // lower bound / magnitude of the distance term
+  if (A.sts) {
+    const int NB = A.n_dist + 1;
+    float mn = 0.f, mx = 0.f;
+    for (int b = lane; b < NB; b += 64) { const float v = wd * A.sts[(size_t)u * NB + b]; mn = fminf(mn, v); mx = fmaxf(mx, fabsf(v)); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    dlb = mn; dmax = mx;
+  }
+  // the k_seed dot products: lanes split the columns, one wave reduction per seed item
+  const float* up = A.users + (size_t)u * D;
+  float lb = -INFINITY, lad = 0.f;             // lane j ends up with the dot product / absolute sum (then the bound) of seed item j
+  for (int j = 0; j < k_seed; ++j) {
+    const int it = __builtin_amdgcn_readlane(id, j);
+    float d = 0.f, ad = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(up + c);
+      const float4 b = ld4t(A.items, (size_t)it * D + c, A.items_f16);
+      d = fmaf(a.x, b.x, d); d = fmaf(a.y, b.y, d); d = fmaf(a.z, b.z, d); d = fmaf(a.w, b.w, d);
+      ad += fabsf(a.x * b.x) + fabsf(a.y * b.y) + fabsf(a.z * b.z) + fabsf(a.w * b.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o, 64); ad += __shfl_xor(ad, o, 64); }
+    if (lane == j) { lb = d; lad = ad; }
+  }
+  // the distance term of lane j's seed item: exact where the kernel can look it up (dense prob row, resident bin matrix - same
+  // element the scoring kernel reads -, or the Haversine bin from the coordinates), else its lower bound over the bins
+  if (lane < k_seed) {
+    float dist = dlb, dm = dmax;
+    if (A.prob) { dist = wd * A.prob[(size_t)u * N + id]; dm = fabsf(dist); }
+    else if (A.ulptai) {
+      // accumulator-order bin matrix (misc.hip::ulptai_kernel): tile (u / 32, id / 32), lane = id % 32 + 32 h, register r with
+      // (r & 3) + 8 (r >> 2) + 4 h == u % 32
+      const int ur = u & 31, hh = (ur >> 2) & 1, r = (ur & 3) + 4 * (ur >> 3), ntile = (N + 31) / 32;
+      const size_t cell = ((size_t)(u >> 5) * ntile + (id >> 5)) * 64 + (id & 31) + 32 * hh;
+      int bin;
+      if (A.bin_bytes == 1) bin = reinterpret_cast<const unsigned char*>(A.ulptai)[cell * 16 + r];
+      else bin = reinterpret_cast<const unsigned short*>(A.ulptai)[cell * 16 + r];
+      dist = wd * A.sts[(size_t)u * (A.n_dist + 1) + bin]; dm = fabsf(dist);
+    } else if (A.geo) {
+      const int lp = A.last_poi[u];
+      int bin;
+      {
+#pragma clang fp contract(off)
+        const double pr = 0.017453292519943295;
+        const double a = (A.coords[2 * lp] - A.coords[2 * id]) * pr;
+        const double b = (A.coords[2 * lp + 1] - A.coords[2 * id + 1]) * pr;
+        const double c = (1.0 - cos_small(a)) / 2 + A.cphi[lp] * A.cphi[id] * (1.0 - cos_small(b)) / 2;
+        bin = bin_of_c(c, A.thr, A.n_dist, (float)(12742.0 * 1000.0 / A.dd));
+      }
+      dist = wd * A.sts[(size_t)u * (A.n_dist + 1) + bin]; dm = fabsf(dist);
+    }
+    const float eps = 5.9604645e-8f;           // 2^-24
+    lb = lb + dist - (4.0f * (float)D * eps * lad + 8.0f * eps * (fabsf(lb) + dm) + 1e-30f);
+  }
+  // K-th largest of the k_seed bounds (rank counting; ties broken by lane)
+  int rank = 0;
+  for (int j = 0; j < k_seed; ++j) {
+    const float oj = readlane_f(lb, j);
+    rank += (oj > lb || (oj == lb && j < lane)) ? 1 : 0;
+  }
+  const unsigned long long at = __ballot(lane < k_seed && rank == K - 1);
+  if (at && lane == 0) {
+    const float tau = readlane_f(lb, __builtin_ctzll(at));
+    const unsigned o = f2ord(tau);
+    if (o > 1u) A.gbound[u] = o - 1u;           // (as compact_user publishes: `score > bound` keeps ties)
+  }
+}
+
+hipError_t launch_topk_seed(const ScoreArgs& A, const int* seed, int k_seed, hipStream_t st) {
+  hipLaunchKernelGGL(topk_seed_kernel, dim3((A.n + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, A, seed, k_seed);
+  return hipGetLastError();
+}
+
 // Per-tile epilogue shared by the scoring kernels.  The 32x32 result tile is in `acc` (C layout:
 // item = lane&31, user row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  The per-user thresholds of this lane's
 // 16 rows live in registers (`thr`, reloaded only after a compaction); the pass flags are computed
@@ -227,6 +339,7 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
   float thr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
+  seed_thresholds(A, T, thr, ut, h);
 
   // A fragment: user row (clamped), k-slices 8m+4h
   float4 af[D8];
@@ -386,6 +499,7 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
   float thr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) thr[r] = -INFINITY;
+  seed_thresholds(A, T, thr, ut, h);
   const float wd = ((A.prob || BINS) && A.wd) ? A.wd[0] : 0.f;
   const float4* bp = A.items_packed + lane;
   const float4* ap = af + lane;
@@ -543,6 +657,7 @@ __global__ __launch_bounds__(SG_NW * 64) void score_kernel_geo_stream(ScoreArgs 
   float thr[16], ub[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { thr[r] = -INFINITY; ub[r] = s_ub[(r & 3) + 8 * (r >> 2) + 4 * h]; }
+  seed_thresholds(A, T, thr, ut, h);
   const float gscale = (float)(12742.0 * 1000.0 / A.dd);
   const float4* bp = A.items_packed + lane;
   const float4* ap = af + lane;

@@ -625,3 +625,80 @@ def test_geo_stream_kernel_ranks_match_the_oracle(pa, dim, f16):
             ctx.unregister_f16(di)
     assert np.array_equal(got[ok], exp[ok])
     assert_close(gsc[ok], np.take_along_axis(full, exp, axis=1)[ok], "top-K scores", rtol=2e-5)
+
+
+@pytest.mark.parametrize("dim,with_prob", [(64, False), (128, True)])
+def test_seeded_topk_is_exact_whatever_the_seed_holds(pa, dim, with_prob):
+    """poi_ctx_set_topk_seed: the seed items' scores only RAISE the starting thresholds to a proven lower bound of the K-th best score,
+    so the fused top-K must return exactly the unseeded result for good seeds (the true top-K), useless seeds (random items), and
+    malformed rows (repeated / out-of-range ids are ignored) - and be consumed by one call."""
+    import torch
+    ctx = pa._lib.context(0)
+    rng = np.random.default_rng(77 + dim)
+    n, N, K = 300, 5000, 20
+    users = (rng.standard_normal((n, dim)) * 0.3).astype(np.float32)
+    items = rng.standard_normal((N, dim)).astype(np.float32)
+    prob = rng.random((n, N)).astype(np.float32) if with_prob else None
+    wd = np.array([0.8], np.float32)
+    du, di = torch.as_tensor(users).cuda(), torch.as_tensor(items).cuda()
+    dp = torch.as_tensor(prob).cuda() if with_prob else None
+    dwd = torch.as_tensor(wd).cuda()
+
+    def run(seed=None, k_seed=K):
+        idx = torch.empty((n, K), dtype=torch.int32, device="cuda")
+        sc = torch.empty((n, K), dtype=torch.float32, device="cuda")
+        if seed is not None:
+            ctx.set_topk_seed(seed, k_seed)
+        ctx.check(ctx.lib.poi_score_topk(ctx.handle, du.data_ptr(), di.data_ptr(), n, N, dim, dwd.data_ptr() if with_prob else None,
+                                         dp.data_ptr() if with_prob else None, K, idx.data_ptr(), sc.data_ptr(), None))
+        return idx.cpu().numpy(), sc.cpu().numpy()
+
+    base_idx, base_sc = run()
+    full = users.astype(np.float64) @ items.astype(np.float64).T + (float(wd[0]) * prob if with_prob else 0.0)
+    exp = O.topk_desc(full, K)
+    srt = np.sort(full, axis=1)[:, ::-1][:, :K + 1]
+    ok = np.min(srt[:, :-1] - srt[:, 1:], axis=1) > 1e-5 * np.abs(srt).max()
+    assert np.array_equal(base_idx[ok], exp[ok])
+    good = torch.as_tensor(base_idx).cuda()
+    rnd = torch.as_tensor(np.stack([rng.choice(N, K, replace=False) for _ in range(n)]).astype(np.int32)).cuda()
+    bad = good.clone(); bad[::3, 5] = bad[::3, 4]; bad[1::3, 0] = N + 7; bad[2::3, 2] = -1        # repeated / out of range / negative
+    wide = torch.as_tensor(np.concatenate([base_idx[:, ::-1], rnd.cpu().numpy()], axis=1).copy()).cuda()      # k_seed = 40 > K (may repeat: ignored rows)
+    for name, seed, ks in (("true top-K", good, K), ("random items", rnd, K), ("malformed rows", bad, K), ("k_seed > K", wide, 2 * K)):
+        idx, sc = run(seed, ks)
+        assert np.array_equal(idx, base_idx), name
+        assert np.array_equal(sc, base_sc), name
+    idx, _ = run()                       # the seed was consumed: this call is unseeded again
+    assert np.array_equal(idx, base_idx)
+
+
+def test_model_level_seeding_across_evaluations(pa):
+    """models.compute_sub_topk seeds each evaluation with the previous one's lists (contiguous user ranges): identical ranks with the
+    seeding on and off, for the bin-matrix path, the on-the-fly path and after the model has moved."""
+    T = toy_problem(91, n_user=96, n_item=900, n_dist=200, dim=64, len_max=9)
+    rng = np.random.default_rng(9)
+    coords = np.stack([40.0 + rng.random(900) * 0.3, -74.0 + rng.random(900) * 0.3], 1)
+    P = spatial_params(91, T)
+    model = _spatial_model(pa, T, P, coords=coords)
+    ids = np.arange(96, dtype=np.int32)
+
+    def evaluate():
+        model.update_trained_items(); model.update_trained_dists()
+        hts, sts = model.predict(ids)
+        model.update_trained_users(hts); model.update_trained_sus(sts)
+        out = {}
+        for ubm in (True, False):
+            model.use_bin_matrix = ubm
+            model.topk_seeding = False
+            ref = model.compute_sub_topk(ids, 20).cpu().numpy()
+            model.topk_seeding = True
+            a = model.compute_sub_topk(ids, 20).cpu().numpy()          # (first time: fills the seeds)
+            b = model.compute_sub_topk(ids, 20).cpu().numpy()          # seeded with its own result
+            assert np.array_equal(a, ref) and np.array_equal(b, ref)
+            out[ubm] = ref
+        return out
+
+    first = evaluate()
+    for u in range(0, 96, 7):
+        model.train(np.int32(u))
+    second = evaluate()                  # seeded with the lists of the first evaluation, under the moved model
+    assert any(not np.array_equal(first[k], second[k]) for k in first), "training did not move any list: the test is vacuous"
