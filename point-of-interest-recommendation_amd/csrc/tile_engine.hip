@@ -184,20 +184,32 @@ __global__ __launch_bounds__(256) void te_len_kernel(TeArgs A) {
   A.soff[k] = A.predict ? L : (L > 0 ? L - 1 : 0);
 }
 __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x, n = A.n_seq;
+  __shared__ int wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = A.n_seq;
   const int per = (n + 1023) / 1024;
   const int b = min(n, tid * per), e = min(n, b + per);
   int s = 0;
   for (int k = b; k < e; ++k) s += A.soff[k];
-  part[tid] = s;
+  // exclusive scan of the 1024 per-thread sums: shuffle scan inside each wave, then over the 16 wave totals (two barriers
+  // instead of the twenty of a Hillis-Steele pass over LDS)
+  int inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); inc += lane >= o ? v : 0; }
+  if (lane == 63) wtot[w] = inc;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) { int v = tid >= o ? part[tid - o] : 0; __syncthreads(); part[tid] += v; __syncthreads(); }
-  int run = tid > 0 ? part[tid - 1] : 0;
+  if (w == 0) {
+    int t = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const int v = __shfl_up(t, o, 64); t += lane >= o ? v : 0; }
+    if (lane < 16) wtot[lane] = t;             // inclusive totals of the waves
+  }
+  __syncthreads();
+  int run = inc - s + (w > 0 ? wtot[w - 1] : 0);
   for (int k = b; k < e; ++k) { const int v = A.soff[k]; A.soff[k] = run; run += v; }
   if (tid == 1023) {
-    A.soff[n] = part[1023];
-    if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (part[1023] + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; A.cnt[4] = 0; A.cnt[5] = 0; }   // slots, hot rows, hot chunks, touched rows, S rows, dx entries of the POI rows
+    const int total = wtot[15];
+    A.soff[n] = total;
+    if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (total + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; A.cnt[4] = 0; A.cnt[5] = 0; }   // slots, hot rows, hot chunks, touched rows, S rows, dx entries of the POI rows
   }
 }
 
