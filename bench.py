@@ -38,7 +38,7 @@ PROFILE_TAG = "r02"         # profiles/<tag>_pmc_traffic.json: committed rocprof
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed training epochs (default: a >= 2 s timed window)")
+    ap.add_argument("--steps", type=int, default=250, help="timed training epochs (default: a >= 2 s timed window)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default="gowalla", choices=["tiny", "foursquare", "gowalla", "x1"],
                     help="x1 = one GPU's slice of BASELINE.json configs[4]: 10 M POIs, 125 k users (1 M / 8), dim 256, fp16 POI table")
@@ -127,7 +127,7 @@ def main():
         a.local = 0.0; a.no_quality = True; a.no_secondary = True; a.no_cpu_baseline = True
         a.eval_users = a.eval_users or 8192
         a.table_dtype = a.table_dtype or "f16"
-        if a.steps == 200:
+        if a.steps == 250:
             a.steps = 20
         if a.batch_users == 12500:
             a.batch_users = 16384      # 512 recurrent tiles of 32 sequences: two full rounds of the 256 CUs (12500 -> 391 tiles: 1.5 rounds)
