@@ -232,7 +232,8 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   // average ~40 % of the longest) - te_gemm_ax then multiplies n_item + 1 rows instead of one row per step
   A.fwd_tab = (c->fwd_tab && A.bintab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap) ? 1 : 0;
   if (A.fwd_tab) {
-    if ((rc = ensure(c, c->ptab, sizeof(float) * (size_t)(P->n_item + 2) * 3 * D, st)) || (rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
+    // (+ spare rows: te_gemm_ntk writes whole 128-row tiles - rows past the table's last land behind it, as in G)
+    if ((rc = ensure(c, c->ptab, sizeof(float) * ((size_t)(P->n_item + 1 + 127) / 128 * 128 + 128) * 3 * D, st)) || (rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
     if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }
     A.ptab = (float*)c->ptab.p; A.iota = (const int*)c->iota.p;
   }
