@@ -589,7 +589,7 @@ def test_geo_stream_kernel_ranks_match_the_oracle(pa, dim, f16):
     from poi_amd.data import bin_thresholds, cal_dis_vec, cos_lat
     ctx = pa._lib.context(0)
     rng = np.random.default_rng(40 + dim)
-    n, N, B, dd, K = 1100, 4000, 200, 200.0, 20
+    n, N, B, dd, K = 1100, 4011, 200, 200.0, 20      # (ragged user and item counts)
     coords = np.stack([40.0 + rng.random(N) * 0.25, -74.0 + rng.random(N) * 0.25], 1)
     last = rng.integers(0, N, n).astype(np.int32)
     users = (rng.standard_normal((n, dim)) * (0.06 if dim == 128 else 0.045)).astype(np.float32)
@@ -671,10 +671,11 @@ def test_seeded_topk_is_exact_whatever_the_seed_holds(pa, dim, with_prob):
     assert np.array_equal(idx, base_idx)
 
 
-def test_model_level_seeding_across_evaluations(pa):
+@pytest.mark.parametrize("n_dist", [200, 300])          # uint8 / uint16 bin matrix
+def test_model_level_seeding_across_evaluations(pa, n_dist):
     """models.compute_sub_topk seeds each evaluation with the previous one's lists (contiguous user ranges): identical ranks with the
     seeding on and off, for the bin-matrix path, the on-the-fly path and after the model has moved."""
-    T = toy_problem(91, n_user=96, n_item=900, n_dist=200, dim=64, len_max=9)
+    T = toy_problem(91, n_user=96, n_item=900, n_dist=n_dist, dim=64, len_max=9)
     rng = np.random.default_rng(9)
     coords = np.stack([40.0 + rng.random(900) * 0.3, -74.0 + rng.random(900) * 0.3], 1)
     P = spatial_params(91, T)

@@ -49,7 +49,8 @@ def _oracle_batch(P, T, users):
 
 @pytest.mark.parametrize("dim,n_dist,engine", [(64, 11, "tile"), (64, 200, "tile"), (128, 40, "tile"), (128, 200, "tile"), (128, 200, "tile32"),
                                                (256, 40, "tile"), (256, 200, "tile"),
-                                               (64, 1520, "tile"), (128, 1520, "tile"), (128, 300, "tile"), (256, 1520, "tile")])      # > 256 bins: chunked head
+                                               (64, 1520, "tile"), (128, 1520, "tile"), (128, 300, "tile"), (256, 1520, "tile"),      # > 256 bins: chunked head
+                                               (64, 256, "tile"), (64, 511, "tile"), (64, 512, "tile"), (64, 2046, "tile")])                # chunk boundaries, the maximum
 def test_tile_single_sequence_is_the_reference_step(pa, dim, n_dist, engine):
     """(tile32 = the streaming recurrent kernels of dim 256 - 32-sequence tiles, weights streamed from L2 - at dim 128)"""
     T = toy_problem(60 + dim + n_dist, n_user=4, n_item=90, n_dist=n_dist, dim=dim, len_max=9)
