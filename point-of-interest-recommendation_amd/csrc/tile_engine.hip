@@ -1293,24 +1293,24 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 #pragma unroll
       for (int i = 0; i < NBP / 8; ++i) mx = fmaxf(mx, o[sub + 8 * i]);     // (uniform trip counts: unrollable)
       mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx));
-      float sum = 0.f;
+      // exp pass: e_k stays in LDS un-normalised; the sum and (training) the sum over the bins <= the target come out of the same pass,
+      // the probabilities are formed where they are consumed (three passes over the row instead of four)
+      const int a = MODE ? 0 : s_a[row], b = MODE ? 0 : s_b[row];
+      float sum = 0.f, cum = 0.f;
 #pragma unroll
-      for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float e = expf(o[k] - mx); o[k] = e; sum += e; }
+      for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float e = expf(o[k] - mx); o[k] = e; sum += e; cum += k <= a ? e : 0.f; }
       sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
       const float inv = 1.0f / sum;
       if (MODE) {
         if (gr < T) for (int k = sub; k < NB; k += 8) A.sts[(size_t)gr * NB + k] = o[k] * inv;
       } else {
-        const int a = s_a[row], b = s_b[row];
         const float he = s_he[row];
         const bool live = gr < T;
-        float cum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float s = o[k] * inv; o[k] = s; cum += k <= a ? s : 0.f; }
         cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
+        cum *= inv;
         // (the 8 lanes of a row now hold identical cum; they all wrote disjoint o[k])
         __builtin_amdgcn_wave_barrier();
-        const float sa = o[a], sb = o[b];
+        const float sa = o[a] * inv, sb = o[b] * inv;
         const float u = he + wd * (sa - sb);
         const float g = live ? -ls1 * sigmoidf_(-u) : 0.f;
         const float dot = ls0 * cum - ls0 + g * wd * (sa - sb);
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
           float ds = (k <= a ? ls0 : 0.f);
           if (k == a) ds += g * wd - ls0 / sa;
           if (k == b) ds -= g * wd;
-          o[k] = (live && k < NB) ? o[k] * (ds - dot) : 0.f;
+          o[k] = (live && k < NB) ? (o[k] * inv) * (ds - dot) : 0.f;
         }
       }
     }
