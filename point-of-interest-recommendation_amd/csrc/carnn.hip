@@ -134,6 +134,303 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train_kernel(CaArgs A) {
   }
 }
 
+// =================================================================================================================
+// Outer-product path (dims 64 / 128).  The per-sequence kernel above spends its time in six D x D rank-one updates per step - three
+// of them float atomics on interval matrices that most workgroups hit at once.  Here the recurrence kernel only RECORDS the
+// vectors of every step (EA: g mp | -g mq | da | g vp | -g vq; Hpk: the hidden states) and six entries (matrix id, a, b) per step;
+// the entries are sorted by matrix id (stable radix sort, te_scatter.hip) and every matrix gradient is the product
+//      d W[id] = sum over the entries of id of a (x) b  =  A_id^T . B_id
+// computed on the matrix cores in 512-entry chunks (ca_outer_kernel) whose partial products are added in chunk order
+// (ca_outer_reduce_kernel): no float atomics on matrices, reproducible, and the recurrence kernel is left with its GEMVs.
+// Matrix ids: 0 .. n_dist = the interval matrices, n_dist + 1 = M.
+// =================================================================================================================
+#define CA_CK 512       // entries per chunk
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// soff = exclusive scan of the step counts (one block; contiguous runs per thread), cnt[0] = 6 * total steps
+__global__ __launch_bounds__(1024) void ca_scan_kernel(CaArgs A) {
+  __shared__ int wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = A.n_seq;
+  const int per = (n + 1023) / 1024;
+  const int b = min(n, tid * per), e = min(n, b + per);
+  int s = 0;
+  for (int k = b; k < e; ++k) { const int u = A.uidx[k], L = A.off[u + 1] - A.off[u]; s += L > 0 ? L - 1 : 0; }
+  int inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); inc += lane >= o ? v : 0; }
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  if (w == 0) {
+    int t = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const int v = __shfl_up(t, o, 64); t += lane >= o ? v : 0; }
+    if (lane < 16) wtot[lane] = t;
+  }
+  __syncthreads();
+  int run = inc - s + (w > 0 ? wtot[w - 1] : 0);
+  for (int k = b; k < e; ++k) { const int u = A.uidx[k], L = A.off[u + 1] - A.off[u]; A.soff[k] = run; run += L > 0 ? L - 1 : 0; }
+  if (tid == 1023) { A.soff[n] = wtot[15]; A.cnt[0] = 6 * wtot[15]; }
+}
+
+// PM[r][i] = sum_c M[i][c] lt[r][c] for every table row: the three M x products of a step (x_t, xp_{t+1}, xq_{t+1}) become row
+// gathers in the recurrence kernel (a launch's ~231 k steps draw their rows from a 100 k-row table).  64 rows per workgroup pass;
+// M^T and the row tile in LDS, thread = (output column i, 4 consecutive rows).
+template <int D>
+__global__ __launch_bounds__(POI_BLOCK) void ca_pm_kernel(CaArgs A) {
+  extern __shared__ __align__(16) float lds_pm[];
+  float* Mt = lds_pm;                    // [c][i], pitch D + 1... (read by consecutive i: conflict-free at any pitch)
+  float* Xt = Mt + D * D;                // [c][64 rows] of the current pass
+  const int tid = threadIdx.x, R = A.n_item + 1;
+  for (int e = tid; e < D * D; e += POI_BLOCK) { const int i = e / D, c = e % D; Mt[c * D + i] = A.M[e]; }
+  constexpr int TPR = POI_BLOCK / D;     // row groups handled at once (2 at D = 128, 4 at D = 64): each covers 16 / TPR x 4 rows
+  const int i = tid % D, rg = tid / D;
+  for (int r0 = blockIdx.x * 64; r0 < R; r0 += gridDim.x * 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * (D / 4); e += POI_BLOCK) {
+      const int r = e / (D / 4), c = (e % (D / 4)) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(A.lt + (size_t)min(r0 + r, R - 1) * D + c);
+      Xt[(c + 0) * 64 + r] = v.x; Xt[(c + 1) * 64 + r] = v.y; Xt[(c + 2) * 64 + r] = v.z; Xt[(c + 3) * 64 + r] = v.w;
+    }
+    __syncthreads();
+    for (int q = rg; q < 16; q += TPR) {           // 16 groups of 4 rows
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < D; ++c) {
+        const float m = Mt[c * D + i];
+        const float4 x = *reinterpret_cast<const float4*>(Xt + c * 64 + 4 * q);
+        a0 = fmaf(m, x.x, a0); a1 = fmaf(m, x.y, a1); a2 = fmaf(m, x.z, a2); a3 = fmaf(m, x.w, a3);
+      }
+      const int r = r0 + 4 * q;
+      if (r < R) A.PM[(size_t)r * D + i] = a0;
+      if (r + 1 < R) A.PM[(size_t)(r + 1) * D + i] = a1;
+      if (r + 2 < R) A.PM[(size_t)(r + 2) * D + i] = a2;
+      if (r + 3 < R) A.PM[(size_t)(r + 3) * D + i] = a3;
+    }
+  }
+}
+
+__global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
+  extern __shared__ __align__(16) float lds_raw[];
+  const int D = A.dim, HD = D * D, tid = threadIdx.x, NB = A.n_dist + 1;
+  (void)HD;
+  CaLds S(lds_raw, D);
+  float* ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+  float* wsV = ws + (size_t)(A.cap + 1) * D;         // cap x 4D : mp | mq | vp | vq   (same carve as carnn_train_kernel)
+  float* wsY = wsV + (size_t)A.cap * 4 * D;          // cap
+  for (int k = blockIdx.x; k < A.n_seq; k += gridDim.x) {
+    const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = L > 0 ? L - 1 : 0;
+    const int *p = A.p + base, *q = A.q + base, *dp = A.dp + base, *dq = A.dq + base;
+    const int r0 = A.soff[k], hr0 = r0 + k;            // packed step rows, rows of Hpk
+    float* H = A.Hpk + (size_t)hr0 * D;
+    count_rows<true>(p, q, L, A.n_item, 2 * (A.len_max - L), A.mult_lt, A.nseq_lt);
+    count_rows<true>(dp, dq, L, A.n_dist, 2 * (A.len_max - L), A.mult_wd, A.nseq_wd);
+    for (int j = tid; j < D; j += POI_BLOCK) { S.hp[j] = 0.f; H[j] = 0.f; }
+    float tot = 0.f;       // meaningful in thread 0
+    __syncthreads();
+    // ------------------------------------------------------------------ forward
+    for (int t = 0; t < ns; ++t) {
+      if (A.PM) {
+        // M x_t, M xp_{t+1}, M xq_{t+1}: rows of the per-launch table PM = lt . M^T
+        load_row4(S.mp, A.PM + (size_t)p[t + 1] * D, D);
+        load_row4(S.mq, A.PM + (size_t)q[t + 1] * D, D);
+        gemv_rows<1>(A.wd + (size_t)dp[t] * D * D, D, S.hp, nullptr, 0, nullptr, A.PM + (size_t)p[t] * D, D, S.h);      // h_t  (:131)
+      } else {      // small launches: the table would cost more than the three products of the launch's steps
+        load_row4(S.x, A.lt + (size_t)p[t] * D, D);
+        load_row4(S.xp, A.lt + (size_t)p[t + 1] * D, D);
+        load_row4(S.xq, A.lt + (size_t)q[t + 1] * D, D);
+        __syncthreads();
+        gemv_rows<1>(A.M, D, S.x, A.wd + (size_t)dp[t] * D * D, D, S.hp, nullptr, D, S.h);
+        gemv_rows<0>(A.M, D, S.xp, nullptr, 0, nullptr, nullptr, D, S.mp);
+        gemv_rows<0>(A.M, D, S.xq, nullptr, 0, nullptr, nullptr, D, S.mq);
+      }
+      __syncthreads();
+      gemv_rows<0>(A.wd + (size_t)dp[t + 1] * D * D, D, S.h, nullptr, 0, nullptr, nullptr, D, S.vp);
+      gemv_rows<0>(A.wd + (size_t)dq[t + 1] * D * D, D, S.h, nullptr, 0, nullptr, nullptr, D, S.vq);
+      __syncthreads();
+      float part = 0.f;
+      for (int j = tid; j < D; j += POI_BLOCK) {
+        part += S.vp[j] * S.mp[j] - S.vq[j] * S.mq[j];                                          // yp - yq (:132-133)
+        H[(size_t)(t + 1) * D + j] = S.h[j];
+        float* v = wsV + (size_t)t * 4 * D;
+        v[j] = S.mp[j]; v[D + j] = S.mq[j]; v[2 * D + j] = S.vp[j]; v[3 * D + j] = S.vq[j];
+        S.hp[j] = S.h[j];
+      }
+      const float y = block_sum(part, S.red);
+      if (tid == 0) { wsY[t] = y; tot += log_sigmoidf_(y); }
+      __syncthreads();
+    }
+    if (tid == 0) A.out[k] = -tot;                                                              // los (:148)
+    // ------------------------------------------------------------------ backward (BPTT)
+    for (int j = tid; j < D; j += POI_BLOCK) S.dh[j] = 0.f;
+    __syncthreads();
+    for (int t = ns - 1; t >= 0; --t) {
+      const float g = -sigmoidf_(-wsY[t]);
+      const float* v = wsV + (size_t)t * 4 * D;
+      load_row4(S.mp, v, D); load_row4(S.mq, v + D, D); load_row4(S.vp, v + 2 * D, D); load_row4(S.vq, v + 3 * D, D);
+      load_row4(S.h, H + (size_t)(t + 1) * D, D);
+      __syncthreads();
+      const float* Wp = A.wd + (size_t)dp[t + 1] * D * D; const float* Wq = A.wd + (size_t)dq[t + 1] * D * D;
+      const float* Wt = A.wd + (size_t)dp[t] * D * D;
+      gemv_cols<false>(Wp, D, D, S.mp, S.t0, S.part);        // Wp^T mp
+      gemv_cols<false>(Wq, D, D, S.mq, S.t1, S.part);        // Wq^T mq
+      gemv_cols<false>(A.M, D, D, S.vp, S.t2, S.part);       // M^T vp
+      gemv_cols<false>(A.M, D, D, S.vq, S.t3, S.part);       // M^T vq
+      {
+        const size_t r = (size_t)(r0 + t);
+        float* ea = A.EA + r * 5 * D;
+        float* gp1 = A.g_lt + (size_t)p[t + 1] * D; float* gq1 = A.g_lt + (size_t)q[t + 1] * D;
+        for (int j = tid; j < D; j += POI_BLOCK) {
+          const float d = S.dh[j] + g * (S.t0[j] - S.t1[j]);
+          S.dh[j] = d;
+          const float da = d * S.h[j] * (1.0f - S.h[j]);
+          S.da[j] = da;
+          ea[j] = g * S.mp[j]; ea[D + j] = -g * S.mq[j]; ea[2 * D + j] = da; ea[3 * D + j] = g * S.vp[j]; ea[4 * D + j] = -g * S.vq[j];
+          atomicAdd(gp1 + j, g * S.t2[j]);
+          atomicAdd(gq1 + j, -g * S.t3[j]);
+        }
+        if (tid < 6) {
+          // entries: (matrix id, EA vector, b source) - d W[dp_{t+1}] += (g mp) (x) h_t, d W[dq_{t+1}] += (-g mq) (x) h_t,
+          // d W[dp_t] += da (x) h_{t-1}, d M += (g vp) (x) xp + (-g vq) (x) xq + da (x) x_t
+          const int e = tid;
+          const int key = e == 0 ? dp[t + 1] : e == 1 ? dq[t + 1] : e == 2 ? dp[t] : NB;
+          const int av = (int)r * 5 + (e == 0 ? 0 : e == 1 ? 1 : e == 2 ? 2 : e == 3 ? 3 : e == 4 ? 4 : 2);
+          const int bs = e < 2 ? hr0 + t + 1 : e == 2 ? hr0 + t : e == 3 ? ~p[t + 1] : e == 4 ? ~q[t + 1] : ~p[t];
+          const size_t eid = r * 6 + e;
+          A.keys0[eid] = key; A.ent_a[eid] = av; A.ent_b[eid] = bs;
+        }
+      }
+      __syncthreads();
+      gemv_cols<false>(A.M, D, D, S.da, S.t0, S.part);       // M^T da  -> d lt[p_t]
+      gemv_cols<false>(Wt, D, D, S.da, S.t1, S.part);        // W_t^T da -> dh_{t-1}
+      {
+        float* gp0 = A.g_lt + (size_t)p[t] * D;
+        for (int j = tid; j < D; j += POI_BLOCK) { atomicAdd(gp0 + j, S.t0[j]); S.dh[j] = S.t1[j]; }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+}
+
+// segment [seg_start, seg_end) of every matrix id in the sorted entry list (the arrays are zero on entry: absent ids stay empty)
+__global__ __launch_bounds__(256) void ca_bounds_kernel(CaArgs A, const int* __restrict__ ks) {
+  const int Ne = A.cnt[0];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Ne; i += gridDim.x * 256) {
+    const int k = ks[i];
+    if (i == 0 || ks[i - 1] != k) A.seg_start[k] = i;
+    if (i == Ne - 1 || ks[i + 1] != k) A.seg_end[k] = i + 1;
+  }
+}
+
+// chunk_first[id] = first 512-entry chunk of matrix id (exclusive scan of the chunk counts), chunk_first[n_id] = total
+__global__ __launch_bounds__(1024) void ca_chunks_kernel(CaArgs A) {
+  __shared__ int s_cnt[2080];
+  const int NK = A.n_dist + 2, tid = threadIdx.x;
+  for (int k = tid; k < NK; k += 1024) s_cnt[k] = (A.seg_end[k] - A.seg_start[k] + CA_CK - 1) / CA_CK;
+  __syncthreads();
+  if (tid == 0) {       // (<= 2050 ids)
+    int run = 0;
+    for (int k = 0; k < NK; ++k) { const int c = s_cnt[k]; A.chunk_first[k] = run; run += c; }
+    A.chunk_first[NK] = run;
+  }
+}
+
+// partial[c] = sum over the entries of chunk c of a (x) b   (D x D, MFMA 32x32x2: K = the entries, staged 32 at a time through LDS
+// as [entry][component] tiles - te_wgrad's transposed-GEMM scheme).  Waves form a 2 x 2 grid of (D/2) x (D/2) quadrants.
+template <int D>
+__global__ __launch_bounds__(POI_BLOCK) void ca_outer_kernel(CaArgs A, const int* __restrict__ vs) {
+  constexpr int LDT = D + 4, Q = D / 64, F4 = 32 * (D / 4) / POI_BLOCK;
+  __shared__ __align__(16) float At[32][LDT];
+  __shared__ __align__(16) float Bt[32][LDT];
+  __shared__ int s_key;
+  const int NK = A.n_dist + 2, c = blockIdx.x, tid = threadIdx.x;
+  if (c >= A.chunk_first[NK]) return;
+  if (tid == 0) {       // the id whose chunk range holds c: last id with chunk_first <= c (empty ids share their successor's value)
+    int lo = 0, hi = NK;          // invariant: chunk_first[lo] <= c < chunk_first[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.chunk_first[mid] <= c) lo = mid; else hi = mid; }
+    s_key = lo;
+  }
+  __syncthreads();
+  const int key = s_key;
+  const int s0 = A.seg_start[key] + (c - A.chunk_first[key]) * CA_CK, s1 = min(A.seg_end[key], s0 + CA_CK);
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
+  const int wm = (w >> 1) * (D / 2), wn = (w & 1) * (D / 2);
+  f32x16 acc[Q][Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i)
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int e0 = s0; e0 < s1; e0 += 32) {
+    float4 ra[F4], rb[F4];
+#pragma unroll
+    for (int s = 0; s < F4; ++s) {
+      const int x = tid + s * POI_BLOCK, r = x / (D / 4), cc = (x % (D / 4)) * 4;
+      const bool in = e0 + r < s1;
+      const int eid = vs[min(e0 + r, s1 - 1)];
+      const int av = A.ent_a[eid], bs = A.ent_b[eid];
+      const float* bp = bs >= 0 ? A.Hpk + (size_t)bs * D : A.lt + (size_t)(~bs) * D;
+      const float4 a4 = *reinterpret_cast<const float4*>(A.EA + (size_t)av * D + cc);
+      const float4 b4 = *reinterpret_cast<const float4*>(bp + cc);
+      ra[s] = make_float4(in ? a4.x : 0.f, in ? a4.y : 0.f, in ? a4.z : 0.f, in ? a4.w : 0.f);
+      rb[s] = make_float4(in ? b4.x : 0.f, in ? b4.y : 0.f, in ? b4.z : 0.f, in ? b4.w : 0.f);
+    }
+    __syncthreads();          // the previous stage's MFMAs are done with the tiles
+#pragma unroll
+    for (int s = 0; s < F4; ++s) {
+      const int x = tid + s * POI_BLOCK, r = x / (D / 4), cc = (x % (D / 4)) * 4;
+      *reinterpret_cast<float4*>(&At[r][cc]) = ra[s];
+      *reinterpret_cast<float4*>(&Bt[r][cc]) = rb[s];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[Q], bv[Q];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) av[i] = At[2 * kk + h][wm + 32 * i + li];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) bv[j] = Bt[2 * kk + h][wn + 32 * j + li];
+#pragma unroll
+      for (int i = 0; i < Q; ++i)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = A.partial + (size_t)c * D * D;
+#pragma unroll
+  for (int i = 0; i < Q; ++i)
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[(size_t)m * D + wn + 32 * j + li] = acc[i][j][r];
+      }
+}
+
+// gradient of matrix id = its chunks' partial products added in chunk order: eight lanes take every eighth chunk, their sums are
+// combined in lane order (fixed tree: reproducible) - into g_wd[id] (zero between launches) or, for M, into slab 0 of the dense apply
+template <int D>
+__global__ __launch_bounds__(POI_BLOCK) void ca_outer_reduce_kernel(CaArgs A) {
+  __shared__ float red[8][32];
+  const int NK = A.n_dist + 2, key = blockIdx.x, HD = D * D;
+  const int first = A.chunk_first[key], nch = A.chunk_first[key + 1] - first;
+  if (nch <= 0) return;
+  const int el = blockIdx.y * 32 + (threadIdx.x & 31), ln = threadIdx.x >> 5;
+  float s = 0.f;
+  for (int q = ln; q < nch; q += 8) s += A.partial[(size_t)(first + q) * HD + el];
+  red[ln][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (ln == 0) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) t += red[l][threadIdx.x];
+    float* dst = key < NK - 1 ? A.g_wd + (size_t)key * HD : A.slab;
+    dst[el] += t;
+  }
+}
+
 // write-back of the lt rows and of the interval matrices: one wavefront per table row (seq_common.h apply_row)
 __global__ __launch_bounds__(POI_BLOCK) void carnn_rows_apply_kernel(CaArgs A, float alpha, float lambda) {
   const int n_lt = A.n_item + 1, n_wd = A.n_dist + 1, HD = A.dim * A.dim;
@@ -257,6 +554,41 @@ hipError_t launch_carnn_train(const CaArgs& A, int grid, float alpha, float lamb
   hipLaunchKernelGGL(carnn_dense_apply_kernel, dim3((D * D + POI_BLOCK - 1) / POI_BLOCK), dim3(POI_BLOCK), 0, st, A, grid, alpha, lambda);
   tm->end(st);
   return hipGetLastError();
+}
+
+template <int D>
+static hipError_t carnn_train2_t(const CaArgs& A, int grid, float alpha, float lambda, hipStream_t st, Timing* tm) {
+  const int NK = A.n_dist + 2;
+  tm->begin("carnn_train", st);
+  hipLaunchKernelGGL(ca_scan_kernel, dim3(1), dim3(1024), 0, st, A);
+  if (A.PM) hipLaunchKernelGGL(ca_pm_kernel<D>, dim3(1024), dim3(POI_BLOCK), sizeof(float) * (D * D + D * 64), st, A);
+  hipLaunchKernelGGL(carnn_train2_kernel, dim3(grid), dim3(POI_BLOCK), sizeof(float) * ca_lds_floats(D), st, A);
+  tm->end(st);
+  tm->begin("carnn_outer", st);
+  int bits = 1; while ((1 << bits) < NK) ++bits;
+  const int *ks = nullptr, *vs = nullptr;
+  hipError_t e = launch_radix_sort(A.keys0, A.keys1, A.vals0, A.vals1, A.cnt, bits, A.hist, st, &ks, &vs);
+  if (e != hipSuccess) return e;
+  // (the workspace is carved per launch size: clear the segment tables instead of relying on the previous launch)
+  if (hipMemsetAsync(A.seg_start, 0, sizeof(int) * (NK + 4), st) != hipSuccess || hipMemsetAsync(A.seg_end, 0, sizeof(int) * (NK + 4), st) != hipSuccess) return hipGetLastError();
+  hipLaunchKernelGGL(ca_bounds_kernel, dim3(1024), dim3(256), 0, st, A, ks);
+  hipLaunchKernelGGL(ca_chunks_kernel, dim3(1), dim3(1024), 0, st, A);
+  hipLaunchKernelGGL(ca_outer_kernel<D>, dim3(A.n_chunk_cap), dim3(POI_BLOCK), 0, st, A, vs);
+  hipLaunchKernelGGL(ca_outer_reduce_kernel<D>, dim3(NK, D * D / 32), dim3(POI_BLOCK), 0, st, A);
+  tm->end(st);
+  tm->begin("carnn_apply", st);
+  int rows = A.n_item + 1 + A.n_dist + 1, g2 = (rows + POI_NWAVE - 1) / POI_NWAVE;
+  if (g2 > 8192) g2 = 8192;
+  hipLaunchKernelGGL(carnn_rows_apply_kernel, dim3(g2), dim3(POI_BLOCK), 0, st, A, alpha, lambda);
+  hipLaunchKernelGGL(carnn_dense_apply_kernel, dim3((D * D + POI_BLOCK - 1) / POI_BLOCK), dim3(POI_BLOCK), 0, st, A, 1, alpha, lambda);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+hipError_t launch_carnn_train2(const CaArgs& A, int grid, float alpha, float lambda, hipStream_t st, Timing* tm) {
+  if (A.dim == 64) return carnn_train2_t<64>(A, grid, alpha, lambda, st, tm);
+  if (A.dim == 128) return carnn_train2_t<128>(A, grid, alpha, lambda, st, tm);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_carnn_predict(const CaArgs& A, int grid, float* wrs, hipStream_t st, Timing* tm) {

@@ -198,8 +198,24 @@ struct CaArgs {
   int *mult_lt, *nseq_lt, *mult_wd, *nseq_wd;
   float* hts;                         // predict output
   float bcap;
+  // ---- outer-product path (carnn_train2: dims 64 / 128): packed per-step state and the (matrix id, a, b) entries whose sorted,
+  // segmented products a (x) b are the gradients of the interval matrices and of M (no float atomics on matrices)
+  int* soff;                          // n + 1: packed step offsets (step t of sequence k = row soff[k] + t)
+  float* Hpk;                         // (T + n) x D: h_0 .. h_ns of sequence k at rows soff[k] + k + t
+  float* EA;                          // T x 5 x D: g mp | -g mq | da | g vp | -g vq of every step
+  int *keys0, *keys1, *vals0, *vals1, *hist, *cnt;      // radix sort of the 6 T entries by matrix id; cnt[0] = 6 T
+  int *ent_a, *ent_b;                 // per entry: EA vector (row of D floats), b source (>= 0: Hpk row, < 0: ~row of lt)
+  int *seg_start, *seg_end, *chunk_first;               // per matrix id (n_dist + 2 ids: the interval matrices, then M)
+  float* partial;                     // per 512-entry chunk: D x D partial product
+  int n_chunk_cap;
+  float* PM;                          // (n_item + 1) x D: lt . M^T, the input product of every POI (computed once per launch)
 };
 size_t carnn_ws_floats(int D, int cap);
+hipError_t launch_carnn_train2(const CaArgs& A, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
+// stable LSD radix sort of (keys, element index) pairs on `bits` key bits; n_ptr[0] = element count (device).  *ks / *vs: the buffers
+// that hold the sorted keys / the original indices in sorted order.  hist: RS_HIST_INTS + RS_MAXBIN ints.
+hipError_t launch_radix_sort(int* keys0, int* keys1, int* vals0, int* vals1, const int* n_ptr, int bits, int* hist, hipStream_t st,
+                             const int** ks, const int** vs);
 hipError_t launch_carnn_train(const CaArgs& A, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
 hipError_t launch_carnn_predict(const CaArgs& A, int grid, float* wrs, hipStream_t st, Timing* tm);
 hipError_t launch_carnn_score(const float* users, const float* items, const float* M, const float* dists, const double* coords, const double* cphi,

@@ -287,6 +287,23 @@ hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st) {
   return hipGetLastError();
 }
 
+hipError_t launch_radix_sort(int* keys0, int* keys1, int* vals0, int* vals1, const int* n_ptr, int bits, int* hist, hipStream_t st,
+                             const int** ks, const int** vs) {
+  const int npass = bits <= 9 ? 1 : bits <= 18 ? 2 : bits <= 27 ? 3 : 4;
+  const int w = (bits + npass - 1) / npass, nbin = 1 << w;
+  const int *kin = keys0, *vin = nullptr;
+  int *kout = keys1, *vout = vals1;
+  for (int p = 0; p < npass; ++p) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(RS_GRID), dim3(RS_BLOCK), 0, st, kin, n_ptr, p * w, nbin, hist);
+    hipLaunchKernelGGL(rs_digit_scan_kernel, dim3(nbin), dim3(RS_GRID), 0, st, hist, hist + RS_HIST_INTS);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(RS_GRID), dim3(RS_BLOCK), 0, st, kin, vin, kout, vout, n_ptr, p * w, nbin, hist, hist + RS_HIST_INTS);
+    kin = kout; vin = vout;
+    if (kout == keys1) { kout = keys0; vout = vals0; } else { kout = keys1; vout = vals1; }
+  }
+  *ks = kin; *vs = vin;
+  return hipGetLastError();
+}
+
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st) {
   const int bits = A.key_bits;
   const int npass = bits <= 9 ? 1 : bits <= 18 ? 2 : bits <= 27 ? 3 : 4;

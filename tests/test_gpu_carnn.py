@@ -53,8 +53,9 @@ def test_carnn_step_parity_sequential(pa, seed, dim, n_dist):
         P = round_f32({**P, **got})
 
 
-def test_carnn_batch_matches_the_batch_rule(pa):
-    T = toy_problem(520, n_user=40, n_item=90, n_dist=11, dim=32, len_max=10, hot=25)
+@pytest.mark.parametrize("dim,n_dist", [(32, 11), (64, 11), (128, 200), (64, 700)])      # 32: per-sequence kernel; 64 / 128: outer-product path
+def test_carnn_batch_matches_the_batch_rule(pa, dim, n_dist):
+    T = toy_problem(520, n_user=40, n_item=90, n_dist=n_dist, dim=dim, len_max=10, hot=25)
     P = _params(520, T)
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     users = np.random.default_rng(1).permutation(40)[:37].astype(np.int32)
@@ -78,6 +79,10 @@ def test_carnn_batch_matches_the_batch_rule(pa):
     # second launch on the updated state: gradient tables / slabs were re-zeroed
     model.train_batch(users[:9])
     assert np.isfinite(_get(model)["wd"]).all()
+    if dim >= 64:      # the matrix gradients of the outer-product path are sums in a fixed order: bitwise reproducible
+        a, b = _model(pa, T, P), _model(pa, T, P)
+        a.train_batch(users); b.train_batch(users)
+        assert np.array_equal(_get(a)["wd"], _get(b)["wd"]) and np.array_equal(_get(a)["M"], _get(b)["M"])
 
 
 def test_carnn_predict_scores_and_topk(pa):
