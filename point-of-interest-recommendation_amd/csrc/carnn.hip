@@ -209,6 +209,33 @@ __global__ __launch_bounds__(POI_BLOCK) void ca_pm_kernel(CaArgs A) {
   }
 }
 
+// gemv_rows for rows of at most 128 floats: a HALF-wave per row (gemv_rows strides a row with 64 float4 lanes - at 128 columns half of
+// them idle), eight rows in flight per wave, sums closed inside the half-waves.  out[r] = act(W[r, :K] . x + bias[r]).
+template <int ACT>
+__device__ __forceinline__ void gemv_rows_half(const float* __restrict__ W, int K, const float* x, const float* __restrict__ bias, int nrows, float* out) {
+  const int lane = lane_id(), w = wave_id(), hl = lane & 31, hh = lane >> 5;
+  for (int r0 = w * 8; r0 < nrows; r0 += POI_NWAVE * 8) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 2 * u + hh;
+      if (r < nrows && hl * 4 < K) acc[u] = dot4(*reinterpret_cast<const float4*>(W + (size_t)r * K + hl * 4), *reinterpret_cast<const float4*>(x + hl * 4));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s = acc[u];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const int r = r0 + 2 * u + hh;
+      if (hl == 0 && r < nrows) {
+        float v = s + (bias ? bias[r] : 0.f);
+        if (ACT == 1) v = sigmoidf_(v);
+        out[r] = v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
   extern __shared__ __align__(16) float lds_raw[];
   const int D = A.dim, HD = D * D, tid = threadIdx.x, NB = A.n_dist + 1;
@@ -233,7 +260,7 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
         // M x_t, M xp_{t+1}, M xq_{t+1}: rows of the per-launch table PM = lt . M^T
         load_row4(S.mp, A.PM + (size_t)p[t + 1] * D, D);
         load_row4(S.mq, A.PM + (size_t)q[t + 1] * D, D);
-        gemv_rows<1>(A.wd + (size_t)dp[t] * D * D, D, S.hp, nullptr, 0, nullptr, A.PM + (size_t)p[t] * D, D, S.h);      // h_t  (:131)
+        gemv_rows_half<1>(A.wd + (size_t)dp[t] * D * D, D, S.hp, A.PM + (size_t)p[t] * D, D, S.h);      // h_t  (:131)
       } else {      // small launches: the table would cost more than the three products of the launch's steps
         load_row4(S.x, A.lt + (size_t)p[t] * D, D);
         load_row4(S.xp, A.lt + (size_t)p[t + 1] * D, D);
@@ -244,8 +271,8 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
         gemv_rows<0>(A.M, D, S.xq, nullptr, 0, nullptr, nullptr, D, S.mq);
       }
       __syncthreads();
-      gemv_rows<0>(A.wd + (size_t)dp[t + 1] * D * D, D, S.h, nullptr, 0, nullptr, nullptr, D, S.vp);
-      gemv_rows<0>(A.wd + (size_t)dq[t + 1] * D * D, D, S.h, nullptr, 0, nullptr, nullptr, D, S.vq);
+      gemv_rows_half<0>(A.wd + (size_t)dp[t + 1] * D * D, D, S.h, nullptr, D, S.vp);
+      gemv_rows_half<0>(A.wd + (size_t)dq[t + 1] * D * D, D, S.h, nullptr, D, S.vq);
       __syncthreads();
       float part = 0.f;
       for (int j = tid; j < D; j += POI_BLOCK) {
