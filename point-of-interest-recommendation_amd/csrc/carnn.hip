@@ -236,6 +236,57 @@ __device__ __forceinline__ void gemv_rows_half(const float* __restrict__ W, int 
   }
 }
 
+// Transposed GEMV without barriers: out[j] = sum_i W[i, j] v[i] (W row-major rows x cols, cols = 64 or 128).  A wave owns cols / 4
+// consecutive columns as CW = cols / 16 float4 lanes and splits the rows over its 64 / CW lane groups; the group sums meet through
+// shuffles inside the wave (gemv_cols: two workgroup barriers and an LDS round trip per call).  The caller publishes `out`.
+__device__ __forceinline__ void gemv_cols_wave(const float* __restrict__ W, int rows, int cols, const float* v, float* out) {
+  const int lane = lane_id(), w = wave_id();
+  const int CW = cols >> 4, RG = 64 / CW;          // float4 columns per wave, row groups
+  const int cc = lane % CW, rg = lane / CW;
+  const int c = (w * CW + cc) * 4;
+  float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  int i = rg;
+  for (; i + RG < rows; i += 2 * RG) {
+    const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)i * cols + c);
+    const float4 w1 = *reinterpret_cast<const float4*>(W + (size_t)(i + RG) * cols + c);
+    const float v0 = v[i], v1 = v[i + RG];
+    a0.x = fmaf(w0.x, v0, a0.x); a0.y = fmaf(w0.y, v0, a0.y); a0.z = fmaf(w0.z, v0, a0.z); a0.w = fmaf(w0.w, v0, a0.w);
+    a1.x = fmaf(w1.x, v1, a1.x); a1.y = fmaf(w1.y, v1, a1.y); a1.z = fmaf(w1.z, v1, a1.z); a1.w = fmaf(w1.w, v1, a1.w);
+  }
+  if (i < rows) {
+    const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)i * cols + c);
+    const float v0 = v[i];
+    a0.x = fmaf(w0.x, v0, a0.x); a0.y = fmaf(w0.y, v0, a0.y); a0.z = fmaf(w0.z, v0, a0.z); a0.w = fmaf(w0.w, v0, a0.w);
+  }
+  float4 s = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
+  for (int o = CW; o < 64; o <<= 1) {
+    s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+  }
+  if (rg == 0) *reinterpret_cast<float4*>(out + c) = s;
+}
+
+// gemv_cols_wave with TWO vectors against one pass over the matrix: out1 = W^T v1, out2 = W^T v2 (the interval matrices are the
+// kernel's L2 stream: every product that shares a matrix shares its read)
+__device__ __forceinline__ void gemv_cols_wave2(const float* __restrict__ W, int rows, int cols, const float* v1, const float* v2,
+                                                float* out1, float* out2) {
+  const int lane = lane_id(), w = wave_id();
+  const int CW = cols >> 4, RG = 64 / CW;
+  const int cc = lane % CW, rg = lane / CW;
+  const int c = (w * CW + cc) * 4;
+  float4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  for (int i = rg; i < rows; i += RG) {
+    const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)i * cols + c);
+    const float x = v1[i], y = v2[i];
+    a.x = fmaf(w0.x, x, a.x); a.y = fmaf(w0.y, x, a.y); a.z = fmaf(w0.z, x, a.z); a.w = fmaf(w0.w, x, a.w);
+    b.x = fmaf(w0.x, y, b.x); b.y = fmaf(w0.y, y, b.y); b.z = fmaf(w0.z, y, b.z); b.w = fmaf(w0.w, y, b.w);
+  }
+  for (int o = CW; o < 64; o <<= 1) {
+    a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+    b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+  }
+  if (rg == 0) { *reinterpret_cast<float4*>(out1 + c) = a; *reinterpret_cast<float4*>(out2 + c) = b; }
+}
+
 __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
   extern __shared__ __align__(16) float lds_raw[];
   const int D = A.dim, HD = D * D, tid = threadIdx.x, NB = A.n_dist + 1;
@@ -260,7 +311,10 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
         // M x_t, M xp_{t+1}, M xq_{t+1}: rows of the per-launch table PM = lt . M^T
         load_row4(S.mp, A.PM + (size_t)p[t + 1] * D, D);
         load_row4(S.mq, A.PM + (size_t)q[t + 1] * D, D);
-        gemv_rows_half<1>(A.wd + (size_t)dp[t] * D * D, D, S.hp, A.PM + (size_t)p[t] * D, D, S.h);      // h_t  (:131)
+        // h_t = sigmoid(M x_t + W[dp_t] h_{t-1})  (:131): the product is the previous step's vp = W[dp_t] h_{t-1} (same matrix,
+        // same vector, same routine: the same bits), and W[dp_0] h_0 = 0 - no recurrent GEMV at all
+        const float* pm = A.PM + (size_t)p[t] * D;
+        for (int j = tid; j < D; j += POI_BLOCK) S.h[j] = sigmoidf_((t > 0 ? S.vp[j] : 0.f) + pm[j]);
       } else {      // small launches: the table would cost more than the three products of the launch's steps
         load_row4(S.x, A.lt + (size_t)p[t] * D, D);
         load_row4(S.xp, A.lt + (size_t)p[t + 1] * D, D);
@@ -298,10 +352,11 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
       __syncthreads();
       const float* Wp = A.wd + (size_t)dp[t + 1] * D * D; const float* Wq = A.wd + (size_t)dq[t + 1] * D * D;
       const float* Wt = A.wd + (size_t)dp[t] * D * D;
-      gemv_cols<false>(Wp, D, D, S.mp, S.t0, S.part);        // Wp^T mp
-      gemv_cols<false>(Wq, D, D, S.mq, S.t1, S.part);        // Wq^T mq
-      gemv_cols<false>(A.M, D, D, S.vp, S.t2, S.part);       // M^T vp
-      gemv_cols<false>(A.M, D, D, S.vq, S.t3, S.part);       // M^T vq
+      if (t == ns - 1) gemv_cols_wave(Wp, D, D, S.mp, S.t0);        // Wp^T mp (later steps: computed with the previous iteration's W_t pass)
+      else for (int j = tid; j < D; j += POI_BLOCK) S.t0[j] = S.xq[j];
+      gemv_cols_wave(Wq, D, D, S.mq, S.t1);                        // Wq^T mq
+      gemv_cols_wave2(A.M, D, D, S.vp, S.vq, S.t2, S.t3);          // M^T vp, M^T vq: one pass over M
+      __syncthreads();
       {
         const size_t r = (size_t)(r0 + t);
         float* ea = A.EA + r * 5 * D;
@@ -327,8 +382,11 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
         }
       }
       __syncthreads();
-      gemv_cols<false>(A.M, D, D, S.da, S.t0, S.part);       // M^T da  -> d lt[p_t]
-      gemv_cols<false>(Wt, D, D, S.da, S.t1, S.part);        // W_t^T da -> dh_{t-1}
+      gemv_cols_wave(A.M, D, D, S.da, S.t0);       // M^T da  -> d lt[p_t]
+      // W_t^T da -> dh_{t-1}, and - the same matrix W[dp_t] is step t-1's Wp - the next iteration's Wp^T mp in the same pass
+      if (t > 0) { load_row4(S.xp, wsV + (size_t)(t - 1) * 4 * D, D); __syncthreads(); gemv_cols_wave2(Wt, D, D, S.da, S.xp, S.t1, S.xq); }
+      else gemv_cols_wave(Wt, D, D, S.da, S.t1);
+      __syncthreads();
       {
         float* gp0 = A.g_lt + (size_t)p[t] * D;
         for (int j = tid; j < D; j += POI_BLOCK) { atomicAdd(gp0 + j, S.t0[j]); S.dh[j] = S.t1[j]; }
