@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
       }
       acc = f4_add(acc, f4_add(f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])), f4_add(f4_add(v[4], v[5]), f4_add(v[6], v[7]))));
     }
-    // per-POI regrouping: the summed dx of the row's step inputs = S[row] . ui, row seg_pidx[row] of X (te_gemm_dx over S)
+    // per-POI regrouping: the summed dx of the row's step inputs = S[row] . ui, row pmark[row] - 1 of X (te_gemm_dx over S)
     const int pmk = (PPOI && in && row <= A.n_item) ? A.pmark[row] : 0;          // S row + 1 (te_passign), 0: not a step input
     if (pmk && !hot) {
       const float4 xs = *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + c);
