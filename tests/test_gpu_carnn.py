@@ -53,9 +53,12 @@ def test_carnn_step_parity_sequential(pa, seed, dim, n_dist):
         P = round_f32({**P, **got})
 
 
-@pytest.mark.parametrize("dim,n_dist", [(32, 11), (64, 11), (128, 200), (64, 700)])      # 32: per-sequence kernel; 64 / 128: outer-product path
-def test_carnn_batch_matches_the_batch_rule(pa, dim, n_dist):
-    T = toy_problem(520, n_user=40, n_item=90, n_dist=n_dist, dim=dim, len_max=10, hot=25)
+@pytest.mark.parametrize("dim,n_dist,min_len", [(32, 11, 4), (64, 11, 4), (128, 200, 4), (64, 700, 4), (64, 11, 1), (128, 37, 1)])
+def test_carnn_batch_matches_the_batch_rule(pa, dim, n_dist, min_len):
+    """(dim 32: per-sequence kernel; 64 / 128: outer-product path; min_len 1: sequences of one and two positions - no step at all /
+    a single step - mixed into the launch)"""
+    T = toy_problem(520, n_user=40, n_item=90, n_dist=n_dist, dim=dim, len_max=10, hot=25, min_len=min_len)
+    assert min_len > 1 or ((T["lens"] == 1).any() and (T["lens"] == 2).any())
     P = _params(520, T)
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     users = np.random.default_rng(1).permutation(40)[:37].astype(np.int32)
