@@ -1703,8 +1703,11 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
   int rt0[F4], rt1[F4];
   unsigned ni[F4];      // unsigned: a signed index is sign-extended right behind its load, i.e. the wave waits for it there
+  // (clamped to the table: a launch WITHOUT steps - every sequence a single position - reads entry 0 of an index array nobody wrote;
+  // whatever an earlier launch left there must still be a valid row.  Found by tools/fuzz_engines.py: an aperture violation)
+  const unsigned nimax = (unsigned)(gdi ? A.n_dist : A.n_item);
 #pragma unroll
-  for (int s = 0; s < F4; ++s) ni[s] = gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)];
+  for (int s = 0; s < F4; ++s) ni[s] = min((unsigned)gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)], nimax);
   auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4]) {
 #pragma unroll
     for (int s = 0; s < F4; ++s) {
@@ -1725,7 +1728,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
         const float* bptr = bsel == 0 ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
         rbv[s] = *reinterpret_cast<const float4*>(bptr);
       }
-      ni[s] = gidx[min(r0 + 32 + r, rmax)];                // indices of the next stage
+      ni[s] = min((unsigned)gidx[min(r0 + 32 + r, rmax)], nimax);                // indices of the next stage
     }
   };
   auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4]) {

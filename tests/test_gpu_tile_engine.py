@@ -460,3 +460,42 @@ def test_forward_table_any_table_size(pa, n_item):
     eh, es = O.spatial_predict(Pn, Pn["lt"], Pn["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
     assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
     model.ctx.set_engine("auto")
+
+
+@pytest.mark.parametrize("dim,n_dist,spatial", [(64, 11, True), (128, 255, True), (128, 300, True), (256, 40, True), (64, 0, False), (128, 0, False)])
+def test_launch_without_a_single_step(pa, dim, n_dist, spatial):
+    """A launch whose sequences all hold ONE position has no step at all: only the L2 decay of the touched rows.  The gather index
+    arrays of such a launch are never written - whatever an earlier, larger launch left in the workspace is read (and must be
+    harmless): run a big launch first, then the empty one, against the oracle's batch rule.  (tools/fuzz_engines.py found an
+    aperture violation here: te_wgrad gathered a table row through a stale index.)"""
+    from tests.gpu_util import gru_params
+    big = toy_problem(77, n_user=700, n_item=900, n_dist=max(n_dist, 300) if spatial else 11, dim=dim, len_max=12)
+    if spatial:
+        pol = _model(pa, big, spatial_params(77, big))
+    else:
+        pol = _gru_model(pa, big, gru_params(77, big))
+    pol.ctx.set_engine("tile")
+    pol.train_batch(np.arange(700, dtype=np.int32))            # fills the workspace with large row ids / float bits
+    T = toy_problem(78, n_user=40, n_item=60, n_dist=max(n_dist, 1), dim=dim, len_max=6, min_len=1)
+    ones = np.nonzero(T["lens"] == 1)[0].astype(np.int32)
+    assert len(ones) >= 3
+    if spatial:
+        P = spatial_params(78, T)
+        exp, outs = _oracle_batch(P, T, ones)
+        model = _model(pa, T, P)
+        names = SP_NAMES
+    else:
+        P = gru_params(78, T)
+        Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
+        news, touched = [], []
+        for u in ones:
+            Pn, _ = O.gru_step(P, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
+            news.append(Pn); touched.append(dict(lt=np.unique(np.concatenate((Pm[u], Qm[u])))))
+        exp = batch_mean_update(P, news, touched, ("lt",), ("ui", "wh", "bi"))
+        model = _gru_model(pa, T, P)
+        names = GRU_NAMES
+    model.ctx.set_engine("tile")
+    model.train_batch(ones)
+    got = _get(model) if spatial else _get_gru(model)
+    assert_step_close(got, exp, P, names, "launch without steps")
+    model.ctx.set_engine("auto")

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Randomised cross-check of the two Distance2Pre engines on odd shapes: the tile engine (all its paths: forward table, per-POI
+regrouping, per-bin tables, chunked head, streaming recurrent kernels, touched-row list) against the per-sequence engine, two
+launches each, every tensor within the parity bar; plus predict and the fused top-K (resident bin matrix vs bins on the fly).
+usage: python tools/fuzz_engines.py [n_configs] [seed0]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import poi_amd  # noqa: E402
+from tests.gpu_util import spatial_params, toy_problem  # noqa: E402
+
+NAMES = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def main():
+    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ctx = poi_amd._lib.context(0)
+    worst = 0.0
+    seeds = [int(x) for x in os.environ["FUZZ_SEEDS"].split(",")] if os.environ.get("FUZZ_SEEDS") else range(seed0, seed0 + n_cfg)
+    for s in seeds:
+        rng = np.random.default_rng(10_000 + s)
+        dim = int(rng.choice([64, 128, 128, 256]))
+        n_dist = int(rng.choice([3, 11, 31, 32, 40, 63, 64, 100, 200, 223, 255, 256, 300, 700]))
+        n_item = int(rng.choice([17, 63, 64, 127, 128, 129, 200, 383, 500, 1000]))
+        n_user = int(rng.integers(1, 260)) if rng.random() < 0.9 else int(rng.integers(600, 2500))      # (some multi-tile / multi-round launches)
+        len_max = int(rng.integers(2, 14))
+        min_len = int(rng.integers(1, len_max + 1))
+        T = toy_problem(5000 + s, n_user=n_user, n_item=n_item, n_dist=n_dist, dim=dim, len_max=len_max, min_len=min_len,
+                        hot=int(rng.integers(2, max(3, n_item // 2))))
+        P = spatial_params(5000 + s, T)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("config", dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len), flush=True)
+        coords = np.stack([40.0 + rng.random(n_item) * 0.3, -74.0 + rng.random(n_item) * 0.3], 1)
+        res = {}
+        engines = tuple(os.environ.get("FUZZ_ENGINES", "tile,seq").split(","))
+        for eng in engines:
+            m = poi_amd.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=n_user,
+                                             n_item=n_item, n_dists=[n_dist, 0.2], n_in=dim, n_hidden=dim, init=P, coords=coords)
+            ctx.set_engine(eng)
+            ctx.set_batch_cap(float(rng.choice([1.0, 4.0, 64.0])) if eng == engines[0] else ctx.batch_cap)
+            outs = []
+            for _ in range(2):
+                k = int(np.random.default_rng(s).integers(1, n_user + 1))
+                users = np.random.default_rng(s + _).permutation(n_user)[:k].astype(np.int32)
+                outs.append(np.asarray(m.train_batch(users)))
+                if os.environ.get("FUZZ_VERBOSE"):
+                    torch.cuda.synchronize(); print("  %s train launch %d (%d users) done" % (eng, _, k), flush=True)
+            m.update_trained_items(); m.update_trained_dists()
+            ids = np.arange(n_user, dtype=np.int32)
+            hts, sts = m.predict(ids)
+            if os.environ.get("FUZZ_VERBOSE"):
+                torch.cuda.synchronize(); print("  %s predict done" % eng, flush=True)
+            res[eng] = (dict((k, getattr(m, k).get_value()) for k in NAMES), outs, hts, sts)
+            if eng == "tile":
+                ctx.set_engine("seq"); h2, s2 = m.predict(ids); ctx.set_engine("tile")      # predict parity on the SAME parameters
+                e = max(rel(hts, h2), rel(sts, s2))
+                assert e <= 1e-4, ("predict", e, dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
+                m.update_trained_users(hts); m.update_trained_sus(sts)
+                k_top = min(20, n_item)
+                m.use_bin_matrix = False; a = m.compute_sub_topk(ids, k_top, return_scores=True)
+                if dim <= 128:
+                    m.use_bin_matrix = True; b = m.compute_sub_topk(ids, k_top, return_scores=True)
+                    sa, sb = a[1].cpu().numpy(), b[1].cpu().numpy()
+                    assert np.allclose(sa, sb, rtol=0, atol=1e-5 * max(np.abs(sa).max(), 1e-30)), ("topk scores: geo vs bin matrix", s)
+        ctx.set_engine("auto"); ctx.set_batch_cap(1.0)
+        if len(engines) < 2:
+            continue
+        tol = 6e-5 if dim >= 256 else 2e-5
+        for k in NAMES:
+            # bar: the parity bar on the weights + 1e-3 of the largest update of the tensor (two launches under a capped-sum rule move
+            # hot rows by many times a single step: float32 noise scales with the update, a wrong row would be off by a whole update)
+            a, b, o = (np.asarray(x, np.float64) for x in (res["tile"][0][k], res["seq"][0][k], P[k]))
+            err, upd = np.abs(a - b).max(), np.abs(b - o).max()
+            e = err / (tol * max(np.abs(b).max(), 1e-30) + 1e-3 * upd); worst = max(worst, e)
+            assert e <= 1.0, ("param", k, err, upd, dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
+        for li, (a, b) in enumerate(zip(res["tile"][1], res["seq"][1])):
+            # (second launch: each engine continues from its own first-launch result - looser)
+            rt = 1e-4 if li == 0 else 2e-3
+            bad = ~np.isclose(a[:, :3], b[:, :3], rtol=rt, atol=rt)
+            assert not bad.any(), ("losses", li, a[bad.any(axis=1)][:3], b[bad.any(axis=1)][:3],
+                                   dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
+        if (s - seed0) % 10 == 9:
+            print("config %d ok (dim %d, %d bins, %d POIs, %d users, L <= %d), worst error / bar so far %.2f" % (s, dim, n_dist, n_item, n_user, len_max, worst), flush=True)
+    print("all %d configurations agree; worst error / bar %.2f" % (n_cfg, worst))
+
+
+if __name__ == "__main__":
+    main()
