@@ -11,9 +11,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import poi_amd  # noqa: E402
-from tests.gpu_util import spatial_params, toy_problem  # noqa: E402
+from tests.gpu_util import gru_params, spatial_params, toy_problem  # noqa: E402
 
-NAMES = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
+SP_NAMES = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
+GRU_NAMES = ("lt", "ui", "wh", "bi")
 
 
 def rel(a, b):
@@ -37,15 +38,21 @@ def main():
         min_len = int(rng.integers(1, len_max + 1))
         T = toy_problem(5000 + s, n_user=n_user, n_item=n_item, n_dist=n_dist, dim=dim, len_max=len_max, min_len=min_len,
                         hot=int(rng.integers(2, max(3, n_item // 2))))
-        P = spatial_params(5000 + s, T)
+        kind = str(rng.choice(["spatial", "spatial", "gru", "minibatch"])) if os.environ.get("FUZZ_KINDS", "1") != "0" else "spatial"
+        NAMES = SP_NAMES if kind == "spatial" else GRU_NAMES
+        P = spatial_params(5000 + s, T) if kind == "spatial" else gru_params(5000 + s, T)
         if os.environ.get("FUZZ_VERBOSE"):
-            print("config", dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len), flush=True)
+            print("config", dict(seed=s, kind=kind, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len), flush=True)
         coords = np.stack([40.0 + rng.random(n_item) * 0.3, -74.0 + rng.random(n_item) * 0.3], 1)
         res = {}
         engines = tuple(os.environ.get("FUZZ_ENGINES", "tile,seq").split(","))
         for eng in engines:
-            m = poi_amd.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=n_user,
-                                             n_item=n_item, n_dists=[n_dist, 0.2], n_in=dim, n_hidden=dim, init=P, coords=coords)
+            if kind == "spatial":
+                m = poi_amd.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=n_user,
+                                                 n_item=n_item, n_dists=[n_dist, 0.2], n_in=dim, n_hidden=dim, init=P, coords=coords)
+            else:
+                m = (poi_amd.models.OboGru if kind == "gru" else poi_amd.models.Gru)(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001],
+                                                                                       n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P)
             ctx.set_engine(eng)
             ctx.set_batch_cap(float(rng.choice([1.0, 4.0, 64.0])) if eng == engines[0] else ctx.batch_cap)
             outs = []
@@ -57,17 +64,23 @@ def main():
                     first = dict((k, getattr(m, k).get_value()) for k in NAMES)
                 if os.environ.get("FUZZ_VERBOSE"):
                     torch.cuda.synchronize(); print("  %s train launch %d (%d users) done" % (eng, _, k), flush=True)
-            m.update_trained_items(); m.update_trained_dists()
+            m.update_trained_items()
+            if kind == "spatial":
+                m.update_trained_dists()
             ids = np.arange(n_user, dtype=np.int32)
-            hts, sts = m.predict(ids)
+            pr = m.predict(ids)
+            hts, sts = pr if kind == "spatial" else (pr, pr)
             if os.environ.get("FUZZ_VERBOSE"):
                 torch.cuda.synchronize(); print("  %s predict done" % eng, flush=True)
             res[eng] = (dict((k, getattr(m, k).get_value()) for k in NAMES), outs, hts, sts, first)
             if eng == "tile":
-                ctx.set_engine("seq"); h2, s2 = m.predict(ids); ctx.set_engine("tile")      # predict parity on the SAME parameters
+                ctx.set_engine("seq"); pr2 = m.predict(ids); ctx.set_engine("tile")      # predict parity on the SAME parameters
+                h2, s2 = pr2 if kind == "spatial" else (pr2, pr2)
                 e = max(rel(hts, h2), rel(sts, s2))
                 assert e <= (3e-4 if dim >= 256 else 1e-4), ("predict", e,      # (dim 256: float32 conditioning)
                  dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
+                if kind != "spatial":
+                    continue
                 m.update_trained_users(hts); m.update_trained_sus(sts)
                 k_top = min(20, n_item)
                 m.use_bin_matrix = False; a = m.compute_sub_topk(ids, k_top, return_scores=True)
@@ -92,11 +105,12 @@ def main():
         for li, (a, b) in enumerate(zip(res["tile"][1], res["seq"][1])):
             # (second launch: each engine continues from its own first-launch result - looser)
             rt = 1e-4 if li == 0 else 2e-3
-            bad = ~np.isclose(a[:, :3], b[:, :3], rtol=rt, atol=rt)
+            a, b = (np.asarray(x).reshape(len(x), -1)[:, :3] for x in (a, b))
+            bad = ~np.isclose(a, b, rtol=rt, atol=rt)
             assert not bad.any(), ("losses", li, a[bad.any(axis=1)][:3], b[bad.any(axis=1)][:3],
                                    dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
         if (s - seed0) % 10 == 9:
-            print("config %d ok (dim %d, %d bins, %d POIs, %d users, L <= %d), worst error / bar so far %.2f" % (s, dim, n_dist, n_item, n_user, len_max, worst), flush=True)
+            print("config %d ok (%s, dim %d, %d bins, %d POIs, %d users, L <= %d), worst error / bar so far %.2f" % (s, kind, dim, n_dist, n_item, n_user, len_max, worst), flush=True)
     print("all %d configurations agree; worst error / bar %.2f" % (n_cfg, worst))
 
 
