@@ -32,7 +32,7 @@ def main():
         rng = np.random.default_rng(10_000 + s)
         dim = int(rng.choice([64, 128, 128, 256]))
         n_dist = int(rng.choice([3, 11, 31, 32, 40, 63, 64, 100, 200, 223, 255, 256, 300, 700]))
-        n_item = int(rng.choice([17, 63, 64, 127, 128, 129, 200, 383, 500, 1000]))
+        n_item = int(rng.choice([17, 63, 64, 127, 128, 129, 200, 383, 500, 1000, 5000, 40000]))      # (the large ones: touched-row list)
         n_user = int(rng.integers(1, 260)) if rng.random() < 0.9 else int(rng.integers(600, 2500))      # (some multi-tile / multi-round launches)
         len_max = int(rng.integers(2, 14))
         min_len = int(rng.integers(1, len_max + 1))
@@ -53,7 +53,7 @@ def main():
             else:
                 m = (poi_amd.models.OboGru if kind == "gru" else poi_amd.models.Gru)(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001],
                                                                                        n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P)
-            ctx.set_engine(eng)
+            ctx.set_engine("tile32" if (eng == "tile" and dim == 128 and s % 5 == 0) else eng)      # (every fifth dim-128 configuration: streaming recurrent kernels)
             ctx.set_batch_cap(float(rng.choice([1.0, 4.0, 64.0])) if eng == engines[0] else ctx.batch_cap)
             outs = []
             for _ in range(2):
