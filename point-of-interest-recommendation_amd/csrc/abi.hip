@@ -509,19 +509,23 @@ int poi_carnn_step(poi_ctx* c, const poi_carnn_params* P, const poi_seq_tables* 
     // outer-product path (carnn.hip): packed per-step state + sorted entries, matrix gradients on the matrix cores
     const size_t Tcap = (size_t)n * (size_t)(T->max_len > 1 ? T->max_len - 1 : 1), Ne = 6 * Tcap, NK = (size_t)P->n_dist + 2;
     const size_t n_chunk = Ne / 512 + NK + 1;
-    const size_t nint = (size_t)n + 8 + 6 * Ne + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 3 * (NK + 8);
-    const size_t nfl = (Tcap + (size_t)n + 1) * D + Tcap * 5 * D + n_chunk * (size_t)D * D + ((size_t)P->n_item + 4) * D + 64;
+    const size_t N2 = 3 * Tcap;
+    const size_t nint = (size_t)n + 8 + 6 * Ne + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 3 * (NK + 8) + 4 * N2 + 2 * ((size_t)P->n_item + 8) + 32;
+    const size_t nfl = (Tcap + (size_t)n + 1) * D + Tcap * 5 * D + n_chunk * (size_t)D * D + ((size_t)P->n_item + 4) * D + N2 * D + 64;
     if ((rc = ensure(c, c->ca2, 4 * (nint + nfl) + 256, st))) return rc;
     float* f = (float*)c->ca2.p;
     auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
     A.Hpk = take((Tcap + (size_t)n + 1) * D); A.EA = take(Tcap * 5 * D); A.partial = take(n_chunk * (size_t)D * D);
     A.PM = take(((size_t)P->n_item + 2) * D);
+    A.vpart = take(N2 * D);
     if (n < 16) A.PM = nullptr;      // a handful of sequences: three GEMVs per step are cheaper than the table (measured: a wash at one)
     int* ip = (int*)f;
     auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
     A.soff = itake((size_t)n + 1); A.keys0 = itake(Ne); A.keys1 = itake(Ne); A.vals0 = itake(Ne); A.vals1 = itake(Ne);
     A.ent_a = itake(Ne); A.ent_b = itake(Ne); A.hist = itake((size_t)RS_HIST_INTS + RS_MAXBIN); A.cnt = itake(8);
     A.seg_start = itake(NK + 4); A.seg_end = itake(NK + 4); A.chunk_first = itake(NK + 4);
+    A.k2a = itake(N2); A.k2b = itake(N2); A.v2a = itake(N2); A.v2b = itake(N2);
+    A.seg2_start = itake((size_t)P->n_item + 4); A.seg2_end = itake((size_t)P->n_item + 4);
     A.n_chunk_cap = (int)n_chunk;
     HIPCHK(c, poi::launch_carnn_train2(A, grid, alpha, lambda, st, &c->tm));
     return POI_OK;

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void ca_scan_kernel(CaArgs A) {
   __syncthreads();
   int run = inc - s + (w > 0 ? wtot[w - 1] : 0);
   for (int k = b; k < e; ++k) { const int u = A.uidx[k], L = A.off[u + 1] - A.off[u]; A.soff[k] = run; run += L > 0 ? L - 1 : 0; }
-  if (tid == 1023) { A.soff[n] = wtot[15]; A.cnt[0] = 6 * wtot[15]; }
+  if (tid == 1023) { A.soff[n] = wtot[15]; A.cnt[0] = 6 * wtot[15]; A.cnt[1] = 3 * wtot[15]; }
 }
 
 // PM[r][i] = sum_c M[i][c] lt[r][c] for every table row: the three M x products of a step (x_t, xp_{t+1}, xq_{t+1}) become row
@@ -355,20 +355,16 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
       if (t == ns - 1) gemv_cols_wave(Wp, D, D, S.mp, S.t0);        // Wp^T mp (later steps: computed with the previous iteration's W_t pass)
       else for (int j = tid; j < D; j += POI_BLOCK) S.t0[j] = S.xq[j];
       gemv_cols_wave(Wq, D, D, S.mq, S.t1);                        // Wq^T mq
-      gemv_cols_wave2(A.M, D, D, S.vp, S.vq, S.t2, S.t3);          // M^T vp, M^T vq: one pass over M
       __syncthreads();
       {
         const size_t r = (size_t)(r0 + t);
         float* ea = A.EA + r * 5 * D;
-        float* gp1 = A.g_lt + (size_t)p[t + 1] * D; float* gq1 = A.g_lt + (size_t)q[t + 1] * D;
         for (int j = tid; j < D; j += POI_BLOCK) {
           const float d = S.dh[j] + g * (S.t0[j] - S.t1[j]);
           S.dh[j] = d;
           const float da = d * S.h[j] * (1.0f - S.h[j]);
           S.da[j] = da;
           ea[j] = g * S.mp[j]; ea[D + j] = -g * S.mq[j]; ea[2 * D + j] = da; ea[3 * D + j] = g * S.vp[j]; ea[4 * D + j] = -g * S.vq[j];
-          atomicAdd(gp1 + j, g * S.t2[j]);
-          atomicAdd(gq1 + j, -g * S.t3[j]);
         }
         if (tid < 6) {
           // entries: (matrix id, EA vector, b source) - d W[dp_{t+1}] += (g mp) (x) h_t, d W[dq_{t+1}] += (-g mq) (x) h_t,
@@ -379,18 +375,19 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
           const int bs = e < 2 ? hr0 + t + 1 : e == 2 ? hr0 + t : e == 3 ? ~p[t + 1] : e == 4 ? ~q[t + 1] : ~p[t];
           const size_t eid = r * 6 + e;
           A.keys0[eid] = key; A.ent_a[eid] = av; A.ent_b[eid] = bs;
+        } else if (tid < 9) {
+          // row entries: d lt[p_{t+1}] += M^T (g vp), d lt[q_{t+1}] += M^T (-g vq), d lt[p_t] += M^T da - M^T is applied once per ROW to the
+          // sum of its vectors (ca_ltgrad_kernel), not per step
+          const int j = tid - 6;
+          A.k2a[r * 3 + j] = j == 0 ? p[t + 1] : j == 1 ? q[t + 1] : p[t];
         }
       }
       __syncthreads();
-      gemv_cols_wave(A.M, D, D, S.da, S.t0);       // M^T da  -> d lt[p_t]
       // W_t^T da -> dh_{t-1}, and - the same matrix W[dp_t] is step t-1's Wp - the next iteration's Wp^T mp in the same pass
       if (t > 0) { load_row4(S.xp, wsV + (size_t)(t - 1) * 4 * D, D); __syncthreads(); gemv_cols_wave2(Wt, D, D, S.da, S.xp, S.t1, S.xq); }
       else gemv_cols_wave(Wt, D, D, S.da, S.t1);
       __syncthreads();
-      {
-        float* gp0 = A.g_lt + (size_t)p[t] * D;
-        for (int j = tid; j < D; j += POI_BLOCK) { atomicAdd(gp0 + j, S.t0[j]); S.dh[j] = S.t1[j]; }
-      }
+      for (int j = tid; j < D; j += POI_BLOCK) S.dh[j] = S.t1[j];
       __syncthreads();
     }
     __syncthreads();
@@ -398,13 +395,82 @@ __global__ __launch_bounds__(POI_BLOCK) void carnn_train2_kernel(CaArgs A) {
 }
 
 // segment [seg_start, seg_end) of every matrix id in the sorted entry list (the arrays are zero on entry: absent ids stay empty)
-__global__ __launch_bounds__(256) void ca_bounds_kernel(CaArgs A, const int* __restrict__ ks) {
-  const int Ne = A.cnt[0];
+__global__ __launch_bounds__(256) void ca_bounds_kernel(const int* __restrict__ n_ptr, const int* __restrict__ ks, int* __restrict__ seg_start,
+                                                        int* __restrict__ seg_end) {
+  const int Ne = *n_ptr;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < Ne; i += gridDim.x * 256) {
     const int k = ks[i];
-    if (i == 0 || ks[i - 1] != k) A.seg_start[k] = i;
-    if (i == Ne - 1 || ks[i + 1] != k) A.seg_end[k] = i + 1;
+    if (i == 0 || ks[i - 1] != k) seg_start[k] = i;
+    if (i == Ne - 1 || ks[i + 1] != k) seg_end[k] = i + 1;
   }
+}
+
+// Sums of the step vectors per POI row, first level: one wave per 64-entry window of the row-sorted entry list walks its entries in
+// order (lane = D / 64 columns of the vector) and stores the sum of every run of equal rows at the sorted position of the run's
+// first entry inside the window (a run that crosses windows leaves one partial per window).
+template <int D>
+__global__ __launch_bounds__(POI_BLOCK) void ca_vsum_kernel(CaArgs A, const int* __restrict__ ks, const int* __restrict__ vs) {
+  constexpr int C = D / 64;
+  const int N2 = A.cnt[1], w = blockIdx.x * POI_NWAVE + wave_id(), lane = lane_id();
+  const int b = w * 64;
+  if (b >= N2) return;
+  const int n = min(64, N2 - b);
+  const int myk = lane < n ? ks[b + lane] : -1, mye = lane < n ? vs[b + lane] : 0;
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  int cur = __builtin_amdgcn_readfirstlane(myk), first = 0;
+  for (int i = 0; i < n; ++i) {
+    const int k = __builtin_amdgcn_readlane(myk, i), e = __builtin_amdgcn_readlane(mye, i);
+    if (k != cur) {
+      float* o = A.vpart + (size_t)(b + first) * D + lane * C;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { o[c] = acc[c]; acc[c] = 0.f; }
+      cur = k; first = i;
+    }
+    const int r = e / 3, j = e - 3 * r;
+    const float* a = A.EA + ((size_t)r * 5 + (j == 0 ? 3 : j == 1 ? 4 : 2)) * D + lane * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] += a[c];
+  }
+  float* o = A.vpart + (size_t)(b + first) * D + lane * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) o[c] = acc[c];
+}
+
+// second level + the product with M: one wave per touched POI row adds the row's partial sums in order (its first entry's position,
+// then every window boundary inside its segment) and writes d lt[row] = M^T v into the (zero) gradient table
+template <int D>
+__global__ __launch_bounds__(POI_BLOCK) void ca_ltgrad_kernel(CaArgs A) {
+  constexpr int C = D / 64;
+  __shared__ float sv[POI_NWAVE][D];
+  const int row = blockIdx.x * POI_NWAVE + wave_id(), lane = lane_id(), w = wave_id();
+  if (row > A.n_item) return;
+  const int s0 = A.seg2_start[row], s1 = A.seg2_end[row];
+  if (s1 == 0) return;
+  float v[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) v[c] = A.vpart[(size_t)s0 * D + lane * C + c];
+  for (int pos = (s0 / 64 + 1) * 64; pos < s1; pos += 64) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] += A.vpart[(size_t)pos * D + lane * C + c];
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) sv[w][lane * C + c] = v[c];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float g[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) g[c] = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < D; ++i) {
+    const float x = sv[w][i];
+    const float* m = A.M + (size_t)i * D + lane * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = fmaf(m[c], x, g[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) A.g_lt[(size_t)row * D + lane * C + c] = g[c];
 }
 
 // chunk_first[id] = first 512-entry chunk of matrix id (exclusive scan of the chunk counts), chunk_first[n_id] = total
@@ -656,10 +722,22 @@ static hipError_t carnn_train2_t(const CaArgs& A, int grid, float alpha, float l
   if (e != hipSuccess) return e;
   // (the workspace is carved per launch size: clear the segment tables instead of relying on the previous launch)
   if (hipMemsetAsync(A.seg_start, 0, sizeof(int) * (NK + 4), st) != hipSuccess || hipMemsetAsync(A.seg_end, 0, sizeof(int) * (NK + 4), st) != hipSuccess) return hipGetLastError();
-  hipLaunchKernelGGL(ca_bounds_kernel, dim3(1024), dim3(256), 0, st, A, ks);
+  hipLaunchKernelGGL(ca_bounds_kernel, dim3(1024), dim3(256), 0, st, A.cnt, ks, A.seg_start, A.seg_end);
   hipLaunchKernelGGL(ca_chunks_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(ca_outer_kernel<D>, dim3(A.n_chunk_cap), dim3(POI_BLOCK), 0, st, A, vs);
   hipLaunchKernelGGL(ca_outer_reduce_kernel<D>, dim3(NK, D * D / 32), dim3(POI_BLOCK), 0, st, A);
+  tm->end(st);
+  tm->begin("carnn_ltgrad", st);
+  {
+    int b2 = 1; while ((1 << b2) <= A.n_item) ++b2;
+    const int *ks2 = nullptr, *vs2 = nullptr;
+    e = launch_radix_sort(A.k2a, A.k2b, A.v2a, A.v2b, A.cnt + 1, b2, A.hist, st, &ks2, &vs2);
+    if (e != hipSuccess) return e;
+    if (hipMemsetAsync(A.seg2_start, 0, sizeof(int) * (A.n_item + 2), st) != hipSuccess || hipMemsetAsync(A.seg2_end, 0, sizeof(int) * (A.n_item + 2), st) != hipSuccess) return hipGetLastError();
+    hipLaunchKernelGGL(ca_bounds_kernel, dim3(1024), dim3(256), 0, st, A.cnt + 1, ks2, A.seg2_start, A.seg2_end);
+    hipLaunchKernelGGL(ca_vsum_kernel<D>, dim3((A.n_chunk_cap * 8 + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, A, ks2, vs2);
+    hipLaunchKernelGGL(ca_ltgrad_kernel<D>, dim3((A.n_item + 1 + POI_NWAVE - 1) / POI_NWAVE), dim3(POI_BLOCK), 0, st, A);
+  }
   tm->end(st);
   tm->begin("carnn_apply", st);
   int rows = A.n_item + 1 + A.n_dist + 1, g2 = (rows + POI_NWAVE - 1) / POI_NWAVE;

@@ -209,6 +209,11 @@ struct CaArgs {
   float* partial;                     // per 512-entry chunk: D x D partial product
   int n_chunk_cap;
   float* PM;                          // (n_item + 1) x D: lt . M^T, the input product of every POI (computed once per launch)
+  // gradient of the POI rows: d lt[row] = M^T (sum of the step vectors that name the row) - three entries (row, EA vector) per step,
+  // sorted by row; 64-entry windows of the sorted list are summed per run (vpart), a wave per row adds its runs in order
+  int *k2a, *k2b, *v2a, *v2b;         // radix sort of the 3 T row entries (cnt[1] = 3 T)
+  int *seg2_start, *seg2_end;         // per POI row (n_item + 2)
+  float* vpart;                       // 3 T x D: partial sums, stored at the sorted position of a run's first entry inside its window
 };
 size_t carnn_ws_floats(int D, int cap);
 hipError_t launch_carnn_train2(const CaArgs& A, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);

@@ -31,5 +31,5 @@ for B in (1, 256, users):
     print("CA-RNN dim %d, %5d sequences per launch: %9.0f seq/s (%.2f ms per %d users)" % (D, B, n / dt, dt * 1e3, n))
     if B == users:
         model.ctx.timing(True); run(); torch.cuda.synchronize()
-        print("   regions (ms per launch): " + ", ".join("%s %.2f" % (k, model.ctx.timing_get(k)[0]) for k in ("carnn_train", "carnn_outer", "carnn_apply")))
+        print("   regions (ms per launch): " + ", ".join("%s %.2f" % (k, model.ctx.timing_get(k)[0]) for k in ("carnn_train", "carnn_outer", "carnn_ltgrad", "carnn_apply")))
         model.ctx.timing(False)
