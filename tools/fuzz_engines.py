@@ -44,6 +44,15 @@ def main():
         if os.environ.get("FUZZ_VERBOSE"):
             print("config", dict(seed=s, kind=kind, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len), flush=True)
         coords = np.stack([40.0 + rng.random(n_item) * 0.3, -74.0 + rng.random(n_item) * 0.3], 1)
+        if s % 3 == 0:      # other models on the same context first: they share its gradient / bookkeeping tables with the engines under test
+            from oracle import poi_oracle as O_
+            Pc = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in O_.init_carnn_params(np.random.default_rng(s), n_item, n_dist, dim).items()}
+            mc = poi_amd.models.OboCARNN(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item,
+                                         n_dists=[n_dist, 0.2], n_in=dim, n_hidden=dim, init=Pc)
+            mc.train_batch(np.arange(n_user, dtype=np.int32))
+            mb = poi_amd.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim)
+            u_, p_, q_ = mb.epoch_triples()
+            mb.train_batch(u_, p_, q_, mode="snapshot")
         res = {}
         engines = tuple(os.environ.get("FUZZ_ENGINES", "tile,seq").split(","))
         for eng in engines:
