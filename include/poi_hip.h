@@ -153,6 +153,9 @@ int poi_gru_step(poi_ctx* ctx, const poi_gru_params* prm, const poi_seq_tables* 
  * n_in == n_hidden, prog_bpr_gru_spatial.py:148-149).  h0 is the zero vector (never trained).
  * poi_carnn_step: seq_train(uidx), :105-170 - out[k] = los = -sum_t log sigmoid(yp_t - yq_t); sparse write-back of the
  *   unique rows of p U q (lt) and of the unique interval MATRICES of dp U dq (wd), dense update of M; batch rule as above.
+ *   dim 64 / 128: the recurrence kernel records the step vectors and every gradient (interval matrices, M, POI rows) is a sorted,
+ *   fixed-order sum on the matrix cores - no float atomics, bitwise reproducible; other dims: one kernel per sequence with float
+ *   atomics on the gradient tables (POI_CARNN_FAST=0 forces it).
  * poi_carnn_predict: seq_predict(start_end), :172-217, literally (the predict graph adds-then-sums, :191:
  *   h_t = sigmoid(M p_t + rowsum(wd[d_t]) + sum(h_{t-1}))); prm->lt / prm->wd must point at the snapshots.
  * poi_carnn_score_all: compute_sub_all_scores(start_end), :91-101, literally:
