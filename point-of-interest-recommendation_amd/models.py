@@ -31,16 +31,22 @@ def _ptr(t):
 class Shared:
     """Stand-in for a Theano shared variable: .get_value() / .set_value() on a device tensor."""
 
-    def __init__(self, tensor, scalar=False):
+    def __init__(self, tensor, scalar=False, pad=None, unpad=None):
         self.t = tensor
         self.scalar = scalar
+        self.pad, self.unpad = pad, unpad      # logical <-> stored layout (models whose dim is padded to a tile-engine dim)
 
     def get_value(self, borrow=False):
         a = self.t.detach().cpu().numpy()
+        if self.unpad is not None:
+            a = np.ascontiguousarray(self.unpad(a))
         return a.reshape(()).copy() if self.scalar else a
 
     def set_value(self, value, borrow=False):
-        v = torch.as_tensor(np.asarray(value, dtype=np.float64), dtype=self.t.dtype).reshape(self.t.shape)
+        v = np.asarray(value, dtype=np.float64)
+        if self.pad is not None:
+            v = self.pad(v)
+        v = torch.as_tensor(v, dtype=self.t.dtype).reshape(self.t.shape)
         self.t.copy_(v.to(self.t.device))
 
 
@@ -212,7 +218,7 @@ class _Base:
         users = self._rows(self.trained_users.t, ids, lo)
         tp, tq, tm = (self._rows(t, ids, lo) for t in (self.tes_buys_masks, self.tes_buys_neg_masks, self.tes_masks))
         out = torch.empty((n, ln), dtype=torch.uint8, device=self.device)
-        self.ctx.check(self.lib.poi_auc_preference(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.dim,
+        self.ctx.check(self.lib.poi_auc_preference(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.kdim,
                                                    _ptr(tp), _ptr(tq), _ptr(tm), ln, _ptr(out), self._stream()))
         return out.cpu().numpy().astype(bool)
 
@@ -232,7 +238,7 @@ class _Base:
         n = ids.numel()
         wd, prob = self._prob_rows(ids, lo)
         out = torch.empty((n, self.n_item), dtype=torch.float32, device=self.device)
-        self.ctx.check(self.lib.poi_score_all(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim,
+        self.ctx.check(self.lib.poi_score_all(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.kdim,
                                               _ptr(wd), _ptr(prob), _ptr(out), self._stream()))
         return out
 
@@ -247,7 +253,7 @@ class _Base:
         idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
         sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
         seed = self._seed_begin(lo, n, k)
-        self.ctx.check(self.lib.poi_score_topk(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim,
+        self.ctx.check(self.lib.poi_score_topk(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.kdim,
                                                _ptr(wd), _ptr(prob), int(k), _ptr(idx), _ptr(sc), self._stream()))
         self._seed_end(seed, idx)
         return (idx, sc) if return_scores else idx
@@ -295,8 +301,17 @@ class GruBasic(_Base):
 
     spatial = False
 
-    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None, table_dtype="f32"):
-        """table_dtype="f16": the POI table `lt` and its evaluation snapshot are STORED as IEEE half (config X of BASELINE.json:
+    _pad_ok = True          # dims other than 64 / 128 / 256 may be zero-padded to the next tile-engine dim (not CA-RNN: sigmoid(0) != 0)
+
+    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None, table_dtype="f32",
+                 pad_dim=True):
+        """pad_dim (default on): a model whose dim is not 64 / 128 / 256 (the reference's own configs use 20 and 32) is STORED with its
+        hidden / embedding width zero-padded to the next of those, so that it trains on the MFMA tile engine instead of the
+        per-sequence engine (dim 20: 1.5 M -> ~9 M sequences/s).  Exact: a padded hidden unit has zero weights and bias, so its gates
+        are sigmoid(0), its candidate tanh(0) = 0 and its state stays 0; every gradient that touches a padded row or column is a
+        product with one of those zeros, and the L2 decay of a zero is zero - the padding stays exactly zero and the other entries
+        see only additional + 0.0 terms.  get_value / set_value / load_params / predict / checkpoints use the logical shapes.
+        table_dtype="f16": the POI table `lt` and its evaluation snapshot are STORED as IEEE half (config X of BASELINE.json:
         "fp16 embeddings"); all arithmetic stays float32 - rows are converted when gathered and rounded to nearest-even when
         written back.  Tile engine only (dim 64 / 128 / 256).  NOTE: an update smaller than half an fp16 ulp of the element
         (2.4e-4 at 0.5) is lost to the rounding; with alpha 0.01 that is most single-sequence updates - use launches with a
@@ -308,20 +323,24 @@ class GruBasic(_Base):
         self.table_dtype = table_dtype
         self._setup(device, alpha_lambda)
         self.n_user, self.n_item, self.dim = int(n_user), int(n_item), int(n_in)
+        D = self.dim
+        self.kdim = D           # the dim the kernels see
+        if pad_dim and self._pad_ok and D not in (64, 128, 256) and D < 256:
+            self.kdim = 64 if D < 64 else 128 if D < 128 else 256
         self._load_tables(train, test)
         rng = np.random.default_rng(seed) if seed is not None else np.random
         u = lambda *s: rng.uniform(-0.5, 0.5, s)
-        D = self.dim
         init = init or {}
         g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
         tdt = torch.float16 if table_dtype == "f16" else torch.float32
-        self.lt = Shared(self._dev(g("lt", lambda: u(n_item + 1, D)), tdt))                # GRU.py:60
-        self.ui = Shared(self._dev(g("ui", lambda: u(3, D, self._xw()))))                  # :61 / GRU_Spatial.py:51
-        self.wh = Shared(self._dev(g("wh", lambda: u(3, D, D))))                           # :62
-        self.bi = Shared(self._dev(g("bi", lambda: np.zeros((3, D)))))                     # :64
-        self.h0 = Shared(torch.zeros(D, dtype=torch.float32, device=self.device))                               # :63 never trained
-        self.trained_items = Shared(self._dev(u(n_item + 1, D), tdt))                      # :71
-        self.trained_users = Shared(self._dev(u(n_user, D)))                               # :72
+        sh = self._shared
+        self.lt = sh(g("lt", lambda: u(n_item + 1, D)), "cols", tdt)                       # GRU.py:60
+        self.ui = sh(g("ui", lambda: u(3, D, self._xw())), "ui")                           # :61 / GRU_Spatial.py:51
+        self.wh = sh(g("wh", lambda: u(3, D, D)), "sq")                                    # :62
+        self.bi = sh(g("bi", lambda: np.zeros((3, D))), "cols")                            # :64
+        self.h0 = Shared(torch.zeros(self.kdim, dtype=torch.float32, device=self.device), unpad=(lambda a: a[:D]) if self.kdim != D else None)   # :63 never trained
+        self.trained_items = sh(u(n_item + 1, D), "cols", tdt)                             # :71
+        self.trained_users = sh(u(n_user, D), "cols")                                      # :72
         if table_dtype == "f16":
             self.ctx.register_f16(self.lt.t); self.ctx.register_f16(self.trained_items.t)
 
@@ -335,12 +354,42 @@ class GruBasic(_Base):
     def _xw(self):
         return self.dim
 
-    def update_trained_users(self, all_hus):
-        """public/GRU.py:89-91."""
-        if isinstance(all_hus, torch.Tensor):
-            self.trained_users.t.copy_(all_hus.to(self.device, torch.float32).reshape(self.n_user, self.dim))
+    def _shared(self, value, kind, dtype=torch.float32):
+        """Device tensor of a parameter in the STORED layout (width kdim) with logical get / set.  kind: "cols" - last axis D -> kdim;
+        "sq" - (3, D, D) -> (3, kdim, kdim); "ui" - (3, D, xw) with xw = D or 2 D column blocks, each block padded on its own."""
+        D, K = self.dim, self.kdim
+        if K == D:
+            return Shared(self._dev(value, dtype))
+        if kind == "cols":
+            pad = lambda a: np.concatenate((a, np.zeros(a.shape[:-1] + (K - D,))), axis=-1)
+            unpad = lambda a: a[..., :D]
+        elif kind == "sq":
+            def pad(a):
+                o = np.zeros((3, K, K)); o[:, :D, :D] = a; return o
+            unpad = lambda a: a[:, :D, :D]
         else:
-            self.trained_users.t.copy_(self._dev(np.asarray(all_hus, np.float64)).reshape(self.n_user, self.dim))
+            nb = self._xw() // D
+            def pad(a):
+                o = np.zeros((3, K, nb * K))
+                for b in range(nb):
+                    o[:, :D, b * K:b * K + D] = a[:, :, b * D:(b + 1) * D]
+                return o
+            unpad = lambda a: np.concatenate([a[:, :D, b * K:b * K + D] for b in range(nb)], axis=2)
+        return Shared(self._dev(pad(np.asarray(value, np.float64)), dtype), pad=pad, unpad=unpad)
+
+    def _pad_cols(self, t):
+        """(n, D) or (n, kdim) device tensor -> (n, kdim)."""
+        if t.shape[-1] == self.kdim:
+            return t
+        o = torch.zeros(t.shape[:-1] + (self.kdim,), dtype=t.dtype, device=t.device)
+        o[..., :self.dim] = t
+        return o
+
+    def update_trained_users(self, all_hus):
+        """public/GRU.py:89-91 ((n_user, D); the padded rows predict_device returns are taken as they are)."""
+        t = all_hus if isinstance(all_hus, torch.Tensor) else self._dev(np.asarray(all_hus, np.float64))
+        t = t.to(self.device, torch.float32).reshape(self.n_user, -1)
+        self.trained_users.t.copy_(self._pad_cols(t))
 
     # ---- ctypes views ---------------------------------------------------------------------------
     def _params(self, snapshot=False):
@@ -348,7 +397,7 @@ class GruBasic(_Base):
         P.lt = (self.trained_items if snapshot else self.lt).t.data_ptr()
         P.ui, P.wh, P.bi = self.ui.t.data_ptr(), self.wh.t.data_ptr(), self.bi.t.data_ptr()
         P.di = P.vs = P.bs = P.wd = P.lw = None
-        P.n_item, P.n_dist, P.dim = self.n_item, 0, self.dim
+        P.n_item, P.n_dist, P.dim = self.n_item, 0, self.kdim
         return P
 
     def _tables(self):
@@ -360,12 +409,13 @@ class GruBasic(_Base):
 
     def predict(self, idxs):
         """public/GRU.py:204-205 -> hts ndarray (n, D)."""
-        return self.predict_device(idxs).cpu().numpy()
+        return np.ascontiguousarray(self.predict_device(idxs)[:, :self.dim].cpu().numpy())
 
     def predict_device(self, idxs):
+        """(n, kdim) device rows (kdim == dim unless the model is stored padded: the padding columns are zero)."""
         ids, out_row = self._by_length(idxs)
         n = ids.numel()
-        hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        hts = torch.empty((n, self.kdim), dtype=torch.float32, device=self.device)
         P, T = self._params(snapshot=True), self._tables()
         self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), _ptr(out_row), n, _ptr(hts), None,
                                                 self._stream()))
@@ -424,10 +474,11 @@ class OboSpatialGru(GruBasic):
     spatial = True
 
     def __init__(self, train, test, dist, alpha_lambda, n_user, n_item, n_dists, n_in, n_hidden,
-                 device="cuda:0", init=None, seed=None, coords=None, table_dtype="f32"):
+                 device="cuda:0", init=None, seed=None, coords=None, table_dtype="f32", pad_dim=True):
         n_dist, dd = n_dists
         self.n_dist, self.dd = int(n_dist), float(dd)                                      # dd in km (ref passes dd/1000)
-        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device=device, init=init, seed=seed, table_dtype=table_dtype)
+        super().__init__(train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device=device, init=init, seed=seed, table_dtype=table_dtype,
+                         pad_dim=pad_dim)
         if self._csr is not None:
             dp, dq, tes_dist_masks = (np.ascontiguousarray(v, np.int32) for v in (self._csr.dp, self._csr.dq, self._csr.tes_dp))
         else:
@@ -443,12 +494,12 @@ class OboSpatialGru(GruBasic):
         D, NB = self.dim, self.n_dist + 1
         init = init or {}
         g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
-        self.di = Shared(self._dev(g("di", lambda: u(NB, D))))                             # :57
-        self.vs = Shared(self._dev(g("vs", lambda: u(NB, D))))                             # :60
+        self.di = self._shared(g("di", lambda: u(NB, D)), "cols")                          # :57
+        self.vs = self._shared(g("vs", lambda: u(NB, D)), "cols")                          # :60
         self.bs = Shared(self._dev(g("bs", lambda: np.zeros(NB))))                         # :61
         self.wd = Shared(self._dev(np.reshape(g("wd", lambda: rng.uniform(0, 0.5)), (1,))), scalar=True)   # :66
         self.loss_weight = Shared(self._dev(g("loss_weight", lambda: u(2))))               # :70
-        self.trained_dists = Shared(self._dev(u(NB, D)))                                   # :74
+        self.trained_dists = self._shared(u(NB, D), "cols")                                # :74
         self.prob = None                       # dense (n_user, n_item) only on request (update_prob)
         self.trained_sus = None                # (n_user, NB) - fused alternative to `prob`
         self.use_bin_matrix = None             # None = auto: resident U x N bin matrix when it is <= 16 GiB, else bins on the fly
@@ -542,7 +593,7 @@ class OboSpatialGru(GruBasic):
         if ubm is None:
             ubm = self.n_user * float(self.n_item) * (1 if self.n_dist <= 255 else 2) <= float(1 << 34)
         if ubm and self.prob is None and self.trained_sus is not None and self.coords is not None and lo is not None and lo % 32 == 0 \
-                and self.dim <= 128:
+                and self.kdim <= 128:
             if getattr(self, "_ulptai", None) is None:
                 self.build_ulptai()
             n = ids.numel()
@@ -552,7 +603,7 @@ class OboSpatialGru(GruBasic):
             sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
             bins = self._ulptai.data_ptr() + (lo // 32) * self._ulptai_row
             seed = self._seed_begin(lo, n, k)
-            self.ctx.check(self.lib.poi_score_topk_ulptai(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim,
+            self.ctx.check(self.lib.poi_score_topk_ulptai(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.kdim,
                                                           _ptr(self.wd.t), _ptr(st), bins, self._ulptai_bytes, self.n_dist, int(k),
                                                           _ptr(idx), _ptr(sc), self._stream()))
             self._seed_end(seed, idx)
@@ -576,7 +627,7 @@ class OboSpatialGru(GruBasic):
         idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
         sc = torch.empty((n, k), dtype=torch.float32, device=self.device) if return_scores else None
         seed = self._seed_begin(lo, n, k)
-        self.ctx.check(self.lib.poi_score_topk_geo(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.dim, _ptr(self.wd.t),
+        self.ctx.check(self.lib.poi_score_topk_geo(self.ctx.handle, _ptr(users), _ptr(self.trained_items.t), n, self.n_item, self.kdim, _ptr(self.wd.t),
                                                    _ptr(st), _ptr(self.coords), _ptr(self._cphi), _ptr(self._binthr), _ptr(lp), self.n_dist,
                                                    self.dd * 1000.0, int(k), _ptr(idx), _ptr(sc), self._stream()))
         self._seed_end(seed, idx)
@@ -629,12 +680,12 @@ class OboSpatialGru(GruBasic):
     def predict(self, idxs):
         """public/GRU_Spatial.py:282-288 -> [hts (n, D), sts (n, n_dist+1)]."""
         h, s = self.predict_device(idxs)
-        return [h.cpu().numpy(), s.cpu().numpy()]
+        return [np.ascontiguousarray(h[:, :self.dim].cpu().numpy()), s.cpu().numpy()]
 
     def predict_device(self, idxs):
         ids, out_row = self._by_length(idxs)
         n = ids.numel()
-        hts = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        hts = torch.empty((n, self.kdim), dtype=torch.float32, device=self.device)
         sts = torch.empty((n, self.n_dist + 1), dtype=torch.float32, device=self.device)
         P, T = self._params(snapshot=True), self._tables()
         self.ctx.check(self.lib.poi_gru_predict(self.ctx.handle, ctypes.byref(P), ctypes.byref(T), _ptr(ids), _ptr(out_row), n, _ptr(hts), _ptr(sts),
@@ -650,6 +701,7 @@ class OboCARNN(GruBasic):
     uploaded: with coords= the scoring kernel computes those bins on the fly (bit-identical, tested)."""
 
     spatial = True          # has distance-bin tables (negatives refresh computes dq)
+    _pad_ok = False
 
     def __init__(self, train, test, dist, alpha_lambda, n_user, n_item, n_dists, n_in, n_hidden, ulptai=None,
                  device="cuda:0", init=None, seed=None, coords=None):
@@ -751,6 +803,7 @@ class MfBasic(_Base):
     def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None):
         self._setup(device, alpha_lambda)
         self.n_user, self.n_item, self.dim = int(n_user), int(n_item), int(n_in)
+        self.kdim = self.dim
         self._load_tables(train, test)
         rng = np.random.default_rng(seed) if seed is not None else np.random
         u = lambda *s: rng.uniform(-0.5, 0.5, s)

@@ -23,18 +23,18 @@ def pa():
     poi_amd._lib.context(0).set_batch_cap(1.0)
 
 
-def _model(pa, T, P):
+def _model(pa, T, P, **kw):
     return pa.models.Gru(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=T["n_user"],
-                         n_item=T["n_item"], n_in=T["dim"], n_hidden=T["dim"], init=P)
+                         n_item=T["n_item"], n_in=T["dim"], n_hidden=T["dim"], init=P, **kw)
 
 
-@pytest.mark.parametrize("dim,engine,n_user,batch", [(20, "seq", 23, 7), (32, "seq", 40, 40), (64, "tile", 50, 16), (64, "seq", 50, 16),
+@pytest.mark.parametrize("dim,engine,n_user,batch", [(20, "seq", 23, 7), (32, "seq", 40, 40), (20, "tile", 23, 7), (100, "tile", 40, 16), (64, "tile", 50, 16), (64, "seq", 50, 16),
                                                      (128, "tile", 90, 64), (256, "tile", 40, 24)])
 def test_minibatch_gru_steps_match_oracle(pa, dim, engine, n_user, batch):
     T = toy_problem(300 + dim, n_user=n_user, n_item=70, dim=dim, len_max=11, hot=16)
     P = gru_params(300 + dim, T)
     Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
-    model = _model(pa, T, P)
+    model = _model(pa, T, P, pad_dim=(engine != "seq"))      # seq: the per-sequence engine at the model's native dim
     model.ctx.set_engine(engine)
     model.ctx.set_batch_cap(4.0)                      # the class switches to the mini-batch rule for its own launches and restores this
     order = np.random.default_rng(2).permutation(n_user).astype(np.int32)

@@ -51,11 +51,12 @@ def test_spatial_step_parity_sequential(pa, seed, dim, n_dist, n_item, engine):
     """model.train(uidx) one user after another == the reference's hot loop #1
     (prog_bpr_gru_spatial.py:249-250): every step must match, and the state carried between steps
     (gradient tables re-zeroed, slabs consumed) must stay consistent."""
-    if engine == "seq" and dim < 64:
-        pytest.skip("auto already is the per-sequence engine at this dim")
     T = toy_problem(seed, n_user=5, n_item=n_item, n_dist=n_dist, dim=dim, len_max=9 if dim > 32 else 10)
     P = spatial_params(seed, T)
-    model = _spatial_model(pa, T, P)
+    # auto: dims 8 / 20 / 32 are stored zero-padded to 64 and train on the tile engine (models.GruBasic pad_dim); seq: the
+    # per-sequence engine at the model's NATIVE dim (pad_dim=False)
+    model = _spatial_model(pa, T, P, pad_dim=(engine == "auto"))
+    assert model.kdim == (dim if engine == "seq" or dim >= 64 else 64)
     model.ctx.set_engine(engine)
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     worst = 0.0
@@ -89,7 +90,7 @@ def test_spatial_batch_matches_mean_rule(pa):
     """n_seq > 1: rows move by the mean of the touching sequences' reference updates."""
     T = toy_problem(11, n_user=7, n_item=40, n_dist=9, dim=16, len_max=8)
     P = spatial_params(11, T)
-    model = _spatial_model(pa, T, P)
+    model = _spatial_model(pa, T, P, pad_dim=False)          # (the per-sequence engine at its native dim)
     Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
     users = [5, 1, 2, 6, 0]
     news, touched, outs = [], [], []
@@ -703,3 +704,43 @@ def test_model_level_seeding_across_evaluations(pa, n_dist):
         model.train(np.int32(u))
     second = evaluate()                  # seeded with the lists of the first evaluation, under the moved model
     assert any(not np.array_equal(first[k], second[k]) for k in first), "training did not move any list: the test is vacuous"
+
+
+@pytest.mark.parametrize("dim", [20, 100])
+def test_padded_dim_is_exact_and_invisible(pa, dim):
+    """A model whose dim is not 64 / 128 / 256 is stored zero-padded to the next of those (tile engine instead of the per-sequence
+    engine).  The padding must stay EXACTLY zero through training, every logical view (get_value, predict, checkpoint values) must
+    have the reference's shapes, and the padded and the native model must agree with the oracle and with each other."""
+    import torch
+    T = toy_problem(900 + dim, n_user=24, n_item=70, n_dist=37, dim=dim, len_max=9)
+    P = spatial_params(900 + dim, T)
+    a, b = _spatial_model(pa, T, P), _spatial_model(pa, T, P, pad_dim=False)
+    K = 64 if dim < 64 else 128
+    assert (a.kdim, b.kdim) == (K, dim) and a.dim == dim
+    users = np.arange(24, dtype=np.int32)
+    for m in (a, b):
+        m.train_batch(users[:17]); m.train_batch(users[5:])
+    ga, gb = _get(a, SP_NAMES), _get(b, SP_NAMES)
+    for k in SP_NAMES:
+        assert np.asarray(ga[k]).shape == np.asarray(P[k]).shape, k
+        assert_close(ga[k], gb[k], "padded vs native " + k, rtol=2e-5)
+    # the padding itself: exactly zero
+    assert float(a.lt.t[:, dim:].abs().max()) == 0.0 and float(a.di.t[:, dim:].abs().max()) == 0.0 and float(a.vs.t[:, dim:].abs().max()) == 0.0
+    assert float(a.wh.t[:, dim:, :].abs().max()) == 0.0 and float(a.wh.t[:, :, dim:].abs().max()) == 0.0 and float(a.bi.t[:, dim:].abs().max()) == 0.0
+    ui = a.ui.t
+    assert float(ui[:, dim:, :].abs().max()) == 0.0 and float(ui[:, :, dim:K].abs().max()) == 0.0 and float(ui[:, :, K + dim:].abs().max()) == 0.0
+    for m in (a, b):
+        m.update_trained_items(); m.update_trained_dists()
+    (ha, sa), (hb, sb) = a.predict(users), b.predict(users)
+    assert ha.shape == (24, dim) and sa.shape == (24, 38)
+    assert_close(ha, hb, "hts", rtol=2e-5); assert_close(sa, sb, "sts", rtol=2e-5)
+    a.update_trained_users(ha); b.update_trained_users(hb)          # logical (n, D) rows in
+    assert float(a.trained_users.t[:, dim:].abs().max()) == 0.0
+    ia, ib = a.compute_sub_topk(users, 10, return_scores=True), b.compute_sub_topk(users, 10, return_scores=True)
+    assert_close(ia[1].cpu().numpy(), ib[1].cpu().numpy(), "top-K scores", rtol=2e-5)
+    # load_params round trip through the logical shapes
+    vals = [getattr(a, k).get_value() for k in ("loss_weight", "wd", "lt", "di", "ui", "wh", "bi", "vs", "bs")]
+    c = _spatial_model(pa, T, P)
+    c.load_params(vals)
+    for k in SP_NAMES:
+        assert np.array_equal(np.asarray(_get(c, SP_NAMES)[k]), np.asarray(ga[k])), k
