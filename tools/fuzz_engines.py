@@ -30,7 +30,7 @@ def main():
     seeds = [int(x) for x in os.environ["FUZZ_SEEDS"].split(",")] if os.environ.get("FUZZ_SEEDS") else range(seed0, seed0 + n_cfg)
     for s in seeds:
         rng = np.random.default_rng(10_000 + s)
-        dim = int(rng.choice([64, 128, 128, 256]))
+        dim = int(rng.choice([64, 128, 128, 256, 8, 20, 36, 100, 200]))      # (the odd ones: stored zero-padded for the tile engine, native for the per-sequence engine)
         n_dist = int(rng.choice([3, 11, 31, 32, 40, 63, 64, 100, 200, 223, 255, 256, 300, 700]))
         n_item = int(rng.choice([17, 63, 64, 127, 128, 129, 200, 383, 500, 1000, 5000, 40000]))      # (the large ones: touched-row list)
         n_user = int(rng.integers(1, 260)) if rng.random() < 0.9 else int(rng.integers(600, 2500))      # (some multi-tile / multi-round launches)
@@ -58,11 +58,11 @@ def main():
         for eng in engines:
             if kind == "spatial":
                 m = poi_amd.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=n_user,
-                                                 n_item=n_item, n_dists=[n_dist, 0.2], n_in=dim, n_hidden=dim, init=P, coords=coords)
+                                                 n_item=n_item, n_dists=[n_dist, 0.2], n_in=dim, n_hidden=dim, init=P, coords=coords, pad_dim=(eng == "tile"))
             else:
                 m = (poi_amd.models.OboGru if kind == "gru" else poi_amd.models.Gru)(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001],
-                                                                                       n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P)
-            ctx.set_engine("tile32" if (eng == "tile" and dim == 128 and s % 5 == 0) else eng)      # (every fifth dim-128 configuration: streaming recurrent kernels)
+                                                                                       n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P, pad_dim=(eng == "tile"))
+            ctx.set_engine("tile32" if (eng == "tile" and 64 < dim <= 128 and s % 5 == 0) else eng)      # (every fifth dim-128 configuration: streaming recurrent kernels)
             ctx.set_batch_cap(float(rng.choice([1.0, 4.0, 64.0])) if eng == engines[0] else ctx.batch_cap)
             outs = []
             for _ in range(2):
@@ -86,7 +86,7 @@ def main():
                 ctx.set_engine("seq"); pr2 = m.predict(ids); ctx.set_engine("tile")      # predict parity on the SAME parameters
                 h2, s2 = pr2 if kind == "spatial" else (pr2, pr2)
                 e = max(rel(hts, h2), rel(sts, s2))
-                assert e <= (3e-4 if dim >= 256 else 1e-4), ("predict", e,      # (dim 256: float32 conditioning)
+                assert e <= (3e-4 if dim > 128 else 1e-4), ("predict", e,      # (dim 256: float32 conditioning)
                  dict(seed=s, dim=dim, n_dist=n_dist, n_item=n_item, n_user=n_user, len_max=len_max, min_len=min_len))
                 if kind != "spatial":
                     continue
@@ -100,7 +100,7 @@ def main():
         ctx.set_engine("auto"); ctx.set_batch_cap(1.0)
         if len(engines) < 2:
             continue
-        tol = 6e-5 if dim >= 256 else 2e-5
+        tol = 6e-5 if dim > 128 else 2e-5
         for k in NAMES:
             # bar: the parity bar on the weights + 1e-3 of the largest update of the tensor (two launches under a capped-sum rule move
             # hot rows by many times a single step: float32 noise scales with the update, a wrong row would be off by a whole update)
