@@ -465,6 +465,18 @@ def main():
                      "train_seq_per_s": nu2 * 400 / t2, "ms_per_epoch": 1e3 * t2 / 400, "eval_users_per_s": nu2 * 20 / te2,
                      "recall_at_20_after_405_epochs": rec2, "auc": auc2}
         del m2
+        # the reference's in-source config (prog_bpr_gru_spatial.py:54-78): latent_size 20 - stored zero-padded to dim 64 (tile engine)
+        m3 = poi_amd.models.OboSpatialGru(train=tab2, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=nu2, n_item=ni2,
+                                          n_dists=[ds2.dist_num, ds2.dd / 1000.0], n_in=20, n_hidden=20, device=dev, seed=7, coords=ds2.coords)
+        for _ in range(5):
+            train_epoch(m3, od2, B2, nu2)
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(400):
+            train_epoch(m3, od2, B2, nu2)
+        torch.cuda.synchronize(dev); t3 = time.perf_counter() - t0
+        secondary["reference_latent_size_20"] = {"train_seq_per_s": nu2 * 400 / t3, "ms_per_epoch": 1e3 * t3 / 400, "kernel_dim": m3.kdim,
+                                                 "note": "same data, dim = 20 (the reference's default): stored zero-padded to the tile engine's dim 64, exact"}
+        del m3
 
     # ---- CPU baseline: plain-C float64 port of the same per-sequence algorithm, 1 thread -------------
     cpu = None
