@@ -417,6 +417,15 @@ __global__ __launch_bounds__(POI_BLOCK) void dense_apply_kernel(SeqArgs A, int n
     float* base = A.slab + i;
     const size_t st = dl.total;
     int s = 0;
+    for (; s + 16 <= ns; s += 16) {         // the tile engine splits K into ~100 chunks (one slab each): sixteen loads in flight
+      float* p0 = base + (size_t)s * st;
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p0[(size_t)u * st];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) p0[(size_t)u * st] = 0.f;
+      g += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+    }
     for (; s + 4 <= ns; s += 4) {           // four independent loads in flight
       float* p0 = base + (size_t)s * st;
       const float v0 = p0[0], v1 = p0[st], v2 = p0[2 * st], v3 = p0[3 * st];

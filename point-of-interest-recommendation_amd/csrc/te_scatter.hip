@@ -218,30 +218,27 @@ __global__ __launch_bounds__(256) void te_passign_kernel(TeArgs A) {
 
 template <int D>
 __global__ __launch_bounds__(3 * D) void te_psum_kernel(TeArgs A) {
-  const int Ndx = A.cnt[5], col = threadIdx.x;
+  const int Ndx = A.cnt[5], col = threadIdx.x, lane = lane_id();
   const int nr = (Ndx + 63) / 64;
   for (int r = blockIdx.x; r < nr; r += gridDim.x) {
     const int j0 = 64 * r, j1 = min(Ndx, j0 + 64);
-    int cur = A.dxs[j0];
+    // the range's entries, one per lane (every wave holds the same lists), handed out through v_readlane: scalar row
+    // addresses, scalar run detection, and all 64 row loads in flight behind one dependent index load
+    const int me = A.dxe[min(j0 + lane, j1 - 1)], ms = A.dxs[min(j0 + lane, j1 - 1)];
+    float v[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) v[u] = A.G[(size_t)__builtin_amdgcn_readlane(me, u) * 3 * D + col];
+    int cur = __builtin_amdgcn_readlane(ms, 0);
     bool first = true;
     float acc = 0.f;
-    for (int j = j0; j < j1; j += 16) {
-      int e[16], sr[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { e[u] = A.dxe[min(j + u, j1 - 1)]; sr[u] = A.dxs[min(j + u, j1 - 1)]; }
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = A.G[(size_t)e[u] * 3 * D + col];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (j + u < j1) {                                  // (block-uniform control flow: every thread sees the same entries)
-          if (sr[u] != cur) {
-            if (first) A.pfirst[(size_t)r * 3 * D + col] = acc; else A.S[(size_t)cur * 3 * D + col] = acc;
-            first = false; cur = sr[u]; acc = 0.f;
-          }
-          acc += v[u];
-        }
+    for (int u = 0; u < 64; ++u) {
+      const int sr = __builtin_amdgcn_readlane(ms, u);     // (clamped past j1: the last entry's S row - no flush; its value is masked)
+      if (sr != cur) {                                      // (block-uniform control flow: every thread sees the same entries)
+        if (first) A.pfirst[(size_t)r * 3 * D + col] = acc; else A.S[(size_t)cur * 3 * D + col] = acc;
+        first = false; cur = sr; acc = 0.f;
       }
+      acc += j0 + u < j1 ? v[u] : 0.f;
     }
     if (first) A.pfirst[(size_t)r * 3 * D + col] = acc; else A.plast[(size_t)r * 3 * D + col] = acc;
   }
@@ -597,26 +594,30 @@ __global__ __launch_bounds__(256) void te_dprep_kernel(TeArgs A) {
 // TE_ENT_FIRST flags (= distinct sequences of the batch rule: a sequence's entries are contiguous in a row segment)
 template <int D>
 __global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
-  const int NB = A.n_dist + 1, col = threadIdx.x;
+  const int NB = A.n_dist + 1, col = threadIdx.x, lane = lane_id();
   const int total = A.dch0[NB];
   for (int ci = blockIdx.x; ci < total; ci += gridDim.x) {
     int lo = 0, hi = NB - 1;                    // last bin with dch0[b] <= ci
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.dch0[mid] <= ci) lo = mid; else hi = mid - 1; }
     const int row = A.n_item + 1 + lo;
     const int c0 = A.seg_start[row] + 64 * (ci - A.dch0[lo]), ce = min(A.seg_end[row], c0 + 64);
+    // the chunk's entries: one per lane (every wave holds the same list), handed out through v_readlane - the row
+    // addresses are scalar, and all 64 row loads are in flight behind ONE dependent index load (16 rows behind
+    // each of four index batches left the memory pipe idle half of the time: 3.6 TB/s)
+    const int mine = A.ent[min(c0 + lane, ce - 1)];
+    const bool in = c0 + lane < ce;
+    const unsigned long long mdx = __ballot(in && (mine & TE_ENT_DX) != 0);
+    const int nf = __builtin_popcountll(__ballot(in && mine < 0));
+    float v[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) v[u] = A.G[(size_t)(__builtin_amdgcn_readlane(mine, u) & TE_ENT_ROW) * 3 * D + col];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int nf = 0;
-    for (int i = c0; i < ce; i += 16) {
-      int e[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) e[u] = A.ent[min(i + u, ce - 1)];
-      float v[16];
+    for (int b = 0; b < 64; b += 16) {          // (the summation order of the four-batch version)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = A.G[(size_t)(e[u] & TE_ENT_ROW) * 3 * D + col];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) { v[u] = (i + u < ce && (e[u] & TE_ENT_DX)) ? v[u] : 0.f; nf += (i + u < ce && e[u] < 0) ? 1 : 0; }
-      s0 += (v[0] + v[4]) + (v[8] + v[12]); s1 += (v[1] + v[5]) + (v[9] + v[13]);
-      s2 += (v[2] + v[6]) + (v[10] + v[14]); s3 += (v[3] + v[7]) + (v[11] + v[15]);
+      for (int u = 0; u < 16; ++u) v[b + u] = ((mdx >> (b + u)) & 1ull) ? v[b + u] : 0.f;
+      s0 += (v[b + 0] + v[b + 4]) + (v[b + 8] + v[b + 12]); s1 += (v[b + 1] + v[b + 5]) + (v[b + 9] + v[b + 13]);
+      s2 += (v[b + 2] + v[b + 6]) + (v[b + 10] + v[b + 14]); s3 += (v[b + 3] + v[b + 7]) + (v[b + 11] + v[b + 15]);
     }
     A.dpart[(size_t)ci * 3 * D + col] = (s0 + s1) + (s2 + s3);
     if (col == 0) A.dnf[ci] = nf;

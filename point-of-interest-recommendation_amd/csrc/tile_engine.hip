@@ -186,28 +186,38 @@ __global__ __launch_bounds__(256) void te_len_kernel(TeArgs A) {
 __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   __shared__ int wtot[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = A.n_seq;
-  const int per = (n + 1023) / 1024;
-  const int b = min(n, tid * per), e = min(n, b + per);
-  int s = 0;
-  for (int k = b; k < e; ++k) s += A.soff[k];
-  // exclusive scan of the 1024 per-thread sums: shuffle scan inside each wave, then over the 16 wave totals (two barriers
-  // instead of the twenty of a Hillis-Steele pass over LDS)
-  int inc = s;
+  // exclusive scan of the step counts, 16384 sequences per pass: a thread holds 16 consecutive counts in registers (independent
+  // loads; a load - store - load loop over soff serialised on the possible aliasing: 22 us for 12500 sequences), then a shuffle scan
+  // inside each wave and over the 16 wave totals (two barriers instead of the twenty of a Hillis-Steele pass over LDS)
+  int carry = 0;
+  for (int base = 0; base < n; base += 16384) {
+    const int i0 = base + tid * 16;
+    int v[16];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); inc += lane >= o ? v : 0; }
-  if (lane == 63) wtot[w] = inc;
-  __syncthreads();
-  if (w == 0) {
-    int t = lane < 16 ? wtot[lane] : 0;
+    for (int u = 0; u < 16; ++u) v[u] = i0 + u < n ? A.soff[i0 + u] : 0;
+    int s = 0;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { const int v = __shfl_up(t, o, 64); t += lane >= o ? v : 0; }
-    if (lane < 16) wtot[lane] = t;             // inclusive totals of the waves
+    for (int u = 0; u < 16; ++u) { const int t = v[u]; v[u] = s; s += t; }
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); inc += lane >= o ? t : 0; }
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    if (w == 0) {
+      int t = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { const int t2 = __shfl_up(t, o, 64); t += lane >= o ? t2 : 0; }
+      if (lane < 16) wtot[lane] = t;             // inclusive totals of the waves
+    }
+    __syncthreads();
+    const int run = carry + inc - s + (w > 0 ? wtot[w - 1] : 0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (i0 + u < n) A.soff[i0 + u] = run + v[u];
+    carry += wtot[15];
+    __syncthreads();
   }
-  __syncthreads();
-  int run = inc - s + (w > 0 ? wtot[w - 1] : 0);
-  for (int k = b; k < e; ++k) { const int v = A.soff[k]; A.soff[k] = run; run += v; }
   if (tid == 1023) {
-    const int total = wtot[15];
+    const int total = carry;
     A.soff[n] = total;
     if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (total + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; A.cnt[4] = 0; A.cnt[5] = 0; }   // slots, hot rows, hot chunks, touched rows, S rows, dx entries of the POI rows
   }
@@ -249,10 +259,17 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
   __shared__ int s_pad[POI_NWAVE][4];
   const int w = wave_id(), lane = lane_id();
   int m_lt = 0, n_lt = 0, m_di = 0, n_di = 0;
+  // the headers of the wave's sequences: lane i fetches sequence i's (uidx -> off is a dependent chain: once per wave, not per sequence)
+  const int kbase = (blockIdx.x * POI_NWAVE + w) * TE_SEQ_PER_WAVE;
+  int hb = 0, hL = 0, hr = 0;
+  if (lane < TE_SEQ_PER_WAVE && kbase + lane < A.n_seq) {
+    const int u = A.uidx[kbase + lane];
+    hb = A.off[u]; hL = A.off[u + 1] - hb; hr = A.soff[kbase + lane];
+  }
   for (int i = 0; i < TE_SEQ_PER_WAVE; ++i) {
-    const int k = (blockIdx.x * POI_NWAVE + w) * TE_SEQ_PER_WAVE + i;
+    const int k = kbase + i;
     if (k >= A.n_seq) break;
-    const int u = A.uidx[k], base = A.off[u], L = A.off[u + 1] - base, ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = A.soff[k];
+    const int base = __shfl(hb, i, 64), L = __shfl(hL, i, 64), ns = A.predict ? L : (L > 0 ? L - 1 : 0), r0 = __shfl(hr, i, 64);
     for (int t = lane; t < ns; t += 64) {
       A.row_src[r0 + t] = base + t; A.row_t[r0 + t] = t;
       A.row_p[r0 + t] = A.p[base + t];                       // table rows of the step's input: the GEMMs gather them
@@ -1194,6 +1211,9 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
 // sequences, H = hts).  Small enough in registers (no d vs accumulators) and LDS (E never staged) for
 // three workgroups per CU, whose MFMA / softmax / staging phases overlap.
 // -------------------------------------------------------------------------------------------------
+#ifndef HEAD_ACC_EXP
+#define HEAD_ACC_EXP 0
+#endif
 template <int D, int NBT, int MODE>
 __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
@@ -1298,7 +1318,9 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
       const int a = MODE ? 0 : s_a[row], b = MODE ? 0 : s_b[row];
       float sum = 0.f, cum = 0.f;
 #pragma unroll
-      for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float e = expf(o[k] - mx); o[k] = e; sum += e; cum += k <= a ? e : 0.f; }
+      // (training: v_exp_f32 of the scaled argument, 2 instructions - expf's range reduction and overflow selects are 17, on 28 elements
+      // per lane and tile, and f32 VALU time is MFMA pipe time; prediction keeps expf: its probabilities are ranked)
+      for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float e = (MODE || HEAD_ACC_EXP) ? expf(o[k] - mx) : __expf(o[k] - mx); o[k] = e; sum += e; cum += k <= a ? e : 0.f; }
       sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
       const float inv = 1.0f / sum;
       if (MODE) {
@@ -1316,8 +1338,9 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
         const float dot = ls0 * cum - ls0 + g * wd * (sa - sb);
         {   // all 8 lanes of the row store the same values (no lane branch around the stores); dead rows -> row T
           const size_t rs = (size_t)min(gr, T);
-          A.rowloss[2 * rs] = cum - logf(sa);
-          A.rowloss[2 * rs + 1] = log_sigmoidf_(u);
+          // (reported losses only: v_log_f32 / v_exp_f32 forms, branch-free - logf and the two-sided log1pf(expf()) are ~300 instructions)
+          A.rowloss[2 * rs] = cum - __logf(sa);
+          A.rowloss[2 * rs + 1] = fminf(u, 0.f) - __logf(1.0f + __expf(-fabsf(u)));
           A.gcoef[rs] = g;
         }
         dwd_acc += sub == 0 ? g * (sa - sb) : 0.f;
