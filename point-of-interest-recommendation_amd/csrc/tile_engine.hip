@@ -26,6 +26,7 @@
 #include "poi_kernels.h"
 
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace poi {
 
@@ -1211,8 +1212,16 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
 // sequences, H = hts).  Small enough in registers (no d vs accumulators) and LDS (E never staged) for
 // three workgroups per CU, whose MFMA / softmax / staging phases overlap.
 // -------------------------------------------------------------------------------------------------
-#ifndef HEAD_ACC_EXP
-#define HEAD_ACC_EXP 0
+// -DTE_HEAD_PROF: per-phase cycle counts of te_head (tools/head_phases.sh); never defined in the product build
+#ifdef TE_HEAD_PROF
+__device__ unsigned long long g_head_prof[4][10];
+#define HP_INIT long long hp_t = clock64(); long long hp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HP(i) { const long long hp_n = clock64(); hp[i] += hp_n - hp_t; hp_t = hp_n; }
+#define HP_END if (lane_id() == 0) { for (int i = 0; i < 10; ++i) atomicAdd(&g_head_prof[wave_id()][i], (unsigned long long)hp[i]); }
+#else
+#define HP_INIT
+#define HP(i)
+#define HP_END
 #endif
 template <int D, int NBT, int MODE>
 __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(TeArgs A) {
@@ -1269,7 +1278,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
   // wait for the prefetch then sits in straight-line code behind the stores that followed it and is counted
   // exactly; at the top of the loop it would merge with the first iteration's "just issued" state, i.e. be a
   // vmcnt(0) that also waits for the previous tile's DH stores.
-  auto stage = [&]() {
+  auto stage = [&](int tid) {
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
       const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
@@ -1284,9 +1293,19 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
     if (!MODE && tid < 32) { s_a[tid] = pab & 0xffff; s_b[tid] = pab >> 16; }
   };
   prefetch(blockIdx.x * 32);
-  stage();
+  stage(tid);
+  HP_INIT
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    // A per-iteration copy of the thread id the compiler cannot see through: the LDS / global addresses derived from it are
+    // recomputed in every tile (a few VALU instructions).  As loop invariants they were hoisted, spilled (the kernel sat at its
+    // 168-register limit) and reloaded with scratch_load + s_waitcnt vmcnt(0) - a wait for EVERY older vector memory operation:
+    // in stage() for the DH stores just issued (13 % of the kernel, tools/head_phases.sh), in the softmax phase for the prefetch.
+    // Without them: 153 registers, no spill, 352 -> 329 us.
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, li = tl & 31;
     lds_barrier();        // staged tile visible; every wave is done with Ot (DH MFMAs of the previous tile)
+    HP(0)
     {   // logits
       f32x16 acc[1][NTW];
 #pragma unroll
@@ -1302,12 +1321,14 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
         for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + bin] = acc[0][j][r] + bsv[j];
       }
     }
+    HP(1)
     lds_barrier();
+    HP(2)
     // next tile's staging rows: requested BEFORE the softmax phase (LDS + VALU only), so that they have landed when the second MFMA
     // block starts waiting for its first B fragment - vmcnt is in order, that wait covers every older load (measured: -3 %)
     prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
     {   // row-wise softmax + losses: 8 lanes per row
-      const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
+      const int row = tl >> 3, sub = tl & 7, gr = r0 + row;
       float* o = Ot + row * LDO;
       float mx = -INFINITY;
 #pragma unroll
@@ -1320,7 +1341,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 #pragma unroll
       // (training: v_exp_f32 of the scaled argument, 2 instructions - expf's range reduction and overflow selects are 17, on 28 elements
       // per lane and tile, and f32 VALU time is MFMA pipe time; prediction keeps expf: its probabilities are ranked)
-      for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float e = (MODE || HEAD_ACC_EXP) ? expf(o[k] - mx) : __expf(o[k] - mx); o[k] = e; sum += e; cum += k <= a ? e : 0.f; }
+      for (int i = 0; i < NBP / 8; ++i) { const int k = sub + 8 * i; const float e = MODE ? expf(o[k] - mx) : __expf(o[k] - mx); o[k] = e; sum += e; cum += k <= a ? e : 0.f; }
       sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
       const float inv = 1.0f / sum;
       if (MODE) {
@@ -1346,17 +1367,26 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
         dwd_acc += sub == 0 ? g * (sa - sb) : 0.f;
         if (sub == 0) s_g[row] = g;
         __builtin_amdgcn_wave_barrier();
+        // d logits: the row's e_k are read in one batch and every element is a select chain (with the LDS read inside an `if` the
+        // compiler emits a branch, a read and a wait per element).  No select on the element either: a dead row's scale is zero,
+        // and a padding bin's e_k is exp(-inf) = 0.
+        const float gwd = g * wd, ca = gwd - ls0 / sa, invl = live ? inv : 0.f;
+        float pv[NBP / 8];
+#pragma unroll
+        for (int i = 0; i < NBP / 8; ++i) pv[i] = o[sub + 8 * i];
 #pragma unroll
         for (int i = 0; i < NBP / 8; ++i) {
           const int k = sub + 8 * i;
           float ds = (k <= a ? ls0 : 0.f);
-          if (k == a) ds += g * wd - ls0 / sa;
-          if (k == b) ds -= g * wd;
-          o[k] = (live && k < NB) ? (o[k] * inv) * (ds - dot) : 0.f;
+          ds = k == a ? ds + ca : ds;
+          ds = k == b ? ds - gwd : ds;
+          o[k] = (pv[i] * invl) * (ds - dot);
         }
       }
     }
+    HP(3)
     lds_barrier();
+    HP(4)
     if (!MODE) {
       // g * E of this lane's DH elements: issued now, consumed after the MFMAs
       int ntd[DTW];
@@ -1369,7 +1399,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
         for (int r = 0; r < 16; ++r)
           ge[j][r] = Esrc[(size_t)min(r0 + c_row(r, lane), T - 1) * D + ntd[j] * 32 + li];
       // d logits -> DL (A operand of the d vs job of te_wgrad), d bs partials
-      for (int e = tid; e < 32 * (NBP / 4); e += TE_BLOCK) {
+      for (int e = tl; e < 32 * (NBP / 4); e += TE_BLOCK) {
         const int r = e / (NBP / 4), c = (e % (NBP / 4)) * 4;
         *reinterpret_cast<float4*>(A.DL + (size_t)min(r0 + r, T) * NBP + c) = *reinterpret_cast<const float4*>(Ot + r * LDO + c);
       }
@@ -1379,6 +1409,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
         for (int r = 0; r < 32; ++r) s += Ot[r * LDO + tid];
         dbs_acc += s;
       }
+      HP(5)
       // DH = d logits . vs + g * E
       f32x16 acc[1][DTW];
 #pragma unroll
@@ -1386,6 +1417,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
       mma_lds_packed<1, DTW, KB8>(acc, Ot, LDO, A.pVs, ntd);
+      HP(6)
 #pragma unroll
       for (int j = 0; j < DTW; ++j) {
         if (w + 4 * j >= NTD) continue;
@@ -1397,8 +1429,11 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
         }
       }
     }
-    stage();              // Ht / s_he / s_a / s_b were last read before the previous barrier
+    HP(7)
+    stage(tl);            // Ht / s_he / s_a / s_b were last read before the previous barrier
+    HP(8)
   }
+  HP_END
   if (!MODE) {
     float* hs = A.hslab + (size_t)blockIdx.x * A.hstride;
     if (tid < NB) hs[tid] += dbs_acc;
@@ -2105,9 +2140,29 @@ static hipError_t te_optin_lds() {
   return e;
 }
 
+#ifdef TE_HEAD_PROF
+static void te_head_prof_dump(const char* what) {
+  unsigned long long h[4][10];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_head_prof), sizeof(h)) != hipSuccess) return;
+  static const char* nm[10] = {"wait top barrier", "logits mfma + Ot write", "wait barrier 2", "prefetch + softmax", "wait barrier 3", "ge loads, DL copy, d bs", "DH mfma", "DH store", "stage", "-"};
+  for (int w = 0; w < 4; ++w) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 9; ++i) tot += h[w][i];
+    fprintf(stderr, "[te_head prof %s] wave %d: total %.3e cycles;", what, w, (double)tot);
+    for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%;", nm[i], 100.0 * (double)h[w][i] / (double)(tot ? tot : 1));
+    fprintf(stderr, "\n");
+  }
+  unsigned long long z[4][10] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_head_prof), z, sizeof(z)) != hipSuccess) return;
+}
+#endif
+
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
   hipError_t e = te_optin_lds();
   if (e != hipSuccess) return e;
+#ifdef TE_HEAD_PROF
+  struct Dump { ~Dump() { te_head_prof_dump("train launch"); } } dump_at_exit;
+#endif
   if (A.dim == 64) return te_train_t<64>(A, num_cu, st, tm);
   if (A.dim == 128) return te_train_t<128>(A, num_cu, st, tm);
   if (A.dim == 256) return te_train_t<256>(A, num_cu, st, tm);
