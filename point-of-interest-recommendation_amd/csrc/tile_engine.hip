@@ -1501,7 +1501,8 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_big_kern
   const int T = MODE ? A.n_seq : A.soff[A.n_seq];
   const float* __restrict__ Hsrc = MODE ? A.hts : A.H;
   const float* __restrict__ Esrc = A.E;
-  const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
+  const int w = wave_id();
+  int tid = threadIdx.x, lane = tid & 63, li = tid & 31;      // (re-derived per tile, see the loop)
   if ((int)blockIdx.x * 32 >= T) return;
   float ls0 = 0.f, ls1 = 1.f, wd = 0.f;
   {
@@ -1565,6 +1566,11 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_big_kern
   prefetch(blockIdx.x * 32);
   stage();
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    // (per-iteration copy of the thread id, as in te_head: address arithmetic is redone per tile instead of hoisted, spilled and
+    // reloaded behind s_waitcnt vmcnt(0); the lambdas above capture tid / lane / li by reference)
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63; li = tid & 31;
     lds_barrier();
     const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
     const int a = MODE ? 0 : s_a[row], b = MODE ? 0 : s_b[row];
