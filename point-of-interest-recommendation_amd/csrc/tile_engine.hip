@@ -1285,8 +1285,11 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
       *reinterpret_cast<float4*>(Ht + r * LDH + c) = make_float4(ph[q].x, ph[q].y, ph[q].z, ph[q].w);
       if (!MODE) {     // h . e of row r: sum over the LPR lanes that hold the row
         float d = (ph[q].x * pe[q].x + ph[q].y * pe[q].y) + (ph[q].z * pe[q].z + ph[q].w * pe[q].w);
+        // (butterfly inside 16 lanes on DPP - VALU latency; only the steps across 16-lane rows go through ds_bpermute: five serial
+        // LDS round trips per staged float4 were most of this function)
+        d += dpp_f<0xB1>(d); d += dpp_f<0x4E>(d); d += dpp_f<0x141>(d); d += dpp_f<0x140>(d);
 #pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+        for (int o = 16; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
         if ((tid % LPR) == 0) s_he[r] = d;
       }
     }
