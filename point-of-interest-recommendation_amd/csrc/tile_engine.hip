@@ -1776,6 +1776,14 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
 #pragma unroll
   for (int s = 0; s < F4; ++s) ni[s] = min((unsigned)gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)], nimax);
   auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4]) {
+    // The indices of the NEXT stage are requested first, the rows of this stage after them: vmcnt retires in order, so the wait for the
+    // indices at the top of the next call then leaves this call's twelve row loads in flight.  Requested last (as they were), that wait
+    // was s_waitcnt vmcnt(0) - every row load had one MFMA block to land instead of the two the pipeline is built for.
+    unsigned nc[F4];
+#pragma unroll
+    for (int s = 0; s < F4; ++s) nc[s] = ni[s];
+#pragma unroll
+    for (int s = 0; s < F4; ++s) ni[s] = min((unsigned)gidx[min(r0 + 32 + (tid + s * TE_BLOCK) / (T / 4), rmax)], nimax);
 #pragma unroll
     for (int s = 0; s < F4; ++s) {
       const int e = tid + s * TE_BLOCK;
@@ -1787,15 +1795,14 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
         // branch-free (a branch around a load drains the queue): both typed loads are always issued from valid addresses - the
         // half one from row 0 of the table when this job does not gather it, the float one from H when it does - and selected
         const bool hb = bsel == 0 && !gdi;
-        const float* bptr = (bsel == 0 && gdi) ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
+        const float* bptr = (bsel == 0 && gdi) ? gtab + (size_t)nc[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
         const float4 fv = *reinterpret_cast<const float4*>(bptr);
-        const float4 hv = ld4(reinterpret_cast<const __half*>(A.lt) + (hb ? goff + (size_t)ni[s] * D + c : (size_t)c));
+        const float4 hv = ld4(reinterpret_cast<const __half*>(A.lt) + (hb ? goff + (size_t)nc[s] * D + c : (size_t)c));
         rbv[s] = make_float4(hb ? hv.x : fv.x, hb ? hv.y : fv.y, hb ? hv.z : fv.z, hb ? hv.w : fv.w);
       } else {
-        const float* bptr = bsel == 0 ? gtab + (size_t)ni[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
+        const float* bptr = bsel == 0 ? gtab + (size_t)nc[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
         rbv[s] = *reinterpret_cast<const float4*>(bptr);
       }
-      ni[s] = min((unsigned)gidx[min(r0 + 32 + r, rmax)], nimax);                // indices of the next stage
     }
   };
   auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4]) {
