@@ -1774,16 +1774,18 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   // whatever an earlier launch left there must still be a valid row.  Found by tools/fuzz_engines.py: an aperture violation)
   const unsigned nimax = (unsigned)(gdi ? A.n_dist : A.n_item);
 #pragma unroll
-  for (int s = 0; s < F4; ++s) ni[s] = min((unsigned)gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)], nimax);
+  for (int s = 0; s < F4; ++s) ni[s] = (unsigned)gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)];
   auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4]) {
     // The indices of the NEXT stage are requested first, the rows of this stage after them: vmcnt retires in order, so the wait for the
     // indices at the top of the next call then leaves this call's twelve row loads in flight.  Requested last (as they were), that wait
     // was s_waitcnt vmcnt(0) - every row load had one MFMA block to land instead of the two the pipeline is built for.
+    // (ni holds the RAW loaded index and is clamped here, where it is consumed: clamped where it is loaded, the min sits right behind
+    // the load and the wave waits a memory latency for it before its MFMA block - 28 % of the kernel, -DTE_HEAD_PROF counters)
     unsigned nc[F4];
 #pragma unroll
-    for (int s = 0; s < F4; ++s) nc[s] = ni[s];
+    for (int s = 0; s < F4; ++s) nc[s] = min(ni[s], nimax);
 #pragma unroll
-    for (int s = 0; s < F4; ++s) ni[s] = min((unsigned)gidx[min(r0 + 32 + (tid + s * TE_BLOCK) / (T / 4), rmax)], nimax);
+    for (int s = 0; s < F4; ++s) ni[s] = (unsigned)gidx[min(r0 + 32 + (tid + s * TE_BLOCK) / (T / 4), rmax)];
 #pragma unroll
     for (int s = 0; s < F4; ++s) {
       const int e = tid + s * TE_BLOCK;
