@@ -1768,6 +1768,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   const float* gtab = (gdi ? A.di : A.lt) + goff;        // (F16 and !gdi: A.lt is re-read as half below, offsets in elements)
   const int* gidx = bsel == 0 ? (gdi ? A.row_dp : pp ? A.urow_p : A.row_p) : A.row_t;
   float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
+  uint2 rh0[F4], rh1[F4];            // F16: the raw half row of the d ui jobs (unused otherwise)
   int rt0[F4], rt1[F4];
   unsigned ni[F4];      // unsigned: a signed index is sign-extended right behind its load, i.e. the wave waits for it there
   // (clamped to the table: a launch WITHOUT steps - every sequence a single position - reads entry 0 of an index array nobody wrote;
@@ -1775,7 +1776,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   const unsigned nimax = (unsigned)(gdi ? A.n_dist : A.n_item);
 #pragma unroll
   for (int s = 0; s < F4; ++s) ni[s] = (unsigned)gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)];
-  auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4]) {
+  auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4], uint2 (&rh)[F4]) {
     // The indices of the NEXT stage are requested first, the rows of this stage after them: vmcnt retires in order, so the wait for the
     // indices at the top of the next call then leaves this call's twelve row loads in flight.  Requested last (as they were), that wait
     // was s_waitcnt vmcnt(0) - every row load had one MFMA block to land instead of the two the pipeline is built for.
@@ -1798,16 +1799,17 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
         // half one from row 0 of the table when this job does not gather it, the float one from H when it does - and selected
         const bool hb = bsel == 0 && !gdi;
         const float* bptr = (bsel == 0 && gdi) ? gtab + (size_t)nc[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
-        const float4 fv = *reinterpret_cast<const float4*>(bptr);
-        const float4 hv = ld4(reinterpret_cast<const __half*>(A.lt) + (hb ? goff + (size_t)nc[s] * D + c : (size_t)c));
-        rbv[s] = make_float4(hb ? hv.x : fv.x, hb ? hv.y : fv.y, hb ? hv.z : fv.z, hb ? hv.w : fv.w);
+        // (both stay RAW in registers until lstore: converted and selected here, the consumer sits right behind the loads and the wave
+        // waits a memory latency in front of its MFMA block - tools/scan_waits.py)
+        rbv[s] = *reinterpret_cast<const float4*>(bptr);
+        rh[s] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(A.lt) + (hb ? goff + (size_t)nc[s] * D + c : (size_t)c));
       } else {
         const float* bptr = bsel == 0 ? gtab + (size_t)nc[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
         rbv[s] = *reinterpret_cast<const float4*>(bptr);
       }
     }
   };
-  auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4]) {
+  auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4], const uint2 (&rh)[F4]) {
 #pragma unroll
     for (int s = 0; s < F4; ++s) {
       const int e = tid + s * TE_BLOCK;
@@ -1816,7 +1818,13 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
       // (component-wise selects: a select between float4 aggregates sends the arrays to scratch)
       const bool oa = in && c < acols, ob = in && rt[s] >= bshift;
       *reinterpret_cast<float4*>(&At[buf][r][c]) = make_float4(oa ? ra[s].x : 0.f, oa ? ra[s].y : 0.f, oa ? ra[s].z : 0.f, oa ? ra[s].w : 0.f);
-      *reinterpret_cast<float4*>(&Bt[buf][r][c]) = make_float4(ob ? rbv[s].x : 0.f, ob ? rbv[s].y : 0.f, ob ? rbv[s].z : 0.f, ob ? rbv[s].w : 0.f);
+      float4 bq = rbv[s];
+      if constexpr (F16) {
+        const bool hb = bsel == 0 && !gdi;
+        const float2 fa = __half22float2(*reinterpret_cast<const __half2*>(&rh[s].x)), fb = __half22float2(*reinterpret_cast<const __half2*>(&rh[s].y));
+        bq = make_float4(hb ? fa.x : bq.x, hb ? fa.y : bq.y, hb ? fb.x : bq.z, hb ? fb.y : bq.w);
+      }
+      *reinterpret_cast<float4*>(&Bt[buf][r][c]) = make_float4(ob ? bq.x : 0.f, ob ? bq.y : 0.f, ob ? bq.z : 0.f, ob ? bq.w : 0.f);
     }
   };
   // operands of MFMA step kk+1 are read from LDS before the MFMAs of step kk are issued (the compiler
@@ -1847,19 +1855,19 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   // around the loads the s_waitcnt vmcnt(n) before each LDS write is exact, i.e. it leaves the stage that
   // was fetched just before the MFMA block in flight.  A chunk is a multiple of 64 rows, so the odd stage
   // of the last iteration is the only work that can be empty.
-  gload(rb, ra0, rb0, rt0); lstore(0, rb, ra0, rb0, rt0);
-  gload(rb + 32, ra0, rb0, rt0);
+  gload(rb, ra0, rb0, rt0, rh0); lstore(0, rb, ra0, rb0, rt0, rh0);
+  gload(rb + 32, ra0, rb0, rt0, rh0);
   __syncthreads();
   for (int r0 = rb; r0 < re; r0 += 64) {
     // even stage: LDS buffer 0; set 0 holds stage +1, set 1 receives stage +2
-    gload(r0 + 64, ra1, rb1, rt1);
+    gload(r0 + 64, ra1, rb1, rt1, rh1);
     mma(0);
-    lstore(1, r0 + 32, ra0, rb0, rt0);
+    lstore(1, r0 + 32, ra0, rb0, rt0, rh0);
     __syncthreads();
     // odd stage: LDS buffer 1; set 1 holds stage +1, set 0 receives stage +2
-    gload(r0 + 96, ra0, rb0, rt0);
+    gload(r0 + 96, ra0, rb0, rt0, rh0);
     mma(1);
-    lstore(0, r0 + 64, ra1, rb1, rt1);
+    lstore(0, r0 + 64, ra1, rb1, rt1, rh1);
     __syncthreads();
   }
   float* out = A.slab + (size_t)kc * A.dl.total + oo;

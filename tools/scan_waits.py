@@ -46,3 +46,20 @@ for i in range(len(pos) - 1):
             vm = sum(1 for x in body if x[1].startswith(("global_", "buffer_", "scratch_")))
             if full and (mf or vm >= 8):
                 print("%-70s loop %5d instr, %3d mfma, %3d vmem: %d x vmcnt(0|1)" % (dem[:70], len(body), mf, vm, len(full)))
+            # second pattern: in an MFMA loop, a wait that targets a load issued with NO MFMA in between (its consumer was scheduled
+            # right behind the load: the wave sits out a memory latency instead of covering it with the MFMA block)
+            if mf >= 16:
+                ops, nm, hot = [], 0, 0
+                for x in body:
+                    if x[1].startswith("v_mfma"):
+                        nm += 1
+                    elif x[1].startswith(("global_load", "buffer_load", "scratch_load", "global_store", "buffer_store", "scratch_store", "global_atomic")):
+                        ops.append((nm, x[1].startswith(("global_load", "buffer_load", "scratch_load"))))
+                    elif x[1] == "s_waitcnt":
+                        m = re.search(r"vmcnt\((\d+)\)", x[2])
+                        if m and len(ops) > int(m.group(1)):
+                            at, is_load = ops[len(ops) - 1 - int(m.group(1))]
+                            if is_load and at == nm:
+                                hot += 1
+                if hot:
+                    print("%-70s loop %5d instr, %3d mfma: %d wait(s) for a load issued since the last MFMA" % (dem[:70], len(body), mf, hot))
