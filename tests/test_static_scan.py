@@ -1,0 +1,42 @@
+"""Static guard on the compiled gfx950 code of the training step's hot kernels (tools/scan_waits.py: llvm-objdump on the library's
+embedded code objects; no GPU).  It pins what DESIGN.md 5 describes as fixed in round 2: no spilled registers in te_head / te_wgrad /
+the recurrent kernels (a spill reload is `scratch_load` + `s_waitcnt vmcnt(0)` = a wait for every older store), and no load in te_wgrad's
+pipeline that is waited for before the next MFMA block (the index prefetch).  Skipped when the ROCm binary tools are not installed."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("scan_waits", os.path.join(ROOT, "tools", "scan_waits.py"))
+scan_waits = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(scan_waits)
+
+HOT = ["te_head_kernel<128, 7, 0>", "te_wgrad_kernel<128, 128, false>", "te_wgrad_kernel<128, 128, true>", "te_rec_fwd16_kernel<128, false, true>",
+       "te_rec_bwd16_kernel<128>", "te_gemm_ntk_kernel<false, true, 128, 128, 384, 128, 384, false, false>",
+       "te_gemm_ntk_kernel<false, false, 384, 0, 128, 384, 256, false, false>"]
+
+
+@pytest.fixture(scope="module")
+def records(tmp_path_factory):
+    import poi_amd
+    poi_amd.build.build_lib()                      # (no-op when the library is up to date)
+    if not scan_waits.available():
+        pytest.skip("llvm-objdump / clang-offload-bundler not installed")
+    return scan_waits.scan(HOT, tmp=str(tmp_path_factory.mktemp("scan")))
+
+
+def test_hot_kernels_are_found_and_do_not_spill(records):
+    kernels = {r["kernel"]: r for r in records if "loop" not in r}
+    for name in HOT:
+        assert name in kernels, "kernel %s not found in the library (renamed? update HOT)" % name
+        assert kernels[name]["spill"] == 0, "%s spills %d registers" % (name, kernels[name]["spill"])
+    # three te_head workgroups per CU need <= 168 registers; two te_wgrad / GEMM workgroups <= 256
+    assert kernels["te_head_kernel<128, 7, 0>"]["vgpr"] <= 168
+
+
+def test_wgrad_pipeline_never_waits_for_a_load_it_has_just_issued(records):
+    for r in records:
+        if "loop" in r and r["kernel"].startswith("te_wgrad_kernel") and r["mfma"] >= 64:
+            assert r["full_drains"] == 0, r
+            assert r["loads_waited_before_next_mfma"] == 0, r
