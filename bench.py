@@ -186,7 +186,7 @@ def main():
     barrier()
     dt = rank_max(time.perf_counter() - t0)
     KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_psum", "te_wgrad", "te_gemm_dx",
-          "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "rows_apply", "dense_apply"]
+          "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "te_tail", "rows_apply", "dense_apply"]
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
     seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
@@ -327,6 +327,11 @@ def main():
                 ent.update(bound="hbm", achieved=rate / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=rate / 1e9 / PEAK_HBM_GBS)
         if k == "te_finalize":
             ent["note"] = "runs on the side stream next to te_wgrad / te_gemm_dx: its span overlaps them and is not part of the serial sum"
+        if k in ("te_dsum", "te_bin_gemm", "te_scatter") and kt["te_tail"][1]:
+            ent["note"] = ("the distance-bin chain (te_dsum, te_bin_gemm; side stream) and te_scatter (POI rows) run CONCURRENTLY: their spans overlap and "
+                           "stretch each other (stand-alone: 0.37 / 0.14 / 0.44 ms per epoch, POI_TE_DBG=1) - te_tail is the fork-to-join span that counts")
+        if k == "te_tail":
+            ent["note"] = "fork-to-join span of te_dsum + te_bin_gemm (side stream) next to te_scatter; the serial sums below use it instead of the three"
         kernels[k] = ent
     dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
     # HBM traffic per launch from the COMMITTED PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
@@ -350,7 +355,8 @@ def main():
     roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
     # ---- gather / scatter against the HBM roofline: three accountings over the SAME kernel time --------------------
     GS = ("te_gather", "te_psum", "te_dsum", "te_scatter", "rows_apply")
-    gs_ms = sum(kernels[k]["ms_per_step"] for k in GS if k in kernels)
+    forked = "te_tail" in kernels          # te_dsum (+ te_bin_gemm) and te_scatter overlap: their time is the fork-to-join span
+    gs_ms = sum(kernels[k]["ms_per_step"] for k in GS if k in kernels and not (forked and k in ("te_dsum", "te_scatter"))) + (kernels["te_tail"]["ms_per_step"] if forked else 0.0)
     gs_impl = sum(work[k][1] for k in GS if k in kernels)
     e = 4.0
     survey_bytes = 3.0 * pos * D * e + 16.0 * pos + uniq_seq * D * e if uniq_seq else None      # SURVEY.md 8(d) bytes_seq, summed
@@ -370,7 +376,7 @@ def main():
     hbm["frac"] = (hbm["survey_8d"] or hbm["implementation"])["frac"]
     total_flops = step_flops(D, NB) * steps_per_epoch
     executed_flops = sum(w for k, (kind, w) in work.items() if kind == "flop" and k in kernels and k != "seq_train") or total_flops
-    train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels if k != "te_finalize")
+    train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels if k not in (("te_finalize", "te_dsum", "te_bin_gemm", "te_scatter") if forked else ("te_finalize", "te_tail")))
 
     solo = rank == 0 and world == 1 and not a.emulate_world
     # ---- the reference's own schedule on the GPU + learning quality at equal wall time --------------------------------

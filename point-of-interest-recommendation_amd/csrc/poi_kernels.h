@@ -24,6 +24,17 @@ struct Timing {
     recs.push_back(r); open_ = true;
   }
   void end(hipStream_t st) { if (open_) { (void)hipEventRecord(recs.back().b, st); open_ = false; } }
+  // a region that spans other regions (a fork / join over two streams): closed through its index; -1 = not recorded
+  long span_begin(const char* name, hipStream_t st) {
+    if (!on || recs.size() >= limit) return -1;
+    Rec r; r.name = name;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    (void)hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.b, st);          // (valid even if span_end is never reached)
+    recs.push_back(r);
+    return (long)recs.size() - 1;
+  }
+  void span_end(long idx, hipStream_t st) { if (idx >= 0 && (size_t)idx < recs.size()) (void)hipEventRecord(recs[(size_t)idx].b, st); }
   void clear() { for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } recs.clear(); }
  private:
   bool open_ = false;

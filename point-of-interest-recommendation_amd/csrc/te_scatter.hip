@@ -727,26 +727,38 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   int grid = (R + 3) / 4;
   if (grid > num_cu * 32) grid = num_cu * 32;
   if (A.side && hipStreamWaitEvent(st, A.ev_sorted, 0) != hipSuccess) return hipGetLastError();     // the sorted entries
+  // The distance-bin chain (per-bin sums of DA -> the two small dense products -> the bin rows' write-back) and the POI rows' reduction
+  // below touch disjoint rows and share only read-only inputs (the sorted entries, DA, H): with a side stream they run next to each
+  // other - te_dsum streams DA at HBM speed while te_reduce is a chain of dependent loads, and the five small kernels of the bin chain
+  // hide behind the reduction.  (The events of the training phase are free again: both streams passed them in launch_te_train.)
+  // Timing: the regions te_dsum / te_bin_gemm (side stream) and te_scatter then OVERLAP and stretch each other; `te_tail` spans fork to join.
+  const bool fork = A.bintab && A.side && !A.dbg;
+  hipStream_t sb = fork ? A.side : st;
+  const long tail = tm->span_begin("te_tail", st);
+  if (fork && (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(sb, A.ev_bwd, 0) != hipSuccess)) return hipGetLastError();
   if (A.bintab) {
     // the per-bin reduction of DA rows is scatter traffic (te_dsum: one pass over DA at HBM speed); the two small
     // dense products that follow (S . ui[:, D:], S^T . di) are timed on their own
-    tm->begin("te_dsum", st);
-    hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, st, A);
-    tm->end(st);
-    tm->begin("te_bin_gemm", st);
-    hipLaunchKernelGGL(te_dred_kernel<D>, dim3(num_cu * 2), dim3(3 * D), 0, st, A);
-    hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, st, A);
-    hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(4 * D), 0, st, A);
-    hipLaunchKernelGGL(te_dapply_kernel<D>, dim3(A.n_dist + 1), dim3(D), 0, st, A, alpha, lambda);
-    tm->end(st);
+    tm->begin("te_dsum", sb);
+    hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(256), 0, sb, A);
+    hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, sb, A);
+    tm->end(sb);
+    tm->begin("te_bin_gemm", sb);
+    hipLaunchKernelGGL(te_dred_kernel<D>, dim3(num_cu * 2), dim3(3 * D), 0, sb, A);
+    hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, sb, A);
+    hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(4 * D), 0, sb, A);
+    hipLaunchKernelGGL(te_dapply_kernel<D>, dim3(A.n_dist + 1), dim3(D), 0, sb, A, alpha, lambda);
+    tm->end(sb);
   }
+  if (fork && hipEventRecord(A.ev_fin, sb) != hipSuccess) return hipGetLastError();
   tm->begin("te_scatter", st);
   if (A.ppoi) hipLaunchKernelGGL((te_reduce_kernel<D, true>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   else hipLaunchKernelGGL((te_reduce_kernel<D, false>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu), dim3(256), 0, st, A, alpha, lambda);
   tm->end(st);
+  if (fork && hipStreamWaitEvent(st, A.ev_fin, 0) != hipSuccess) return hipGetLastError();       // join: dense_apply reads te_dui's slab
+  tm->span_end(tail, st);
   return hipGetLastError();
 }
 
