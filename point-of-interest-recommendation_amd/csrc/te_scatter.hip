@@ -732,7 +732,8 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   // other - te_dsum streams DA at HBM speed while te_reduce is a chain of dependent loads, and the five small kernels of the bin chain
   // hide behind the reduction.  (The events of the training phase are free again: both streams passed them in launch_te_train.)
   // Timing: the regions te_dsum / te_bin_gemm (side stream) and te_scatter then OVERLAP and stretch each other; `te_tail` spans fork to join.
-  const bool fork = A.bintab && A.side && !A.dbg;
+  // (large launches only: the two cross-stream dependencies cost ~35 us, more than the whole tail of a one-sequence launch)
+  const bool fork = A.bintab && A.side && !A.dbg && A.n_seq >= 2048;
   hipStream_t sb = fork ? A.side : st;
   const long tail = tm->span_begin("te_tail", st);
   if (fork && (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(sb, A.ev_bwd, 0) != hipSuccess)) return hipGetLastError();
