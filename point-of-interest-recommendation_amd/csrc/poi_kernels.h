@@ -66,7 +66,7 @@ struct SeqArgs {
 
 // te_wgrad's (job, K-chunk) grid: `slots` workgroups, nui d ui jobs contracting over P rows and (jobs - nui) jobs over T rows.  Every
 // workgroup should get the same number of rows: n_o chunks for the T-row jobs, n_u ~ n_o * P / T for the ui jobs, filling `slots`.
-__host__ __device__ inline void te_wgrad_split(int slots, int nui, int jobs, int P, int T, int* n_o, int* n_u) {
+__host__ __device__ inline void te_wgrad_split(int slots, int nui, int jobs, int P, int T, int* n_o, int* n_u, bool xcd = true) {
   float rho = (T > 0 && P > 0) ? (float)P / (float)T : 1.f;
   rho = rho < 0.02f ? 0.02f : rho > 1.f ? 1.f : rho;
   int o = (int)((float)slots / ((float)nui * rho + (float)(jobs - nui)));
@@ -74,6 +74,17 @@ __host__ __device__ inline void te_wgrad_split(int slots, int nui, int jobs, int
   int u = (int)((float)o * rho + 0.5f);
   if (u < 1) u = 1;
   while (o > 1 && nui * u + (jobs - nui) * o > slots) --o;
+  // A chunk count that is a multiple of 8 puts the T-row jobs of one K-chunk on ONE XCD (workgroup ids go round the 8 XCDs and the
+  // jobs of chunk kc sit n_o ids apart): they stream the same h / r*h rows at the same time, so four of the five reads of every H row hit
+  // that XCD's L2 instead of HBM.  The slots this frees go to the d ui jobs.
+  // (Only where it costs little: at >= 64 chunks the rounding lengthens a chunk by < 11 %; the d ui jobs never get more chunks than
+  // the T-row jobs, which is what the slabs are sized for.)
+  if (xcd && o >= 64) {
+    o &= ~7;
+    const int uu = (slots - (jobs - nui) * o) / (nui > 0 ? nui : 1);
+    if (nui > 0 && uu > u) u = uu < 2 * u ? uu : 2 * u;
+    if (u > o) u = o;
+  }
   *n_o = o; *n_u = u;
 }
 
