@@ -84,6 +84,7 @@ __host__ __device__ inline void te_wgrad_split(int slots, int nui, int jobs, int
     const int uu = (slots - (jobs - nui) * o) / (nui > 0 ? nui : 1);
     if (nui > 0 && uu > u) u = uu < 2 * u ? uu : 2 * u;
     if (u > o) u = o;
+    if (u >= 16) u &= ~7;          // (the d ui jobs of one chunk gather the same POI rows: same XCD for them too)
   }
   *n_o = o; *n_u = u;
 }
