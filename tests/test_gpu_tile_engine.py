@@ -499,3 +499,29 @@ def test_launch_without_a_single_step(pa, dim, n_dist, spatial):
     got = _get(model) if spatial else _get_gru(model)
     assert_step_close(got, exp, P, names, "launch without steps")
     model.ctx.set_engine("auto")
+
+
+def test_forked_write_back_is_bitwise_the_serial_one(pa, monkeypatch):
+    """Launches of >= 2048 sequences run the distance-bin chain (te_dsum .. te_dapply) on the side stream next to the POI rows' reduction
+    (te_scatter.hip).  The two touch disjoint rows and share only read-only inputs, so the result must be the serial launch's
+    (POI_TE_DBG=1) bit for bit - weights, tables and per-sequence losses - over two consecutive launches."""
+    T = toy_problem(1901, n_user=2400, n_item=2500, n_dist=200, dim=128, len_max=21, hot=300)
+    P = spatial_params(1901, T)
+    users = np.random.default_rng(5).permutation(2400).astype(np.int32)
+    res, outs = {}, {}
+    for mode in ("fork", "serial"):
+        if mode == "serial":
+            monkeypatch.setenv("POI_TE_DBG", "1")
+        else:
+            monkeypatch.delenv("POI_TE_DBG", raising=False)
+        model = _model(pa, T, P)
+        model.ctx.set_engine("tile")
+        o1 = np.asarray(model.train_batch(users))
+        o2 = np.asarray(model.train_batch(users[::-1].copy()))
+        outs[mode] = np.concatenate([o1, o2])
+        res[mode] = _get(model)
+    monkeypatch.delenv("POI_TE_DBG", raising=False)
+    pa._lib.context(0).set_engine("auto")
+    assert np.array_equal(outs["fork"], outs["serial"])
+    for k in SP_NAMES:
+        assert np.array_equal(res["fork"][k], res["serial"][k]), k
