@@ -88,8 +88,14 @@ int poi_ctx_num_cu(const poi_ctx* ctx);
  * n_dist+1 <= 2048 - also for a single sequence, where it is ~5x faster -, per-sequence engine otherwise; beyond 256 bins the
  * head runs bin-chunked with an online softmax and the distance-bin half of the input goes through the GEMMs again),
  * 1 = per-sequence engine, 2 = tile engine whenever supported, 3 = tile engine with the streaming recurrent kernels of
- * dim 256 (32-sequence tiles, weights streamed from L2) also at dim 128 - a testing aid.  Both implement the same arithmetic
- * (only the f32 summation order differs).  Also settable with POI_ENGINE=seq|tile. */
+ * dim 256 (32-sequence tiles, weights streamed from L2) also at dim 128 - a testing aid.  Engines 0 - 3 implement the same float32
+ * arithmetic (only the summation order differs).
+ * 4 = EXACT: float64 arithmetic end to end (exact_engine.hip; the reference's Theano floatX is float64, public/GRU.py:57) - the float32
+ * tables are converted when gathered and rounded to nearest once at the write-back, every intermediate (gates, hidden states, softmax,
+ * BPTT, dense and sparse gradient sums, the SGD update) is float64, and alpha / lambda are taken as the shortest decimals that round to
+ * the given floats (0.01f -> 0.01).  The opt-in mode for BASELINE.json's "weights within 1e-5 after one step" on EVERY row at the full
+ * shapes, where float32 BPTT misses it on ~0.1 % of the rows; any dim % 4 == 0 up to 256, <= 4095 bins, float32
+ * tables; ~30x slower than the tile engine.  Also settable with POI_ENGINE=seq|tile|exact. */
 int poi_ctx_set_engine(poi_ctx* ctx, int engine);
 /* hipGraph replay of the tile engine's training launch (poi_spatial_step / poi_gru_step): the ~40 kernels a launch enqueues on two
  * streams are captured once per launch shape (second launch with the same parameters / tables / n / alpha / lambda) and replayed with

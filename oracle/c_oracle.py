@@ -52,13 +52,14 @@ def score_topk(users, items, k):
     return out
 
 
-def spatial_batch_mean(P, off, p, q, dp, dq, ids, len_max, alpha, lam, threads=None, cap=1.0):
+def spatial_batch_mean(P, off, p, q, dp, dq, ids, len_max, alpha, lam, threads=None, cap=1.0, absmass=False):
     """Oracle side of the batch rule (include/poi_hip.h): every sequence's reference update evaluated at P, each
     table row moved by the MEAN of the deltas of the sequences touching it, dense tensors by the mean over all
     sequences; with cap > 1, min(k, cap) / k times the SUM of the k touching sequences' deltas
     (poi_ctx_set_batch_cap).  The launch is cut into `threads` slices run concurrently (ctypes releases the GIL); the slices'
     float64 accumulators are added in slice order.  Returns (P_new, out (n, 5), touched) with touched = dict of the
-    boolean row masks of lt / di.  P is not modified."""
+    boolean row masks of lt / di.  P is not modified.  absmass=True: touched also carries "absmass" = {tensor name: the same
+    combination of the sequences' |deltas|} - the scale a row's float32 summation noise is proportional to (tests/gpu_util)."""
     import concurrent.futures as cf
     import os as _os
     lib = load()
@@ -77,13 +78,17 @@ def spatial_batch_mean(P, off, p, q, dp, dq, ids, len_max, alpha, lam, threads=N
         acc_lt = np.zeros_like(A["lt"]); acc_di = np.zeros_like(A["di"])
         c_lt = np.zeros(n_item + 1, np.int32); c_di = np.zeros(n_dist + 1, np.int32)
         acc_d = np.zeros(nd)
+        ab_lt = np.zeros_like(A["lt"]) if absmass else None
+        ab_di = np.zeros_like(A["di"]) if absmass else None
+        ab_d = np.zeros(nd) if absmass else None
         o = np.zeros((hi - lo, 5))
         sl = np.ascontiguousarray(ids[lo:hi])
         lib.poi_oracle_spatial_batch(_d(A["lt"]), _d(A["di"]), _d(A["ui"]), _d(A["wh"]), _d(A["bi"]), _d(A["vs"]), _d(A["bs"]),
                                      _d(wd), _d(A["loss_weight"]), ctypes.c_int(n_item), ctypes.c_int(n_dist), ctypes.c_int(D),
                                      _i(off), _i(p), _i(q), _i(dp), _i(dq), _i(sl), ctypes.c_int(hi - lo), ctypes.c_int(int(len_max)),
-                                     ctypes.c_double(alpha), ctypes.c_double(lam), _d(acc_lt), _i(c_lt), _d(acc_di), _i(c_di), _d(acc_d), _d(o))
-        return acc_lt, c_lt, acc_di, c_di, acc_d, o
+                                     ctypes.c_double(alpha), ctypes.c_double(lam), _d(acc_lt), _i(c_lt), _d(acc_di), _i(c_di), _d(acc_d), _d(o),
+                                     _d(ab_lt) if absmass else None, _d(ab_di) if absmass else None, _d(ab_d) if absmass else None)
+        return acc_lt, c_lt, acc_di, c_di, acc_d, o, ab_lt, ab_di, ab_d
 
     with cf.ThreadPoolExecutor(T) as ex:
         parts = list(ex.map(run, range(T)))
@@ -102,4 +107,15 @@ def spatial_batch_mean(P, off, p, q, dp, dq, ids, len_max, alpha, lam, threads=N
         o += A[k].size
     N["wd"] = float(wd[0] + acc_d[o] * (min(n, cap) / n))
     N["loss_weight"] = A["loss_weight"] + acc_d[o + 1:o + 3] * (min(n, cap) / n)
-    return N, out, dict(lt=c_lt > 0, di=c_di > 0)
+    touched = dict(lt=c_lt > 0, di=c_di > 0)
+    if absmass:
+        ab_lt = sum(x[6] for x in parts); ab_di = sum(x[7] for x in parts); ab_d = sum(x[8] for x in parts)
+        M = {"lt": ab_lt * sc(c_lt)[:, None], "di": ab_di * sc(c_di)[:, None]}
+        o = 0
+        for k in ("ui", "wh", "bi", "vs", "bs"):
+            M[k] = ab_d[o:o + A[k].size].reshape(A[k].shape) * (min(n, cap) / n)
+            o += A[k].size
+        M["wd"] = float(ab_d[o] * (min(n, cap) / n))
+        M["loss_weight"] = ab_d[o + 1:o + 3] * (min(n, cap) / n)
+        touched["absmass"] = M
+    return N, out, touched

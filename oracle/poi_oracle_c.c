@@ -254,24 +254,31 @@ int poi_oracle_spatial_seq(double* lt, double* di, double* ui, double* wh, doubl
  * acc_dense = [ui | wh | bi | vs | bs | wd | lw0 | lw1].  The caller divides by the counts (rows) / n (dense) -
  * possibly after adding up the accumulators of several threads, each of which ran a slice of the launch.
  * out5 (n x 5) receives the per-sequence losses.  Nothing in the parameter arrays is modified. */
-typedef struct { double *lt, *di; int *clt, *cdi; int D; } acc_ctx;
+typedef struct { double *lt, *di; int *clt, *cdi; int D; double *alt, *adi; } acc_ctx;
 static void emit_acc(void* c, int table, int row, const double* d) {
   acc_ctx* x = c;
   double* tr = (table ? x->di : x->lt) + (size_t)row * x->D;
   for (int j = 0; j < x->D; ++j) tr[j] += d[j];
   (table ? x->cdi : x->clt)[row] += 1;
+  double* ab = table ? x->adi : x->alt;
+  if (ab) { ab += (size_t)row * x->D; for (int j = 0; j < x->D; ++j) ab[j] += fabs(d[j]); }
 }
 
 int poi_oracle_spatial_batch(const double* lt, const double* di, const double* ui, const double* wh, const double* bi,
                              const double* vs, const double* bs, const double* wd_p, const double* lw, int n_item, int n_dist, int D,
                              const int* off, const int* p, const int* q, const int* dp, const int* dq,
                              const int* ids, int n, int len_max, double alpha, double lam,
-                             double* acc_lt, int* cnt_lt, double* acc_di, int* cnt_di, double* acc_dense, double* out5) {
+                             double* acc_lt, int* cnt_lt, double* acc_di, int* cnt_di, double* acc_dense, double* out5,
+                             double* abs_lt, double* abs_di, double* abs_dense) {
+  /* abs_* (optional, may be NULL): the same accumulators over |delta| - a row's "absolute mass", the scale float32
+   * summation noise of a hot row is proportional to (tests/gpu_util.delta_excess) */
   const int NB = n_dist + 1, XW = 2 * D;
   const double wd = *wd_p;
   const size_t n_ui = (size_t)3 * D * XW, n_wh = (size_t)3 * D * D, n_bi = 3 * D, n_vs = (size_t)NB * D, n_bs = NB;
   double *a_ui = acc_dense, *a_wh = a_ui + n_ui, *a_bi = a_wh + n_wh, *a_vs = a_bi + n_bi, *a_bs = a_vs + n_vs, *a_sc = a_bs + n_bs;
-  acc_ctx c = {acc_lt, acc_di, cnt_lt, cnt_di, D};
+  acc_ctx c = {acc_lt, acc_di, cnt_lt, cnt_di, D, abs_lt, abs_di};
+  double* b_ui = abs_dense; double *b_wh = NULL, *b_bi = NULL, *b_vs = NULL, *b_bs = NULL, *b_sc = NULL;
+  if (abs_dense) { b_wh = b_ui + n_ui; b_bi = b_wh + n_wh; b_vs = b_bi + n_bi; b_bs = b_vs + n_vs; b_sc = b_bs + n_bs; }
   for (int k = 0; k < n; ++k) {
     const int u = ids[k], b = off[u], L = off[u + 1] - b;
     seq_grad G;
@@ -290,6 +297,15 @@ int poi_oracle_spatial_batch(const double* lt, const double* di, const double* u
       const double d0 = G.sur + lam * G.ls0, d1 = G.upq + lam * G.ls1, dt = d0 * G.ls0 + d1 * G.ls1;
       a_sc[1] -= alpha * G.ls0 * (d0 - dt);
       a_sc[2] -= alpha * G.ls1 * (d1 - dt);
+      if (abs_dense) { b_sc[1] += fabs(alpha * G.ls0 * (d0 - dt)); b_sc[2] += fabs(alpha * G.ls1 * (d1 - dt)); }
+    }
+    if (abs_dense) {
+      for (size_t i = 0; i < n_ui; ++i) b_ui[i] += fabs(alpha * (g_ui[i] + lam * ui[i]));
+      for (size_t i = 0; i < n_wh; ++i) b_wh[i] += fabs(alpha * (g_wh[i] + lam * wh[i]));
+      for (size_t i = 0; i < n_bi; ++i) b_bi[i] += fabs(alpha * (g_bi[i] + lam * bi[i]));
+      for (size_t i = 0; i < n_vs; ++i) b_vs[i] += fabs(alpha * (g_vs[i] + lam * vs[i]));
+      for (size_t i = 0; i < n_bs; ++i) b_bs[i] += fabs(alpha * (g_bs[i] + lam * bs[i]));
+      b_sc[0] += fabs(alpha * (G.g_wd + lam * wd));
     }
     seq_grad_free(&G);
   }

@@ -154,8 +154,8 @@ class Context:
         return self.lib.poi_ctx_num_cu(self.handle)
 
     def set_engine(self, name):
-        """'auto' | 'seq' | 'tile' | 'tile32' (see poi_ctx_set_engine)."""
-        self.check(self.lib.poi_ctx_set_engine(self.handle, {"auto": 0, "seq": 1, "tile": 2, "tile32": 3}[name]))
+        """'auto' | 'seq' | 'tile' | 'tile32' | 'exact' (float64 arithmetic; see poi_ctx_set_engine)."""
+        self.check(self.lib.poi_ctx_set_engine(self.handle, {"auto": 0, "seq": 1, "tile": 2, "tile32": 3, "exact": 4}[name]))
 
     def set_graph(self, on, min_n=0, max_n=1 << 30):
         """hipGraph replay of the tile engine's training launches (poi_ctx_set_graph)."""

@@ -27,7 +27,8 @@ struct poi_ctx {
   std::string err;
   // per-sequence engine
   DevBuf ws, slab, te_ws, hslab, zrow;
-  int engine = 0;   // 0 auto, 1 per-sequence, 2 tile
+  DevBuf ex_ws, ex_slab, ex_glt, ex_gdi;      // exact (float64) engine
+  int engine = 0;   // 0 auto, 1 per-sequence, 2 tile, 3 tile with streaming recurrent kernels, 4 exact (float64)
   float batch_cap = 1.0f;   // poi_ctx_set_batch_cap
   int wgrad_rounds = 2;
   int head_rounds = 3;      // workgroups per CU for te_head (POI_HEAD_ROUNDS, tuning)     // workgroups per CU for te_wgrad (POI_WGRAD_ROUNDS, tuning)
@@ -128,7 +129,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_CARNN_FAST")) c->carnn_fast = atoi(e) != 0;
   if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
-  if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; }
+  if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; else if (!strcmp(e, "exact")) c->engine = 4; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   const char* sd = getenv("POI_TE_SIDE");
   if (!sd || atoi(sd) != 0) {
@@ -153,7 +154,7 @@ static void drop_graphs(poi_ctx* c) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
+  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
   (void)hipDeviceSynchronize();
   c->tm.clear();
@@ -283,8 +284,60 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
 // GEMVs streamed from L2 by one workgroup), 7x at 16 and 64.  The per-sequence engine serves the other dims / bin counts.
 static bool use_tile(const poi_ctx* c, const poi_gru_params* P, bool spatial, int n) {
   (void)n;
-  if (c->engine == 1 || !poi::te_supported(P->dim, spatial ? P->n_dist : -1)) return false;
+  if (c->engine == 1 || c->engine == 4 || !poi::te_supported(P->dim, spatial ? P->n_dist : -1)) return false;
   return true;
+}
+
+// The caller's float32 alpha / lambda are the nearest floats to short decimals (0.01, 0.001: prog_bpr_gru_spatial.py:66-67); the
+// float64 engine takes the SHORTEST decimal that rounds to the given float - 0.01, not 0.00999999977648 - so that its step equals
+// the float64 reference's to rounding, not to 2e-8.
+static double shortest_decimal(float x) {
+  char buf[64];
+  for (int prec = 1; prec <= 9; ++prec) {
+    snprintf(buf, sizeof buf, "%.*g", prec, (double)x);
+    if (strtof(buf, nullptr) == x) return strtod(buf, nullptr);
+  }
+  return (double)x;
+}
+
+static void fill_ex(poi::ExArgs& A, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int n) {
+  memset(&A, 0, sizeof A);
+  A.lt = P->lt; A.di = P->di; A.ui = P->ui; A.wh = P->wh; A.bi = P->bi; A.vs = P->vs; A.bs = P->bs; A.wd = P->wd; A.lw = P->lw;
+  A.n_item = P->n_item; A.n_dist = P->n_dist; A.dim = P->dim;
+  A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq;
+  A.len_max = T->len_max; A.cap = T->max_len;
+  A.uidx = uidx; A.n_seq = n; A.bcap = 1.0f;
+}
+
+// engine 4: float64 arithmetic end to end (exact_engine.hip)
+static int exact_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
+                      float alpha, float lambda, float* out, hipStream_t st, bool spatial) {
+  if (is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "the exact engine supports float32 tables only");
+  const int D = P->dim, XW = spatial ? 2 * D : D, NB = spatial ? P->n_dist + 1 : 0;
+  if (NB > 4096) return fail(c, POI_ENOTSUP, "the exact engine supports at most 4095 distance bins");
+  int grid = c->num_cu * c->wg_per_cu;
+  if (grid > n) grid = n;
+  const poi::DenseLayout dl = poi::dense_layout(D, XW, NB);
+  const size_t wsd = poi::ex_ws_doubles(D, NB, T->max_len);
+  int rc;
+  if ((rc = ensure(c, c->ex_ws, sizeof(double) * wsd * grid, st))) return rc;
+  if ((rc = ensure(c, c->ex_slab, sizeof(double) * (size_t)dl.total * grid, st))) return rc;
+  if ((rc = ensure(c, c->ex_glt, sizeof(double) * (size_t)(P->n_item + 1) * D, st))) return rc;
+  if ((rc = ensure(c, c->mult_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
+  if ((rc = ensure(c, c->nseq_lt, sizeof(int) * (size_t)(P->n_item + 1), st))) return rc;
+  if (spatial) {
+    if ((rc = ensure(c, c->ex_gdi, sizeof(double) * (size_t)(P->n_dist + 1) * D, st))) return rc;
+    if ((rc = ensure(c, c->mult_di, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
+    if ((rc = ensure(c, c->nseq_di, sizeof(int) * (size_t)(P->n_dist + 1), st))) return rc;
+  }
+  poi::ExArgs A;
+  fill_ex(A, P, T, uidx, n);
+  A.out = out; A.bcap = c->batch_cap == 0.0f ? -(float)n : c->batch_cap;
+  A.ws = (double*)c->ex_ws.p; A.ws_stride = wsd; A.slab = (double*)c->ex_slab.p;
+  A.g_lt = (double*)c->ex_glt.p; A.g_di = (double*)c->ex_gdi.p;
+  A.mult_lt = (int*)c->mult_lt.p; A.nseq_lt = (int*)c->nseq_lt.p; A.mult_di = (int*)c->mult_di.p; A.nseq_di = (int*)c->nseq_di.p;
+  HIPCHK(c, poi::launch_ex_train(A, spatial, grid, shortest_decimal(alpha), shortest_decimal(lambda), st, &c->tm));
+  return POI_OK;
 }
 
 static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T, const int32_t* uidx, int32_t n,
@@ -295,6 +348,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (n == 0) return POI_OK;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->engine == 4) return exact_step(c, P, T, uidx, n, alpha, lambda, out, st, spatial);
   const int D = P->dim, XW = spatial ? 2 * D : D, NB = spatial ? P->n_dist + 1 : 0;
   int grid = c->num_cu * c->wg_per_cu;
   if (grid > n) grid = n;
@@ -448,11 +502,19 @@ int poi_gru_predict(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     return POI_OK;
   }
   if (is_f16(c, P->lt)) return fail(c, POI_ENOTSUP, "a half POI table needs the tile engine (dim 64 / 128 / 256, <= 2048 bins)");
+  int grid = c->num_cu * c->wg_per_cu;
+  if (grid > n) grid = n;
+  if (c->engine == 4) {
+    if (spatial && P->n_dist + 1 > 4096) return fail(c, POI_ENOTSUP, "the exact engine supports at most 4095 distance bins");
+    poi::ExArgs X;
+    fill_ex(X, P, T, uidx, n);
+    X.hts = hts; X.sts = sts; X.out_row = out_row;
+    HIPCHK(c, poi::launch_ex_predict(X, spatial, grid, (hipStream_t)stream, &c->tm));
+    return POI_OK;
+  }
   poi::SeqArgs A;
   fill_args(A, P, T, uidx, n);
   A.hts = hts; A.sts = sts; A.out_row = out_row;
-  int grid = c->num_cu * c->wg_per_cu;
-  if (grid > n) grid = n;
   HIPCHK(c, poi::launch_seq_predict(A, spatial, grid, (hipStream_t)stream, &c->tm));
   return POI_OK;
 }
@@ -604,6 +666,10 @@ struct UlptaiArg { const void* bins; int bin_bytes; const float* sts; int n_dist
 static int score_common(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,
                         const float* wd, const float* prob, float* scores, int32_t k, int32_t* idx_out, float* score_out,
                         void* stream, const UlptaiArg* U = nullptr) {
+  // the top-K seed is "consumed by the next call" whatever that call does: taken (and cleared) before any early return, so a failed or
+  // empty call can never leave a stale pointer - sized for another n - armed for a later one
+  const int32_t* seed_idx = c ? c->seed_idx : nullptr; const int seed_k = c ? c->seed_k : 0;
+  if (c) { c->seed_idx = nullptr; c->seed_k = 0; }
   if (!c || !users || !items) return fail(c, POI_EINVAL, "score: NULL argument");
   if (dim <= 0 || dim % 4 != 0 || dim > 256) return fail(c, POI_ENOTSUP, "dim must be a multiple of 4 in [4, 256] (got %d)", dim);
   if (n < 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
@@ -644,7 +710,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     if ((rc = ensure(c, c->cand_s, sizeof(float) * cand, st))) return rc;
     if ((rc = ensure(c, c->cand_i, sizeof(int) * cand, st))) return rc;
     A.cand_score = (float*)c->cand_s.p; A.cand_idx = (int*)c->cand_i.p;
-    const bool seeded = c->seed_idx && c->seed_k >= k && c->seed_k <= 64;
+    const bool seeded = seed_idx && seed_k >= k && seed_k <= 64;
     if (n_split > 1 || seeded) {
       if ((rc = ensure(c, c->gbound, sizeof(unsigned) * (size_t)n_pad, st))) return rc;
       HIPCHK(c, hipMemsetAsync(c->gbound.p, 0, sizeof(unsigned) * (size_t)n_pad, st));
@@ -652,12 +718,11 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     }
     if (seeded) {
       c->tm.begin("topk_seed", st);
-      HIPCHK(c, poi::launch_topk_seed(A, c->seed_idx, c->seed_k, st));
+      HIPCHK(c, poi::launch_topk_seed(A, seed_idx, seed_k, st));
       c->tm.end(st);
       A.seeded = 1;
     }
   }
-  c->seed_idx = nullptr; c->seed_k = 0;
   if (variant == 2) {
     const int d8 = dim <= 128 ? 16 : 32;
     if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
@@ -818,7 +883,7 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
 }
 
 int poi_ctx_set_engine(poi_ctx* c, int engine) {
-  if (!c || engine < 0 || engine > 3) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence), 2 (tile) or 3 (tile, streaming recurrent kernels)");
+  if (!c || engine < 0 || engine > 4) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence), 2 (tile), 3 (tile, streaming recurrent kernels) or 4 (exact: float64)");
   c->engine = engine;
   return POI_OK;
 }

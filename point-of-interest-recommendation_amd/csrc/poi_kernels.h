@@ -203,6 +203,26 @@ hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alp
 hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, int n_slab_head, float alpha, float lambda, hipStream_t st, Timing* tm);
 
 size_t seq_ws_floats(int D, int NB, int cap);
+
+// Arguments of the exact (float64) engine, exact_engine.hip: SeqArgs with float64 scratch.  Tables stay float32.
+struct ExArgs {
+  float *lt, *di, *ui, *wh, *bi, *vs, *bs, *wd, *lw;
+  int n_item, n_dist, dim;
+  const int *off, *p, *q, *dp, *dq;
+  int len_max, cap;
+  const int* uidx;
+  int n_seq;
+  float* out;
+  double* ws; size_t ws_stride;     // per-workgroup activations (float64)
+  double* slab;                     // per-workgroup dense-gradient slabs (float64)
+  double *g_lt, *g_di;              // zero-initialised float64 gradient tables
+  int *mult_lt, *nseq_lt, *mult_di, *nseq_di;
+  float *hts, *sts; const int* out_row;
+  float bcap;
+};
+size_t ex_ws_doubles(int D, int NB, int cap);
+hipError_t launch_ex_train(const ExArgs& A, bool spatial, int grid, double alpha, double lambda, hipStream_t st, Timing* tm);
+hipError_t launch_ex_predict(const ExArgs& A, bool spatial, int grid, hipStream_t st, Timing* tm);
 hipError_t launch_seq_train(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
 hipError_t launch_seq_predict(const SeqArgs& A, bool spatial, int grid, hipStream_t st, Timing* tm);
 

@@ -650,7 +650,10 @@ __global__ __launch_bounds__(SG_NW * 64) void score_kernel_geo_stream(ScoreArgs 
       for (int b = lane; b < NB; b += 64) mx = fmaxf(mx, wd * A.sts[(size_t)(ut * 32 + u) * NB + b]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-      if (lane == 0) s_ub[u] = mx;
+      // The epilogue's score is ONE rounding of the exact acc + wd * pv (hipcc contracts it to an FMA), while mx is a maximum of ROUNDED
+      // products: widened by 2^-21 it is >= every exact product wd * sts[b] (fl(x) >= x (1 - 2^-24)), and rounding is monotone, so
+      // fl(acc + ub) >= fl(acc + wd * pv) for every pair - a pair the bound prunes could not have beaten the threshold.
+      if (lane == 0) s_ub[u] = mx * 1.00000048f;
     }
   }
   __syncthreads();

@@ -7,19 +7,29 @@
 // of a single process over all users), MEAN (model averaging) or MEAN_TOUCHED (per table row: mean over the replicas
 // that moved the row - the launch-level batch rule of include/poi_hip.h one level up).
 //
-// RCCL is bound at run time (dlopen of the librccl.so.1 the process already holds - torch's - or the system one), so
-// the library itself links against nothing but the HIP runtime and loads on a box without RCCL.
+// RCCL is bound at run time (dlopen of the librccl the process already holds - torch maps its copy as librccl.so - or the system
+// one), so the library itself links against nothing but the HIP runtime and both builds and loads on a box without RCCL: the
+// handful of nccl types / enum values the five entry points need are declared here (ABI-stable since NCCL 2.0), not included.
 #include "../../include/poi_hip.h"
 #include "poi_common.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <mutex>
 #include <string>
 #include <vector>
+
+// ---- the slice of the NCCL / RCCL C API this file binds (rccl.h: ncclResult_t, ncclUniqueId, ncclComm_t, ncclDataType_t, ncclRedOp_t)
+typedef int ncclResult_t;
+enum { ncclSuccess = 0 };
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclDataType_t;
+enum { ncclFloat32 = 7 };
+typedef int ncclRedOp_t;
+enum { ncclSum = 0 };
 
 namespace poi {
 
@@ -37,8 +47,11 @@ static Rccl* rccl() {
   static Rccl R;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy this process already mapped (torch's)
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    // first the copy this process already mapped, under either soname (torch ships torch/lib/librccl.so): a second RCCL of another
+    // version in one process is what must not happen
+    void* h = nullptr;
+    for (int i = 0; !h && i < 2; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
     for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!h) { R.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
     R.h = h;

@@ -70,15 +70,12 @@ def bin_thresholds(dd, dist_num):
 
 
 def cos_lat(coords):
-    """cos(lat * pi/180) per POI with the scalar libm cos the reference calls (cal_dis :35).  numpy's float64 cos is the same libm
-    routine on the platforms tested (checked element by element on the first 4096 POIs, scalar fallback otherwise)."""
+    """cos(lat * pi/180) per POI with the SCALAR libm cos the reference calls (cal_dis :35) - always: numpy's vectorised float64 cos
+    is a SIMD routine that is not correctly rounded and may differ from libm in the last bit on rare inputs, and one ulp of cos(lat)
+    can flip a distance bin at a threshold.  ~0.15 us per POI (1.5 s at 10 M POIs, once per data set)."""
     import math
     lat = np.asarray(coords)[:, 0].astype(np.float64) * DEG
-    out = np.cos(lat)
-    head = np.array([math.cos(float(v)) for v in lat[:4096]], np.float64)
-    if not np.array_equal(out[:len(head)], head):
-        out = np.array([math.cos(float(v)) for v in lat], np.float64)
-    return out
+    return np.fromiter(map(math.cos, lat.tolist()), np.float64, count=len(lat))
 
 
 def padded_to_csr(rows, lens):

@@ -55,6 +55,8 @@ class HipSyncBackend:
         segs = (_lib.SyncSeg * len(self.tensors))()
         for s, t, r in zip(segs, self.tensors, rules):
             width = t.shape[-1] if t.dim() >= 1 and t.shape[-1] > 0 else 1
+            if r == "mean_touched" and t.dim() > 2:
+                width = t.numel() // t.shape[0]          # a table of matrices (CA-RNN's interval matrices): one matrix = one row
             s.cur, s.rows, s.width, s.rule = t.data_ptr(), t.numel() // width, width, RULES[r]
             s.dtype = 1 if t.dtype == torch.float16 else 0
         h = ctypes.c_void_p()
@@ -213,7 +215,12 @@ class ReplicaSync:
 
 
 def model_sync(model, names=None, rules=None, **kw):
-    """ReplicaSync over a model's parameters with DEFAULT_RULES (override per name with rules={...})."""
-    names = names or [n for n in ("lt", "di", "ux", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight") if hasattr(model, n)]
+    """ReplicaSync over EVERY trainable tensor of a model with DEFAULT_RULES (override per name with rules={...}).  The names come
+    from the model class (`sync_names`: the tables + model.params - CA-RNN: lt, wd, M) or, failing that, from the attributes the
+    model has; a `wd` that is a table of matrices (CA-RNN) takes the "wd_table" rule, the Distance2Pre scalar the "wd" rule."""
+    names = names or getattr(model, "sync_names", None) or \
+        [n for n in ("lt", "di", "ux", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight", "M") if hasattr(getattr(model, n, None), "t")]
+    names = list(names)
     r = dict(DEFAULT_RULES); r.update(rules or {})
-    return ReplicaSync([getattr(model, n).t for n in names], rules=[r[n] for n in names], ctx=model.ctx, names=names, **kw)
+    key = lambda n: "wd_table" if (n == "wd" and getattr(model, n).t.dim() >= 3 and "wd" not in (rules or {})) else n
+    return ReplicaSync([getattr(model, n).t for n in names], rules=[r[key(n)] for n in names], ctx=model.ctx, names=names, **kw)

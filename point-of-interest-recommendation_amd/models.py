@@ -702,6 +702,7 @@ class OboCARNN(GruBasic):
 
     spatial = True          # has distance-bin tables (negatives refresh computes dq)
     _pad_ok = False
+    sync_names = ("lt", "wd", "M")      # every trainable tensor (dist.model_sync): POI table, interval matrices, input matrix
 
     def __init__(self, train, test, dist, alpha_lambda, n_user, n_item, n_dists, n_in, n_hidden, ulptai=None,
                  device="cuda:0", init=None, seed=None, coords=None):

@@ -1,8 +1,12 @@
 """-m gpu: BASELINE.json's full shapes.  (1) The TIMED path against the oracle: a 12500-user launch of the
-Gowalla shape (configs[2]: what bench.py times) and the whole-shard launch + a sequential reference-schedule
+Gowalla shape in EXACTLY bench.py's configuration (configs[2]: data with 80 % local transitions - skewed distance
+bins -, batch cap 64, users sorted by length) and the whole-shard launch + a sequential reference-schedule
 run of the Foursquare shape (configs[1]) are compared with the plain-C float64 restatement of the batch rule /
 the sequential epoch (oracle/poi_oracle_c.c, threaded over the launch), all nine tensors, weights within 1e-5
-AND updates within 1e-4 per row.  (2) Size-independent properties at the Gowalla shape (100 k POIs, 50 k users,
+AND updates within 1e-4 of every ROW's own absolute mass (tests/gpu_util.delta_excess with absmass) - for the float32
+tile engine with the documented loosening of the POI table (FULL_SIZE_LT), and for the EXACT engine (float64 arithmetic,
+poi_ctx_set_engine(4)) with no loosening at all: every row of every tensor inside 1e-5, every update inside 1e-6 of its mass,
+300 sequential steps inside 1e-5.  (2) Size-independent properties at the Gowalla shape (100 k POIs, 50 k users,
 L <= 50, D = 128, 200 bins):
   * a 12500-user launch leaves every table row that no sequence of the launch touches bit-identical,
     moves every touched row, keeps everything finite and is bitwise reproducible (lt / di);
@@ -24,7 +28,7 @@ def setup():
     import poi_amd
     from poi_amd import data as pdata
     n_item, n_user, max_len, D = pdata.SHAPES["gowalla"]
-    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=77)
+    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=77, local=0.8)      # bench.py's generator setting (--local 0.8)
     tab = ds.shard(0, n_user)
 
     def model():
@@ -103,12 +107,13 @@ def _state(m):
     return out
 
 
-def test_gowalla_timed_launch_matches_the_oracle_batch_rule(setup):
-    """One 12500-user launch of bench.py's configuration (tile engine, per-bin tables, sorted scatter) against the
-    float64 oracle of the batch rule on the same launch: per-sequence losses, the nine tensors to 1e-5 of their
-    max-norm and every row's UPDATE to 1e-4 (tests/gpu_util.assert_delta_close)."""
+BENCH_CAP = 64.0      # bench.py --batch-cap
+
+
+def _gowalla_launch(setup, engine):
+    """One 12500-user launch of bench.py's configuration (local transitions, cap 64, length-sorted) on `engine` and the float64 oracle
+    of the same launch with the rows' absolute masses."""
     from oracle import c_oracle as C
-    from tests.gpu_util import FULL_SIZE_LT, assert_close, assert_step_close, rows_within
     pa, ds, tab, make = setup
     users = np.random.default_rng(5).permutation(ds.n_user)[:12500].astype(np.int32)
     lens = np.diff(tab.off.astype(np.int64))
@@ -116,29 +121,86 @@ def test_gowalla_timed_launch_matches_the_oracle_batch_rule(setup):
     m = make()
     P = _state(m)
     P["h0"] = np.zeros(P["lt"].shape[1])
-    out = np.asarray(m.train_batch(users))
+    m.ctx.set_engine(engine); m.ctx.set_batch_cap(BENCH_CAP)
+    try:
+        out = np.asarray(m.train_batch(users))
+    finally:
+        m.ctx.set_engine("auto"); m.ctx.set_batch_cap(1.0)
     got = _state(m)
-    exp, eout, touched = C.spatial_batch_mean(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, users, tab.len_max, 0.01, 0.001)
+    key = "gowalla_oracle"
+    if key not in _CACHE:
+        _CACHE[key] = C.spatial_batch_mean(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, users, tab.len_max, 0.01, 0.001, cap=BENCH_CAP, absmass=True)
+    exp, eout, touched = _CACHE[key]
+    return P, out, got, exp, eout, touched
+
+
+_CACHE = {}
+
+
+def test_gowalla_timed_launch_matches_the_oracle_batch_rule(setup):
+    """The float32 tile engine (per-bin tables, per-POI regrouping, three-level per-bin sums, sorted scatter, te_dapply) on the TIMED
+    configuration against the float64 oracle of the capped-sum rule: per-sequence losses, the nine tensors to 1e-5 of their
+    max-norm (lt: FULL_SIZE_LT) and every row's UPDATE to 1e-4 of the row's own absolute mass."""
+    from tests.gpu_util import FULL_SIZE_LT, assert_close, assert_step_close, rows_within
+    P, out, got, exp, eout, touched = _gowalla_launch(setup, "auto")
     assert_close(out[:, :3], eout[:, :3], "losses of the launch", rtol=2e-5)
-    worst = assert_step_close(got, exp, P, SP_NAMES, "gowalla 12500-user launch", loose=FULL_SIZE_LT)
+    worst = assert_step_close(got, exp, P, SP_NAMES, "gowalla 12500-user launch", loose=FULL_SIZE_LT, absmass=touched["absmass"])
     assert rows_within(got["lt"], exp["lt"]) >= 0.999, "more than 0.1 % of the POI rows miss the 1e-5 bar"
     assert np.array_equal((got["lt"] != P["lt"]).any(axis=1), touched["lt"])
-    print("gowalla launch vs oracle: worst weight rel err %.2e" % worst)
+    print("gowalla launch vs oracle (float32 tile engine): worst weight rel err %.2e" % worst)
+
+
+def test_gowalla_timed_launch_exact_engine_meets_the_contract_on_every_row(setup):
+    """The same launch on the exact engine: NO loosening - all nine tensors within 1e-5 (max-norm, i.e. every row), every row's
+    update within 1e-6 of its absolute mass + the float32 storage rounding, losses to 1e-6."""
+    from tests.gpu_util import EXACT_DELTA_RTOL, assert_close, assert_step_close, rows_within
+    P, out, got, exp, eout, touched = _gowalla_launch(setup, "exact")
+    assert_close(out[:, :3], eout[:, :3], "losses of the launch (exact)", rtol=1e-6)
+    worst = assert_step_close(got, exp, P, SP_NAMES, "gowalla 12500-user launch, exact engine", delta_rtol=EXACT_DELTA_RTOL, absmass=touched["absmass"])
+    assert rows_within(got["lt"], exp["lt"], rtol=1e-6) == 1.0
+    assert np.array_equal((got["lt"] != P["lt"]).any(axis=1), touched["lt"])
+    print("gowalla launch vs oracle (exact engine): worst weight rel err %.2e" % worst)
+
+
+def test_delta_bar_catches_a_padding_multiplicity_off_by_one_at_the_gowalla_shape(setup):
+    """What the per-row bar is for, at full size.  A write-back whose L2 multiplicity of a padding row is off by one in every
+    sequence (2 (len_max - L) + 1) shifts the row by min(k, cap) alpha lambda |row| = 64 x 5e-6; the exact engine's bar (1e-6 of the row's absolute mass) flags it on lt AND on di (whose padding row also sums every
+    sequence's position-0 input gradient).  And ONE L2-decay term (alpha lambda |row| = 5e-6, the mean rule's off-by-one) on
+    lt[n_item] is over the float32 engines' per-row bar, while the old whole-tensor term (1e-5 of the largest update of the
+    tensor: single-occurrence rows move by 0.2 - 0.6 here) was as large as the error itself."""
+    from tests.gpu_util import EXACT_DELTA_RTOL, assert_close, delta_excess
+    P, out, got, exp, eout, touched = _gowalla_launch(setup, "exact")
+    pa, ds, tab, make = setup
+    for name, pad in (("lt", ds.n_item), ("di", ds.dist_num)):
+        bad = np.array(exp[name], copy=True)
+        bad[pad] -= BENCH_CAP * 0.01 * 0.001 * P[name][pad]
+        ex, row = delta_excess(bad, exp[name], P[name], rtol=EXACT_DELTA_RTOL, absmass=touched["absmass"][name])
+        assert ex > 3.0 and row == pad, (name, ex, row)
+        print("systematic off-by-one on %s[pad] under cap 64: %.1fx over the exact engine's per-row bar" % (name, ex))
+    bad = np.array(exp["lt"], copy=True)
+    bad[ds.n_item] -= 0.01 * 0.001 * P["lt"][ds.n_item]
+    assert_close(bad, exp["lt"], "lt with one extra L2-decay term")          # the weight bar does not see it
+    ex_new, row = delta_excess(bad, exp["lt"], P["lt"], absmass=touched["absmass"]["lt"])
+    ex_old, _ = delta_excess(bad, exp["lt"], P["lt"])
+    assert ex_new > 1.5 and row == ds.n_item, (ex_new, row)
+    print("one L2-decay term on lt[pad]: %.2fx over the per-row bar (old whole-tensor bar: %.2fx)" % (ex_new, ex_old))
 
 
 def test_foursquare_shape_full_size_against_the_oracle():
     """configs[1] (10 k POIs, 5 k users, L <= 20, D = 64 - the two-table path of the tile engine) at FULL size:
     (a) the whole shard in one launch == the oracle's batch rule; (b) the reference schedule (one user per step,
-    prog_bpr_gru_spatial.py:249-250) over 300 users of the shuffled order == the sequential float64 epoch (errors
-    compound over the steps: 2e-4); (c) predict + all-POI top-20 == float64 scores' ranks on gap-checked rows."""
+    prog_bpr_gru_spatial.py:249-250) over 300 users of the shuffled order == the sequential float64 epoch (float32 engine:
+    errors compound over the steps, 2e-4); (a') / (b') the same on the EXACT engine with no loosening - every row of the nine
+    tensors inside 1e-5 after the launch AND after the 300 sequential steps, predict to 2e-7;
+    (c) predict + all-POI top-20 == float64 scores' ranks on gap-checked rows."""
     import torch
     import poi_amd
     from oracle import c_oracle as C
     from oracle import poi_oracle as O
     from poi_amd import data as pdata
-    from tests.gpu_util import FULL_SIZE_LT, assert_close, assert_step_close, rows_within
+    from tests.gpu_util import EXACT_DELTA_RTOL, FULL_SIZE_LT, assert_close, assert_step_close, rows_within
     n_item, n_user, max_len, D = pdata.SHAPES["foursquare"]
-    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=78)
+    ds = pdata.make_synthetic(n_user, n_item, max_len, seed=78, local=0.8)
     tab = ds.shard(0, n_user)
 
     def make():
@@ -149,14 +211,42 @@ def test_foursquare_shape_full_size_against_the_oracle():
     users = np.random.default_rng(6).permutation(n_user).astype(np.int32)
     out = np.asarray(m.train_batch(users))
     got = _state(m)
-    exp, eout, _ = C.spatial_batch_mean(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, users, tab.len_max, 0.01, 0.001)
+    exp, eout, tch = C.spatial_batch_mean(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, users, tab.len_max, 0.01, 0.001, absmass=True)
     assert_close(out[:, :3], eout[:, :3], "losses", rtol=2e-5)
-    assert_step_close(got, exp, P, SP_NAMES, "foursquare whole-shard launch", loose=FULL_SIZE_LT)
+    assert_step_close(got, exp, P, SP_NAMES, "foursquare whole-shard launch", loose=FULL_SIZE_LT, absmass=tch["absmass"])
     assert rows_within(got["lt"], exp["lt"]) >= 0.999
-    # (b) reference schedule
+    # (a') the same launch on the exact engine: the contract on every row, no loosening
+    m = make()
+    m.ctx.set_engine("exact")
+    try:
+        out = np.asarray(m.train_batch(users))
+        got_x = _state(m)
+        assert_close(out[:, :3], eout[:, :3], "losses (exact)", rtol=1e-6)
+        assert_step_close(got_x, exp, P, SP_NAMES, "foursquare whole-shard launch, exact engine", delta_rtol=EXACT_DELTA_RTOL, absmass=tch["absmass"])
+        # (b') reference schedule on the exact engine: 300 sequential steps stay inside the ONE-step bar
+        m = make()
+        Pc = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in P.items()}
+        order = users[:300]
+        eo = C.spatial_epoch(Pc, tab.off, tab.p, tab.q, tab.dp, tab.dq, order, tab.len_max, 0.01, 0.001)
+        go = np.array([[r[0], r[1], r[2]] for r in (m.train(np.int32(u)) for u in order)])
+        assert_close(go, eo[:, :3], "sequential losses (exact)", rtol=1e-5)
+        got_x = _state(m)
+        for k in SP_NAMES:
+            assert_close(got_x[k], Pc[k], "after 300 sequential steps (exact): " + k, rtol=1e-5)
+        # predict on the exact engine
+        m.update_trained_items(); m.update_trained_dists()
+        sub = np.arange(0, n_user, 16).astype(np.int32)
+        hx, sx = m.predict(sub)
+    finally:
+        m.ctx.set_engine("auto")
+    off = tab.off.astype(np.int64)
+    rows = lambda flat, pad: [np.r_[flat[off[u]:off[u + 1]], np.full(max_len - (off[u + 1] - off[u]), pad)] for u in sub]
+    masks = [np.r_[np.ones(off[u + 1] - off[u], int), np.zeros(max_len - (off[u + 1] - off[u]), int)] for u in sub]
+    eh, es = O.spatial_predict(got_x | {"h0": np.zeros(D)}, got_x["lt"], got_x["di"], rows(tab.p, n_item), rows(tab.dp, ds.dist_num), masks)
+    assert_close(hx, eh, "hts (exact)", rtol=2e-7); assert_close(sx, es, "sts (exact)", rtol=2e-7)
+    # (b) reference schedule, float32 tile engine
     m = make()
     Pc = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in P.items()}
-    order = users[:300]
     eo = C.spatial_epoch(Pc, tab.off, tab.p, tab.q, tab.dp, tab.dq, order, tab.len_max, 0.01, 0.001)
     go = np.array([[r[0], r[1], r[2]] for r in (m.train(np.int32(u)) for u in order)])
     assert_close(go, eo[:, :3], "sequential losses", rtol=2e-4)

@@ -121,6 +121,49 @@ def test_two_shards_from_one_snapshot_reconcile_to_the_oracle(pa, engine, rules)
         s.close()
 
 
+def test_carnn_replicas_reconcile_every_trainable_tensor(pa):
+    """model_sync must cover M (and the interval matrices with the per-matrix mean_touched rule) for OboCARNN, and
+    report() must checksum them - two replicas trained on different shards are bit-identical after the reconciliation and M is
+    theta_start + mean of the two deltas."""
+    import torch
+    from oracle import poi_oracle as O
+    from tests.gpu_util import round_f32
+    T = toy_problem(77, n_user=40, n_item=90, n_dist=11, dim=64, len_max=10, hot=25)
+    P = round_f32(O.init_carnn_params(np.random.default_rng(5), T["n_item"], T["n_dist"], T["dim"]))
+    mk = lambda: pa.models.OboCARNN(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=T["n_user"],
+                                    n_item=T["n_item"], n_dists=[T["n_dist"], 0.2], n_in=64, n_hidden=64, init=P)
+    models = [mk(), mk()]
+    syncs = [pa.dist.model_sync(m, force_backend=True) for m in models]
+    assert syncs[0].names == ["lt", "wd", "M"] and syncs[0].rules == ["mean_touched", "mean_touched", "mean"]
+    base = {k: getattr(models[0], k).t.clone() for k in ("lt", "wd", "M")}
+    shards = [np.arange(0, 22, dtype=np.int32), np.arange(22, 40, dtype=np.int32)]
+    flats, after = [], []
+    for m, s, ids in zip(models, syncs, shards):
+        s.backend.begin_epoch()
+        m.train_batch(ids)
+        after.append({k: getattr(m, k).t.clone() for k in ("lt", "wd", "M")})
+        flats.append(s.backend.make_delta().clone())
+    assert not torch.equal(after[0]["M"], after[1]["M"])
+    for s in syncs:
+        s.backend.flat.copy_(flats[0] + flats[1])
+        s.backend.apply(2)
+    assert syncs[0].backend.checksum() == syncs[1].backend.checksum(), "CA-RNN replicas differ after the reconciliation"
+    for k in ("lt", "wd", "M"):
+        assert torch.equal(getattr(models[0], k).t, getattr(models[1], k).t), k
+    expM = base["M"] + ((after[0]["M"] - base["M"]) + (after[1]["M"] - base["M"])) / 2
+    assert torch.allclose(models[0].M.t, expM, rtol=0, atol=3e-7)
+    # an interval matrix only shard A moved keeps its whole update; one both moved takes the mean
+    dA = (after[0]["wd"] - base["wd"]).flatten(1).abs().amax(dim=1) > 0
+    dB = (after[1]["wd"] - base["wd"]).flatten(1).abs().amax(dim=1) > 0
+    cnt = (dA.float() + dB.float()).clamp(min=1.0)[:, None, None]
+    expW = base["wd"] + ((after[0]["wd"] - base["wd"]) + (after[1]["wd"] - base["wd"])) / cnt
+    assert torch.allclose(models[0].wd.t, expW, rtol=0, atol=3e-7)
+    rep = syncs[0].report()
+    assert rep["replica_checksums_equal"] and set(rep["rules"]) == {"lt", "wd", "M"}
+    for s in syncs:
+        s.close()
+
+
 def test_rccl_entry_points_world_size_1(pa):
     """poi_comm_unique_id / poi_comm_init_rank / poi_allreduce_tables / poi_sync_end_epoch through the library's own RCCL
     communicator, under a one-rank torch.distributed group (the all-reduce of one rank is the identity)."""
