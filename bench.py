@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-engine (float64) timing")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--quality-seconds", type=float, default=3.0, help="training wall time of the batched modes in the quality block")
     ap.add_argument("--reference-seconds", type=float, default=15.0, help="training wall time of the reference schedule (one user per step)")
@@ -124,7 +125,7 @@ def main():
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
     if a.shape == "x1":
         # 10 M POIs: i.i.d. Zipf check-ins (the neighbour structure of --local needs a k-d tree over 10 M points), throughput only
-        a.local = 0.0; a.no_quality = True; a.no_secondary = True; a.no_cpu_baseline = True
+        a.local = 0.0; a.no_quality = True; a.no_secondary = True; a.no_cpu_baseline = True; a.no_exact = True
         a.eval_users = a.eval_users or 8192
         a.table_dtype = a.table_dtype or "f16"
         if a.steps == 250:
@@ -178,7 +179,9 @@ def main():
     torch.cuda.synchronize(dev)
     for _ in range(a.warmup):
         train_epoch()
-    ctx.timing(True)
+    # live HIP-event timing INSIDE the timed region, on every (2 n_launch + 1)-th launch: each launch position of the epoch is sampled
+    # in turn and the event pairs (~7 us of stream serialisation per kernel) stay below 1 % of the region
+    ctx.timing(True, period=2 * len(batches) + 1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -191,6 +194,49 @@ def main():
     ctx.timing(False)
     seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
     multi = sync.report()
+    if world > 1 and not a.emulate_world:
+        # a SCALE run validates itself: the collective must have seen every rank and the replicas must agree bit for bit
+        bad = []
+        if multi.get("rccl_world_size", world) != a.gpus:
+            bad.append("RCCL saw world size %s, --gpus %d" % (multi.get("rccl_world_size"), a.gpus))
+        if not multi.get("replica_checksums_equal", False):
+            bad.append("replica checksums differ after the last reconciliation")
+        if bad:
+            if rank == 0:
+                print(json.dumps({"error": "multi-GPU self-check failed: " + "; ".join(bad), "multi_gpu": multi}), flush=True)
+            sys.exit(3)
+    # steady window: the driver's --steps 20 is a 0.17 s window; when the timed region is shorter than 2 s a second, >= 2 s window
+    # of the same epochs is timed and reported beside it (thermally settled clocks; never `value`)
+    steady = None
+    if dt < 2.0:
+        n_st = int(np.ceil(2.2 / max(dt / a.steps, 1e-6)))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_st):
+            train_epoch()
+        barrier()
+        dts = rank_max(time.perf_counter() - t0)
+        steady = {"seconds": dts, "epochs": n_st, "ms_per_epoch": 1e3 * dts / n_st,
+                  "seq_per_s": (n_user if not a.emulate_world else n_local) * n_st / dts}
+    # exact mode (float64 arithmetic, poi_ctx_set_engine(4)): the same launches on the engine that meets the 1e-5 contract on every row
+    exact_mode = None
+    if rank == 0 and world == 1 and not a.emulate_world and a.table_dtype == "f32" and not a.no_exact:
+        mx = new_model(tab, n_local, seed=7)
+        ctx.set_engine("exact")
+        try:
+            mx.train_batch(order[:B], sync=True)
+            torch.cuda.synchronize(dev); t0 = time.perf_counter()
+            nb = 0
+            for b0 in list(range(0, n_local, B))[:2]:
+                mx.train_batch(order[b0:b0 + B], sync=False); nb += min(B, n_local - b0)
+            torch.cuda.synchronize(dev); tx = time.perf_counter() - t0
+        finally:
+            ctx.set_engine("auto")
+        exact_mode = {"engine": "exact (float64 arithmetic end to end, float32 tables; exact_engine.hip)", "seq_per_s": nb / tx, "ms_per_launch": 1e3 * tx / 2,
+                      "fast_seq_per_s": seq_per_s, "slowdown": seq_per_s / (nb / tx),
+                      "parity": "every row of all nine tensors within 1e-5 of the float64 oracle at this shape (tests/test_gpu_fullsize.py); the float32 "
+                                "tile engine: 99.9 % of the POI rows, worst row 6e-6 .. 3e-5 depending on the data"}
+        del mx
 
     # ---- evaluation: snapshot -> user vectors -> fused distance term + all-POI score + top-20 -------
     eval_users_per_s = None
@@ -353,6 +399,7 @@ def main():
     roofline = dict(kernel=dom, traffic=traffic.get(dom), traffic_source=traffic_src,
                     **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
     roofline["note"] = "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)"
+    roofline_gs_hook = roofline
     # ---- gather / scatter against the HBM roofline: three accountings over the SAME kernel time --------------------
     GS = ("te_gather", "te_psum", "te_dsum", "te_scatter", "rows_apply")
     forked = "te_tail" in kernels          # te_dsum (+ te_bin_gemm) and te_scatter overlap: their time is the fork-to-join span
@@ -374,6 +421,8 @@ def main():
                "embedding_rows_only": "table rows only: the two rows of E per step + every touched row read and written once per launch"}}
     hbm["achieved"] = (hbm["survey_8d"] or hbm["implementation"])["achieved_GBps"]
     hbm["frac"] = (hbm["survey_8d"] or hbm["implementation"])["frac"]
+    roofline_gs_hook["gather_scatter"] = {"bound": "hbm", "kernels": hbm["kernels"], "ms_per_epoch": gs_ms, "frac_survey_8d": (hbm["survey_8d"] or {}).get("frac"),
+                                          "frac_bytes_moved": (hbm["implementation"] or {}).get("frac"), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
     total_flops = step_flops(D, NB) * steps_per_epoch
     executed_flops = sum(w for k, (kind, w) in work.items() if kind == "flop" and k in kernels and k != "seq_train") or total_flops
     train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels if k not in (("te_finalize", "te_dsum", "te_bin_gemm", "te_scatter") if forked else ("te_finalize", "te_tail")))
@@ -540,12 +589,24 @@ def main():
                        "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence",
                        "s_rows_per_step": rho},
             "timed_window_s": dt,
-            "eval_users_per_s": eval_users_per_s, "eval": eval_detail,
-            "roofline": roofline, "roofline_gather_scatter": hbm, "kernels": kernels,
+            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary,
             "train_step_tflops": executed_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "train_step_tflops_reference_formulation": total_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
-            "reference_schedule": reference_schedule, "quality": quality, "multi_gpu": multi, "secondary": secondary,
-            "cpu_baseline": cpu,
+            "reference_schedule": reference_schedule, "eval": eval_detail, "roofline_gather_scatter": hbm,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "steady_window": steady, "exact_mode": exact_mode, "eval_users_per_s": eval_users_per_s,
+        }
+        # compact recap LAST: a record that keeps only the tail of this line still holds every headline number
+        out["headline"] = {
+            "train_seq_per_s": seq_per_s, "ms_per_epoch": 1e3 * dt / a.steps, "steady_seq_per_s": steady and steady["seq_per_s"],
+            "eval_users_per_s": eval_users_per_s, "ms_per_eval": eval_detail.get("ms_per_eval"),
+            "score_topk_frac_of_f32_mfma_peak": eval_detail.get("score_topk_frac_of_f32_mfma_peak"),
+            "dominant_kernel": roofline["kernel"], "dominant_frac": roofline["frac"],
+            "gather_scatter_frac_survey_8d": (hbm.get("survey_8d") or {}).get("frac"), "gather_scatter_ms_per_epoch": hbm["ms_per_epoch"],
+            "exact_seq_per_s": exact_mode and exact_mode["seq_per_s"],
+            "reference_schedule_steps_per_s": reference_schedule and reference_schedule["seq_per_s"],
+            "recall_headline_vs_reference": quality and quality["headline_vs_reference"]["recall_ratio"],
+            "cpu_1core_seq_per_s": cpu and cpu["value"], "cpu_allcores_seq_per_s": cpu and cpu["all_cores"] and cpu["all_cores"]["value"],
         }
         print(json.dumps(out))
     sync.close()

@@ -332,7 +332,9 @@ int poi_checksum(poi_ctx* ctx, const float* x, int64_t n, uint64_t* out_dev, voi
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's live roofline figures).
  * Kernel names: "seq_train", "rows_apply", "dense_apply", "seq_predict", "bpr_hogwild", "bpr_grad",
  * "bpr_apply", "score_topk", "score_all", "dist_prob", "sample_neg", "neg_dist", "carnn_train", "carnn_predict", "carnn_score", and for the tile engine "te_prep", "te_gather", "te_gemm_ax",
- * "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx", "te_finalize", "te_predict".  poi_timing_get synchronises the device. */
+ * "te_rec_fwd", "te_head", "te_rec_bwd", "te_wgrad", "te_gemm_dx", "te_finalize", "te_predict".  poi_timing_get synchronises the device.
+ * poi_timing_enable(ctx, N) with N > 1 instruments only every N-th training launch (poi_spatial_step / poi_gru_step): the event pairs
+ * cost ~7 us of stream serialisation per kernel, and the sampled launches' average is the launch duration either way. */
 int poi_timing_enable(poi_ctx* ctx, int on);
 int poi_timing_reset(poi_ctx* ctx);
 int poi_timing_get(poi_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);

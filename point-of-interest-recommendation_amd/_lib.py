@@ -180,9 +180,10 @@ class Context:
     def unregister_f16(self, tensor):
         self.check(self.lib.poi_ctx_unregister_f16(self.handle, tensor.data_ptr()))
 
-    def timing(self, on=True):
+    def timing(self, on=True, period=1):
+        """Per-kernel HIP-event timing; period N > 1 instruments only every N-th training launch (poi_timing_enable)."""
         self.check(self.lib.poi_timing_reset(self.handle))
-        self.check(self.lib.poi_timing_enable(self.handle, 1 if on else 0))
+        self.check(self.lib.poi_timing_enable(self.handle, (max(int(period), 1) if on else 0)))
 
     def timing_get(self, kernel):
         """(total milliseconds, launches) recorded for `kernel` since the last timing() call."""

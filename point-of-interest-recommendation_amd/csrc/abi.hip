@@ -348,6 +348,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (n == 0) return POI_OK;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(c, hipSetDevice(c->device));
+  c->tm.tick();
   if (c->engine == 4) return exact_step(c, P, T, uidx, n, alpha, lambda, out, st, spatial);
   const int D = P->dim, XW = spatial ? 2 * D : D, NB = spatial ? P->n_dist + 1 : 0;
   int grid = c->num_cu * c->wg_per_cu;
@@ -928,6 +929,7 @@ int poi_ctx_set_batch_cap(poi_ctx* c, float cap) {
 int poi_timing_enable(poi_ctx* c, int on) {
   if (!c) return fail(c, POI_EINVAL, "NULL ctx");
   c->tm.on = on != 0;
+  c->tm.period = on > 1 ? on : 1; c->tm.count = 0; c->tm.active = true;
   return POI_OK;
 }
 
