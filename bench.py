@@ -284,7 +284,11 @@ def main():
             barrier()
             dte += rank_max(time.perf_counter() - t0)
             ctx.lib.poi_timing_enable(ctx.handle, 0)
-        ms_score, n_score = ctx.timing_get("score_topk")
+        ms_one, n_score = ctx.timing_get("score_topk")
+        ms_filter, ms_rescore, ms_pack = ctx.timing_get("score_filter")[0], ctx.timing_get("score_rescore")[0], ctx.timing_get("pack_items")[0]
+        ms_seedk = ctx.timing_get("topk_seed")[0]
+        ms_score = ms_one + ms_filter + ms_rescore
+        fstats = ctx.topk_filter_stats()
         ms_pred = ctx.timing_get("seq_predict")[0] + ctx.timing_get("te_predict")[0]
         ms_dist = ctx.timing_get("dist_prob")[0]
         ctx.timing(False)
@@ -298,6 +302,14 @@ def main():
                        "ms_predict_per_eval": ms_pred / a.eval_steps, "ms_score_topk_per_eval": ms_score / a.eval_steps,
                        "ms_dist_prob_per_eval": ms_dist / a.eval_steps, "ms_ulptai_build_once": ms_ulptai,
                        "eval_chunk_users": a.eval_chunk,
+                       "two_stage": {"what": "seeded calls: f16 filter pass (v_mfma_f32_32x32x16_f16 + rigorous error bound) -> exact float32 rescoring of the "
+                                             "survivors; bit-identical lists (include/poi_hip.h, poi_ctx_set_topk_filter)",
+                                     "ms_filter_per_eval": ms_filter / a.eval_steps, "ms_rescore_per_eval": ms_rescore / a.eval_steps,
+                                     "ms_one_stage_fallback_per_eval": ms_one / a.eval_steps, "ms_pack_items_per_eval": ms_pack / a.eval_steps,
+                                     "ms_seed_kernel_per_eval": ms_seedk / a.eval_steps,
+                                     "survivors_per_user_last_call": fstats["survivors"] / max(fstats["users"], 1),
+                                     "tiles_flagged_last_call": fstats["tiles_flagged"], "tiles_last_call": fstats["tiles"],
+                                     "filter_frac_of_f16_mfma_peak": (fl / (ms_filter * 1e-3) / 1e12 / 2500.0) if ms_filter > 0 else None},
                        "cadence": "one training epoch between evaluations (untimed), as the reference driver; top-K thresholds seeded from the previous evaluation's lists",
                        "ms_per_eval_unseeded": 1e3 * dte_cold,
                        "eval_users_per_s_unseeded": (n_user if n_eval == n_local else n_eval) / dte_cold}

@@ -47,6 +47,8 @@ SIGNATURES = {
     "poi_ctx_set_batch_cap": (c_int, [c_void_p, c_float]),
     "poi_ctx_set_graph": (c_int, [c_void_p, c_int, c_int, c_int]),
     "poi_ctx_set_topk_seed": (c_int, [c_void_p, c_void_p, c_int32]),
+    "poi_ctx_set_topk_filter": (c_int, [c_void_p, c_int]),
+    "poi_ctx_topk_filter_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "poi_ctx_graph_replays": (c_int64, [c_void_p]),
     "poi_ctx_register_f16": (c_int, [c_void_p, c_void_p, c_int64]),
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
@@ -164,6 +166,16 @@ class Context:
     def set_topk_seed(self, seed, k_seed):
         """Seed ids of the next fused top-K call (poi_ctx_set_topk_seed): an (n, k_seed) int32 device tensor or None."""
         self.check(self.lib.poi_ctx_set_topk_seed(self.handle, None if seed is None else seed.data_ptr(), int(k_seed)))
+
+    def set_topk_filter(self, on):
+        """Two-stage fused top-K (f16 filter + exact float32 rescoring) for seeded calls: poi_ctx_set_topk_filter."""
+        self.check(self.lib.poi_ctx_set_topk_filter(self.handle, int(bool(on))))
+
+    def topk_filter_stats(self):
+        """dict(users, survivors, tiles, tiles_flagged) of the last two-stage fused top-K call (poi_ctx_topk_filter_stats)."""
+        v = [c_int64(0) for _ in range(4)]
+        self.check(self.lib.poi_ctx_topk_filter_stats(self.handle, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("users", "survivors", "tiles", "tiles_flagged"), (x.value for x in v)))
 
     def graph_replays(self):
         return int(self.lib.poi_ctx_graph_replays(self.handle))

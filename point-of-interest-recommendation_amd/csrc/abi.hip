@@ -59,6 +59,9 @@ struct poi_ctx {
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
   DevBuf cand_s, cand_i, items_pk, gbound;
+  DevBuf items_pk16, inorm, surv_cnt, surv_idx, tflag;      // two-stage fused top-K (score_filter.hip)
+  int topk_filter = 1;      // poi_ctx_set_topk_filter / POI_TOPK_FILTER=0: one-stage float32 kernel only
+  int last_two_n = 0, last_two_tiles = 0;      // users / user tiles of the last two-stage call (poi_ctx_topk_filter_stats)
   const int32_t* seed_idx = nullptr; int seed_k = 0;      // poi_ctx_set_topk_seed: consumed by the next fused top-K call
   // selftest
   DevBuf st;
@@ -129,6 +132,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_CARNN_FAST")) c->carnn_fast = atoi(e) != 0;
   if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
+  if (const char* e = getenv("POI_TOPK_FILTER")) c->topk_filter = atoi(e) != 0;
   if (const char* e = getenv("POI_ENGINE")) { if (!strcmp(e, "seq")) c->engine = 1; else if (!strcmp(e, "tile")) c->engine = 2; else if (!strcmp(e, "exact")) c->engine = 4; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, POI_EHIP, "hipSetDevice failed"); }
   const char* sd = getenv("POI_TE_SIDE");
@@ -155,7 +159,8 @@ static void drop_graphs(poi_ctx* c) {
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
   DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
-                   &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st};
+                   &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
+                   &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->tflag};
   (void)hipDeviceSynchronize();
   c->tm.clear();
   drop_graphs(c);
@@ -724,6 +729,23 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
       A.seeded = 1;
     }
   }
+  if (k > 0 && c->topk_filter && variant == 1 && poi::score_two_stage_supported(A)) {
+    // two-stage: f16 filter pass + exact float32 rescoring of the survivors (score_filter.hip); the one-stage kernel below then only
+    // runs the user tiles whose survivor lists overflowed (A.tile_flag)
+    const int kg = dim / 16, cap = poi::score_filter_cap();
+    if ((rc = ensure(c, c->items_pk16, sizeof(uint4) * (size_t)ntile * kg * 64, st)) || (rc = ensure(c, c->inorm, sizeof(float2) * (size_t)ntile * 32, st)) ||
+        (rc = ensure(c, c->surv_cnt, sizeof(int) * (size_t)n_pad, st)) || (rc = ensure(c, c->surv_idx, sizeof(int) * (size_t)n_pad * cap, st)) ||
+        (rc = ensure(c, c->tflag, sizeof(int) * (size_t)n_utile, st))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->surv_cnt.p, 0, sizeof(int) * (size_t)n_pad, st));
+    HIPCHK(c, hipMemsetAsync(c->tflag.p, 0, sizeof(int) * (size_t)n_utile, st));
+    A.items_packed16 = (const uint4*)c->items_pk16.p; A.inorm = (const float2*)c->inorm.p;
+    A.surv_cnt = (int*)c->surv_cnt.p; A.surv_idx = (int*)c->surv_idx.p; A.tile_flag = (int*)c->tflag.p;
+    int nsf = ((4 * c->num_cu + n_utile - 1) / n_utile) * 4;      // >= 4 workgroups (16 waves) per CU
+    if (nsf > (ntile / 4) * 4) nsf = (ntile / 4) * 4;
+    if (nsf < 4) nsf = 4;
+    HIPCHK(c, poi::launch_score_two_stage(A, nsf, st, &c->tm));
+    c->last_two_n = n; c->last_two_tiles = n_utile;
+  }
   if (variant == 2) {
     const int d8 = dim <= 128 ? 16 : 32;
     if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
@@ -886,6 +908,26 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
 int poi_ctx_set_engine(poi_ctx* c, int engine) {
   if (!c || engine < 0 || engine > 4) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence), 2 (tile), 3 (tile, streaming recurrent kernels) or 4 (exact: float64)");
   c->engine = engine;
+  return POI_OK;
+}
+
+int poi_ctx_set_topk_filter(poi_ctx* c, int on) {
+  if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_topk_filter: on must be 0 or 1");
+  c->topk_filter = on;
+  return POI_OK;
+}
+
+int poi_ctx_topk_filter_stats(poi_ctx* c, int64_t* users, int64_t* survivors, int64_t* tiles, int64_t* tiles_flagged) {
+  if (!c || !users || !survivors || !tiles || !tiles_flagged) return fail(c, POI_EINVAL, "poi_ctx_topk_filter_stats: NULL argument");
+  *users = c->last_two_n; *tiles = c->last_two_tiles; *survivors = 0; *tiles_flagged = 0;
+  if (c->last_two_n <= 0) return POI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  std::vector<int> cnt((size_t)c->last_two_n), fl((size_t)c->last_two_tiles);
+  HIPCHK(c, hipMemcpy(cnt.data(), c->surv_cnt.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(fl.data(), c->tflag.p, sizeof(int) * fl.size(), hipMemcpyDeviceToHost));
+  for (int v : cnt) *survivors += v;
+  for (int v : fl) *tiles_flagged += v != 0;
   return POI_OK;
 }
 

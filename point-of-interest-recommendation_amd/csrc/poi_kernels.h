@@ -308,7 +308,14 @@ struct ScoreArgs {
   unsigned* gbound;         // (n_pad) per-user lower bound of the K-th best score shared by all item ranges
   int seeded;               // gbound starts from the caller's seed items' scores (topk_seed_kernel), not from zero
   int* idx_out; float* score_out;
+  // two-stage path (score_filter.hip): half-precision item fragments + per-item norms of the bound, per-user survivor lists, and the
+  // per-user-tile overflow flags; the one-stage kernels and the merge skip every tile whose flag is clear when tile_flag is set
+  const uint4* items_packed16; const float2* inorm;
+  int* surv_cnt; int* surv_idx; int* tile_flag;
 };
+bool score_two_stage_supported(const ScoreArgs& A);
+hipError_t launch_score_two_stage(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm);
+int score_filter_cap();
 hipError_t launch_ulptai(const double* coords, const double* cphi, const double* thr, const int* last_poi, int n, int n_item,
                          int n_dist, double dd, void* out, int bin_bytes, hipStream_t st);
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm);

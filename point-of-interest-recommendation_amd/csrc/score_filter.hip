@@ -1,0 +1,345 @@
+// Two-stage fused scoring + top-K (public/Valuate.py:132-146 over public/GRU_Spatial.py:117-125): an f16 FILTER pass on the 16x-faster
+// matrix rate followed by an EXACT float32 rescoring of the survivors - the same lists, bit for bit, as the one-stage float32 kernel
+// (score_topk.hip), which remains the cold path and the fallback.
+//
+//   stage 1  score_filter_kernel   users / items rounded to IEEE half, v_mfma_f32_32x32x16_f16 (8 instructions per 32 x 32 tile at dim
+//            128 instead of 64 f32 ones), the distance term added exactly as the float32 kernel adds it, and a RIGOROUS bound on
+//            |approximate - float32 score| per pair:
+//                c1 |u|_2 |v|_2 + 2^-25 (|u|_1 + |v|_1) + rounding slack,   c1 = 2^-10 + 2^-22 + D (2^-22 + 2^-23) + 2^-21
+//            (half rounding of both operands: relative 2^-11 each, absolute 2^-25 in the subnormal range; D f32 accumulation steps of
+//            the f16 MFMA at <= 2^-22 each and of the f32 MFMA at <= 2^-23; Cauchy-Schwarz for sum |u_i v_i|).  A pair SURVIVES when
+//            approximate + bound can exceed the user's threshold - a true lower bound of the final K-th best score, seeded from the
+//            previous evaluation's list by topk_seed_kernel (poi_ctx_set_topk_seed).  Survivors (~K + a few per user) go to per-user
+//            lists in global memory; a user whose list overflows (bad seed) flags its 32-user tile.
+//   stage 2  score_rescore_kernel  per user tile, the survivors of its 32 users in chunks of 32 items: item rows gathered straight into
+//            B fragments, the SAME v_mfma_f32_32x32x2_f32 sequence over k as the one-stage kernels (an element of the result tile
+//            depends only on its row of A, its column of B and the k order: same bits), the same fused distance term, then per user
+//            the K best by (score desc, id asc).  Flagged tiles are left to the one-stage kernel (ScoreArgs.tile_flag), which starts
+//            from the same seeded thresholds.
+// Exactness never depends on the seed: thresholds are true lower bounds, every pair that could beat them is rescored exactly, and
+// overflowing tiles take the exact path.  tests: test_gpu_parity.py (two-stage == one-stage, ids AND scores), tools/fuzz_score.py.
+#include "poi_common.h"
+#include "poi_kernels.h"
+#include <limits.h>
+
+namespace poi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float sf_ord2f(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+__device__ __forceinline__ unsigned sf_f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+// Items -> IEEE half in the fragment order of v_mfma_f32_32x32x16_f16 + the two norms of the bound.
+//   P[(tile * KG + m) * 64 + lane] = 8 halfs items[32 tile + j][16 m + 8 h + e], e = 0..7, lane = 32 h + j        (KG = D / 16)
+//   inorm[item] = { |v|_2 (rounded up), 2^-25 * 1.01 * |v|_1 }; an item with a value outside the half range gets |v|_2 = +inf
+// One workgroup per 32-item tile: thread (row j = t / 8, segment s = t % 8) converts D / 8 consecutive columns.
+template <int D>
+__global__ __launch_bounds__(256) void pack_items_f16_kernel(const float* __restrict__ items, int items_f16, int n_item, uint4* __restrict__ out,
+                                                             float2* __restrict__ inorm) {
+  constexpr int KG = D / 16, CPT = D / 8;
+  const int tile = blockIdx.x, t = threadIdx.x, j = t >> 3, s = t & 7;
+  const int gi = tile * 32 + j;
+  const bool valid = gi < n_item;
+  float x[CPT];
+#pragma unroll
+  for (int q = 0; q < CPT / 4; ++q) {
+    const float4 v = valid ? ld4t(items, (size_t)gi * D + s * CPT + 4 * q, items_f16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+  }
+  float n2 = 0.f, n1 = 0.f; bool bad = false;
+#pragma unroll
+  for (int g = 0; g < CPT / 8; ++g) {
+    h8 hv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = x[8 * g + e];
+      hv[e] = (_Float16)v;                       // round to nearest even
+      n2 = fmaf(v, v, n2); n1 += fabsf(v);
+      bad |= !(fabsf(v) <= 65000.f);             // (also NaN)
+    }
+    const int col0 = s * CPT + 8 * g, m = col0 >> 4, h = (col0 >> 3) & 1;
+    out[((size_t)tile * KG + m) * 64 + 32 * h + j] = __builtin_bit_cast(uint4, hv);
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) { n2 += __shfl_xor(n2, o, 64); n1 += __shfl_xor(n1, o, 64); bad |= __shfl_xor((int)bad, o, 64) != 0; }
+  if (s == 0 && valid) inorm[gi] = make_float2(bad ? INFINITY : sqrtf(n2) * 1.000002f, n1 * (2.98023224e-8f * 1.01f));
+}
+
+#define SF_CAP 128        // survivor slots per user (K <= 32: K + the pairs inside the bound; an overflow flags the tile)
+
+// stage 1.  BINS: 0 = no distance term, 1 / 2 = resident bin matrix (uint8 / uint16, misc.hip::ulptai_kernel) + the users' bin probabilities
+template <int D, int BINS>
+__global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
+  constexpr int KG = D / 16, CPT = D / 8, QN = BINS ? BINS : 1;
+  extern __shared__ __align__(16) float dyn[];
+  uint4* af = reinterpret_cast<uint4*>(dyn);               // [KG][64] half fragments of the user tile
+  float* s_au = dyn + KG * 64 * 4;                         // 32: c1 |u|_2
+  float* s_c = s_au + 32;                                  // 32: threshold - user part of the bound
+  float* s_n2 = s_c + 32; float* s_n1 = s_n2 + 32;         // 32 + 32
+  float* s_sts = s_n1 + 32;                                // 32 x NB (BINS)
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, t = threadIdx.x;
+  const int N = A.n_item, NB = A.n_dist + 1;
+  const int ut = blockIdx.x;
+  const int split = blockIdx.y * POI_NWAVE + w;
+  const int ntile = (N + 31) / 32;
+  const int tps = (ntile + A.n_split - 1) / A.n_split;
+  const int t_begin = split * tps, t_end = min(ntile, t_begin + tps);
+  const float wd = (BINS && A.wd) ? A.wd[0] : 0.f;
+  {
+    const int j = t >> 3, s = t & 7;
+    const int urow = min(ut * 32 + j, A.n - 1);
+    const float* up = A.users + (size_t)urow * D + s * CPT;
+    float n2 = 0.f, n1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < CPT / 8; ++g) {
+      const float4 v0 = *reinterpret_cast<const float4*>(up + 8 * g), v1 = *reinterpret_cast<const float4*>(up + 8 * g + 4);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      h8 hv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hv[e] = (_Float16)x[e]; n2 = fmaf(x[e], x[e], n2); n1 += fabsf(x[e]); }
+      const int col0 = s * CPT + 8 * g, m = col0 >> 4, hh = (col0 >> 3) & 1;
+      af[m * 64 + 32 * hh + j] = __builtin_bit_cast(uint4, hv);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { n2 += __shfl_xor(n2, o, 64); n1 += __shfl_xor(n1, o, 64); }
+    if (s == 0) { s_n2[j] = n2; s_n1[j] = n1; }
+    if (BINS) for (int i = t; i < 32 * NB; i += 256) s_sts[i] = A.sts[(size_t)ut * 32 * NB + i];
+  }
+  __syncthreads();
+  if (t < 32) {
+    const int urow = ut * 32 + t;
+    float pmax = 0.f;
+    if (BINS) for (int b = 0; b < NB; ++b) pmax = fmaxf(pmax, fabsf(s_sts[t * NB + b]));
+    const unsigned g = urow < A.n ? A.gbound[urow] : 0u;
+    const float thr = g ? sf_ord2f(g) : -INFINITY;
+    const float nu2 = sqrtf(s_n2[t]) * 1.000002f;
+    constexpr float c1 = (9.765625e-4f * 1.0005f + (float)D * (2.38418579e-7f * 1.001f + 1.19209290e-7f) + 4.76837158e-7f) * 1.00001f;
+    const float bu = s_n1[t] * (2.98023224e-8f * 1.01f) + 4.76837158e-7f * (fabsf(wd) * pmax + (g ? fabsf(thr) : 0.f)) + 1e-30f;
+    s_au[t] = c1 * nu2;
+    s_c[t] = urow < A.n ? thr - bu : INFINITY;             // rows past n: nothing survives
+  }
+  __syncthreads();
+  // (the norm part of the bound uses the LARGEST c1 |u|_2 of the tile's 32 users: one fma per lane and tile instead of one per pair and
+  // sixteen registers less - the hidden states of a model have similar norms, so the bound loosens by a few per cent at most)
+  float cc[16], au = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cc[r] = s_c[(r & 3) + 8 * (r >> 2) + 4 * h];
+  for (int i = 0; i < 32; ++i) au = fmaxf(au, s_au[i]);
+  const uint4* bp = A.items_packed16 + lane;
+  const uint4* qp = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)ut * ntile * 64 + lane) * QN;
+  const int sbase = 4 * h * NB;
+  uint4 b[KG], qn[QN];
+  float2 nm = make_float2(0.f, 0.f);
+  if (t_begin < t_end) {
+#pragma unroll
+    for (int m = 0; m < KG; ++m) b[m] = bp[((size_t)t_begin * KG + m) * 64];
+    if (BINS) {
+#pragma unroll
+      for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)t_begin * 64 * QN + q];
+    }
+    nm = A.inorm[min(t_begin * 32 + li, N - 1)];
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int nt = min(tile + 1, t_end - 1);               // (branch-free: the last tile reloads itself)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < KG; ++m) {
+      const h8 a = __builtin_bit_cast(h8, af[m * 64 + lane]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(h8, b[m]), acc, 0, 0, 0);
+      b[m] = bp[((size_t)nt * KG + m) * 64];               // this k-group of the NEXT tile
+    }
+    const int j = tile * 32 + li;
+    const bool jvalid = j < N;
+    const float tb = __fmaf_rn(au, nm.x, nm.y);
+    unsigned pass = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r == 8) __builtin_amdgcn_sched_barrier(0);       // two batches of eight gathers: sixteen in flight cost the occupancy
+      float pv = 0.f;
+      if (BINS) {
+        int bin;
+        if (BINS == 1) { const unsigned wv = r < 4 ? qn[0].x : r < 8 ? qn[0].y : r < 12 ? qn[0].z : qn[0].w; bin = (wv >> (8 * (r & 3))) & 255u; }
+        else { const uint4 qq = qn[(r >> 3) & (QN - 1)]; const int e = r & 7; const unsigned wv = e < 2 ? qq.x : e < 4 ? qq.y : e < 6 ? qq.z : qq.w; bin = (wv >> (16 * (e & 1))) & 65535u; }
+        pv = s_sts[sbase + ((r & 3) + 8 * (r >> 2)) * NB + bin];
+      }
+      const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
+      pass |= !(up <= cc[r]) ? (1u << r) : 0u;             // (a NaN survives)
+    }
+    if (BINS) {
+#pragma unroll
+      for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)nt * 64 * QN + q];
+    }
+    nm = A.inorm[min(nt * 32 + li, N - 1)];
+    if (!jvalid) pass = 0;
+    if (__any(pass != 0)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (pass & (1u << r)) {
+          const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int pos = atomicAdd(A.surv_cnt + urow, 1);
+          if (pos < SF_CAP) A.surv_idx[(size_t)urow * SF_CAP + pos] = j;
+          else A.tile_flag[ut] = 1;
+        }
+      }
+    }
+  }
+}
+
+// stage 2.  D8 = k-groups of 8 of the one-stage kernels (dim 64: 8, dim 128: 16): the same MFMA sequence, hence the same bits.
+template <int D8, int BINS>
+__global__ __launch_bounds__(256) void score_rescore_kernel(ScoreArgs A) {
+  extern __shared__ __align__(16) float dyn[];
+  float4* af = reinterpret_cast<float4*>(dyn);             // [D8][64]
+  float* cs = dyn + D8 * 64 * 4;                           // 32 x SF_CAP scores
+  int* ci = reinterpret_cast<int*>(cs + 32 * SF_CAP);      // 32 x SF_CAP ids
+  __shared__ int s_pre[33], s_n[32];
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, t = threadIdx.x;
+  const int D = A.dim, N = A.n_item, K = A.k, NB = A.n_dist + 1;
+  const int ut = blockIdx.x;
+  if (A.tile_flag[ut]) return;                              // overflow: the one-stage kernel takes this tile
+  const int ntile = (N + 31) / 32;
+  {
+    const int urow = min(ut * 32 + li, A.n - 1);
+    const float* up = A.users + (size_t)urow * D;
+    for (int m = w; m < D8; m += POI_NWAVE) {
+      const int k0 = 8 * m + 4 * h;
+      af[m * 64 + lane] = k0 < D ? *reinterpret_cast<const float4*>(up + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (t < 32) {
+    const int urow = ut * 32 + t;
+    const int c = urow < A.n ? min(A.surv_cnt[urow], SF_CAP) : 0;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int v = __shfl_up(inc, o, 64); inc += t >= o ? v : 0; }
+    s_pre[t + 1] = inc; s_n[t] = 0;
+    if (t == 0) s_pre[0] = 0;
+  }
+  __syncthreads();
+  const int total = s_pre[32];
+  const float wd = (BINS && A.wd) ? A.wd[0] : 0.f;
+  for (int c0 = 32 * w; c0 < total; c0 += 32 * POI_NWAVE) {
+    const int flat = c0 + li;
+    const bool valid = flat < total;
+    int own = 0;
+    if (valid) {
+#pragma unroll
+      for (int sft = 16; sft > 0; sft >>= 1) if (own + sft < 32 && s_pre[own + sft] <= flat) own += sft;      // largest i with pre[i] <= flat
+    }
+    const int id = valid ? A.surv_idx[(size_t)(ut * 32 + own) * SF_CAP + (flat - s_pre[own])] : 0;
+    float4 bf[D8];
+#pragma unroll
+    for (int m = 0; m < D8; ++m) {
+      const int k0 = 8 * m + 4 * h;
+      bf[m] = k0 < D ? ld4t(A.items, (size_t)id * D + k0, A.items_f16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < D8; ++m) {
+      const float4 a = af[m * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[m].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[m].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[m].w, acc, 0, 0, 0);
+    }
+    // the pair (owner, item) sits in half-wave (owner >> 2) & 1, register (i & 3) + 4 (i >> 3) with i = owner - 4 h
+    const bool mine = valid && h == ((own >> 2) & 1);
+    const int ip = own - 4 * h, r_own = (ip & 3) + 4 * (ip >> 3);
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a = r == r_own ? acc[r] : a;
+    if (mine) {
+      float pv = 0.f;
+      if (BINS) {
+        const size_t cell = ((size_t)ut * ntile + (id >> 5)) * 64 + (id & 31) + 32 * h;
+        int bin;
+        if (BINS == 1) bin = reinterpret_cast<const unsigned char*>(A.ulptai)[cell * 16 + r_own];
+        else bin = reinterpret_cast<const unsigned short*>(A.ulptai)[cell * 16 + r_own];
+        pv = A.sts[(size_t)(ut * 32 + own) * NB + bin];
+      }
+      const float sc = __fmaf_rn(wd, pv, a);                // the one-stage kernels' expression (tile_epilogue)
+      const int pos = atomicAdd(&s_n[own], 1);
+      cs[own * SF_CAP + pos] = sc; ci[own * SF_CAP + pos] = id;
+    }
+  }
+  __syncthreads();
+  // per user: the K best of its <= SF_CAP exact scores by (score desc, id asc) - rank counting, two candidates per lane
+  for (int i = w; i < 32; i += POI_NWAVE) {
+    const int urow = ut * 32 + i;
+    if (urow >= A.n) continue;
+    const int n = s_n[i];
+    const bool v0 = lane < n, v1 = lane + 64 < n;
+    const float s0 = v0 ? cs[i * SF_CAP + lane] : -INFINITY, s1 = v1 ? cs[i * SF_CAP + lane + 64] : -INFINITY;
+    const int i0 = v0 ? ci[i * SF_CAP + lane] : INT_MAX, i1 = v1 ? ci[i * SF_CAP + lane + 64] : INT_MAX;
+    const unsigned long long k0 = ((unsigned long long)sf_f2ord(s0) << 32) | (unsigned)(0x7FFFFFFF - i0);
+    const unsigned long long k1 = ((unsigned long long)sf_f2ord(s1) << 32) | (unsigned)(0x7FFFFFFF - i1);
+    const unsigned h0 = (unsigned)(k0 >> 32), l0 = (unsigned)k0, h1 = (unsigned)(k1 >> 32), l1 = (unsigned)k1;
+    int r0 = 0, r1 = 0;
+    const int na = n < 64 ? n : 64;
+    for (int j = 0; j < na; ++j) {
+      const unsigned long long kj = ((unsigned long long)__builtin_amdgcn_readlane(h0, j) << 32) | (unsigned)__builtin_amdgcn_readlane(l0, j);
+      r0 += kj > k0 ? 1 : 0; r1 += kj > k1 ? 1 : 0;
+    }
+    for (int j = 64; j < n; ++j) {
+      const unsigned long long kj = ((unsigned long long)__builtin_amdgcn_readlane(h1, j - 64) << 32) | (unsigned)__builtin_amdgcn_readlane(l1, j - 64);
+      r0 += kj > k0 ? 1 : 0; r1 += kj > k1 ? 1 : 0;
+    }
+    if (v0 && r0 < K) { A.idx_out[(size_t)urow * K + r0] = i0; if (A.score_out) A.score_out[(size_t)urow * K + r0] = s0; }
+    if (v1 && r1 < K) { A.idx_out[(size_t)urow * K + r1] = i1; if (A.score_out) A.score_out[(size_t)urow * K + r1] = s1; }
+    if (lane >= n && lane < K) { A.idx_out[(size_t)urow * K + lane] = -1; if (A.score_out) A.score_out[(size_t)urow * K + lane] = -INFINITY; }
+  }
+}
+
+bool score_two_stage_supported(const ScoreArgs& A) {
+  return A.k > 0 && A.seeded && !A.prob && !A.geo && !A.scores && (A.dim == 64 || A.dim == 128) && A.n >= 128 && A.n_dist + 1 <= 1024;      // (the users' bin probabilities live in LDS: 32 x (n_dist + 1) floats)
+}
+
+size_t score_filter_lds(int dim, int n_dist, bool bins) { return sizeof(float) * ((size_t)(dim / 16) * 64 * 4 + 128 + (bins ? 32 * (size_t)(n_dist + 1) : 0)); }
+
+template <int D>
+static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm) {
+  const int ntile = (A.n_item + 31) / 32, n_utile = (A.n + 31) / 32;
+  const int bins = A.ulptai ? (A.bin_bytes == 1 ? 1 : 2) : 0;
+  tm->begin("pack_items", st);
+  hipLaunchKernelGGL(pack_items_f16_kernel<D>, dim3(ntile), dim3(256), 0, st, A.items, A.items_f16, A.n_item, const_cast<uint4*>(A.items_packed16), const_cast<float2*>(A.inorm));
+  tm->end(st);
+  ScoreArgs F = A; F.n_split = n_split_f;
+  const size_t lds = score_filter_lds(D, A.n_dist, bins != 0);
+  const dim3 grid(n_utile, n_split_f / POI_NWAVE);
+  static bool optin = false;
+  if (!optin) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    optin = true;
+  }
+  tm->begin("score_filter", st);
+  if (bins == 1) hipLaunchKernelGGL((score_filter_kernel<D, 1>), grid, dim3(256), lds, st, F);
+  else if (bins == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2>), grid, dim3(256), lds, st, F);
+  else hipLaunchKernelGGL((score_filter_kernel<D, 0>), grid, dim3(256), lds, st, F);
+  tm->end(st);
+  constexpr int D8 = D / 8;
+  const size_t lds2 = sizeof(float) * ((size_t)D8 * 64 * 4 + 2 * 32 * SF_CAP);
+  tm->begin("score_rescore", st);
+  if (bins == 1) hipLaunchKernelGGL((score_rescore_kernel<D8, 1>), dim3(n_utile), dim3(256), lds2, st, A);
+  else if (bins == 2) hipLaunchKernelGGL((score_rescore_kernel<D8, 2>), dim3(n_utile), dim3(256), lds2, st, A);
+  else hipLaunchKernelGGL((score_rescore_kernel<D8, 0>), dim3(n_utile), dim3(256), lds2, st, A);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+// stage 1 + stage 2; the caller then runs the one-stage kernel + merge with A.tile_flag set (they skip every tile that is not flagged)
+hipError_t launch_score_two_stage(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm) {
+  if (A.dim == 64) return launch_two_stage_t<64>(A, n_split_f, st, tm);
+  if (A.dim == 128) return launch_two_stage_t<128>(A, n_split_f, st, tm);
+  return hipErrorInvalidValue;
+}
+
+int score_filter_cap() { return SF_CAP; }
+
+}  // namespace poi

@@ -248,7 +248,7 @@ __device__ __forceinline__ void tile_epilogue(const ScoreArgs& A, WaveTopk& T, c
   bool any = false;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    sc[r] = acc[r] + wd * pv[r];
+    sc[r] = __fmaf_rn(wd, pv[r], acc[r]);      // ONE rounding of acc + wd * pv: the expression score_rescore_kernel repeats (score_filter.hip)
     any |= sc[r] > thr[r];
   }
   if (A.scores) {
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
   const int D = A.dim, N = A.n_item, K = A.k;
   const int ut = blockIdx.x;
+  if (A.tile_flag && !A.tile_flag[ut]) return;       // two-stage path: only the tiles whose survivor lists overflowed
   const int split = blockIdx.y * POI_NWAVE + w;
   const int ntile = (N + 31) / 32;
   const int tps = (ntile + A.n_split - 1) / A.n_split;
@@ -732,6 +733,7 @@ __global__ __launch_bounds__(POI_BLOCK) void topk_merge_kernel(ScoreArgs A, int 
   const int lane = lane_id();
   const int u = blockIdx.x * POI_NWAVE + wave_id();
   if (u >= A.n) return;
+  if (A.tile_flag && !A.tile_flag[u >> 5]) return;   // two-stage path: this user's list was written by score_rescore_kernel
   const int K = A.k;
   const int total = n_lists * K;
   float s = -INFINITY; int idx = INT_MAX;

@@ -744,3 +744,72 @@ def test_padded_dim_is_exact_and_invisible(pa, dim):
     c.load_params(vals)
     for k in SP_NAMES:
         assert np.array_equal(np.asarray(_get(c, SP_NAMES)[k]), np.asarray(ga[k])), k
+
+
+@pytest.mark.parametrize("dim,n_dist,N", [(64, 0, 5000), (128, 0, 20000), (128, 200, 6000), (64, 300, 3000)])
+def test_two_stage_topk_is_bitwise_the_one_stage_result(pa, dim, n_dist, N):
+    """poi_ctx_set_topk_filter: a SEEDED fused top-K runs an f16 filter pass (v_mfma_f32_32x32x16_f16 on half-rounded users / items, a
+    rigorous bound on |approximate - float32 score|) and rescores the survivors with the one-stage kernel's own float32 MFMA sequence:
+    ids AND scores must equal the one-stage kernel's bit for bit - for good seeds (almost nothing survives), seeds from a moved model,
+    random seeds and malformed rows (survivor lists overflow: the flagged tiles take the one-stage kernel), with and without the
+    distance term (uint8 / uint16 bin matrix), ragged user counts, and against the float64 oracle on gap-checked rows."""
+    import torch
+    ctx = pa._lib.context(0)
+    rng = np.random.default_rng(500 + dim + n_dist)
+    n, K = 421, 20
+    users = (rng.standard_normal((n, dim)) * 0.4).astype(np.float32)
+    items = (rng.standard_normal((N, dim)) * 0.5).astype(np.float32)
+    items[::97] *= 1e-6                                        # rows in the half-precision subnormal range
+    du, di = torch.as_tensor(users).cuda(), torch.as_tensor(items).cuda()
+    bins = None
+    if n_dist:
+        coords = np.stack([40.0 + rng.random(N) * 0.3, -74.0 + rng.random(N) * 0.3], 1)
+        last = rng.integers(0, N, n).astype(np.int32)
+        from poi_amd.data import bin_thresholds, cos_lat
+        dd = 200.0
+        thr = torch.as_tensor(bin_thresholds(dd, n_dist)).cuda(); cph = torch.as_tensor(cos_lat(coords)).cuda()
+        dc = torch.as_tensor(coords).cuda(); dl = torch.as_tensor(last).cuda()
+        bb = 1 if n_dist <= 255 else 2
+        ntile = (N + 31) // 32
+        bins = torch.zeros(((n + 31) // 32) * ntile * 1024 * bb, dtype=torch.uint8, device="cuda")
+        ctx.check(ctx.lib.poi_ulptai_build(ctx.handle, dc.data_ptr(), cph.data_ptr(), thr.data_ptr(), dl.data_ptr(), n, N, n_dist, dd, bins.data_ptr(), bb, None))
+        sts = rng.random((((n + 31) // 32) * 32, n_dist + 1)).astype(np.float32); sts /= sts.sum(axis=1, keepdims=True); sts[:, n_dist] = 0.0
+        dsts = torch.as_tensor(sts).cuda()
+        dwd = torch.as_tensor(np.array([3.5], np.float32)).cuda()
+
+    def run(seed, two_stage, uu=du):
+        idx = torch.full((n, K), -7, dtype=torch.int32, device="cuda")
+        sc = torch.zeros((n, K), dtype=torch.float32, device="cuda")
+        ctx.set_topk_filter(two_stage)
+        if seed is not None:
+            ctx.set_topk_seed(seed, seed.shape[1])
+        try:
+            if n_dist:
+                ctx.check(ctx.lib.poi_score_topk_ulptai(ctx.handle, uu.data_ptr(), di.data_ptr(), n, N, dim, dwd.data_ptr(), dsts.data_ptr(), bins.data_ptr(), bb,
+                                                        n_dist, K, idx.data_ptr(), sc.data_ptr(), None))
+            else:
+                ctx.check(ctx.lib.poi_score_topk(ctx.handle, uu.data_ptr(), di.data_ptr(), n, N, dim, None, None, K, idx.data_ptr(), sc.data_ptr(), None))
+        finally:
+            ctx.set_topk_filter(True)
+        return idx.cpu().numpy(), sc.cpu().numpy()
+
+    base_idx, base_sc = run(None, False)
+    if not n_dist:
+        full = users.astype(np.float64) @ items.astype(np.float64).T
+        exp = O.topk_desc(full, K)
+        srt = np.sort(full, axis=1)[:, ::-1][:, :K + 1]
+        ok = np.min(srt[:, :-1] - srt[:, 1:], axis=1) > 1e-5 * np.abs(srt).max()
+        assert ok.sum() > n // 2 and np.array_equal(base_idx[ok], exp[ok])
+    good = torch.as_tensor(base_idx).cuda()
+    # the lists of a slightly different model (what the next evaluation's seeds are)
+    moved = torch.as_tensor(users + (rng.standard_normal(users.shape) * 0.02).astype(np.float32)).cuda()
+    prev_idx, _ = run(None, False, uu=moved)
+    prev = torch.as_tensor(prev_idx).cuda()
+    rnd = torch.as_tensor(np.stack([rng.choice(N, K, replace=False) for _ in range(n)]).astype(np.int32)).cuda()
+    bad = good.clone(); bad[::3, 5] = bad[::3, 4]; bad[1::3, 0] = N + 7
+    for name, seed in (("true top-K", good), ("previous model's lists", prev), ("random items", rnd), ("malformed rows", bad)):
+        one_idx, one_sc = run(seed, False)
+        two_idx, two_sc = run(seed, True)
+        assert np.array_equal(one_idx, base_idx) and np.array_equal(one_sc, base_sc), name
+        assert np.array_equal(two_idx, base_idx), "two-stage ids differ: " + name
+        assert np.array_equal(two_sc.view(np.uint32), base_sc.view(np.uint32)), "two-stage scores differ: " + name
