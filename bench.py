@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-engine (float64) timing")
+    ap.add_argument("--no-x1", action="store_true", help="skip the secondary_x1 block (one GPU's slice of BASELINE.json configs[4], training only, a subprocess of ~12 s)")
+    ap.add_argument("--f16-rounding", default=None, choices=["nearest", "stochastic"],
+                    help="write-back rounding of a half POI table (poi_ctx_set_f16_rounding); default: stochastic for --table-dtype f16 - keeps the L2 decay")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--quality-seconds", type=float, default=3.0, help="training wall time of the batched modes in the quality block")
     ap.add_argument("--reference-seconds", type=float, default=15.0, help="training wall time of the reference schedule (one user per step)")
@@ -125,7 +128,7 @@ def main():
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
     if a.shape == "x1":
         # 10 M POIs: i.i.d. Zipf check-ins (the neighbour structure of --local needs a k-d tree over 10 M points), throughput only
-        a.local = 0.0; a.no_quality = True; a.no_secondary = True; a.no_cpu_baseline = True; a.no_exact = True
+        a.local = 0.0; a.no_quality = True; a.no_secondary = True; a.no_cpu_baseline = True; a.no_exact = True; a.no_x1 = True
         a.eval_users = a.eval_users or 8192
         a.table_dtype = a.table_dtype or "f16"
         if a.steps == 250:
@@ -146,6 +149,8 @@ def main():
     model = new_model(tab, n_local)
     ctx = model.ctx
     ctx.set_batch_cap(a.batch_cap)
+    a.f16_rounding = a.f16_rounding or ("stochastic" if a.table_dtype == "f16" else "nearest")
+    ctx.set_f16_rounding(a.f16_rounding, seed=1)
     sync = poi_amd.dist.model_sync(model, force=os.environ.get("POI_BENCH_FORCE_SYNC") == "1")
 
     lens_local = np.diff(tab.off.astype(np.int64))
@@ -545,6 +550,22 @@ def main():
                                                  "note": "same data, dim = 20 (the reference's default): stored zero-padded to the tile engine's dim 64, exact"}
         del m3
 
+    # ---- secondary_x1: one GPU's slice of BASELINE.json configs[4] (10 M POIs, 125 k users, dim 256, half POI table), training only -----
+    secondary_x1 = None
+    if solo and not a.no_x1 and a.shape == "gowalla":
+        import subprocess
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape", "x1", "--steps", "8", "--warmup", "2", "--no-eval"],
+                               capture_output=True, text=True, timeout=240)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            secondary_x1 = {"workload": j["config"]["workload"], "table_storage": j["table_storage"], "f16_rounding": j["config"].get("f16_rounding"),
+                            "train_seq_per_s": j["value"], "ms_per_epoch": j["ms_per_step"], "batch_users_per_launch": j["config"]["batch_users_per_launch"],
+                            "dominant_kernel": j["roofline"]["kernel"], "dominant_frac": j["roofline"]["frac"], "wall_s_incl_data_generation": time.perf_counter() - t0,
+                            "tests": "tests/test_gpu_configx.py: the 10 M x 256 half table at full size (touched rows vs the float64 oracle, > 2^31-element indexing, stochastic rounding, GEO top-K over 10 M POIs)"}
+        except Exception as e:          # (the block is informational: a failure must not cost the headline line)
+            secondary_x1 = {"error": repr(e)[:300]}
+
     # ---- CPU baseline: plain-C float64 port of the same per-sequence algorithm, 1 thread -------------
     cpu = None
     if solo and not a.no_cpu_baseline:
@@ -598,10 +619,11 @@ def main():
                                                                   "their reference updates (include/poi_hip.h); see `quality` for what it learns" % a.batch_cap,
                        "batch_cap": a.batch_cap, "local_transition_fraction": a.local,
                        "parallelism": "user-shard x%d, per-epoch delta all-reduce" % world,
+                       "f16_rounding": a.f16_rounding if a.table_dtype == "f16" else None,
                        "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence",
                        "s_rows_per_step": rho},
             "timed_window_s": dt,
-            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary,
+            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_x1": secondary_x1,
             "train_step_tflops": executed_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "train_step_tflops_reference_formulation": total_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "reference_schedule": reference_schedule, "eval": eval_detail, "roofline_gather_scatter": hbm,
@@ -618,6 +640,7 @@ def main():
             "exact_seq_per_s": exact_mode and exact_mode["seq_per_s"],
             "reference_schedule_steps_per_s": reference_schedule and reference_schedule["seq_per_s"],
             "recall_headline_vs_reference": quality and quality["headline_vs_reference"]["recall_ratio"],
+            "x1_train_seq_per_s": secondary_x1 and secondary_x1.get("train_seq_per_s"),
             "cpu_1core_seq_per_s": cpu and cpu["value"], "cpu_allcores_seq_per_s": cpu and cpu["all_cores"] and cpu["all_cores"]["value"],
         }
         print(json.dumps(out))

@@ -113,6 +113,12 @@ int64_t poi_ctx_graph_replays(const poi_ctx* ctx);
  * return POI_ENOTSUP for a half table.  poi_ctx_unregister_f16(ptr) forgets the buffer (call it before freeing). */
 int poi_ctx_register_f16(poi_ctx* ctx, const void* ptr, int64_t bytes);
 int poi_ctx_unregister_f16(poi_ctx* ctx, const void* ptr);
+/* Rounding of the sparse SGD write-back into a HALF POI table (poi_spatial_step / poi_gru_step, tile engine): mode 0 = round to nearest
+ * even (default; an update below half an fp16 ulp of the element - e.g. the whole L2 decay alpha lambda |x| of a row without a loss
+ * gradient - is lost), mode 1 = STOCHASTIC rounding: the element rounds up with probability (value - floor) / ulp, so the expected stored
+ * value is the float32 result and sub-ulp updates (the decay the reference applies at every step, public/GRU_Spatial.py:202-209) act in
+ * expectation.  Counter-based: the same seed and launch sequence reproduce the same tables. */
+int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
 
 /* Seeded top-K (optional, exact): seed_idx (n x k_seed int32, device) holds, for every user of the NEXT fused top-K call
  * (poi_score_topk / _ulptai / _geo with the same n and user order), k_seed >= k distinct item ids - typically the user's top-K of the

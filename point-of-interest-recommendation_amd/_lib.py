@@ -52,6 +52,7 @@ SIGNATURES = {
     "poi_ctx_graph_replays": (c_int64, [c_void_p]),
     "poi_ctx_register_f16": (c_int, [c_void_p, c_void_p, c_int64]),
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
+    "poi_ctx_set_f16_rounding": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                              c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
     "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
@@ -188,6 +189,10 @@ class Context:
     def register_f16(self, tensor):
         """Declare a torch.float16 device tensor as an IEEE-half POI table (poi_ctx_register_f16)."""
         self.check(self.lib.poi_ctx_register_f16(self.handle, tensor.data_ptr(), tensor.numel() * 2))
+
+    def set_f16_rounding(self, mode, seed=0):
+        """'nearest' | 'stochastic' write-back of a half POI table (poi_ctx_set_f16_rounding)."""
+        self.check(self.lib.poi_ctx_set_f16_rounding(self.handle, {"nearest": 0, "stochastic": 1}[mode], int(seed) & 0xFFFFFFFF))
 
     def unregister_f16(self, tensor):
         self.check(self.lib.poi_ctx_unregister_f16(self.handle, tensor.data_ptr()))

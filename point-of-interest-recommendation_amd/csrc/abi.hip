@@ -60,6 +60,8 @@ struct poi_ctx {
   // scoring
   DevBuf cand_s, cand_i, items_pk, gbound;
   DevBuf items_pk16, inorm, surv_cnt, surv_idx, tflag;      // two-stage fused top-K (score_filter.hip)
+  int f16_rounding = 0;     // poi_ctx_set_f16_rounding: 0 nearest, 1 stochastic (write-back of a half POI table)
+  unsigned sr_counter = 0;  // launches so far (salt of the stochastic rounding)
   int topk_filter = 1;      // poi_ctx_set_topk_filter / POI_TOPK_FILTER=0: one-stage float32 kernel only
   int last_two_n = 0, last_two_tiles = 0;      // users / user tiles of the last two-stage call (poi_ctx_topk_filter_stats)
   const int32_t* seed_idx = nullptr; int seed_k = 0;      // poi_ctx_set_topk_seed: consumed by the next fused top-K call
@@ -404,6 +406,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     if ((rc = te_setup(c, E, P, T, uidx, n, false, spatial, st))) return rc;
     if ((rc = ensure(c, c->zrow, sizeof(float) * 1024, st))) return rc;
     E.zrow = (const float*)c->zrow.p;
+    E.sr_salt = (c->f16_rounding && E.lt_f16) ? (++c->sr_counter) * 0x9E3779B1u | 1u : 0u;
     E.out = out; E.bcap = bcap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
     E.kc_dev = (poi::te_bintab(D, spatial, spatial ? P->n_dist : -1) && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
@@ -417,7 +420,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       return e;
     };
     const size_t out_bytes = sizeof(float) * (size_t)n * (spatial ? 5 : 1);
-    if (!c->graph_mode || c->tm.on || !c->side || n < c->graph_min_n || n > c->graph_max_n) { HIPCHK(c, run(st)); return POI_OK; }
+    if (!c->graph_mode || c->tm.on || !c->side || n < c->graph_min_n || n > c->graph_max_n || E.sr_salt) { HIPCHK(c, run(st)); return POI_OK; }
     // ---- graph replay ----
     if ((rc = ensure(c, c->uidx_stage, sizeof(int32_t) * (size_t)n, st)) || (rc = ensure(c, c->out_stage, out_bytes, st))) return rc;
     std::vector<uint64_t> key;
@@ -908,6 +911,12 @@ int poi_delta_apply(poi_ctx* c, float* cur, const float* base, const float* delt
 int poi_ctx_set_engine(poi_ctx* c, int engine) {
   if (!c || engine < 0 || engine > 4) return fail(c, POI_EINVAL, "engine must be 0 (auto), 1 (per-sequence), 2 (tile), 3 (tile, streaming recurrent kernels) or 4 (exact: float64)");
   c->engine = engine;
+  return POI_OK;
+}
+
+int poi_ctx_set_f16_rounding(poi_ctx* c, int mode, uint32_t seed) {
+  if (!c || mode < 0 || mode > 1) return fail(c, POI_EINVAL, "poi_ctx_set_f16_rounding: mode must be 0 (nearest) or 1 (stochastic)");
+  c->f16_rounding = mode; c->sr_counter = seed;
   return POI_OK;
 }
 

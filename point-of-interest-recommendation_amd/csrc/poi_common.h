@@ -76,12 +76,35 @@ __device__ __forceinline__ void st4(__half* p, float4 v) {
   uint2 u; u.x = *reinterpret_cast<const unsigned*>(&a); u.y = *reinterpret_cast<const unsigned*>(&b);
   *reinterpret_cast<uint2*>(p) = u;
 }
+// Stochastic rounding float32 -> half (poi_ctx_set_f16_rounding): the 13 mantissa bits a half drops decide - a uniform 13-bit number is
+// added below the half's last place and the sum truncated, so the value rounds up with probability (v - floor) / ulp and the EXPECTED stored
+// value is v.  With round-to-nearest an SGD update below half an fp16 ulp of the element (the whole L2 decay alpha lambda |x| = 1e-5 |x|
+// against a half ulp of 2.4e-4 |x| .. 4.9e-4 |x|) is lost every time; stochastically it is applied in expectation.  `rnd` = 32 random
+// bits per 4 elements (hash of the element index and the launch's salt): reproducible for a given launch sequence.  Values below the
+// half's normal range (2^-14) are rounded to nearest.
+__device__ __forceinline__ unsigned sr_hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ __half sr_half(float v, unsigned r13) {
+  const unsigned u = __float_as_uint(v);
+  if ((u & 0x7f800000u) < 0x38800000u) return __float2half_rn(v);            // |v| < 2^-14 (or zero): nearest
+  return __float2half_rz(__uint_as_float((u + (r13 & 0x1FFFu)) & ~0x1FFFu)); // exact conversion: the low 13 bits are zero
+}
+__device__ __forceinline__ void st4_sr(__half* p, float4 v, unsigned seed) {
+  const unsigned r0 = sr_hash(seed), r1 = sr_hash(seed ^ 0x9E3779B9u);
+  const __half2 a = __halves2half2(sr_half(v.x, r0), sr_half(v.y, r0 >> 13)), b = __halves2half2(sr_half(v.z, r1), sr_half(v.w, r1 >> 13));
+  uint2 w; w.x = *reinterpret_cast<const unsigned*>(&a); w.y = *reinterpret_cast<const unsigned*>(&b);
+  *reinterpret_cast<uint2*>(p) = w;
+}
 // runtime-typed (f16 is wave-uniform)
 __device__ __forceinline__ float4 ld4t(const void* base, size_t off, int f16) {
   return f16 ? ld4(reinterpret_cast<const __half*>(base) + off) : ld4(reinterpret_cast<const float*>(base) + off);
 }
 __device__ __forceinline__ void st4t(void* base, size_t off, int f16, float4 v) {
   if (f16) st4(reinterpret_cast<__half*>(base) + off, v); else st4(reinterpret_cast<float*>(base) + off, v);
+}
+// ... with stochastic rounding of a half table when salt != 0 (`eidx` = element index of v.x in the table)
+__device__ __forceinline__ void st4t_sr(void* base, size_t off, int f16, float4 v, unsigned salt, size_t eidx) {
+  if (f16 && salt) st4_sr(reinterpret_cast<__half*>(base) + off, v, (unsigned)(eidx >> 2) * 0x85ebca6bu + (unsigned)(eidx >> 34) + salt);
+  else st4t(base, off, f16, v);
 }
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) {

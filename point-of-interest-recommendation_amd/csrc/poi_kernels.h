@@ -175,6 +175,7 @@ struct TeArgs {
   int wg_slots;                       // te_wgrad: workgroups of the (job, K-chunk) grid (2 per CU)
   int* kc_dev;                        // {K-chunks of the non-ui jobs, of the d ui jobs}: chosen ON THE DEVICE from the launch's own S-row / step counts
                                       // (te_wgrad_split) - the split-K order is a function of the launch alone, not of its history
+  unsigned sr_salt;                   // != 0: a half POI table is written back with stochastic rounding (poi_ctx_set_f16_rounding), salt of this launch
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
 };
 // entry code: packed-row index of the position (28 bits) + what the position contributes

@@ -370,7 +370,8 @@ __device__ __forceinline__ float4 seg_sum(const TeArgs& A, int s, int cnt, int d
 
 // row <- row - alpha * min(nseq, cap) / nseq * (G + lambda * mult * row)      (batch rule, include/poi_hip.h)
 template <int D>
-__device__ __forceinline__ void apply_sum(float* __restrict__ trow, int f16, float4 g, int mult, int nseq, float alpha, float lambda, float cap) {
+__device__ __forceinline__ void apply_sum(float* __restrict__ trow, int f16, float4 g, int mult, int nseq, float alpha, float lambda, float cap,
+                                          unsigned salt = 0, size_t erow = 0) {
   constexpr int LPR = D / 4;
   const int lane = lane_id();
   if (lane >= LPR) return;
@@ -378,7 +379,7 @@ __device__ __forceinline__ void apply_sum(float* __restrict__ trow, int f16, flo
   float4 tv = ld4t(trow, (size_t)lane * 4, f16);
   tv.x -= sc * (g.x + lm * tv.x); tv.y -= sc * (g.y + lm * tv.y);
   tv.z -= sc * (g.z + lm * tv.z); tv.w -= sc * (g.w + lm * tv.w);
-  st4t(trow, (size_t)lane * 4, f16, tv);
+  st4t_sr(trow, (size_t)lane * 4, f16, tv, salt, erow + (size_t)lane * 4);
 }
 
 struct RowInfo { float* trow; int* pm; int* pn; int doff; int f16; };      // f16: trow addresses IEEE half elements
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
       float4 tv = ld4t(ri.trow, (size_t)c, ri.f16);
       tv.x -= sc * (acc.x + lm * tv.x); tv.y -= sc * (acc.y + lm * tv.y);
       tv.z -= sc * (acc.z + lm * tv.z); tv.w -= sc * (acc.w + lm * tv.w);
-      st4t(ri.trow, (size_t)c, ri.f16, tv);
+      st4t_sr(ri.trow, (size_t)c, ri.f16, tv, A.sr_salt, (size_t)row * D + c);
       if (lane == lead) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
     }
   }
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
       acc = f4_add(acc, *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + c));
       if (lane == 0) A.pmark[row] = 0;
     }
-    apply_sum<D>(ri.trow, ri.f16, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap);
+    apply_sum<D>(ri.trow, ri.f16, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap, A.sr_salt, (size_t)row * D);
     if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
 }

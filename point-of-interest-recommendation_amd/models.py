@@ -80,6 +80,8 @@ class _Base:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _dev(self, a, dtype=torch.float32):
+        if isinstance(a, torch.Tensor):          # (a device tensor is taken as it is: 10 M-row tables are generated on the device)
+            return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(self.device).contiguous()
 
     def _ids(self, idxs):
@@ -331,15 +333,22 @@ class GruBasic(_Base):
         rng = np.random.default_rng(seed) if seed is not None else np.random
         u = lambda *s: rng.uniform(-0.5, 0.5, s)
         init = init or {}
-        g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
+        g = lambda k, v: (init[k] if isinstance(init[k], torch.Tensor) else np.asarray(init[k], np.float64)) if k in init else v()
         tdt = torch.float16 if table_dtype == "f16" else torch.float32
         sh = self._shared
-        self.lt = sh(g("lt", lambda: u(n_item + 1, D)), "cols", tdt)                       # GRU.py:60
+        big = (n_item + 1) * D > (1 << 28) and self.kdim == D
+        if big:
+            # tables of hundreds of millions of elements (config X: 10 M x 256) are drawn ON the device: the host draw is 20 GB of float64
+            gen = torch.Generator(device=self.device).manual_seed(0 if seed is None else int(seed))
+            u_tab = lambda rows: (torch.rand((rows, D), generator=gen, device=self.device, dtype=torch.float32) - 0.5).to(tdt)
+        else:
+            u_tab = lambda rows: u(rows, D)
+        self.lt = sh(g("lt", lambda: u_tab(n_item + 1)), "cols", tdt)                      # GRU.py:60
         self.ui = sh(g("ui", lambda: u(3, D, self._xw())), "ui")                           # :61 / GRU_Spatial.py:51
         self.wh = sh(g("wh", lambda: u(3, D, D)), "sq")                                    # :62
         self.bi = sh(g("bi", lambda: np.zeros((3, D))), "cols")                            # :64
         self.h0 = Shared(torch.zeros(self.kdim, dtype=torch.float32, device=self.device), unpad=(lambda a: a[:D]) if self.kdim != D else None)   # :63 never trained
-        self.trained_items = sh(u(n_item + 1, D), "cols", tdt)                             # :71
+        self.trained_items = sh(u_tab(n_item + 1), "cols", tdt)                            # :71
         self.trained_users = sh(u(n_user, D), "cols")                                      # :72
         if table_dtype == "f16":
             self.ctx.register_f16(self.lt.t); self.ctx.register_f16(self.trained_items.t)
