@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--quality-seconds", type=float, default=3.0, help="training wall time of the batched modes in the quality block")
     ap.add_argument("--reference-seconds", type=float, default=15.0, help="training wall time of the reference schedule (one user per step)")
     ap.add_argument("--emulate-world", type=int, default=0, help="tuning aid: train only rank 0's shard of an N-way split on one GPU")
+    ap.add_argument("--replica-schedule", default="quality", choices=["quality", "throughput"],
+                    help="N > 1: launches per replica and epoch - as many as the one-GPU run (quality, default) or ~--batch-users users each (plan_shard)")
     return ap.parse_args()
 
 
@@ -88,6 +90,23 @@ def make_batches(n_local, lens_local, batch_users, seed=123):
         ids = perm[b0:b0 + B]
         batches.append(ids[np.argsort(-lens_local[ids], kind="stable")])
     return perm, B, batches
+
+
+def plan_shard(n_user, lens, world, rank, batch_users, schedule="quality", seed=123):
+    """This rank's user range and launch schedule.  Users are sharded by check-ins (data.shard_users).  schedule:
+      "quality"     as many launches per replica and epoch as the ONE-GPU run makes (round(n_user / batch_users)): N replicas then learn
+                    like one GPU (DESIGN.md section 7: recall 0.534 vs 0.551, against 0.446 with one launch per replica) - the default;
+      "throughput"  launches of about batch_users users: at N = 8 one 6250-user launch per replica (the larger effective batch costs epochs).
+    Returns (lo, hi, B, batches): batches are local ids, each sorted by descending length."""
+    from poi_amd import data as pdata
+    lo, hi = pdata.shard_users(n_user, world, rank, lens)
+    n_local = hi - lo
+    bu = batch_users
+    if schedule == "quality" and world > 1:
+        n_launch = max(1, int(round(n_user / float(batch_users))))
+        bu = max(1, -(-n_local // n_launch))
+    _, B, batches = make_batches(n_local, np.asarray(lens[lo:hi]), bu, seed=seed)
+    return lo, hi, B, batches
 
 
 def evaluate_model(model, tab, n_local, dev, chunk=16384):
@@ -137,7 +156,7 @@ def main():
             a.batch_users = 16384      # 512 recurrent tiles of 32 sequences: two full rounds of the 256 CUs (12500 -> 391 tiles: 1.5 rounds)
     a.table_dtype = a.table_dtype or "f32"
     ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local, dd=a.dd, ud_km=a.ud_km)
-    lo, hi = pdata.shard_users(n_user, a.emulate_world or world, rank, ds.lens)
+    lo, hi, B, batches = plan_shard(n_user, ds.lens, a.emulate_world or world, rank, a.batch_users, a.replica_schedule)
     tab = ds.shard(lo, hi)
     n_local = hi - lo
     NB = ds.dist_num + 1
@@ -154,7 +173,7 @@ def main():
     sync = poi_amd.dist.model_sync(model, force=os.environ.get("POI_BENCH_FORCE_SYNC") == "1")
 
     lens_local = np.diff(tab.off.astype(np.int64))
-    perm, B, batches = make_batches(n_local, lens_local, a.batch_users)
+    perm = np.random.default_rng(123).permutation(n_local)
     order = torch.as_tensor(np.concatenate(batches).astype(np.int32)).to(dev)
     steps_per_epoch = float(np.maximum(lens_local - 1, 0).sum())
 
@@ -619,6 +638,7 @@ def main():
                                                                   "their reference updates (include/poi_hip.h); see `quality` for what it learns" % a.batch_cap,
                        "batch_cap": a.batch_cap, "local_transition_fraction": a.local,
                        "parallelism": "user-shard x%d, per-epoch delta all-reduce" % world,
+                       "replica_schedule": a.replica_schedule if (world > 1 or a.emulate_world) else None, "launches_per_epoch_per_replica": len(batches),
                        "f16_rounding": a.f16_rounding if a.table_dtype == "f16" else None,
                        "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence",
                        "s_rows_per_step": rho},

@@ -197,6 +197,7 @@ class ReplicaSync:
                 out["rccl_world_size"] = self.backend.lib.poi_comm_world(self.backend.comm)
             else:
                 out["allreduce_bytes"] = self.backend.n * 4
+        if hasattr(self.backend, "checksum"):
             cs = self.backend.checksum()
             if dist.is_initialized():
                 t = torch.tensor([cs], dtype=torch.int64, device=self.tensors[0].device)
@@ -207,6 +208,7 @@ class ReplicaSync:
                 allcs = [cs]
             out["replica_checksums_equal"] = len(set(allcs)) == 1
             out["replica_checksum"] = "%016x" % (allcs[0] & 0xFFFFFFFFFFFFFFFF)
+            out["world_size_seen_by_all_gather"] = len(allcs)
         return out
 
     def close(self):

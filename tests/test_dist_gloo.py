@@ -110,3 +110,64 @@ def test_replica_sync_is_identity_at_world1():
     lt += 1.0
     sync.end_epoch()
     assert torch.equal(lt, before + 1.0)
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's own N > 1 plumbing on CPU tensors: plan_shard (sharding + launch schedule), the per-epoch ReplicaSync with the default
+    rules, and the self-validation block bench.py prints (report(): world size seen, replica checksums)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    n_user, n_item = 400, 300
+    ds = make_synthetic(n_user, n_item, 12, seed=3)
+    plans = {sch: bench.plan_shard(n_user, ds.lens, world, rank, 100, sch) for sch in ("quality", "throughput")}
+    lo, hi, B, batches = plans["quality"]
+    lt = torch.zeros(n_item + 1, 4); wh = torch.zeros(8)
+    names, rules = ["lt", "wh"], [poi_amd.dist.DEFAULT_RULES["lt"], poi_amd.dist.DEFAULT_RULES["wh"]]
+
+    class B2(HostBackend):
+        def checksum(self):
+            return int(sum(int(x.view(torch.int32).to(torch.int64).sum()) for x in self.t))
+    sync = poi_amd.dist.ReplicaSync([lt, wh], rules=rules, backend=B2([lt, wh], rules), names=names)
+    tab = ds.shard(lo, hi)
+    for epoch in range(2):
+        for ids in batches:                       # one "launch" per batch: every user of the launch moves its first POI's row
+            for u in ids:
+                lt[int(tab.p[tab.off[u]])] += 1.0
+            wh += 0.125
+        sync.end_epoch()
+    rep = sync.report()
+    q.put((rank, {k: (v[0], v[1], v[2], [np.asarray(b) + v[0] for b in v[3]]) for k, v in plans.items()}, lt.numpy().copy(), wh.numpy().copy(), rep))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_sharding_schedule_and_self_check_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import bench
+    ds = make_synthetic(400, 300, 12, seed=3)
+    one = bench.plan_shard(400, ds.lens, 1, 0, 100)
+    assert len(one[3]) == 4
+    for sch, n_launch in (("quality", 4), ("throughput", 2)):
+        (lo0, hi0, B0, b0), (lo1, hi1, B1, b1) = res[0][1][sch], res[1][1][sch]
+        assert lo0 == 0 and hi0 == lo1 and hi1 == 400                        # the shards partition the users
+        assert len(b0) == n_launch and len(b1) == n_launch                   # quality: as many launches per replica as the one-GPU run
+        allu = np.sort(np.concatenate(b0 + b1))
+        assert np.array_equal(allu, np.arange(400))                          # every user trained exactly once per epoch
+        for b in b0:                                                         # launches sorted by descending length
+            assert np.all(np.diff(ds.lens[b]) <= 0)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    for r in res:
+        rep = r[4]
+        assert rep["world_size"] == 2 and rep["replica_checksums_equal"] and rep["world_size_seen_by_all_gather"] == 2 and rep["epochs_synced"] == 2
+        assert rep["rules"] == {"lt": "mean_touched", "wh": "mean"}
+    assert np.allclose(res[0][3], 2 * 4 * 0.125)                              # dense: mean over the replicas of 4 launches x 2 epochs
