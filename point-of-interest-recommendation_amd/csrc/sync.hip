@@ -221,6 +221,8 @@ int poi_sync_create(poi_ctx* ctx, int device, const poi_sync_seg* segs_host, int
     delete s;
     return sfail(nullptr, POI_ENOMEM, "poi_sync_create: allocation failed");
   }
+  // the alignment gaps between the segments are never written by the kernels but travel through the all-reduce: zero them once
+  if (hipMemset(s->delta, 0, sizeof(float) * (size_t)s->n_total) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(s->base); (void)hipFree(s->delta); delete s; return sfail(nullptr, POI_EHIP, "poi_sync_create: memset failed"); }
   *out = s;
   return POI_OK;
 }

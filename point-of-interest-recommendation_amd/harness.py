@@ -177,3 +177,25 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
         if p["gru"] == 2 and p.get("save_per_epoch", 0) and epoch % p["save_per_epoch"] == 0 and epoch != 0:      # :320-330
             save_checkpoint(model, checkpoint_path(p, model.__class__.__name__, epoch, p.get("model_root", "./model")))
     return model, best, history
+
+
+def cal_s(ds, p, device="cuda:0", out_root="./Lmdd", log=print):
+    """Mode 's' of the reference driver (prog_bpr_gru_spatial.py:337-362): build the Distance2Pre model, load the checkpoint of
+    p['load_epoch'], snapshot the tables, predict every user and save the (n_user, n_dist + 1) bin probabilities `sts` with np.save under
+    ./Lmdd/<dataset>_size<D>_UD<UD>_dd<dd>_epoch<e>last1(.npy).  Returns (path, sts)."""
+    if p["gru"] != 2:
+        raise ValueError("cal_s is the Distance2Pre (gru = 2) mode of the reference driver")
+    model = build_model(ds, p, device, seed=p.get("seed"))
+    path = checkpoint_path(p, model.__class__.__name__, p["load_epoch"], p.get("model_root", "./model"))
+    log("Loading model ...")
+    load_checkpoint(model, path)
+    log("\tPredicting ...")
+    model.update_trained_items(); model.update_trained_dists()
+    all_sus = []
+    for se in compute_start_end(ds.n_user, max(int(p["batch_size_test"]), 16384)):          # (:354-356; rows are the same for any chunking)
+        all_sus.append(model.predict_device(se)[1])
+    sts = torch.cat(all_sus).cpu().numpy()
+    os.makedirs(out_root, exist_ok=True)
+    out = os.path.join(out_root, "%s_size%s_UD%s_dd%s_epoch%slast1" % (p["dataset"], p["latent_size"], p["UD"], p["dd"], p["load_epoch"]))
+    np.save(out, sts)
+    return out + ".npy", sts

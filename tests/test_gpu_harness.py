@@ -2,6 +2,8 @@
 end to end: one-user-per-step training must reproduce the reference's sequential epoch (checked against
 the plain-C float64 oracle on the same shuffled order), and the evaluator's ranks / metrics must match
 the oracle's on the scores the model produces."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,3 +105,20 @@ def test_checkpoint_resume_reproduces_an_uninterrupted_run(pa, tmp_path):
     resumed, _, _ = harness.train_valid_or_test(make_synthetic(96, 300, 10, seed=21), dict(base, load_epoch=1), log=lambda *a: None)
     for k in harness.CKPT_ORDER:
         assert_close(np.asarray(resumed.__dict__[k].get_value(), np.float64), np.asarray(full.__dict__[k].get_value(), np.float64), k, rtol=1e-5)
+
+
+def test_cal_s_mode_saves_the_bin_probabilities_of_a_checkpoint(pa, tmp_path):
+    """Mode 's' of the reference driver (prog_bpr_gru_spatial.py:337-362): load a checkpoint, predict every user, np.save(sts)."""
+    from poi_amd import data as pdata, harness
+    ds = pdata.make_synthetic(60, 120, 9, seed=5)
+    p = harness.default_params(); p.update(latent_size=64, epochs=3, batch_users=20, save_per_epoch=1, model_root=str(tmp_path / "model"), dataset="toy")
+    model, _, _ = harness.train_valid_or_test(ds, p, log=lambda *a: None)
+    p2 = dict(p); p2["load_epoch"] = 2
+    path, sts = harness.cal_s(ds, p2, out_root=str(tmp_path / "Lmdd"), log=lambda *a: None)
+    assert path.endswith("toy_size64_UD40_dd200_epoch2last1.npy") and os.path.exists(path)
+    saved = np.load(path)
+    assert saved.shape == (60, ds.dist_num + 1) and np.allclose(saved.sum(axis=1), 1.0, atol=1e-5)
+    # the same rows as predicting with the trained model itself (the checkpoint of the last epoch IS the final state)
+    model.update_trained_items(); model.update_trained_dists()
+    _, exp = model.predict(np.arange(60, dtype=np.int32))
+    assert np.allclose(saved, exp, rtol=1e-6, atol=1e-7)
