@@ -118,8 +118,15 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
     const float bu = s_n1[t] * (2.98023224e-8f * 1.01f) + 4.76837158e-7f * (fabsf(wd) * pmax + (g ? fabsf(thr) : 0.f)) + 1e-30f;
     s_au[t] = c1 * nu2;
     s_c[t] = urow < A.n ? thr - bu : INFINITY;             // rows past n: nothing survives
+    s_n2[t] = (urow < A.n && !g) ? 1.f : 0.f;              // an unseeded user (no bound: malformed / missing seed row)
   }
   __syncthreads();
+  {
+    // a tile with an unseeded user would keep every pair of that user: it goes to the one-stage kernel as a whole, at once
+    bool unseeded = false;
+    for (int i = 0; i < 32; ++i) unseeded |= s_n2[i] != 0.f;
+    if (unseeded) { if (t == 0) A.tile_flag[ut] = 1; return; }
+  }
   // (the norm part of the bound uses the LARGEST c1 |u|_2 of the tile's 32 users: one fma per lane and tile instead of one per pair and
   // sixteen registers less - the hidden states of a model have similar norms, so the bound loosens by a few per cent at most)
   float cc[16], au = 0.f;
@@ -140,7 +147,14 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
     }
     nm = A.inorm[min(t_begin * 32 + li, N - 1)];
   }
+  int flagv = 0;
   for (int tile = t_begin; tile < t_end; ++tile) {
+    // a tile whose survivor lists overflowed (useless seeds: thresholds far below the final ones) is rescored by the one-stage kernel
+    // anyway: the flag is polled every 16 item tiles, one poll period ahead (no wait on the load), and the wave stops
+    if (((tile - t_begin) & 15) == 0) {
+      if (flagv) break;
+      flagv = __hip_atomic_load(A.tile_flag + ut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int nt = min(tile + 1, t_end - 1);               // (branch-free: the last tile reloads itself)
     f32x16 acc;
 #pragma unroll

@@ -734,7 +734,7 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   // hide behind the reduction.  (The events of the training phase are free again: both streams passed them in launch_te_train.)
   // Timing: the regions te_dsum / te_bin_gemm (side stream) and te_scatter then OVERLAP and stretch each other; `te_tail` spans fork to join.
   // (large launches only: the two cross-stream dependencies cost ~35 us, more than the whole tail of a one-sequence launch)
-  const bool fork = A.bintab && A.side && !A.dbg && A.n_seq >= 2048;
+  const bool fork = A.bintab && A.side && !(A.dbg & 1) && A.n_seq >= 2048;
   hipStream_t sb = fork ? A.side : st;
   const long tail = tm->span_begin("te_tail", st);
   if (fork && (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(sb, A.ev_bwd, 0) != hipSuccess)) return hipGetLastError();

@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   const int Tsteps = A.soff[A.n_seq];
   const int NB_TOT = NB_UI + NB_ZR + NB_C + (A.spatial ? ((te_nbp_dev(A.n_dist) + T - 1) / T) * (D / T) : 0);
   int n_o = nkc, n_u = nkc;
-  if (A.ppoi) te_wgrad_split(A.wg_slots, NB_UI, NB_TOT, A.cnt[4], Tsteps, &n_o, &n_u, A.dbg != 2);      // (POI_TE_DBG=2: plain split, for A/B runs)
+  if (A.ppoi) te_wgrad_split(A.wg_slots, NB_UI, NB_TOT, A.cnt[4], Tsteps, &n_o, &n_u, !(A.dbg & 2));      // (POI_TE_DBG bit 2: plain split, for A/B runs)
   if (A.kc_dev && blockIdx.x == 0 && threadIdx.x == 0) { A.kc_dev[0] = n_o; A.kc_dev[1] = n_u; }
   int job, kc;
   {

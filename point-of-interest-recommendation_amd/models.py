@@ -270,14 +270,17 @@ class _Base:
         seeds = self.__dict__.setdefault("_topk_seeds", {})
         t = seeds.get(int(k))
         if t is None:
-            t = seeds[int(k)] = torch.full((self.n_user, int(k)), -1, dtype=torch.int32, device=self.device)
-        rows = t[lo:lo + n]
-        self.ctx.set_topk_seed(rows, k)
-        return rows
+            t = seeds[int(k)] = (torch.full((self.n_user, int(k)), -1, dtype=torch.int32, device=self.device), np.zeros(self.n_user, bool))
+        rows = t[0][lo:lo + n]
+        if t[1][lo:lo + n].all():                 # seed only with lists a previous evaluation wrote (the first one runs unseeded)
+            self.ctx.set_topk_seed(rows, k)
+        return rows, t[1], lo, n
 
-    def _seed_end(self, rows, idx):
-        if rows is not None:
+    def _seed_end(self, seed, idx):
+        if seed is not None:
+            rows, filled, lo, n = seed
             rows.copy_(idx)
+            filled[lo:lo + n] = True
 
 
     def _topk_from_scores(self, start_end, k, return_scores=False):

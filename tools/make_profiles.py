@@ -39,7 +39,7 @@ try:
 except Exception:
     pass
 with open(os.path.join(P, tag + "_kernel_stats.md"), "w") as f:
-    f.write("# %s - rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --eval-steps 2 --no-cpu-baseline --no-quality --no-secondary`\n\n" % tag)
+    f.write("# %s - rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --eval-steps 2 --no-cpu-baseline --no-quality --no-secondary --no-exact --no-x1`\n\n" % tag)
     f.write("Gowalla-shape synthetic (100 k POIs, 50 k users, L <= 50, D = 128, 200 bins; 80 %% of the transitions local), one MI355X; 4 training\n"
             "epochs of 4 launches (12500 users each) + 3 evaluation passes.  Full CSV: `%s_kernel_stats.csv`.\n\n" % tag)
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
