@@ -534,6 +534,29 @@ def main():
             rec, auc = evaluate_model(m, tab, n_local, dev)
             return {"batch_users_per_launch": Bq_, "batch_cap": cap, "train_seconds": t, "epochs": ep[0], "seq_per_s": n / t,
                     "recall_at_20": rec, "auc": auc}
+        # time to quality: training seconds until recall@20 reaches the reference schedule's (evaluated every 0.25 s of training, 4 s budget)
+        def time_to_recall(Bq, cap, target, budget=4.0, slice_s=0.25):
+            ctx.set_batch_cap(cap)
+            m = new_model(tab, n_local, seed=11)
+            _, Bq_, bt = make_batches(n_local, lens_local, Bq, seed=321)
+            od = torch.as_tensor(np.concatenate(bt).astype(np.int32)).to(dev)
+            t_train, ep, best = 0.0, 0, 0.0
+            while t_train < budget:
+                torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                while time.perf_counter() - t0 < slice_s:
+                    if ep:
+                        m.resample_negatives_device(99 * 1000003 + ep)
+                    train_epoch(m, od, Bq_, n_local); ep += 1
+                    torch.cuda.synchronize(dev)
+                t_train += time.perf_counter() - t0
+                rec, _ = evaluate_model(m, tab, n_local, dev)
+                best = max(best, rec)
+                if rec >= target:
+                    return {"batch_users_per_launch": Bq_, "batch_cap": cap, "seconds": t_train, "epochs": ep, "recall_at_20": rec}
+            return {"batch_users_per_launch": Bq_, "batch_cap": cap, "seconds": None, "epochs": ep, "best_recall_at_20_in_budget": best, "budget_s": budget}
+        ttr = {"target_recall_at_20": rec_ref, "what": "training seconds until recall@20 reaches what the reference schedule (one user per step) has after %.1f s" % t_ref,
+               "B=1 (reference schedule)": {"seconds": t_ref, "recall_at_20": rec_ref},
+               "B=256": time_to_recall(256, 16.0, rec_ref), "B=1563": time_to_recall(1563, 32.0, rec_ref), "B=12500": time_to_recall(a.batch_users, a.batch_cap, rec_ref)}
         modes = {"headline": batched(a.batch_users, a.batch_cap, a.quality_seconds),
                  "headline_mean_rule": batched(a.batch_users, 1.0, a.quality_seconds),
                  "small_launches": batched(256, 16.0, a.quality_seconds)}
@@ -542,7 +565,7 @@ def main():
                    "random_recall_at_20": 20.0 / n_item, "popularity_recall_at_20": float(np.isin(tab.tes_p.reshape(-1), top).mean()),
                    "reference_schedule": {"train_seconds": t_ref, "users_trained": n_ref, "epochs": n_ref / float(n_local),
                                           "recall_at_20": rec_ref, "auc": auc_ref},
-                   "modes": modes,
+                   "modes": modes, "time_to_recall": ttr,
                    "headline_vs_reference": {"recall_ratio": modes["headline"]["recall_at_20"] / max(rec_ref, 1e-9),
                                              "wall_time_ratio": modes["headline"]["train_seconds"] / t_ref,
                                              "statement": "headline mode (B = %d, cap = %g) after %.1f s of training vs the reference schedule after %.1f s"
@@ -679,6 +702,7 @@ def main():
             "exact_seq_per_s": exact_mode and exact_mode["seq_per_s"],
             "reference_schedule_steps_per_s": reference_schedule and reference_schedule["seq_per_s"],
             "recall_headline_vs_reference": quality and quality["headline_vs_reference"]["recall_ratio"],
+            "time_to_reference_recall_s": quality and {k: (v.get("seconds") if isinstance(v, dict) else v) for k, v in quality["time_to_recall"].items() if k.startswith("B=")},
             "x1_train_seq_per_s": secondary_x1 and secondary_x1.get("train_seq_per_s"),
             "cpu_1core_seq_per_s": cpu and cpu["value"], "cpu_allcores_seq_per_s": cpu and cpu["all_cores"] and cpu["all_cores"]["value"],
         }

@@ -59,7 +59,7 @@ struct poi_ctx {
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
   DevBuf cand_s, cand_i, items_pk, gbound;
-  DevBuf items_pk16, inorm, surv_cnt, surv_idx, tflag;      // two-stage fused top-K (score_filter.hip)
+  DevBuf items_pk16, inorm, surv_cnt, surv_idx, surv_sc, tflag;      // two-stage fused top-K (score_filter.hip)
   int f16_rounding = 0;     // poi_ctx_set_f16_rounding: 0 nearest, 1 stochastic (write-back of a half POI table)
   unsigned sr_counter = 0;  // launches so far (salt of the stochastic rounding)
   int topk_filter = 1;      // poi_ctx_set_topk_filter / POI_TOPK_FILTER=0: one-stage float32 kernel only
@@ -162,7 +162,7 @@ int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
   DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
-                   &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->tflag};
+                   &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag};
   (void)hipDeviceSynchronize();
   c->tm.clear();
   drop_graphs(c);
@@ -732,17 +732,18 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
       A.seeded = 1;
     }
   }
-  if (k > 0 && c->topk_filter && variant == 1 && poi::score_two_stage_supported(A)) {
+  if (k > 0 && c->topk_filter && (variant == 1 || A.geo) && poi::score_two_stage_supported(A)) {
     // two-stage: f16 filter pass + exact float32 rescoring of the survivors (score_filter.hip); the one-stage kernel below then only
     // runs the user tiles whose survivor lists overflowed (A.tile_flag)
     const int kg = dim / 16, cap = poi::score_filter_cap();
     if ((rc = ensure(c, c->items_pk16, sizeof(uint4) * (size_t)ntile * kg * 64, st)) || (rc = ensure(c, c->inorm, sizeof(float2) * (size_t)ntile * 32, st)) ||
         (rc = ensure(c, c->surv_cnt, sizeof(int) * (size_t)n_pad, st)) || (rc = ensure(c, c->surv_idx, sizeof(int) * (size_t)n_pad * cap, st)) ||
+        (rc = ensure(c, c->surv_sc, sizeof(float) * (size_t)n_pad * cap, st)) ||
         (rc = ensure(c, c->tflag, sizeof(int) * (size_t)n_utile, st))) return rc;
     HIPCHK(c, hipMemsetAsync(c->surv_cnt.p, 0, sizeof(int) * (size_t)n_pad, st));
     HIPCHK(c, hipMemsetAsync(c->tflag.p, 0, sizeof(int) * (size_t)n_utile, st));
     A.items_packed16 = (const uint4*)c->items_pk16.p; A.inorm = (const float2*)c->inorm.p;
-    A.surv_cnt = (int*)c->surv_cnt.p; A.surv_idx = (int*)c->surv_idx.p; A.tile_flag = (int*)c->tflag.p;
+    A.surv_cnt = (int*)c->surv_cnt.p; A.surv_idx = (int*)c->surv_idx.p; A.surv_sc = (float*)c->surv_sc.p; A.tile_flag = (int*)c->tflag.p;
     int nsf = ((4 * c->num_cu + n_utile - 1) / n_utile) * 4;      // >= 4 workgroups (16 waves) per CU
     if (nsf > (ntile / 4) * 4) nsf = (ntile / 4) * 4;
     if (nsf < 4) nsf = 4;

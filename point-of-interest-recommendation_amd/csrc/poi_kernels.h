@@ -312,7 +312,7 @@ struct ScoreArgs {
   // two-stage path (score_filter.hip): half-precision item fragments + per-item norms of the bound, per-user survivor lists, and the
   // per-user-tile overflow flags; the one-stage kernels and the merge skip every tile whose flag is clear when tile_flag is set
   const uint4* items_packed16; const float2* inorm;
-  int* surv_cnt; int* surv_idx; int* tile_flag;
+  int* surv_cnt; int* surv_idx; float* surv_sc; int* tile_flag;
 };
 bool score_two_stage_supported(const ScoreArgs& A);
 hipError_t launch_score_two_stage(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm);

@@ -66,12 +66,15 @@ __global__ __launch_bounds__(256) void pack_items_f16_kernel(const float* __rest
   if (s == 0 && valid) inorm[gi] = make_float2(bad ? INFINITY : sqrtf(n2) * 1.000002f, n1 * (2.98023224e-8f * 1.01f));
 }
 
-#define SF_CAP 128        // survivor slots per user (K <= 32: K + the pairs inside the bound; an overflow flags the tile)
+#define SF_CAP 4096       // survivor slots per user in global memory (good seeds leave ~K + 1 of them; an overflow flags the tile)
 
-// stage 1.  BINS: 0 = no distance term, 1 / 2 = resident bin matrix (uint8 / uint16, misc.hip::ulptai_kernel) + the users' bin probabilities
+// stage 1.  BINS: 0 = no distance term, 1 / 2 = resident bin matrix (uint8 / uint16, misc.hip::ulptai_kernel) + the users' bin probabilities,
+// 3 = GEO: bins computed on the fly from the coordinates (poi_score_topk_geo: no U x N matrix; config X) - only for the pairs whose
+// approximate score + bound + the LARGEST possible distance term of the user can exceed the threshold (as score_kernel_geo_stream)
 template <int D, int BINS>
-__global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
-  constexpr int KG = D / 16, CPT = D / 8, QN = BINS ? BINS : 1;
+__global__ __launch_bounds__(256, (BINS == 3 ? 2 : 3)) void score_filter_kernel(ScoreArgs A) {
+  constexpr int KG = D / 16, CPT = D / 8, QN = (BINS == 1 || BINS == 2) ? BINS : 1;
+  constexpr bool GEO = BINS == 3;
   extern __shared__ __align__(16) float dyn[];
   uint4* af = reinterpret_cast<uint4*>(dyn);               // [KG][64] half fragments of the user tile
   float* s_au = dyn + KG * 64 * 4;                         // 32: c1 |u|_2
@@ -80,6 +83,10 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
   float* s_sts = s_n1 + 32;                                // 32 x NB (BINS)
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, t = threadIdx.x;
   const int N = A.n_item, NB = A.n_dist + 1;
+  // GEO: thr[n_dist] | user lat[32] | lon[32] | cos(lat)[32] (doubles, 8-byte aligned behind the float block) | ub[32]
+  double* s_geo = reinterpret_cast<double*>(s_sts + ((32 * NB + 1) & ~1));
+  double* s_ulat = s_geo + A.n_dist; double* s_ulon = s_ulat + 32; double* s_ucp = s_ulon + 32;
+  float* s_ub = reinterpret_cast<float*>(s_ucp + 32);
   const int ut = blockIdx.x;
   const int split = blockIdx.y * POI_NWAVE + w;
   const int ntile = (N + 31) / 32;
@@ -105,6 +112,13 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
     for (int o = 1; o < 8; o <<= 1) { n2 += __shfl_xor(n2, o, 64); n1 += __shfl_xor(n1, o, 64); }
     if (s == 0) { s_n2[j] = n2; s_n1[j] = n1; }
     if (BINS) for (int i = t; i < 32 * NB; i += 256) s_sts[i] = A.sts[(size_t)ut * 32 * NB + i];
+    if (GEO) {
+      for (int i = t; i < A.n_dist; i += 256) s_geo[i] = A.thr[i];
+      if (t < 32) {
+        const int lp = A.last_poi[min(ut * 32 + t, A.n - 1)];
+        s_ulat[t] = A.coords[2 * lp]; s_ulon[t] = A.coords[2 * lp + 1]; s_ucp[t] = A.cphi[lp];
+      }
+    }
   }
   __syncthreads();
   if (t < 32) {
@@ -119,6 +133,11 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
     s_au[t] = c1 * nu2;
     s_c[t] = urow < A.n ? thr - bu : INFINITY;             // rows past n: nothing survives
     s_n2[t] = (urow < A.n && !g) ? 1.f : 0.f;              // an unseeded user (no bound: malformed / missing seed row)
+    if (GEO) {                                             // ub = max_b wd sts[b] (>= 0: column n_dist is zero), widened: >= every exact product
+      float mx = 0.f;
+      for (int b = 0; b < NB; ++b) mx = fmaxf(mx, wd * s_sts[t * NB + b]);
+      s_ub[t] = mx * 1.00000048f;
+    }
   }
   __syncthreads();
   {
@@ -133,6 +152,9 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) cc[r] = s_c[(r & 3) + 8 * (r >> 2) + 4 * h];
   for (int i = 0; i < 32; ++i) au = fmaxf(au, s_au[i]);
+  float ubt = 0.f;                 // GEO: the largest distance term any user of the tile can get (one register instead of sixteen)
+  if (GEO) for (int i = 0; i < 32; ++i) ubt = fmaxf(ubt, s_ub[i]);
+  const float gscale = GEO ? (float)(12742.0 * 1000.0 / A.dd) : 0.f;
   const uint4* bp = A.items_packed16 + lane;
   const uint4* qp = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)ut * ntile * 64 + lane) * QN;
   const int sbase = 4 * h * NB;
@@ -141,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
   if (t_begin < t_end) {
 #pragma unroll
     for (int m = 0; m < KG; ++m) b[m] = bp[((size_t)t_begin * KG + m) * 64];
-    if (BINS) {
+    if (BINS == 1 || BINS == 2) {
 #pragma unroll
       for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)t_begin * 64 * QN + q];
     }
@@ -169,6 +191,34 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
     const bool jvalid = j < N;
     const float tb = __fmaf_rn(au, nm.x, nm.y);
     unsigned pass = 0;
+    if constexpr (GEO) {
+      // coarse test with the largest distance term the user can get; the float64 Haversine bin only for the (tile, row) pairs that pass
+      unsigned coarse = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) coarse |= !((acc[r] + ubt) + tb <= cc[r]) ? (1u << r) : 0u;
+      if (!jvalid) coarse = 0;
+      if (__any(coarse != 0)) {
+        const int jc = min(j, N - 1);
+        const double jlat = A.coords[2 * jc], jlon = A.coords[2 * jc + 1], jcp = A.cphi[jc];
+        const double pr = 0.017453292519943295;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (!__any((coarse >> r) & 1u)) continue;
+          const int ul = (r & 3) + 8 * (r >> 2) + 4 * h;
+          int bin;
+          {
+#pragma clang fp contract(off)
+            const double a = (s_ulat[ul] - jlat) * pr;
+            const double bb = (s_ulon[ul] - jlon) * pr;
+            const double c = (1.0 - cos_small(a)) / 2 + s_ucp[ul] * jcp * (1.0 - cos_small(bb)) / 2;
+            bin = bin_of_c(c, s_geo, A.n_dist, gscale);
+          }
+          const float pv = s_sts[ul * NB + bin];
+          const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
+          pass |= (((coarse >> r) & 1u) && !(up <= cc[r])) ? (1u << r) : 0u;
+        }
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (r == 8) __builtin_amdgcn_sched_barrier(0);       // two batches of eight gathers: sixteen in flight cost the occupancy
@@ -182,7 +232,8 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
       const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
       pass |= !(up <= cc[r]) ? (1u << r) : 0u;             // (a NaN survives)
     }
-    if (BINS) {
+    }
+    if (BINS == 1 || BINS == 2) {
 #pragma unroll
       for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)nt * 64 * QN + q];
     }
@@ -202,14 +253,32 @@ __global__ __launch_bounds__(256, 3) void score_filter_kernel(ScoreArgs A) {
   }
 }
 
-// stage 2.  D8 = k-groups of 8 of the one-stage kernels (dim 64: 8, dim 128: 16): the same MFMA sequence, hence the same bits.
+// 64-lane bitonic sort, best (highest score, then lowest id) first - as score_topk.hip's merge
+__device__ __forceinline__ void sf_wave_sort_desc(float& s, int& idx) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float ps = __shfl_xor(s, j, 64);
+      const int pi = __shfl_xor(idx, j, 64);
+      const bool up = ((lane & k) == 0), lower = ((lane & j) == 0);
+      const bool mine = (s > ps) || (s == ps && idx < pi);
+      const bool keep = (up == lower) ? mine : !mine;
+      if (!keep) { s = ps; idx = pi; }
+    }
+  }
+}
+
+// stage 2.  D8 = k-groups of 8 of the one-stage kernels (dim 64: 8, dim 128: 16, dim 256: 32): the same MFMA sequence, hence the same bits.
+// The exact score of survivor `slot` of user u goes to surv_sc[u * SF_CAP + slot] (every survivor has its own slot: no atomics); after
+// the workgroup's barrier one wave per user keeps the K best by (score desc, id asc) with the merge of topk_merge_kernel: lanes [0, K)
+// hold the running best, lanes [K, 64) take the next 64 - K candidates, one bitonic sort per round.
 template <int D8, int BINS>
 __global__ __launch_bounds__(256) void score_rescore_kernel(ScoreArgs A) {
   extern __shared__ __align__(16) float dyn[];
   float4* af = reinterpret_cast<float4*>(dyn);             // [D8][64]
-  float* cs = dyn + D8 * 64 * 4;                           // 32 x SF_CAP scores
-  int* ci = reinterpret_cast<int*>(cs + 32 * SF_CAP);      // 32 x SF_CAP ids
-  __shared__ int s_pre[33], s_n[32];
+  __shared__ int s_pre[33];
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, t = threadIdx.x;
   const int D = A.dim, N = A.n_item, K = A.k, NB = A.n_dist + 1;
   const int ut = blockIdx.x;
@@ -229,7 +298,7 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(ScoreArgs A) {
     int inc = c;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) { const int v = __shfl_up(inc, o, 64); inc += t >= o ? v : 0; }
-    s_pre[t + 1] = inc; s_n[t] = 0;
+    s_pre[t + 1] = inc;
     if (t == 0) s_pre[0] = 0;
   }
   __syncthreads();
@@ -243,7 +312,8 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(ScoreArgs A) {
 #pragma unroll
       for (int sft = 16; sft > 0; sft >>= 1) if (own + sft < 32 && s_pre[own + sft] <= flat) own += sft;      // largest i with pre[i] <= flat
     }
-    const int id = valid ? A.surv_idx[(size_t)(ut * 32 + own) * SF_CAP + (flat - s_pre[own])] : 0;
+    const size_t slot = (size_t)(ut * 32 + own) * SF_CAP + (valid ? flat - s_pre[own] : 0);
+    const int id = valid ? A.surv_idx[slot] : 0;
     float4 bf[D8];
 #pragma unroll
     for (int m = 0; m < D8; ++m) {
@@ -269,80 +339,98 @@ __global__ __launch_bounds__(256) void score_rescore_kernel(ScoreArgs A) {
     for (int r = 0; r < 16; ++r) a = r == r_own ? acc[r] : a;
     if (mine) {
       float pv = 0.f;
-      if (BINS) {
+      if (BINS == 1 || BINS == 2) {
         const size_t cell = ((size_t)ut * ntile + (id >> 5)) * 64 + (id & 31) + 32 * h;
         int bin;
         if (BINS == 1) bin = reinterpret_cast<const unsigned char*>(A.ulptai)[cell * 16 + r_own];
         else bin = reinterpret_cast<const unsigned short*>(A.ulptai)[cell * 16 + r_own];
         pv = A.sts[(size_t)(ut * 32 + own) * NB + bin];
+      } else if (BINS == 3) {         // GEO: the bin of (the owner's last train POI, item) from the coordinates, as the one-stage GEO kernels
+        const int lp = A.last_poi[ut * 32 + own];
+        int bin;
+        {
+#pragma clang fp contract(off)
+          const double pr = 0.017453292519943295;
+          const double aa = (A.coords[2 * lp] - A.coords[2 * id]) * pr;
+          const double bb = (A.coords[2 * lp + 1] - A.coords[2 * id + 1]) * pr;
+          const double c = (1.0 - cos_small(aa)) / 2 + A.cphi[lp] * A.cphi[id] * (1.0 - cos_small(bb)) / 2;
+          bin = bin_of_c(c, A.thr, A.n_dist, (float)(12742.0 * 1000.0 / A.dd));
+        }
+        pv = A.sts[(size_t)(ut * 32 + own) * NB + bin];
       }
-      const float sc = __fmaf_rn(wd, pv, a);                // the one-stage kernels' expression (tile_epilogue)
-      const int pos = atomicAdd(&s_n[own], 1);
-      cs[own * SF_CAP + pos] = sc; ci[own * SF_CAP + pos] = id;
+      A.surv_sc[slot] = __fmaf_rn(wd, pv, a);               // the one-stage kernels' expression (tile_epilogue)
     }
   }
-  __syncthreads();
-  // per user: the K best of its <= SF_CAP exact scores by (score desc, id asc) - rank counting, two candidates per lane
+  __syncthreads();                                          // (also orders the global score stores before the reads below)
   for (int i = w; i < 32; i += POI_NWAVE) {
     const int urow = ut * 32 + i;
     if (urow >= A.n) continue;
-    const int n = s_n[i];
-    const bool v0 = lane < n, v1 = lane + 64 < n;
-    const float s0 = v0 ? cs[i * SF_CAP + lane] : -INFINITY, s1 = v1 ? cs[i * SF_CAP + lane + 64] : -INFINITY;
-    const int i0 = v0 ? ci[i * SF_CAP + lane] : INT_MAX, i1 = v1 ? ci[i * SF_CAP + lane + 64] : INT_MAX;
-    const unsigned long long k0 = ((unsigned long long)sf_f2ord(s0) << 32) | (unsigned)(0x7FFFFFFF - i0);
-    const unsigned long long k1 = ((unsigned long long)sf_f2ord(s1) << 32) | (unsigned)(0x7FFFFFFF - i1);
-    const unsigned h0 = (unsigned)(k0 >> 32), l0 = (unsigned)k0, h1 = (unsigned)(k1 >> 32), l1 = (unsigned)k1;
-    int r0 = 0, r1 = 0;
-    const int na = n < 64 ? n : 64;
-    for (int j = 0; j < na; ++j) {
-      const unsigned long long kj = ((unsigned long long)__builtin_amdgcn_readlane(h0, j) << 32) | (unsigned)__builtin_amdgcn_readlane(l0, j);
-      r0 += kj > k0 ? 1 : 0; r1 += kj > k1 ? 1 : 0;
+    const int n = s_pre[i + 1] - s_pre[i];
+    const size_t base0 = (size_t)urow * SF_CAP;
+    float sc = -INFINITY; int idx = INT_MAX;
+    const int room = 64 - K;
+    for (int base = 0; base < n; base += room) {
+      const int c = base + (lane - K);
+      if (lane >= K) {
+        if (c < n) { sc = A.surv_sc[base0 + c]; idx = A.surv_idx[base0 + c]; }
+        else { sc = -INFINITY; idx = INT_MAX; }
+      }
+      sf_wave_sort_desc(sc, idx);
     }
-    for (int j = 64; j < n; ++j) {
-      const unsigned long long kj = ((unsigned long long)__builtin_amdgcn_readlane(h1, j - 64) << 32) | (unsigned)__builtin_amdgcn_readlane(l1, j - 64);
-      r0 += kj > k0 ? 1 : 0; r1 += kj > k1 ? 1 : 0;
+    if (lane < K) {
+      A.idx_out[(size_t)urow * K + lane] = idx == INT_MAX ? -1 : idx;
+      if (A.score_out) A.score_out[(size_t)urow * K + lane] = sc;
     }
-    if (v0 && r0 < K) { A.idx_out[(size_t)urow * K + r0] = i0; if (A.score_out) A.score_out[(size_t)urow * K + r0] = s0; }
-    if (v1 && r1 < K) { A.idx_out[(size_t)urow * K + r1] = i1; if (A.score_out) A.score_out[(size_t)urow * K + r1] = s1; }
-    if (lane >= n && lane < K) { A.idx_out[(size_t)urow * K + lane] = -1; if (A.score_out) A.score_out[(size_t)urow * K + lane] = -INFINITY; }
   }
 }
 
 bool score_two_stage_supported(const ScoreArgs& A) {
-  return A.k > 0 && A.seeded && !A.prob && !A.geo && !A.scores && (A.dim == 64 || A.dim == 128) && A.n >= 128 && A.n_dist + 1 <= 1024;      // (the users' bin probabilities live in LDS: 32 x (n_dist + 1) floats)
+  if (!(A.k > 0 && A.seeded && !A.prob && !A.scores && A.n >= 128 && A.n_dist + 1 <= 1024)) return false;
+  return A.geo ? (A.dim == 64 || A.dim == 128 || A.dim == 256) : (A.dim == 64 || A.dim == 128);      // (the users' bin probabilities live in LDS: 32 x (n_dist + 1) floats)
 }
 
-size_t score_filter_lds(int dim, int n_dist, bool bins) { return sizeof(float) * ((size_t)(dim / 16) * 64 * 4 + 128 + (bins ? 32 * (size_t)(n_dist + 1) : 0)); }
+size_t score_filter_lds(int dim, int n_dist, bool bins, bool geo) {
+  return sizeof(float) * ((size_t)(dim / 16) * 64 * 4 + 128 + (bins ? ((32 * (size_t)(n_dist + 1) + 1) & ~(size_t)1) : 0)) + (geo ? sizeof(double) * (size_t)(n_dist + 96) + sizeof(float) * 32 : 0);
+}
 
 template <int D>
 static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm) {
   const int ntile = (A.n_item + 31) / 32, n_utile = (A.n + 31) / 32;
-  const int bins = A.ulptai ? (A.bin_bytes == 1 ? 1 : 2) : 0;
+  const int bins = A.geo ? 3 : A.ulptai ? (A.bin_bytes == 1 ? 1 : 2) : 0;
   tm->begin("pack_items", st);
   hipLaunchKernelGGL(pack_items_f16_kernel<D>, dim3(ntile), dim3(256), 0, st, A.items, A.items_f16, A.n_item, const_cast<uint4*>(A.items_packed16), const_cast<float2*>(A.inorm));
   tm->end(st);
   ScoreArgs F = A; F.n_split = n_split_f;
-  const size_t lds = score_filter_lds(D, A.n_dist, bins != 0);
+  const size_t lds = score_filter_lds(D, A.n_dist, bins != 0, bins == 3);
   const dim3 grid(n_utile, n_split_f / POI_NWAVE);
   static bool optin = false;
   if (!optin) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (D <= 128) {
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_rescore_kernel<D / 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     optin = true;
   }
   tm->begin("score_filter", st);
-  if (bins == 1) hipLaunchKernelGGL((score_filter_kernel<D, 1>), grid, dim3(256), lds, st, F);
-  else if (bins == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2>), grid, dim3(256), lds, st, F);
-  else hipLaunchKernelGGL((score_filter_kernel<D, 0>), grid, dim3(256), lds, st, F);
+  if (bins == 3) hipLaunchKernelGGL((score_filter_kernel<D, 3>), grid, dim3(256), lds, st, F);
+  else if constexpr (D <= 128) {
+    if (bins == 1) hipLaunchKernelGGL((score_filter_kernel<D, 1>), grid, dim3(256), lds, st, F);
+    else if (bins == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2>), grid, dim3(256), lds, st, F);
+    else hipLaunchKernelGGL((score_filter_kernel<D, 0>), grid, dim3(256), lds, st, F);
+  } else return hipErrorInvalidValue;
   tm->end(st);
   constexpr int D8 = D / 8;
-  const size_t lds2 = sizeof(float) * ((size_t)D8 * 64 * 4 + 2 * 32 * SF_CAP);
+  const size_t lds2 = sizeof(float) * ((size_t)D8 * 64 * 4);
   tm->begin("score_rescore", st);
-  if (bins == 1) hipLaunchKernelGGL((score_rescore_kernel<D8, 1>), dim3(n_utile), dim3(256), lds2, st, A);
-  else if (bins == 2) hipLaunchKernelGGL((score_rescore_kernel<D8, 2>), dim3(n_utile), dim3(256), lds2, st, A);
-  else hipLaunchKernelGGL((score_rescore_kernel<D8, 0>), dim3(n_utile), dim3(256), lds2, st, A);
+  if (bins == 3) hipLaunchKernelGGL((score_rescore_kernel<D8, 3>), dim3(n_utile), dim3(256), lds2, st, A);
+  else if constexpr (D <= 128) {
+    if (bins == 1) hipLaunchKernelGGL((score_rescore_kernel<D8, 1>), dim3(n_utile), dim3(256), lds2, st, A);
+    else if (bins == 2) hipLaunchKernelGGL((score_rescore_kernel<D8, 2>), dim3(n_utile), dim3(256), lds2, st, A);
+    else hipLaunchKernelGGL((score_rescore_kernel<D8, 0>), dim3(n_utile), dim3(256), lds2, st, A);
+  }
   tm->end(st);
   return hipGetLastError();
 }
@@ -351,6 +439,7 @@ static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStrea
 hipError_t launch_score_two_stage(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm) {
   if (A.dim == 64) return launch_two_stage_t<64>(A, n_split_f, st, tm);
   if (A.dim == 128) return launch_two_stage_t<128>(A, n_split_f, st, tm);
+  if (A.dim == 256) return launch_two_stage_t<256>(A, n_split_f, st, tm);
   return hipErrorInvalidValue;
 }
 

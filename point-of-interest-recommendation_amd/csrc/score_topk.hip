@@ -326,6 +326,7 @@ __global__ __launch_bounds__(POI_BLOCK) void score_kernel(ScoreArgs A) {
   const int li = lane & 31, h = lane >> 5;
   const int D = A.dim, N = A.n_item, K = A.k;
   const int ut = blockIdx.x;
+  if (A.tile_flag && !A.tile_flag[ut]) return;       // two-stage path: only the tiles whose survivor lists overflowed
   const int split = blockIdx.y * POI_NWAVE + w;
   const int ntile = (N + 31) / 32;
   const int tps = (ntile + A.n_split - 1) / A.n_split;
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(SG_NW * 64) void score_kernel_geo_stream(ScoreArgs 
   const int lane = lane_id(), w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
   const int D = A.dim, N = A.n_item, K = A.k;
   const int ut = blockIdx.x;
+  if (A.tile_flag && !A.tile_flag[ut]) return;       // two-stage path: only the tiles whose survivor lists overflowed
   const int split = blockIdx.y * SG_NW + w;
   const int ntile = (N + 31) / 32;
   const int tps = (ntile + A.n_split - 1) / A.n_split;

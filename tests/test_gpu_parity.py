@@ -813,3 +813,59 @@ def test_two_stage_topk_is_bitwise_the_one_stage_result(pa, dim, n_dist, N):
         assert np.array_equal(one_idx, base_idx) and np.array_equal(one_sc, base_sc), name
         assert np.array_equal(two_idx, base_idx), "two-stage ids differ: " + name
         assert np.array_equal(two_sc.view(np.uint32), base_sc.view(np.uint32)), "two-stage scores differ: " + name
+
+
+@pytest.mark.parametrize("dim,f16", [(128, False), (256, False), (256, True)])
+def test_two_stage_geo_topk_is_bitwise_the_one_stage_result(pa, dim, f16):
+    """The two-stage path of poi_score_topk_geo (bins computed on the fly, config X's dim 256 / half table): the f16 filter keeps a pair when
+    approximate score + bound + the tile's LARGEST possible distance term can beat the threshold, computes the float64 Haversine bin only
+    for those, and the rescoring kernel repeats the one-stage arithmetic: ids and scores bit for bit, for good / moved / random seeds."""
+    import torch
+    from poi_amd.data import bin_thresholds, cos_lat
+    ctx = pa._lib.context(0)
+    rng = np.random.default_rng(900 + dim + f16)
+    n, N, K, n_dist, dd = 333, 7000, 20, 200, 200.0
+    users = (rng.standard_normal((n, dim)) * 0.3).astype(np.float32)
+    items = (rng.standard_normal((N, dim)) * 0.4).astype(np.float32)
+    coords = np.stack([40.0 + rng.random(N) * 0.3, -74.0 + rng.random(N) * 0.3], 1)
+    last = rng.integers(0, N, n).astype(np.int32)
+    du = torch.as_tensor(users).cuda()
+    di = torch.as_tensor(items).cuda().to(torch.float16 if f16 else torch.float32).contiguous()
+    if f16:
+        ctx.register_f16(di)
+    thr = torch.as_tensor(bin_thresholds(dd, n_dist)).cuda(); cph = torch.as_tensor(cos_lat(coords)).cuda()
+    dc = torch.as_tensor(coords).cuda(); dl = torch.as_tensor(last).cuda()
+    sts = rng.random((((n + 31) // 32) * 32, n_dist + 1)).astype(np.float32) ** 4; sts /= sts.sum(axis=1, keepdims=True); sts[:, n_dist] = 0.0
+    dsts = torch.as_tensor(sts).cuda()
+    dwd = torch.as_tensor(np.array([6.0], np.float32)).cuda()
+
+    def run(seed, two_stage, uu=du):
+        idx = torch.full((n, K), -7, dtype=torch.int32, device="cuda")
+        sc = torch.zeros((n, K), dtype=torch.float32, device="cuda")
+        ctx.set_topk_filter(two_stage)
+        if seed is not None:
+            ctx.set_topk_seed(seed, seed.shape[1])
+        try:
+            ctx.check(ctx.lib.poi_score_topk_geo(ctx.handle, uu.data_ptr(), di.data_ptr(), n, N, dim, dwd.data_ptr(), dsts.data_ptr(), dc.data_ptr(), cph.data_ptr(),
+                                                 thr.data_ptr(), dl.data_ptr(), n_dist, dd, K, idx.data_ptr(), sc.data_ptr(), None))
+        finally:
+            ctx.set_topk_filter(True)
+        return idx.cpu().numpy(), sc.cpu().numpy()
+
+    try:
+        base_idx, base_sc = run(None, False)
+        good = torch.as_tensor(base_idx).cuda()
+        moved = torch.as_tensor(users + (rng.standard_normal(users.shape) * 0.02).astype(np.float32)).cuda()
+        prev = torch.as_tensor(run(None, False, uu=moved)[0]).cuda()
+        rnd = torch.as_tensor(np.stack([rng.choice(N, K, replace=False) for _ in range(n)]).astype(np.int32)).cuda()
+        for name, seed in (("true top-K", good), ("previous model's lists", prev), ("random items", rnd)):
+            one_idx, one_sc = run(seed, False)
+            two_idx, two_sc = run(seed, True)
+            assert np.array_equal(one_idx, base_idx) and np.array_equal(one_sc, base_sc), name
+            assert np.array_equal(two_idx, base_idx), "two-stage GEO ids differ: " + name
+            assert np.array_equal(two_sc.view(np.uint32), base_sc.view(np.uint32)), "two-stage GEO scores differ: " + name
+        st = ctx.topk_filter_stats()
+        assert st["users"] == n
+    finally:
+        if f16:
+            ctx.unregister_f16(di)
