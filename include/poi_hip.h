@@ -127,12 +127,14 @@ int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
  * of -inf and insert little more than the final top-K.  The result is the exact top-K whatever the seed holds (rows with an id
  * outside [0, n_item) or a repeated id are simply not seeded).  Consumed by the next call; NULL clears. */
 int poi_ctx_set_topk_seed(poi_ctx* ctx, const int32_t* seed_idx, int32_t k_seed);
-/* Two-stage fused top-K (default on; POI_TOPK_FILTER=0 / on = 0: the one-stage float32 kernel only).  A SEEDED poi_score_topk /
- * poi_score_topk_ulptai call at dim 64 / 128 (no dense prob matrix, <= 1023 bins) first runs a FILTER pass on half-rounded users / items
+/* Two-stage fused top-K (default on; POI_TOPK_FILTER=0 / on = 0: the one-stage float32 kernel only).  A poi_score_topk /
+ * poi_score_topk_ulptai / poi_score_topk_geo call (no dense prob matrix, <= 1023 bins, >= 128 users) runs a FILTER pass on half-rounded users / items
  * (v_mfma_f32_32x32x16_f16, 16x the float32 matrix rate) with a rigorous bound on |approximate - float32 score| per pair, keeps the pairs
  * that could beat the user's seeded threshold (~K + a few per user), and rescores exactly those with the one-stage kernel's own float32
- * MFMA sequence and distance term: the same ids AND scores, bit for bit.  User tiles whose survivor lists overflow (a useless seed) are
- * handed to the one-stage kernel.  Unseeded calls are one-stage. */
+ * MFMA sequence and distance term: the same ids AND scores, bit for bit.  The path seeds itself: unseeded calls first run the one-stage
+ * kernel on the first 1/16 of the item tiles (any subset's K-th best exact score is a valid threshold); seeded calls do the same on 1/64
+ * when the table has >= 2^20 items, so a useless seed costs nothing but survivors.  User tiles whose survivor lists still overflow
+ * (4096 slots per user) are handed to the one-stage kernel.  poi_score_topk_geo: dims 64 / 128 / 256, bins computed on the fly. */
 int poi_ctx_set_topk_filter(poi_ctx* ctx, int on);
 /* Host-side statistics of the LAST two-stage call (synchronises): users scored, pairs the filter kept (all users), 32-user tiles, and the
  * tiles whose survivor lists overflowed and were handed to the one-stage kernel.  users == 0: no two-stage call so far. */

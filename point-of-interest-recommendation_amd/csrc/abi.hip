@@ -59,7 +59,7 @@ struct poi_ctx {
   DevBuf g_ux, cnt_ux, g_blt, cnt_blt;
   // scoring
   DevBuf cand_s, cand_i, items_pk, gbound;
-  DevBuf items_pk16, inorm, surv_cnt, surv_idx, surv_sc, tflag;      // two-stage fused top-K (score_filter.hip)
+  DevBuf items_pk16, inorm, surv_cnt, surv_idx, surv_sc, tflag, pre_idx, pre_sc;      // two-stage fused top-K (score_filter.hip)
   int f16_rounding = 0;     // poi_ctx_set_f16_rounding: 0 nearest, 1 stochastic (write-back of a half POI table)
   unsigned sr_counter = 0;  // launches so far (salt of the stochastic rounding)
   int topk_filter = 1;      // poi_ctx_set_topk_filter / POI_TOPK_FILTER=0: one-stage float32 kernel only
@@ -162,7 +162,7 @@ int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
   DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
-                   &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag};
+                   &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag, &c->pre_idx, &c->pre_sc};
   (void)hipDeviceSynchronize();
   c->tm.clear();
   drop_graphs(c);
@@ -704,23 +704,58 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
   // ... or, for enough users to fill the chip with eight-wave workgroups and a wide model, the packed-stream GEO kernel
   if (U && !U->bins && k > 0 && n >= 1024 && dim >= 128 && poi::score_geo_stream_lds(dim, U->n_dist) <= 160 * 1024 && c->score_variant != 0) variant = 2;
   const int n_utile = (n + 31) / 32;
-  const int units = n_utile;
-  // long item streams keep per-user thresholds high (few top-K compactions)
-  int want = (c->num_cu * 8 + units - 1) / units;   // 8 waves per CU
-  if (want > ntile / 8) want = ntile / 8;      // >= 8 tiles per stream: amortise the per-wave top-K epilogue
-  if (want < 1) want = 1;
-  if (want < (ntile + 2046) / 2047) want = (ntile + 2046) / 2047;      // candidate lists hold 16-bit item offsets: < 65536 items per range
-  int n_split = variant == 2 ? ((want + 7) / 8) * 8 : ((want + 3) / 4) * 4;
+  // item ranges per user tile for a table of nt item tiles: long item streams keep per-user thresholds high (few top-K compactions)
+  auto splits_for = [&](int nt) {
+    int want = (c->num_cu * 8 + n_utile - 1) / n_utile;   // 8 waves per CU
+    if (want > nt / 8) want = nt / 8;          // >= 8 tiles per stream: amortise the per-wave top-K epilogue
+    if (want < 1) want = 1;
+    if (want < (nt + 2046) / 2047) want = (nt + 2046) / 2047;      // candidate lists hold 16-bit item offsets: < 65536 items per range
+    return variant == 2 ? ((want + 7) / 8) * 8 : ((want + 3) / 4) * 4;
+  };
+  const int n_split = splits_for(ntile);
   A.n_split = n_split;
   const int n_pad = n_utile * 32;
   int rc;
+  // one-stage kernel of the chosen variant + merge of the per-range lists, on the item table X describes
+  auto one_stage = [&](poi::ScoreArgs& X) -> int {
+    const int nt = (X.n_item + 31) / 32;
+    if (variant == 2) {
+      const int d8 = dim <= 128 ? 16 : 32;
+      int r2 = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)nt * d8 * 64, st);
+      if (r2) return r2;
+      X.items_packed = (float4*)c->items_pk.p;
+      HIPCHK(c, poi::launch_score_geo_stream(X, st, &c->tm));
+    } else if (variant == 1) {
+      const int d8 = dim <= 32 ? 4 : dim <= 64 ? 8 : 16;
+      int r2 = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)nt * d8 * 64, st);
+      if (r2) return r2;
+      X.items_packed = (float4*)c->items_pk.p;
+      HIPCHK(c, poi::launch_score_packed(X, st, &c->tm));
+    } else {
+      HIPCHK(c, poi::launch_score(X, st, &c->tm));
+    }
+    if (k > 0) HIPCHK(c, poi::launch_topk_merge(X, X.n_split, n_pad, st));
+    return POI_OK;
+  };
+  bool two_stage = false;
   if (k > 0) {
     const size_t cand = (size_t)n_split * n_pad * k;
     if ((rc = ensure(c, c->cand_s, sizeof(float) * cand, st))) return rc;
     if ((rc = ensure(c, c->cand_i, sizeof(int) * cand, st))) return rc;
     A.cand_score = (float*)c->cand_s.p; A.cand_idx = (int*)c->cand_i.p;
     const bool seeded = seed_idx && seed_k >= k && seed_k <= 64;
-    if (n_split > 1 || seeded) {
+    {
+      poi::ScoreArgs probe = A; probe.seeded = 1;
+      two_stage = c->topk_filter && (variant == 1 || A.geo) && poi::score_two_stage_supported(probe);
+    }
+    // SELF-SEEDING pre-pass of the two-stage path: the one-stage kernel on the first 1/16 of the item tiles (1/64 when the caller's
+    // seed already gave bounds) - the K-th best EXACT score of any subset is a lower bound of the final K-th best, so the filter pass
+    // starts from thresholds that leave ~16 K (64 K) survivors per user whatever the seed holds: an unseeded call (the first evaluation
+    // of a run) or a useless seed (a model that moved a lot) no longer sends its tiles to the one-stage kernel.  Unseeded calls always
+    // take it; seeded ones when the table has >= 2^20 items (there it costs < 2 % of the call).
+    const int sub_tiles = !two_stage ? 0 : !seeded ? (ntile >= 256 ? ntile / 16 : 0) : (n_item >= (1 << 20) ? ntile / 64 : 0);
+    if (two_stage && !seeded && sub_tiles == 0) two_stage = false;      // (a small table and no seed: one-stage)
+    if (n_split > 1 || seeded || two_stage) {
       if ((rc = ensure(c, c->gbound, sizeof(unsigned) * (size_t)n_pad, st))) return rc;
       HIPCHK(c, hipMemsetAsync(c->gbound.p, 0, sizeof(unsigned) * (size_t)n_pad, st));
       A.gbound = (unsigned*)c->gbound.p;
@@ -731,8 +766,21 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
       c->tm.end(st);
       A.seeded = 1;
     }
+    if (two_stage && sub_tiles > 0) {
+      if ((rc = ensure(c, c->pre_idx, sizeof(int) * (size_t)n_pad * k, st)) || (rc = ensure(c, c->pre_sc, sizeof(float) * (size_t)n_pad * k, st))) return rc;
+      poi::ScoreArgs S = A;
+      S.n_item = sub_tiles * 32; S.bins_ntile = ntile; S.n_split = splits_for(sub_tiles);
+      S.idx_out = (int*)c->pre_idx.p; S.score_out = (float*)c->pre_sc.p;
+      if ((size_t)S.n_split * n_pad * k > cand) {
+        if ((rc = ensure(c, c->cand_s, sizeof(float) * (size_t)S.n_split * n_pad * k, st)) || (rc = ensure(c, c->cand_i, sizeof(int) * (size_t)S.n_split * n_pad * k, st))) return rc;
+        A.cand_score = S.cand_score = (float*)c->cand_s.p; A.cand_idx = S.cand_idx = (int*)c->cand_i.p;
+      }
+      if ((rc = one_stage(S))) return rc;
+      HIPCHK(c, poi::launch_topk_bound(S.score_out, n, k, A.gbound, st));
+      A.seeded = 1;
+    }
   }
-  if (k > 0 && c->topk_filter && (variant == 1 || A.geo) && poi::score_two_stage_supported(A)) {
+  if (two_stage) {
     // two-stage: f16 filter pass + exact float32 rescoring of the survivors (score_filter.hip); the one-stage kernel below then only
     // runs the user tiles whose survivor lists overflowed (A.tile_flag)
     const int kg = dim / 16, cap = poi::score_filter_cap();
@@ -750,21 +798,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     HIPCHK(c, poi::launch_score_two_stage(A, nsf, st, &c->tm));
     c->last_two_n = n; c->last_two_tiles = n_utile;
   }
-  if (variant == 2) {
-    const int d8 = dim <= 128 ? 16 : 32;
-    if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
-    A.items_packed = (float4*)c->items_pk.p;
-    HIPCHK(c, poi::launch_score_geo_stream(A, st, &c->tm));
-  } else if (variant == 1) {
-    const int d8 = dim <= 32 ? 4 : dim <= 64 ? 8 : 16;
-    if ((rc = ensure(c, c->items_pk, sizeof(float) * 4 * (size_t)ntile * d8 * 64, st))) return rc;
-    A.items_packed = (float4*)c->items_pk.p;
-    HIPCHK(c, poi::launch_score_packed(A, st, &c->tm));
-  } else {
-    HIPCHK(c, poi::launch_score(A, st, &c->tm));
-  }
-  if (k > 0) HIPCHK(c, poi::launch_topk_merge(A, n_split, n_pad, st));
-  return POI_OK;
+  return one_stage(A);
 }
 
 int poi_score_all(poi_ctx* c, const float* users, const float* items, int32_t n, int32_t n_item, int32_t dim,

@@ -313,10 +313,12 @@ struct ScoreArgs {
   // per-user-tile overflow flags; the one-stage kernels and the merge skip every tile whose flag is clear when tile_flag is set
   const uint4* items_packed16; const float2* inorm;
   int* surv_cnt; int* surv_idx; float* surv_sc; int* tile_flag;
+  int bins_ntile;           // item tiles per user-tile row of the bin matrix when the call scores only a PREFIX of the item table (0: = tiles of n_item)
 };
 bool score_two_stage_supported(const ScoreArgs& A);
 hipError_t launch_score_two_stage(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm);
 int score_filter_cap();
+hipError_t launch_topk_bound(const float* score_k, int n, int k, unsigned* gbound, hipStream_t st);
 hipError_t launch_ulptai(const double* coords, const double* cphi, const double* thr, const int* last_poi, int n, int n_item,
                          int n_dist, double dd, void* out, int bin_bytes, hipStream_t st);
 hipError_t launch_score(const ScoreArgs& A, hipStream_t st, Timing* tm);

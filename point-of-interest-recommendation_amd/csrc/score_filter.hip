@@ -445,4 +445,19 @@ hipError_t launch_score_two_stage(const ScoreArgs& A, int n_split_f, hipStream_t
 
 int score_filter_cap() { return SF_CAP; }
 
+// gbound[u] = max(gbound[u], order-mapped (K-th best score of the pre-pass list - 1 ulp)): the K-th best exact score of a SUBSET of the items
+// bounds the final K-th best from below (`score > bound` keeps ties, as compact_user publishes)
+__global__ __launch_bounds__(256) void topk_bound_kernel(const float* __restrict__ score_k, int n, int k, unsigned* __restrict__ gbound) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= n) return;
+  const float s = score_k[(size_t)u * k + (k - 1)];
+  if (!(s > -INFINITY)) return;                 // fewer than K items in the subset (or NaN): no bound
+  const unsigned o = sf_f2ord(s);
+  if (o > 1u && o - 1u > gbound[u]) gbound[u] = o - 1u;
+}
+hipError_t launch_topk_bound(const float* score_k, int n, int k, unsigned* gbound, hipStream_t st) {
+  hipLaunchKernelGGL(topk_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, st, score_k, n, k, gbound);
+  return hipGetLastError();
+}
+
 }  // namespace poi

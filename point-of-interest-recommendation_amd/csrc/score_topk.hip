@@ -195,7 +195,7 @@ __global__ __launch_bounds__(POI_BLOCK) void topk_seed_kernel(ScoreArgs A, const
     else if (A.ulptai) {
       // accumulator-order bin matrix (misc.hip::ulptai_kernel): tile (u / 32, id / 32), lane = id % 32 + 32 h, register r with
       // (r & 3) + 8 (r >> 2) + 4 h == u % 32
-      const int ur = u & 31, hh = (ur >> 2) & 1, r = (ur & 3) + 4 * (ur >> 3), ntile = (N + 31) / 32;
+      const int ur = u & 31, hh = (ur >> 2) & 1, r = (ur & 3) + 4 * (ur >> 3), ntile = A.bins_ntile ? A.bins_ntile : (N + 31) / 32;
       const size_t cell = ((size_t)(u >> 5) * ntile + (id >> 5)) * 64 + (id & 31) + 32 * hh;
       int bin;
       if (A.bin_bytes == 1) bin = reinterpret_cast<const unsigned char*>(A.ulptai)[cell * 16 + r];
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(POI_BLOCK, 2) void score_kernel_packed(ScoreArgs A)
   const float4* ap = af + lane;
   const int NB = A.n_dist + 1;
   constexpr int QN = BINS ? BINS : 1, DH = D8 / 2;
-  const uint4* qp = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)ut * ntile * 64 + lane) * QN;
+  const uint4* qp = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)ut * (A.bins_ntile ? A.bins_ntile : ntile) * 64 + lane) * QN;
   uint4 qn[QN];
   const int sbase = (ut * 32 + 4 * h) * NB;      // sts offsets fit 32 bits (checked by the host)
   // The packed item stream runs a full tile ahead: two register sets of two half tiles each; while tile t
