@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--quality-seconds", type=float, default=3.0, help="training wall time of the batched modes in the quality block")
     ap.add_argument("--reference-seconds", type=float, default=15.0, help="training wall time of the reference schedule (one user per step)")
     ap.add_argument("--emulate-world", type=int, default=0, help="tuning aid: train only rank 0's shard of an N-way split on one GPU")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="testing aid: gloo + --same-device runs the whole N > 1 path (sharding, schedules, reconciliation, self-check) with several ranks on ONE GPU")
+    ap.add_argument("--same-device", action="store_true", help="testing aid: every rank uses cuda:0 (with --dist-backend gloo)")
     ap.add_argument("--replica-schedule", default="quality", choices=["quality", "throughput"],
                     help="N > 1: launches per replica and epoch - as many as the one-GPU run (quality, default) or ~--batch-users users each (plan_shard)")
     return ap.parse_args()
@@ -138,11 +141,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if a.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if world > 1 or under_launcher:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     n_item, n_user, max_len, D = pdata.SHAPES[a.shape]
     if a.shape == "x1":
