@@ -391,7 +391,7 @@ def main():
     # half of the step input goes through per-bin tables: te_gemm_ax / te_gemm_dx / the d ui jobs of
     # te_wgrad only multiply the POI half, i.e. 36 D^2 + 6 NB D executed against the 54 D^2 + 6 NB D of the
     # reference formulation (step_flops)
-    bintab = D >= 128 and NB <= 256      # (beyond 256 bins the two-table path runs: te_bintab)
+    bintab = D >= 128 and NB <= 2048     # (te_bintab)
     xk = 6 if bintab else 12
     # per-POI regrouping (bintab): te_gemm_dx and the d ui jobs of te_wgrad contract over the S rows (distinct step-input POIs of a
     # launch) instead of over the steps - rho = S rows / steps
@@ -621,6 +621,23 @@ def main():
                                                  "note": "same data, dim = 20 (the reference's default): stored zero-padded to the tile engine's dim 64, exact"}
         del m3
 
+    # ---- secondary_dd25: the reference's other spatial configuration (dd = 25 m: 1520 bins, public/GRU_Spatial.py:247), training only --------
+    secondary_dd25 = None
+    if solo and not a.no_secondary and a.shape == "gowalla" and a.dd == 200.0:
+        ds5 = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=a.local, dd=25.0, ud_km=38.0)
+        tab5 = ds5.shard(0, n_user)
+        m5 = poi_amd.models.OboSpatialGru(train=tab5, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item,
+                                          n_dists=[ds5.dist_num, ds5.dd / 1000.0], n_in=D, n_hidden=D, device=dev, seed=7, coords=ds5.coords)
+        for _ in range(3):
+            train_epoch(m5, order, B, n_local)
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(40):
+            train_epoch(m5, order, B, n_local)
+        torch.cuda.synchronize(dev); t5 = time.perf_counter() - t0
+        secondary_dd25 = {"workload": "gowalla shape with dd = 25 m, UD = 38 km: %d distance bins (chunked head, per-bin tables beyond 256 bins)" % ds5.dist_num,
+                          "train_seq_per_s": n_user * 40 / t5, "ms_per_epoch": 1e3 * t5 / 40}
+        del m5, tab5, ds5
+
     # ---- secondary_x1: one GPU's slice of BASELINE.json configs[4] (10 M POIs, 125 k users, dim 256, half POI table), training only -----
     secondary_x1 = None
     if solo and not a.no_x1 and a.shape == "gowalla":
@@ -695,7 +712,7 @@ def main():
                        "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence",
                        "s_rows_per_step": rho},
             "timed_window_s": dt,
-            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_x1": secondary_x1,
+            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_dd25": secondary_dd25, "secondary_x1": secondary_x1,
             "train_step_tflops": executed_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "train_step_tflops_reference_formulation": total_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "reference_schedule": reference_schedule, "eval": eval_detail, "roofline_gather_scatter": hbm,
@@ -714,6 +731,7 @@ def main():
             "recall_headline_vs_reference": quality and quality["headline_vs_reference"]["recall_ratio"],
             "time_to_reference_recall_s": quality and {k: (v.get("seconds") if isinstance(v, dict) else v) for k, v in quality["time_to_recall"].items() if k.startswith("B=")},
             "x1_train_seq_per_s": secondary_x1 and secondary_x1.get("train_seq_per_s"),
+            "dd25_1520_bins_train_seq_per_s": secondary_dd25 and secondary_dd25["train_seq_per_s"],
             "cpu_1core_seq_per_s": cpu and cpu["value"], "cpu_allcores_seq_per_s": cpu and cpu["all_cores"] and cpu["all_cores"]["value"],
         }
         print(json.dumps(out))

@@ -232,7 +232,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t n_prange = Tcap / 64 + 4;
   const size_t pfl = A.ppoi ? Tcap * (size_t)(3 * D) + 2 * n_prange * (size_t)(3 * D) + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl + pfl;
-  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 2 * NBt + 64 : 0) + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
+  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 4 * NBt + 64 : 0) + NBt + 16 + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
@@ -276,12 +276,12 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.urow = listed ? itake(Ncap) : nullptr;
     A.hot_rows = (int4*)itake(4 * n_hot); A.hot_chunks = (int2*)itake(2 * n_chunk); A.hot_nf = itake(n_chunk);
     A.seg_start = (int*)c->seg_s.p; A.seg_end = (int*)c->seg_e.p;
-    A.dch0 = itake(260);
+    A.dch0 = itake(NBt + 8);
     if (A.ppoi) {
       A.urow_p = itake(Tcap); A.pblk = itake(2 * 1024); A.dxe = itake(Tcap); A.dxs = itake(Tcap); A.dstart = itake(Tcap + 4);
       A.pmark = (int*)c->pmark.p;
     }
-    if (A.bintab) { A.dch1 = itake(260); A.dnf = itake(n_dchunk); A.dnf2 = itake(n_dsuper); A.dbn = itake(NBt + 4); }
+    if (A.bintab) { A.dch1 = itake(NBt + 8); A.dnf = itake(n_dchunk); A.dnf2 = itake(n_dsuper); A.dbn = itake(NBt + 4); }
   }
   return POI_OK;
 }

@@ -573,22 +573,32 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
 // three-level tree - 64-entry chunks (te_dsum), TE_DSUPER-chunk groups (te_dred), groups of a bin (te_dfin) - every level
 // added in index order: reproducible, and no level walks more than a few dozen partials serially.
 #define TE_DSUPER 32
-__global__ __launch_bounds__(256) void te_dprep_kernel(TeArgs A) {
-  __shared__ int s[256], s2[256];
+#define TE_DPREP_T 1024           // two bins per thread: up to 2048 bins (te_supported's limit)
+__global__ __launch_bounds__(TE_DPREP_T) void te_dprep_kernel(TeArgs A) {
+  __shared__ int s[2 * TE_DPREP_T], s2[2 * TE_DPREP_T];
   const int NB = A.n_dist + 1, t = threadIdx.x;
-  int n = 0;
-  if (t < NB) { const int row = A.n_item + 1 + t, end = A.seg_end[row]; n = end ? (end - A.seg_start[row] + 63) / 64 : 0; }
-  const int n2 = (n + TE_DSUPER - 1) / TE_DSUPER;
-  s[t] = n; s2[t] = n2;
+  int n[2], n2[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int b = t + u * TE_DPREP_T;
+    n[u] = 0;
+    if (b < NB) { const int row = A.n_item + 1 + b, end = A.seg_end[row]; n[u] = end ? (end - A.seg_start[row] + 63) / 64 : 0; }
+    n2[u] = (n[u] + TE_DSUPER - 1) / TE_DSUPER;
+    s[b] = n[u]; s2[b] = n2[u];
+  }
   __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    const int v = t >= o ? s[t - o] : 0, v2 = t >= o ? s2[t - o] : 0;
+  for (int o = 1; o < 2 * TE_DPREP_T; o <<= 1) {          // inclusive Hillis-Steele scan over the 2048 slots
+    int v[2], v2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; v[u] = b >= o ? s[b - o] : 0; v2[u] = b >= o ? s2[b - o] : 0; }
     __syncthreads();
-    s[t] += v; s2[t] += v2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; s[b] += v[u]; s2[b] += v2[u]; }
     __syncthreads();
   }
-  if (t < NB) { A.dch0[t] = s[t] - n; A.dch1[t] = s2[t] - n2; }
-  if (t == 255) { A.dch0[NB] = s[255]; A.dch1[NB] = s2[255]; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; if (b < NB) { A.dch0[b] = s[b] - n[u]; A.dch1[b] = s2[b] - n2[u]; } }
+  if (t == TE_DPREP_T - 1) { A.dch0[NB] = s[2 * TE_DPREP_T - 1]; A.dch1[NB] = s2[2 * TE_DPREP_T - 1]; }
 }
 
 // one 64-entry chunk of one bin per workgroup iteration, thread = column of DA; thread 0 also counts the chunk's
@@ -742,7 +752,7 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
     // the per-bin reduction of DA rows is scatter traffic (te_dsum: one pass over DA at HBM speed); the two small
     // dense products that follow (S . ui[:, D:], S^T . di) are timed on their own
     tm->begin("te_dsum", sb);
-    hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(256), 0, sb, A);
+    hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(TE_DPREP_T), 0, sb, A);
     hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, sb, A);
     tm->end(sb);
     tm->begin("te_bin_gemm", sb);

@@ -1955,7 +1955,7 @@ int te_wgrad_ui_jobs(int D, int n_dist, bool spatial) {
 }
 
 // Distance2Pre at D >= 128: the distance-bin half of the input goes through per-bin tables (te_ztab / te_dsum)
-bool te_bintab(int D, bool spatial, int n_dist) { return spatial && D >= 128 && n_dist + 1 <= 256; }
+bool te_bintab(int D, bool spatial, int n_dist) { return spatial && D >= 128 && n_dist + 1 <= 2048; }      // (te_dprep: two bins per thread)
 
 bool te_supported(int D, int n_dist) { return (D == 64 || D == 128 || D == 256) && n_dist + 1 <= 2048; }   // plain GRU: n_dist == -1
 
