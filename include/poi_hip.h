@@ -119,6 +119,13 @@ int poi_ctx_unregister_f16(poi_ctx* ctx, const void* ptr);
  * value is the float32 result and sub-ulp updates (the decay the reference applies at every step, public/GRU_Spatial.py:202-209) act in
  * expectation.  Counter-based: the same seed and launch sequence reproduce the same tables. */
 int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
+/* Arithmetic of the recurrent kernels of the tile engine at dim 64 / 128 (h_{t-1} . wh^T forward, da . wh backward - the contractions
+ * of public/GRU_Spatial.py:127-171 that sit on the per-step dependency chain).  on = 1 (default): SPLIT products - both operands as three
+ * bf16 planes (x = x1 + x2 + x3 to 2^-27), the six partial products down to 2^-16 on v_mfma_f32_16x16x32_bf16 with float32 accumulation:
+ * the float32-input MFMA runs at the vector rate on gfx950, this form at 2.7x less matrix time and a product error of 2^-25 (below the
+ * float32 accumulation noise; the timed Gowalla launch measures 4.7e-6 against the float64 oracle, 5.7e-6 with on = 0).
+ * on = 0: float32-input v_mfma_f32_16x16x4_f32 (rounds 1 - 2).  Environment override at context creation: POI_TE_SPLIT=0|1. */
+int poi_ctx_set_split_products(poi_ctx* ctx, int on);
 
 /* Seeded top-K (optional, exact): seed_idx (n x k_seed int32, device) holds, for every user of the NEXT fused top-K call
  * (poi_score_topk / _ulptai / _geo with the same n and user order), k_seed >= k distinct item ids - typically the user's top-K of the

@@ -53,6 +53,7 @@ SIGNATURES = {
     "poi_ctx_register_f16": (c_int, [c_void_p, c_void_p, c_int64]),
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
     "poi_ctx_set_f16_rounding": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
+    "poi_ctx_set_split_products": (c_int, [c_void_p, c_int]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                              c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
     "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
@@ -193,6 +194,10 @@ class Context:
     def set_f16_rounding(self, mode, seed=0):
         """'nearest' | 'stochastic' write-back of a half POI table (poi_ctx_set_f16_rounding)."""
         self.check(self.lib.poi_ctx_set_f16_rounding(self.handle, {"nearest": 0, "stochastic": 1}[mode], int(seed) & 0xFFFFFFFF))
+
+    def set_split_products(self, on=True):
+        """Recurrent kernels of the tile engine on bf16 x 3 split products (default) or float32-input MFMAs (poi_ctx_set_split_products)."""
+        self.check(self.lib.poi_ctx_set_split_products(self.handle, 1 if on else 0))
 
     def unregister_f16(self, tensor):
         self.check(self.lib.poi_ctx_unregister_f16(self.handle, tensor.data_ptr()))

@@ -44,6 +44,7 @@ struct poi_ctx {
   DevBuf ptab, iota;        // forward table (te_rec_fwd16<FT>): lt . ui[:, :D]^T per table row; 0..n_item, n_item + 1
   int iota_n = -1;          // rows the iota buffer currently describes
   int fwd_tab = 1;          // POI_TE_FWDTAB=0 disables (A/B)
+  int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
   // A launch is captured the second time its key (every pointer / size / scalar the kernels receive) is seen; the caller's uidx /
   // out are staged through context buffers so that the key does not depend on them.
@@ -132,6 +133,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
   if (const char* e = getenv("POI_CARNN_FAST")) c->carnn_fast = atoi(e) != 0;
   if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
   if (const char* e = getenv("POI_TOPK_FILTER")) c->topk_filter = atoi(e) != 0;
@@ -210,6 +212,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.lt_f16 = is_f16(c, P->lt);
   A.bintab = poi::te_bintab(D, spatial, n_dist) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
+  A.rec_split = (!A.rec32 && c->rec_split) ? 1 : 0;
   A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
@@ -253,7 +256,8 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.RH = take(Tcap * D); A.DH = take(Tcap * D); A.rowloss = take(Tcap * 2);
   A.uiT = take((size_t)6 * D * D); A.uiP = take((size_t)3 * D * D);
   A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
-  A.pWhT16 = (float4*)take((size_t)3 * D * D); A.pWhc16 = (float4*)take((size_t)D * D); A.pWhzr16 = (float4*)take((size_t)2 * D * D);
+  // (x 1.5: the split-operand recurrent kernels keep every weight as three bf16 planes)
+  A.pWhT16 = (float4*)take((size_t)9 * D * D / 2); A.pWhc16 = (float4*)take((size_t)3 * D * D / 2); A.pWhzr16 = (float4*)take((size_t)3 * D * D);
   if (A.bintab) {
     A.ztab = take(NBt * 3 * D); A.dsum = take(NBt * 3 * D); A.dgd = take(NBt * D);
     if (sorted) { A.dpart = take(n_dchunk * (size_t)(3 * D)); A.dpart2 = take(n_dsuper * (size_t)(3 * D)); }
@@ -434,7 +438,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
       const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
-                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)c->fwd_tab};
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1))};
       add(bufs, sizeof bufs);
     }
     poi_ctx::StepGraph* g = nullptr;
@@ -793,6 +797,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     A.items_packed16 = (const uint4*)c->items_pk16.p; A.inorm = (const float2*)c->inorm.p;
     A.surv_cnt = (int*)c->surv_cnt.p; A.surv_idx = (int*)c->surv_idx.p; A.surv_sc = (float*)c->surv_sc.p; A.tile_flag = (int*)c->tflag.p;
     int nsf = ((4 * c->num_cu + n_utile - 1) / n_utile) * 4;      // >= 4 workgroups (16 waves) per CU
+    if (const char* e = getenv("POI_SF_NSPLIT")) { const int v = atoi(e); if (v >= 4) nsf = (v / 4) * 4; }
     if (nsf > (ntile / 4) * 4) nsf = (ntile / 4) * 4;
     if (nsf < 4) nsf = 4;
     HIPCHK(c, poi::launch_score_two_stage(A, nsf, st, &c->tm));
@@ -952,6 +957,12 @@ int poi_ctx_set_engine(poi_ctx* c, int engine) {
 int poi_ctx_set_f16_rounding(poi_ctx* c, int mode, uint32_t seed) {
   if (!c || mode < 0 || mode > 1) return fail(c, POI_EINVAL, "poi_ctx_set_f16_rounding: mode must be 0 (nearest) or 1 (stochastic)");
   c->f16_rounding = mode; c->sr_counter = seed;
+  return POI_OK;
+}
+
+int poi_ctx_set_split_products(poi_ctx* c, int on) {
+  if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_split_products: on must be 0 or 1");
+  c->rec_split = on;
   return POI_OK;
 }
 

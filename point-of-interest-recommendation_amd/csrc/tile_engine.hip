@@ -67,8 +67,42 @@ __device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r 
 struct PackJob { const float* src; int sk, sn, K, N, K8, NT; float4* dst; int n16; };
 struct PackJobs { PackJob j[12]; int n; };
 
+// n16 == 2: fragments of v_mfma_f32_16x16x32_bf16 for the split-operand recurrent kernels (te_rec_fwd16 / bwd16 <SP>): every float32
+// weight as THREE bf16 planes (split3: w = w1 + w2 + w3 exactly), n tiles of 16 columns, k groups of 32 (K8 field = K / 32):
+//   P[((nt * KG + m) * 3 + plane) * 64 + lane] = 8 x bf16 { B_plane[32m + 8g + c][16 nt + j], c = 0..7 },  lane = g*16 + j.
+// split3: w1 = bf16(w) rounded to nearest (v_cvt_pk_bf16_f32), w2 = the top 8 bits of the exact remainder r1 = w - w1, w3 = r1 - w2
+// (<= 8 significant bits: exact), so w = w1 + w2 + w3 exactly and |w2| <= 2^-9 |w|, |w3| <= 2^-17 |w|.  The rounding of w1 gives the
+// remainder a random sign relative to w: the dropped cross terms do not add up.  (Truncating w1 as well is one instruction shorter,
+// but every dropped term then has the sign of the product: measured 7.0e-6 instead of 4.7e-6 on the timed Gowalla launch.)
+// Returns the planes as float32 bit patterns with zero low halves (bf16 = the high 16 bits).
+__device__ __forceinline__ void split3(float v, unsigned& u1, unsigned& u2, unsigned& u3) {
+  const __bf16 h1 = (__bf16)v;
+  u1 = (unsigned)__builtin_bit_cast(unsigned short, h1) << 16;
+  const float r1 = v - __uint_as_float(u1);
+  u2 = __float_as_uint(r1) & 0xFFFF0000u;
+  u3 = __float_as_uint(r1 - __uint_as_float(u2));
+}
+
 __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
   const PackJob& j = J.j[blockIdx.y];
+  if (j.n16 == 2) {
+    const int total3 = j.NT * j.K8 * 3 * 64;
+    for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < total3; e += gridDim.x * TE_BLOCK) {
+      const int lane = e & 63, f = e >> 6, pl = f % 3, m = (f / 3) % j.K8, nt = (f / 3) / j.K8;
+      const int n = nt * 16 + (lane & 15), k0 = 32 * m + 8 * (lane >> 4);
+      unsigned h[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int k = k0 + c;
+        const float v = (k < j.K && n < j.N) ? j.src[(size_t)k * j.sk + (size_t)n * j.sn] : 0.f;
+        unsigned u[3];
+        split3(v, u[0], u[1], u[2]);
+        h[c] = (pl == 0 ? u[0] : pl == 1 ? u[1] : u[2]) >> 16;
+      }
+      reinterpret_cast<uint4*>(j.dst)[e] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    }
+    return;
+  }
   const int total = j.NT * j.K8 * 64;
   for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < total; e += gridDim.x * TE_BLOCK) {
     const int lane = e & 63, m = (e >> 6) % j.K8, nt = (e >> 6) / j.K8;
@@ -169,6 +203,75 @@ __device__ __forceinline__ void mma16_regb(f32x4 (&acc)[NG], const float* __rest
     __builtin_amdgcn_sched_barrier(0);
   }
   if (NG == 1) acc[0] += alt;
+}
+
+// Split-operand contraction of the recurrent kernels (<SP>): the float32-input MFMA runs at the vector rate on gfx950 (1/16 of the
+// bf16 rate), and a recurrent step IS one CU's matrix throughput.  Both operands are therefore held as three bf16 planes
+// (split3: x = x1 + x2 + x3 exactly, 8 + 8 + 8 mantissa bits) and the product is the six partial products down to 2^-16
+//   x1 y1  +  (x1 y2 + x2 y1)  +  (x1 y3 + x2 y2 + x3 y1)
+// on v_mfma_f32_16x16x32_bf16 (exact bf16 products, float32 accumulation): 6 MFMAs of 16 cycles per 32 k against 8 float32 ones of
+// 32 cycles - 2.7x less matrix time.  Dropped: x2 y3 + x3 y2 + x3 y3 <= 2^-25 |x y| per product, signs random (measured on random
+// operands: 6e-9 rms of the result against 2e-7 of float32 accumulation noise for the same product).  The leading products go to one accumulator,
+// the five small ones to another (added once at the end).
+// A planes in LDS: plane p of tile row i at ldsA[(16 p + i) * ldh ..], bf16; B planes resident (te_pack, n16 == 2).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16b(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// planes 1 and 2 of n tile `nt` -> registers; plane 3 -> LDS in fragment order (dst[m * 64 + lane]: lane-linear 16-byte reads).
+// The register file of a CU cannot hold all three planes of the recurrent weights next to the working set of a step (288 of 512 KB);
+// the third plane enters one MFMA in six, so it is the one that is read from LDS every step.
+template <int KG>
+__device__ __forceinline__ void load_bfrag3(uint4 (&b)[KG][2], uint4* __restrict__ dst, const float4* __restrict__ bp, int nt) {
+  const uint4* q = reinterpret_cast<const uint4*>(bp) + ((size_t)nt * KG) * 3 * 64 + lane_id();
+#pragma unroll
+  for (int m = 0; m < KG; ++m) {
+    b[m][0] = q[(m * 3 + 0) * 64]; b[m][1] = q[(m * 3 + 1) * 64];
+    dst[m * 64 + lane_id()] = q[(m * 3 + 2) * 64];
+  }
+}
+// x -> its three planes at LDS element `at` (plane stride ps elements); ds_write_b16_d16_hi stores the high halves directly
+__device__ __forceinline__ void split3_store(unsigned short* __restrict__ at, int ps, float x) {
+  unsigned u1, u2, u3;
+  split3(x, u1, u2, u3);
+  at[0] = (unsigned short)(u1 >> 16); at[ps] = (unsigned short)(u2 >> 16); at[2 * ps] = (unsigned short)(u3 >> 16);
+}
+// two gates sharing the A planes: hi / lo accumulators of gate 0 and gate 1 (four independent MFMA chains); c0 / c1: the gates'
+// third B planes in LDS (already offset by the lane)
+template <int KG>
+__device__ __forceinline__ void mma16s_g2(f32x4& h0, f32x4& l0, f32x4& h1, f32x4& l1, const unsigned short* __restrict__ ldsA, int ldh,
+                                          const uint4 (&b0)[KG][2], const uint4 (&b1)[KG][2], const uint4* __restrict__ c0, const uint4* __restrict__ c1) {
+  const int lane = lane_id(), ps = 16 * ldh;
+  const unsigned short* arow = ldsA + (lane & 15) * ldh + 8 * (lane >> 4);
+#pragma unroll
+  for (int m = 0; m < KG; ++m) {
+    const uint4 a1 = *reinterpret_cast<const uint4*>(arow + 32 * m), a2 = *reinterpret_cast<const uint4*>(arow + ps + 32 * m),
+                a3 = *reinterpret_cast<const uint4*>(arow + 2 * ps + 32 * m);
+    const uint4 b03 = c0[m * 64], b13 = c1[m * 64];
+    h0 = mfma16b(a1, b0[m][0], h0); h1 = mfma16b(a1, b1[m][0], h1);
+    l0 = mfma16b(a1, b0[m][1], l0); l1 = mfma16b(a1, b1[m][1], l1);
+    l0 = mfma16b(a2, b0[m][0], l0); l1 = mfma16b(a2, b1[m][0], l1);
+    l0 = mfma16b(a2, b0[m][1], l0); l1 = mfma16b(a2, b1[m][1], l1);
+    l0 = mfma16b(a3, b0[m][0], l0); l1 = mfma16b(a3, b1[m][0], l1);
+    l0 = mfma16b(a1, b03, l0); l1 = mfma16b(a1, b13, l1);
+  }
+}
+// one gate: the small products alternate between two accumulators (three chains)
+template <int KG>
+__device__ __forceinline__ void mma16s_g1(f32x4& h, f32x4& l, f32x4& l2, const unsigned short* __restrict__ ldsA, int ldh, const uint4 (&b)[KG][2],
+                                          const uint4* __restrict__ c) {
+  const int lane = lane_id(), ps = 16 * ldh;
+  const unsigned short* arow = ldsA + (lane & 15) * ldh + 8 * (lane >> 4);
+#pragma unroll
+  for (int m = 0; m < KG; ++m) {
+    const uint4 a1 = *reinterpret_cast<const uint4*>(arow + 32 * m), a2 = *reinterpret_cast<const uint4*>(arow + ps + 32 * m),
+                a3 = *reinterpret_cast<const uint4*>(arow + 2 * ps + 32 * m);
+    const uint4 b3 = c[m * 64];
+    h = mfma16b(a1, b[m][0], h);
+    l = mfma16b(a1, b[m][1], l); l2 = mfma16b(a2, b[m][0], l2);
+    l = mfma16b(a3, b[m][0], l); l2 = mfma16b(a2, b[m][1], l2);
+    l = mfma16b(a1, b3, l);
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -721,12 +824,16 @@ __global__ __launch_bounds__(256) void te_transpose_kernel(const float* __restri
 // so te_gemm_ax multiplies the TABLE once (te_launch_ax_t) and the recurrence gathers.  Same operands, same single addition as the
 // table epilogue of te_gemm_ax: bitwise the same pre-activations.  The row ids of step t+2 are fetched while step t computes
 // (a dependent load chain of two).
-template <int D, bool predict, bool FT = false>      // (compile-time: a runtime flag puts a branch around every store of the step)
+// SP (split operands, mma16s_*): h_{t-1} / r*h_{t-1} live in LDS as three bf16 planes, the weights as three resident bf16 planes.
+template <int D, bool predict, bool FT = false, bool SP = false>      // (compile-time: a runtime flag puts a branch around every store of the step)
 __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int KG = D / 16, LDA = D + 4, NW = D / 16;
+  constexpr int KG = D / 16, LDA = D + 4, NW = D / 16, KG2 = D / 32, LDH = D + 8, PS = 16 * LDH;
   float* Hb = lds;                       // h_{t-1}, overwritten by h_t   16 x LDA
   float* RHb = Hb + 16 * LDA;            // r * h_{t-1}
+  unsigned short* Hs = reinterpret_cast<unsigned short*>(lds);      // SP: 3 planes x 16 x LDH (bf16)
+  unsigned short* RHs = Hs + 3 * PS;
+  uint4* B3 = reinterpret_cast<uint4*>(RHs + 3 * PS) + (size_t)wave_id() * 3 * KG2 * 64;      // SP: this wave's third weight planes (z | r | c)
   __shared__ int s_r0[16], s_ns[16];
   const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, g4 = 4 * (lane >> 4);
   const int col = 16 * w + (lane & 15);
@@ -737,17 +844,26 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
     if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
   }
-  for (int e = tid; e < 16 * LDA; e += blockDim.x) Hb[e] = 0.f;
+  if constexpr (SP) { for (int e = tid; e < 3 * PS; e += blockDim.x) Hs[e] = 0; }
+  else { for (int e = tid; e < 16 * LDA; e += blockDim.x) Hb[e] = 0.f; }
   lds_barrier();
   int ns_max = 0;
   for (int i = 0; i < 16; ++i) ns_max = max(ns_max, s_ns[i]);
   int rowb[4], nsr[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { rowb[r] = s_r0[g4 + r]; nsr[r] = s_ns[g4 + r]; }
-  float4 wz[1][KG], wr[1][KG], wc[1][KG];
-  load_bfrag<KG>(wz[0], A.pWhT16, w);
-  load_bfrag<KG>(wr[0], A.pWhT16, NW + w);
-  load_bfrag<KG>(wc[0], A.pWhT16, 2 * NW + w);
+  float4 wz[1][SP ? 1 : KG], wr[1][SP ? 1 : KG], wc[1][SP ? 1 : KG];
+  uint4 bz[SP ? KG2 : 1][2], br[SP ? KG2 : 1][2], bc[SP ? KG2 : 1][2];
+  const uint4 *cz3 = B3 + lane, *cr3 = B3 + KG2 * 64 + lane, *cc3 = B3 + 2 * KG2 * 64 + lane;
+  if constexpr (SP) {
+    load_bfrag3<KG2>(bz, B3, A.pWhT16, w);
+    load_bfrag3<KG2>(br, B3 + KG2 * 64, A.pWhT16, NW + w);
+    load_bfrag3<KG2>(bc, B3 + 2 * KG2 * 64, A.pWhT16, 2 * NW + w);
+  } else {
+    load_bfrag<KG>(wz[0], A.pWhT16, w);
+    load_bfrag<KG>(wr[0], A.pWhT16, NW + w);
+    load_bfrag<KG>(wc[0], A.pWhT16, 2 * NW + w);
+  }
   // pre-activations of the NEXT step are fetched while the current step computes (G still holds
   // X.ui^T + bi for rows not yet visited)
   float cz[4], cr[4], cc[4];
@@ -758,6 +874,42 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
   float hcur[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's elements of h_{t-1} (it wrote them itself)
   // one step of the recurrence from the pre-activations cz / cr / cc
   auto compute = [&](int t) {
+    if constexpr (SP) {
+      f32x4 hr, lr = {0.f, 0.f, 0.f, 0.f}, hz, lz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { hr[r] = cr[r]; hz[r] = cz[r]; }
+      mma16s_g2<KG2>(hr, lr, hz, lz, Hs, LDH, br, bz, cr3, cz3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = g4 + r;
+        const float rv = fast_sigmoid(hr[r] + lr[r]);
+        const float rh = rv * hcur[r];
+        split3_store(RHs + i * LDH + col, PS, rh);
+        const size_t row = (size_t)(t < nsr[r] ? rowb[r] + t : Tsp);
+        if (!predict) { A.G[row * 3 * D + D + col] = rv; A.RH[row * D + col] = rh; }
+      }
+      lds_barrier();
+      f32x4 hc, lc = {0.f, 0.f, 0.f, 0.f}, lc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hc[r] = cc[r];
+      mma16s_g1<KG2>(hc, lc, lc2, RHs, LDH, bc, cc3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = g4 + r;
+        const bool on = t < nsr[r];
+        const float zv = fast_sigmoid(hz[r] + lz[r]);
+        const float c = fast_tanh(hc[r] + (lc[r] + lc2[r]));
+        const float hn = on ? (1.0f - zv) * hcur[r] + zv * c : hcur[r];
+        split3_store(Hs + i * LDH + col, PS, hn);
+        hcur[r] = hn;
+        if (!predict) {
+          const size_t row = (size_t)(on ? rowb[r] + t : Tsp);
+          A.G[row * 3 * D + col] = zv; A.G[row * 3 * D + 2 * D + col] = c;
+          A.H[row * D + col] = hn;
+        }
+      }
+      lds_barrier();
+    } else {
     // r gate first: its sigmoid, the r*h exchange and the stores then overlap the z-gate MFMAs (of this
     // wave and of its SIMD partner) instead of sitting between the MFMA block and the barrier
     f32x4 ar[1], az[1], ac[1];
@@ -796,6 +948,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
       }
     }
     lds_barrier();
+    }
   };
   if constexpr (!FT) {
     float nz[4], nr[4], nc[4];
@@ -881,12 +1034,15 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwd16_kernel(TeArgs A) {
 // te_rec_bwd16: BPTT per 16-sequence tile, t descending; wave w owns hidden columns [16w, 16w+16)
 // (same layout and reasoning as te_rec_fwd16).
 // -------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool SP = false>
 __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int KG = D / 16, LDA = D + 4, LDB = 2 * D + 4;
+  constexpr int KG = D / 16, LDA = D + 4, LDB = 2 * D + 4, KG2 = D / 32, LHA = D + 8, LHB = 2 * D + 8;
   float* Ac = lds;                       // da_c           16 x LDA
   float* Azr = Ac + 16 * LDA;            // da_z | da_r    16 x LDB
+  unsigned short* Acs = reinterpret_cast<unsigned short*>(lds);      // SP: 3 planes x 16 x LHA (bf16)
+  unsigned short* Azrs = Acs + 3 * 16 * LHA;                          //     3 planes x 16 x LHB
+  uint4* B3 = reinterpret_cast<uint4*>(Azrs + 3 * 16 * LHB) + (size_t)wave_id() * 3 * KG2 * 64;      // this wave's third weight planes (c | zr)
   __shared__ int s_r0[16], s_ns[16];
   const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, g4 = 4 * (lane >> 4);
   const int col = 16 * w + (lane & 15);
@@ -903,9 +1059,16 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
   int rowb[4], nsr[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { rowb[r] = s_r0[g4 + r]; nsr[r] = s_ns[g4 + r]; }
-  float4 wcb[1][KG], wzrb[1][2 * KG];
-  load_bfrag<KG>(wcb[0], A.pWhc16, w);
-  load_bfrag<2 * KG>(wzrb[0], A.pWhzr16, w);
+  float4 wcb[1][SP ? 1 : KG], wzrb[1][SP ? 1 : 2 * KG];
+  uint4 bcb[SP ? KG2 : 1][2], bzrb[SP ? 2 * KG2 : 1][2];
+  const uint4 *cc3 = B3 + lane, *czr3 = B3 + KG2 * 64 + lane;
+  if constexpr (SP) {
+    load_bfrag3<KG2>(bcb, B3, A.pWhc16, w);
+    load_bfrag3<2 * KG2>(bzrb, B3 + KG2 * 64, A.pWhzr16, w);
+  } else {
+    load_bfrag<KG>(wcb[0], A.pWhc16, w);
+    load_bfrag<2 * KG>(wzrb[0], A.pWhzr16, w);
+  }
   float dhn[4], sbz = 0.f, sbr = 0.f, sbc = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) dhn[r] = 0.f;
@@ -950,13 +1113,20 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
       dz[r] = dh * (c - h);
       dhp[r] = dh * (1.0f - z);
       dacv[r] = dh * z * (1.0f - c * c);
-      Ac[i * LDA + col] = dacv[r];
+      if constexpr (SP) split3_store(Acs + i * LHA + col, 16 * LHA, dacv[r]);
+      else Ac[i * LDA + col] = dacv[r];
     }
     lds_barrier();
     f32x4 m[1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) m[0][r] = 0.f;
-    mma16_regb<KG, 1>(m, Ac, LDA, wcb);
+    if constexpr (SP) {
+      f32x4 ml = {0.f, 0.f, 0.f, 0.f}, ml2 = {0.f, 0.f, 0.f, 0.f};
+      mma16s_g1<KG2>(m[0], ml, ml2, Acs, LHA, bcb, cc3);
+      m[0] += ml + ml2;
+    } else {
+      mma16_regb<KG, 1>(m, Ac, LDA, wcb);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = g4 + r;
@@ -965,8 +1135,13 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
       dhp[r] += mv * rv[r];
       const float daz = dz[r] * zv[r] * (1.0f - zv[r]);
       const float dar = dr * rv[r] * (1.0f - rv[r]);
-      Azr[i * LDB + col] = daz;
-      Azr[i * LDB + D + col] = dar;
+      if constexpr (SP) {
+        split3_store(Azrs + i * LHB + col, 16 * LHB, daz);
+        split3_store(Azrs + i * LHB + D + col, 16 * LHB, dar);
+      } else {
+        Azr[i * LDB + col] = daz;
+        Azr[i * LDB + D + col] = dar;
+      }
       float* g = A.G + (size_t)(t < nsr[r] ? rowb[r] + t : Tsp) * 3 * D;
       g[col] = daz; g[D + col] = dar; g[2 * D + col] = dacv[r];
       sbz += daz; sbr += dar; sbc += dacv[r];        // zero for inactive steps (dh == 0)
@@ -975,7 +1150,13 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
     f32x4 acc[1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[0][r] = 0.f;
-    mma16_regb<2 * KG, 1>(acc, Azr, LDB, wzrb);
+    if constexpr (SP) {
+      f32x4 al = {0.f, 0.f, 0.f, 0.f}, al2 = {0.f, 0.f, 0.f, 0.f};
+      mma16s_g1<2 * KG2>(acc[0], al, al2, Azrs, LHB, bzrb, czr3);
+      acc[0] += al + al2;
+    } else {
+      mma16_regb<2 * KG, 1>(acc, Azr, LDB, wzrb);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) dhn[r] = (t < nsr[r]) ? dhp[r] + acc[0][r] : 0.f;
     // No barrier here: Ac is free once every wave passed the second barrier (its readers ran before
@@ -2002,6 +2183,9 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     if (A.rec32) {      // 32-column fragments of the streaming recurrent kernels (same buffers)
       J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 8, D / 32, A.pWhc16, 0};
       J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 8, D / 32, A.pWhzr16, 0};
+    } else if (A.rec_split) {      // bf16 x 3 planes, 16x16x32 fragments (same buffers, 1.5 x the bytes)
+      J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 32, D / 16, A.pWhc16, 2};
+      J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 32, D / 16, A.pWhzr16, 2};
     } else {
       J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 16, D / 16, A.pWhc16, 1};
       J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 16, D / 16, A.pWhzr16, 1};
@@ -2009,6 +2193,7 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   }
   // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments (32-column ones for the streaming kernels)
   if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
+  else if (A.rec_split && !A.fwd_tab) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table launches keep the float32 kernel)
   else J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
   J.n = n;
 }
@@ -2085,8 +2270,13 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
-      if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
-      else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+      const dim3 g((n + 15) / 16), b(D * 4);
+      const size_t ldsf = sizeof(float) * 2 * 16 * (D + 4), ldss = sizeof(short) * (2 * 3 * 16 * (D + 8) + 3 * D * D);
+      // (forward table = large launches, where the kernel is bound by its HBM streams, not by the matrix pipe: 300 us for 782 tiles
+      // either way - and the two-step table prefetch next to the split planes does not fit the register file: float32-input MFMAs)
+      if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false, true>), g, b, ldsf, st, A);
+      else if (A.rec_split) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false, false, true>), g, b, ldss, st, A);
+      else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false>), g, b, ldsf, st, A);
     }
   }
   tm->end(st);
@@ -2103,7 +2293,10 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (A.rec32) hipLaunchKernelGGL((te_rec_bwd32_kernel<D, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
   }
   if constexpr (D <= 128) {
-    if (!A.rec32) hipLaunchKernelGGL(te_rec_bwd16_kernel<D>, dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
+    if (!A.rec32) {
+      if (A.rec_split) hipLaunchKernelGGL((te_rec_bwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
+      else hipLaunchKernelGGL((te_rec_bwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
+    }
   }
   tm->end(st);
   // per-sequence losses and the fixed-order partial sums only need te_head / te_rec_bwd: two small kernels that
@@ -2162,6 +2355,10 @@ static hipError_t te_optin_lds() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  // split-operand recurrent kernels at D = 128: 96 KB of third weight planes next to the operand planes
+  auto optin = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); };
+  optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, false, false, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, true, false, true>));
+  optin(reinterpret_cast<const void*>(&te_rec_bwd16_kernel<128, true>));
   done = e == hipSuccess;
   return e;
 }
@@ -2210,8 +2407,11 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
-      if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
-      else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * 2 * 16 * (D + 4), st, A);
+      const dim3 g((n + 15) / 16), b(D * 4);
+      const size_t ldsf = sizeof(float) * 2 * 16 * (D + 4), ldss = sizeof(short) * (2 * 3 * 16 * (D + 8) + 3 * D * D);
+      if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, true>), g, b, ldsf, st, A);
+      else if (A.rec_split) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, false, true>), g, b, ldss, st, A);
+      else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), g, b, ldsf, st, A);
     }
   }
   hipError_t e = hipSuccess;
