@@ -126,6 +126,12 @@ int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
  * float32 accumulation noise; the timed Gowalla launch measures 4.7e-6 against the float64 oracle, 5.7e-6 with on = 0).
  * on = 0: float32-input v_mfma_f32_16x16x4_f32 (rounds 1 - 2).  Environment override at context creation: POI_TE_SPLIT=0|1. */
 int poi_ctx_set_split_products(poi_ctx* ctx, int on);
+/* Small launches: launches of at most max_sequences sequences (default 1024; 0 disables; dim 64 / 128) run the recurrence of every
+ * sequence in its own workgroup on the vector ALUs (te_rec_fwd1 / bwd1, weights resident in registers) instead of 16-sequence MFMA
+ * tiles - a tile step costs the same whether it holds 16 sequences or one, so the reference schedule (one user per step,
+ * prog_bpr_gru_spatial.py:249-250) and launches that do not fill the chip are bound by it.  Same formulas, float32 FMA chains; the
+ * summation order differs from the tile kernels.  Environment override at context creation: POI_TE_REC1=<max_sequences>. */
+int poi_ctx_set_small_launch(poi_ctx* ctx, int max_sequences);
 
 /* Seeded top-K (optional, exact): seed_idx (n x k_seed int32, device) holds, for every user of the NEXT fused top-K call
  * (poi_score_topk / _ulptai / _geo with the same n and user order), k_seed >= k distinct item ids - typically the user's top-K of the

@@ -44,6 +44,7 @@ struct poi_ctx {
   DevBuf ptab, iota;        // forward table (te_rec_fwd16<FT>): lt . ui[:, :D]^T per table row; 0..n_item, n_item + 1
   int iota_n = -1;          // rows the iota buffer currently describes
   int fwd_tab = 1;          // POI_TE_FWDTAB=0 disables (A/B)
+  int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
   // A launch is captured the second time its key (every pointer / size / scalar the kernels receive) is seen; the caller's uidx /
@@ -134,6 +135,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
   if (const char* e = getenv("POI_CARNN_FAST")) c->carnn_fast = atoi(e) != 0;
   if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
   if (const char* e = getenv("POI_TOPK_FILTER")) c->topk_filter = atoi(e) != 0;
@@ -213,6 +215,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.bintab = poi::te_bintab(D, spatial, n_dist) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
   A.rec_split = (!A.rec32 && c->rec_split) ? 1 : 0;
+  A.rec1 = (!A.rec32 && n <= c->rec1_max) ? 1 : 0;
   A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
@@ -224,7 +227,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const bool sorted = !predict;
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
   const size_t n_hot = Ncap / (TE_COLD_MAX + 1) + 2, n_chunk = Ncap / TE_HOT_CHUNK + n_hot + 2;
-  const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)((n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
+  const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)(n <= c->rec1_max ? n : (n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
   const int Rrows = P->n_item + 1 + n_dist + 1;
   const bool listed = sorted && (size_t)Rrows > 4 * Ncap;      // table much larger than the launch's footprint: touched-row list
   const size_t sin = sorted ? 7 * Ncap + (listed ? Ncap : 0) + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
@@ -243,7 +246,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (A.ppoi && (rc = ensure(c, c->pmark, sizeof(int) * (size_t)(P->n_item + 2), st))) return rc;
   // forward table: worth it when the table has clearly fewer rows than the launch has steps (Tcap is the upper bound: sequences
   // average ~40 % of the longest) - te_gemm_ax then multiplies n_item + 1 rows instead of one row per step
-  A.fwd_tab = (c->fwd_tab && A.bintab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap) ? 1 : 0;
+  A.fwd_tab = (c->fwd_tab && A.bintab && !A.rec32 && !A.rec1 && 2 * (size_t)(P->n_item + 1) <= Tcap) ? 1 : 0;      // (the per-sequence kernels read G)
   if (A.fwd_tab) {
     // (+ spare rows: te_gemm_ntk writes whole 128-row tiles - rows past the table's last land behind it, as in G)
     if ((rc = ensure(c, c->ptab, sizeof(float) * ((size_t)(P->n_item + 1 + 127) / 128 * 128 + 128) * 3 * D, st)) || (rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
@@ -265,7 +268,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (A.ppoi) { A.S = take(Tcap * (size_t)(3 * D)); A.pfirst = take(n_prange * (size_t)(3 * D)); A.plast = take(n_prange * (size_t)(3 * D)); }
   if (sorted) {
     A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP);
-    A.bi_part = take((size_t)((n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);
+    A.bi_part = take((size_t)(A.rec1 ? n : (n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);
   }
   int* ip = (int*)f;
   auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
@@ -438,7 +441,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
       const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
-                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1))};
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1) | ((unsigned)c->rec1_max << 2))};
       add(bufs, sizeof bufs);
     }
     poi_ctx::StepGraph* g = nullptr;
@@ -963,6 +966,12 @@ int poi_ctx_set_f16_rounding(poi_ctx* c, int mode, uint32_t seed) {
 int poi_ctx_set_split_products(poi_ctx* c, int on) {
   if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_split_products: on must be 0 or 1");
   c->rec_split = on;
+  return POI_OK;
+}
+
+int poi_ctx_set_small_launch(poi_ctx* c, int max_sequences) {
+  if (!c || max_sequences < 0) return fail(c, POI_EINVAL, "poi_ctx_set_small_launch: max_sequences must be >= 0");
+  c->rec1_max = max_sequences;
   return POI_OK;
 }
 

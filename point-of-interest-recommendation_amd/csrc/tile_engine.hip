@@ -85,6 +85,14 @@ __device__ __forceinline__ void split3(float v, unsigned& u1, unsigned& u2, unsi
 
 __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
   const PackJob& j = J.j[blockIdx.y];
+  if (j.n16 == 3) {      // plain transposed copy for the per-sequence recurrent kernels: dst[n * K + k] = B[k][n]
+    float* dst = reinterpret_cast<float*>(j.dst);
+    for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < j.K * j.N; e += gridDim.x * TE_BLOCK) {
+      const int k = e / j.N, n = e % j.N;                  // (reads coalesced along n, writes strided: 64 K elements, once per launch)
+      dst[(size_t)n * j.K + k] = j.src[(size_t)k * j.sk + (size_t)n * j.sn];
+    }
+    return;
+  }
   if (j.n16 == 2) {
     const int total3 = j.NT * j.K8 * 3 * 64;
     for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < total3; e += gridDim.x * TE_BLOCK) {
@@ -1183,6 +1191,170 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// te_rec_fwd1 / te_rec_bwd1: the recurrence of ONE sequence per workgroup on the vector ALUs, for launches too small to fill the
+// chip with 16-sequence tiles (TeArgs.rec1: n_seq <= rec1_max).  The float32-input MFMA has no rate advantage over v_fma_f32 on
+// gfx950, and a 16-row MFMA tile that holds one sequence wastes 15/16 of it: a tile step is ~2.5 us whatever it holds, a step here
+// ~0.5 us (3 D^2 FMAs over 512 threads with the weights RESIDENT in registers - 96 per thread at D = 128 - and h_{t-1} broadcast
+// from LDS).  A launch of n <= 256 sequences runs them all at once, one per CU: 49 steps in ~30 us against ~125 us; the reference
+// schedule (one user per step) spends 2 x 15 us here instead of 2 x 65 us.
+//   forward : 4 D threads; a thread owns FOUR outputs and one k-slice (8 slices in the z|r phase, 16 in the c phase; adjacent lanes:
+//             DPP sums) - one 16-byte LDS read of h feeds 16 FMAs (one output per thread made the kernel LDS-bound: 1.25 us per
+//             step).  Reads the pre-activations from G (te_gemm_ax), writes z | r | c over them, H, RH - the buffers the rest of
+//             the step reads, as the tile kernels do.
+//   backward: thread (g, s) owns hidden columns 4g .. 4g+3 and the j-slice s of 16: m = da_c . Wc and dh_{t-1} += [da_z | da_r] . Wzr
+//             with the TRANSPOSED weights (te_pack n16 == 3 -> pWhc16 / pWhzr16 as plain float matrices) contiguous per thread.
+//   d bi partials: one row per sequence (bi_part is sized for it), summed in order by te_parts.
+// Same formulas as te_rec_fwd16 / bwd16; summation order differs (tolerance-tested against the oracle and the tile kernels).
+// -------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ float group_sum(float v) {      // sum over N = 8 / 16 adjacent lanes, in every lane
+  v += dpp_f<0xB1>(v);                     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);                    // row_half_mirror (quads already uniform)
+  if (N >= 16) v += dpp_f<0x140>(v);       // row_mirror
+  return v;
+}
+// a[o] += w[o][:] . x[:] for FOUR outputs sharing the LDS slice x (one 16-byte LDS read feeds 16 FMAs)
+template <int L>
+__device__ __forceinline__ void dot4_reg_lds(const float (&w)[4][L], const float* __restrict__ x, float (&a)[4]) {
+#pragma unroll
+  for (int i = 0; i < L; i += 4) {
+    const float4 u = *reinterpret_cast<const float4*>(x + i);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      a[o] = __fmaf_rn(w[o][i], u.x, a[o]); a[o] = __fmaf_rn(w[o][i + 1], u.y, a[o]);
+      a[o] = __fmaf_rn(w[o][i + 2], u.z, a[o]); a[o] = __fmaf_rn(w[o][i + 3], u.w, a[o]);
+    }
+  }
+}
+template <int L>
+__device__ __forceinline__ void load_rows4(float (&w)[4][L], const float* __restrict__ src, int ld) {       // w[o][:] = src[o * ld + 0 .. L)
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int i = 0; i < L; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)o * ld + i);
+      w[o][i] = v.x; w[o][i + 1] = v.y; w[o][i + 2] = v.z; w[o][i + 3] = v.w;
+    }
+}
+__device__ __forceinline__ float pick4(const float (&a)[4], int o) { return o == 0 ? a[0] : o == 1 ? a[1] : o == 2 ? a[2] : a[3]; }
+
+// 4 D threads.  A thread owns FOUR outputs and one k-slice: z|r phase 8 slices of D / 8, c phase 16 slices of D / 16 (adjacent lanes: DPP
+// sums); lanes 0 - 3 of a group then finish one output each (activation, state update, stores).
+template <int D, bool predict>
+__global__ __launch_bounds__(4 * D) void te_rec_fwd1_kernel(TeArgs A) {
+  constexpr int LZ = D / 8, LC = D / 16;
+  __shared__ __align__(16) float hs[D], rhs[D], zs[D];
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int gz = tid >> 3, sz = tid & 7, gc = tid >> 4, sc = tid & 15;
+  const int jz = 4 * gz + (sz & 3), jc = 4 * gc + (sc & 3);        // the output this lane finishes (lanes sz / sc < 4)
+  const bool isr = jz >= D;
+  const int jr = isr ? jz - D : jz;
+  const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
+  float wzr[4][LZ], wc[4][LC];
+  load_rows4<LZ>(wzr, A.wh + (size_t)4 * gz * D + sz * LZ, D);
+  load_rows4<LC>(wc, A.wh + (size_t)(2 * D + 4 * gc) * D + sc * LC, D);
+  if (tid < D) hs[tid] = 0.f;
+  __syncthreads();
+  // pre-activations of the next step are requested a step ahead (G row r0 + t + 1 is not written before step t + 1)
+  float gzr = 0.f, gcc = 0.f;
+  if (ns > 0) { gzr = A.G[(size_t)r0 * 3 * D + jz]; gcc = A.G[(size_t)r0 * 3 * D + 2 * D + jc]; }
+  for (int t = 0; t < ns; ++t) {
+    const size_t row = (size_t)(r0 + t), rn = (size_t)(r0 + min(t + 1, ns - 1));
+    const float nzr = A.G[rn * 3 * D + jz], nc = A.G[rn * 3 * D + 2 * D + jc];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    dot4_reg_lds<LZ>(wzr, hs + sz * LZ, a);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) a[o] = group_sum<8>(a[o]);
+    if (sz < 4) {
+      const float v = fast_sigmoid(pick4(a, sz) + gzr);
+      if (isr) {
+        const float rh = v * hs[jr];
+        rhs[jr] = rh;
+        if (!predict) { A.G[row * 3 * D + D + jr] = v; A.RH[row * D + jr] = rh; }
+      } else {
+        zs[jr] = v;
+      }
+    }
+    lds_barrier();
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    dot4_reg_lds<LC>(wc, rhs + sc * LC, b);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) b[o] = group_sum<16>(b[o]);
+    if (sc < 4) {
+      const float c = fast_tanh(pick4(b, sc) + gcc);
+      const float z = zs[jc];
+      const float hn = (1.0f - z) * hs[jc] + z * c;
+      hs[jc] = hn;                         // (the c phase reads rhs only)
+      if (!predict) { A.G[row * 3 * D + jc] = z; A.G[row * 3 * D + 2 * D + jc] = c; A.H[row * D + jc] = hn; }
+    }
+    lds_barrier();
+    gzr = nzr; gcc = nc;
+  }
+  if (predict && tid < D) A.hts[(size_t)(A.out_row ? A.out_row[k] : k) * D + tid] = hs[tid];
+}
+
+// thread (g, s): hidden columns 4g .. 4g+3, j-slice s of 16 - of D / 16 (m = da_c . Wc) and of D / 8 ([da_z | da_r] . Wzr)
+template <int D>
+__global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
+  constexpr int LC = D / 16, LZ = D / 8;
+  __shared__ __align__(16) float dac[D], dazr[2 * D];
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int g = tid >> 4, s = tid & 15;
+  const int kk = 4 * g + (s & 3);          // the column this lane finishes (lanes s < 4)
+  const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
+  float wc[4][LC], wzr[4][LZ];
+  load_rows4<LC>(wc, reinterpret_cast<const float*>(A.pWhc16) + (size_t)4 * g * D + s * LC, D);              // Wc^T:  [k][j]
+  load_rows4<LZ>(wzr, reinterpret_cast<const float*>(A.pWhzr16) + (size_t)4 * g * 2 * D + s * LZ, 2 * D);     // Wzr^T: [k][j], j < 2D
+  float dhn = 0.f, sbz = 0.f, sbr = 0.f, sbc = 0.f;
+  // operands of step t - 1 are requested while step t computes
+  float z = 0.f, r = 0.f, c = 0.f, hp = 0.f, dd = 0.f;
+  auto fetch = [&](int t, float& fz, float& fr, float& fc, float& fh, float& fd) {
+    const size_t row = (size_t)(r0 + max(t, 0));
+    const float* gp = A.G + row * 3 * D;
+    fz = gp[kk]; fr = gp[D + kk]; fc = gp[2 * D + kk];
+    fh = A.H[(row - (t > 0 ? 1 : 0)) * D + kk];
+    fd = A.DH[row * D + kk];
+  };
+  if (ns > 0) fetch(ns - 1, z, r, c, hp, dd);
+  for (int t = ns - 1; t >= 0; --t) {
+    float nz, nr, nc, nh, nd;
+    fetch(t - 1, nz, nr, nc, nh, nd);
+    const float h = t > 0 ? hp : 0.f;
+    const float dh = dhn + dd;
+    const float dz = dh * (c - h);
+    float dhp = dh * (1.0f - z);
+    const float dacv = dh * z * (1.0f - c * c);
+    if (s < 4) dac[kk] = dacv;
+    lds_barrier();
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    dot4_reg_lds<LC>(wc, dac + s * LC, a);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) a[o] = group_sum<16>(a[o]);
+    const float m = pick4(a, s & 3);
+    const float dr = m * h;
+    dhp += m * r;
+    const float daz = dz * z * (1.0f - z), dar = dr * r * (1.0f - r);
+    if (s < 4) {
+      dazr[kk] = daz; dazr[D + kk] = dar;
+      float* gp = A.G + (size_t)(r0 + t) * 3 * D;
+      gp[kk] = daz; gp[D + kk] = dar; gp[2 * D + kk] = dacv;
+      sbz += daz; sbr += dar; sbc += dacv;
+    }
+    lds_barrier();
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    dot4_reg_lds<LZ>(wzr, dazr + s * LZ, b);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) b[o] = group_sum<16>(b[o]);
+    dhn = dhp + pick4(b, s & 3);
+    z = nz; r = nr; c = nc; hp = nh; dd = nd;
+  }
+  if (s < 4) {
+    float* bp = A.bi_part + (size_t)k * 3 * D;
+    bp[kk] = sbz; bp[D + kk] = sbr; bp[2 * D + kk] = sbc;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // te_rec_fwd32 / te_rec_bwd32: the recurrent kernels for D = 256 (config X; also instantiable at D = 128).  At D = 256 the
 // recurrent weights are 786 KB: the register-resident scheme of the 16-sequence kernels would need 192 registers per wave
 // with four waves per SIMD.  Here a workgroup (4 waves) owns a tile of 32 sequences, keeps h_{t-1} / r*h_{t-1} in LDS and
@@ -2180,7 +2352,10 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     if (A.spatial) J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
     // 16-column fragments of the recurrent kernels (16x16x4 MFMA): B[k][n] = wh[2][k][n] (K = D, N = D) and
     // B[k][n] = wh_flat[k][n], k < 2D (K = 2D, N = D)
-    if (A.rec32) {      // 32-column fragments of the streaming recurrent kernels (same buffers)
+    if (A.rec1) {       // per-sequence kernels: plain transposes (the forward kernel reads wh itself)
+      J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, 0, 0, A.pWhc16, 3};
+      J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 0, 0, A.pWhzr16, 3};
+    } else if (A.rec32) {      // 32-column fragments of the streaming recurrent kernels (same buffers)
       J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 8, D / 32, A.pWhc16, 0};
       J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 8, D / 32, A.pWhzr16, 0};
     } else if (A.rec_split) {      // bf16 x 3 planes, 16x16x32 fragments (same buffers, 1.5 x the bytes)
@@ -2192,7 +2367,8 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     }
   }
   // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments (32-column ones for the streaming kernels)
-  if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
+  if (A.rec1) {}      // (te_rec_fwd1 reads wh directly)
+  else if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
   else if (A.rec_split && !A.fwd_tab) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table launches keep the float32 kernel)
   else J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
   J.n = n;
@@ -2272,6 +2448,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (!A.rec32) {
       const dim3 g((n + 15) / 16), b(D * 4);
       const size_t ldsf = sizeof(float) * 2 * 16 * (D + 4), ldss = sizeof(short) * (2 * 3 * 16 * (D + 8) + 3 * D * D);
+      if (A.rec1) hipLaunchKernelGGL((te_rec_fwd1_kernel<D, false>), dim3(n), dim3(4 * D), 0, st, A);
+      else
       // (forward table = large launches, where the kernel is bound by its HBM streams, not by the matrix pipe: 300 us for 782 tiles
       // either way - and the two-step table prefetch next to the split planes does not fit the register file: float32-input MFMAs)
       if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, false, true>), g, b, ldsf, st, A);
@@ -2294,7 +2472,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
-      if (A.rec_split) hipLaunchKernelGGL((te_rec_bwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
+      if (A.rec1) hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(n), dim3(4 * D), 0, st, A);
+      else if (A.rec_split) hipLaunchKernelGGL((te_rec_bwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
       else hipLaunchKernelGGL((te_rec_bwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
     }
   }
@@ -2305,7 +2484,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   auto finalize = [&](hipStream_t s) {
     tm->begin("te_finalize", s);
     hipLaunchKernelGGL(te_finalize_kernel, dim3(n_fin), dim3(TE_BLOCK), 0, s, A);
-    hipLaunchKernelGGL(te_parts_kernel, dim3((n_out + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, s, A, A.rec32 ? (n + 31) / 32 : (n + 15) / 16, n_fin);
+    hipLaunchKernelGGL(te_parts_kernel, dim3((n_out + POI_NWAVE - 1) / POI_NWAVE), dim3(TE_BLOCK), 0, s, A, A.rec1 ? n : A.rec32 ? (n + 31) / 32 : (n + 15) / 16, n_fin);
     tm->end(s);
   };
   if (A.side) {
@@ -2409,7 +2588,8 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
     if (!A.rec32) {
       const dim3 g((n + 15) / 16), b(D * 4);
       const size_t ldsf = sizeof(float) * 2 * 16 * (D + 4), ldss = sizeof(short) * (2 * 3 * 16 * (D + 8) + 3 * D * D);
-      if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, true>), g, b, ldsf, st, A);
+      if (A.rec1) hipLaunchKernelGGL((te_rec_fwd1_kernel<D, true>), dim3(n), dim3(4 * D), 0, st, A);
+      else if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, true>), g, b, ldsf, st, A);
       else if (A.rec_split) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, false, true>), g, b, ldss, st, A);
       else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), g, b, ldsf, st, A);
     }

@@ -528,20 +528,21 @@ def test_forked_write_back_is_bitwise_the_serial_one(pa, monkeypatch):
 
 
 @pytest.mark.parametrize("dim,n_item,n_user", [(128, 120, 150), (128, 5000, 150), (64, 120, 70)])
-def test_split_products_and_float32_mfma_both_meet_the_oracle(pa, dim, n_item, n_user):
-    """poi_ctx_set_split_products: the recurrent kernels on bf16 x 3 split products (default) and on float32-input MFMAs, with the forward
-    table (n_item small against the launch: te_rec_fwd16<FT>) and without (n_item 5000: pre-activations from G) - training launch against
-    the oracle's mean rule at the usual bars, predict against the oracle, and the two modes against each other (same bars: they are two
-    float32-accurate evaluations of the same step)."""
+def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user):
+    """The three arithmetic forms of the recurrence - 16-sequence MFMA tiles on bf16 x 3 split products (poi_ctx_set_split_products, default
+    for launches above the small-launch threshold), on float32-input MFMAs, and one sequence per workgroup on the vector ALUs
+    (poi_ctx_set_small_launch, default for launches of <= 1024 sequences) - with the forward table (n_item small against the launch) and
+    without (n_item 5000): training launch against the oracle's mean rule at the usual bars, predict against the oracle, and the
+    variants against each other (same bars: float32-accurate evaluations of the same step)."""
     T = toy_problem(900 + dim + n_item, n_user=n_user, n_item=n_item, n_dist=40, dim=dim, len_max=11, hot=60)
     P = spatial_params(900 + dim, T)
     users = np.random.default_rng(5).permutation(n_user)[: n_user - 5].astype(np.int32)
     exp, outs = _oracle_batch(P, T, users)
     res = {}
     try:
-        for split in (True, False):
+        for split in (True, False, "per-sequence"):
             model = _model(pa, T, P)
-            model.ctx.set_engine("tile"); model.ctx.set_split_products(split)
+            model.ctx.set_engine("tile"); model.ctx.set_split_products(split is True); model.ctx.set_small_launch(1024 if split == "per-sequence" else 0)
             got_out = model.train_batch(users)
             for k, out in enumerate(outs):
                 assert_close(got_out[k][:3], out[:3], "losses[%d]" % k, rtol=2e-5)
@@ -555,7 +556,8 @@ def test_split_products_and_float32_mfma_both_meet_the_oracle(pa, dim, n_item, n
             eh, es = O.spatial_predict(Pn, Pn["lt"], Pn["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
             assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
             res[split] = (got, hts)
-        assert_step_close(res[True][0], {k: np.asarray(v, np.float64) if k != "wd" else float(v) for k, v in res[False][0].items()}, P, SP_NAMES, "split vs float32 MFMA")
-        assert not all(np.array_equal(res[True][0][k], res[False][0][k]) for k in ("wh", "ui")), "the switch did not change the arithmetic"
+        for other in (False, "per-sequence"):
+            assert_step_close(res[True][0], {k: np.asarray(v, np.float64) if k != "wd" else float(v) for k, v in res[other][0].items()}, P, SP_NAMES, "split vs %s" % other)
+            assert not all(np.array_equal(res[True][0][k], res[other][0][k]) for k in ("wh", "ui")), "the switch did not change the arithmetic"
     finally:
-        pa._lib.context(0).set_split_products(True); pa._lib.context(0).set_engine("auto")
+        pa._lib.context(0).set_split_products(True); pa._lib.context(0).set_small_launch(1024); pa._lib.context(0).set_engine("auto")
