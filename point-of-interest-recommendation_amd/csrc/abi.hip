@@ -44,6 +44,7 @@ struct poi_ctx {
   DevBuf ptab, iota;        // forward table (te_rec_fwd16<FT>): lt . ui[:, :D]^T per table row; 0..n_item, n_item + 1
   int iota_n = -1;          // rows the iota buffer currently describes
   int fwd_tab = 1;          // POI_TE_FWDTAB=0 disables (A/B)
+  int one_path = 1;         // launches of ONE Distance2Pre sequence take the five-kernel path (te_one_*); POI_TE_ONE=0 -> the batched pipeline
   int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
@@ -136,6 +137,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
+  if (const char* e = getenv("POI_TE_ONE")) c->one_path = atoi(e) != 0;
   if (const char* e = getenv("POI_CARNN_FAST")) c->carnn_fast = atoi(e) != 0;
   if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
   if (const char* e = getenv("POI_TOPK_FILTER")) c->topk_filter = atoi(e) != 0;
@@ -420,7 +422,10 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)
+    // one sequence (the reference schedule): the whole step in five kernels (tile_engine.hip, te_one_*)
+    const bool one = n == 1 && c->one_path && E.rec1 && !E.lt_f16 && poi::te_one_supported(D, spatial, T->max_len);
     auto run = [&](hipStream_t s) -> hipError_t {
+      if (one) return poi::launch_te_one(E, alpha, lambda, T->max_len, s, &c->tm);
       hipError_t e = poi::launch_te_train(E, c->num_cu, s, &c->tm);
       if (e == hipSuccess) e = poi::launch_te_scatter(E, alpha, lambda, c->num_cu, s, &c->tm);
       if (e == hipSuccess) e = poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, s, &c->tm);
@@ -441,7 +446,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
       const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
-                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1) | ((unsigned)c->rec1_max << 2))};
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1) | (c->one_path << 2) | ((unsigned)c->rec1_max << 3))};
       add(bufs, sizeof bufs);
     }
     poi_ctx::StepGraph* g = nullptr;

@@ -205,6 +205,8 @@ int te_wgrad_ui_jobs(int D, int n_dist, bool spatial);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 int te_nbp(int n_dist);
 void launch_te_iota(int* buf, int n, hipStream_t st);
+hipError_t launch_te_one(TeArgs& A, float alpha, float lambda, int l_cap, hipStream_t st, Timing* tm);      // n_seq == 1, whole step
+bool te_one_supported(int D, bool spatial, int max_len);
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);

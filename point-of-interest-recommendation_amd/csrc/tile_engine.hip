@@ -83,11 +83,11 @@ __device__ __forceinline__ void split3(float v, unsigned& u1, unsigned& u2, unsi
   u3 = __float_as_uint(r1 - __uint_as_float(u2));
 }
 
-__global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
-  const PackJob& j = J.j[blockIdx.y];
+// (vb of nvb: the virtual block of the job - te_pack_kernel's own grid, or a slice of te_one_in_kernel's)
+__device__ __forceinline__ void te_pack_block(const PackJob& j, const int vb, const int nvb) {
   if (j.n16 == 3) {      // plain transposed copy for the per-sequence recurrent kernels: dst[n * K + k] = B[k][n]
     float* dst = reinterpret_cast<float*>(j.dst);
-    for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < j.K * j.N; e += gridDim.x * TE_BLOCK) {
+    for (int e = vb * TE_BLOCK + threadIdx.x; e < j.K * j.N; e += nvb * TE_BLOCK) {
       const int k = e / j.N, n = e % j.N;                  // (reads coalesced along n, writes strided: 64 K elements, once per launch)
       dst[(size_t)n * j.K + k] = j.src[(size_t)k * j.sk + (size_t)n * j.sn];
     }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
   }
   if (j.n16 == 2) {
     const int total3 = j.NT * j.K8 * 3 * 64;
-    for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < total3; e += gridDim.x * TE_BLOCK) {
+    for (int e = vb * TE_BLOCK + threadIdx.x; e < total3; e += nvb * TE_BLOCK) {
       const int lane = e & 63, f = e >> 6, pl = f % 3, m = (f / 3) % j.K8, nt = (f / 3) / j.K8;
       const int n = nt * 16 + (lane & 15), k0 = 32 * m + 8 * (lane >> 4);
       unsigned h[8];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
     return;
   }
   const int total = j.NT * j.K8 * 64;
-  for (int e = blockIdx.x * TE_BLOCK + threadIdx.x; e < total; e += gridDim.x * TE_BLOCK) {
+  for (int e = vb * TE_BLOCK + threadIdx.x; e < total; e += nvb * TE_BLOCK) {
     const int lane = e & 63, m = (e >> 6) % j.K8, nt = (e >> 6) / j.K8;
     const int n = j.n16 ? nt * 16 + (lane & 15) : nt * 32 + (lane & 31);
     const int k0 = j.n16 ? 16 * m + 4 * (lane >> 4) : 8 * m + 4 * (lane >> 5);
@@ -125,6 +125,8 @@ __global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) {
     j.dst[e] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
+
+__global__ __launch_bounds__(TE_BLOCK) void te_pack_kernel(PackJobs J) { te_pack_block(J.j[blockIdx.y], blockIdx.x, gridDim.x); }
 
 // acc[i][j] += A_i (32 x 8*K8, LDS row-major, leading dim lda) . B_j (packed n-tile j of `bp`)
 // Explicit software pipeline, one k-group deep: the packed B fragments (L2) and the A fragments (LDS)
@@ -2294,6 +2296,206 @@ __global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile
 }
 
 // -------------------------------------------------------------------------------------------------
+// One-sequence path (TeArgs n_seq == 1: the reference schedule, prog_bpr_gru_spatial.py:249-250 - one user per step).  The batched
+// pipeline spends a launch of one sequence in ~40 dependent dispatches of 4 - 30 us each (sort, regrouping, split-K slabs, write-back
+// chains - machinery that pays at thousands of sequences); here the step is FIVE kernels:
+//   te_one_in   prep + gather + G = X . ui^T + bi on the vector ALUs (24 workgroups of 16 gate rows), E rows, weight packs for te_head /
+//               te_rec_bwd1, and two snapshots the last kernel needs: the step inputs X (T x 2D) and ui (before its update)
+//   te_rec_fwd1, te_head, te_rec_bwd1                      (as in the batched path)
+//   te_one_out  everything after BPTT in one launch: d ui / d wh / d vs as K = T products with the SGD step applied in the epilogue
+//               (no slabs), bi / bs / wd / loss_weight / losses by one workgroup, and the sparse write-back with one workgroup per
+//               table touch (3 L slots: first occurrence of a row sums the row's touches in slot order - dx on the fly from DA and the
+//               ui snapshot, +- g h - and applies the step; the padding rows' analytic multiplicities as in te_rowmap).
+// Same formulas and batch rule (n_seq = 1) as te_scatter / dense_apply; T <= 64 steps.
+// -------------------------------------------------------------------------------------------------
+#define ONE_TMAX 64
+__device__ __forceinline__ void one_header(const TeArgs& A, int& base, int& L, int& ns) {
+  const int u = A.uidx[0];
+  base = A.off[u]; L = A.off[u + 1] - base; ns = L > 0 ? L - 1 : 0;
+}
+
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_one_in_kernel(TeArgs A, PackJobs J, int n_ax, int n_pk) {
+  constexpr int XW = 2 * D, LDX = XW + 4;
+  __shared__ __align__(16) float Xc[16][LDX], U[16][LDX];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  int base, L, ns; one_header(A, base, L, ns);
+  if (b >= n_ax + 1) {                       // weight packs (te_head's vs fragments, the transposes of te_rec_bwd1)
+    const int v = b - n_ax - 1;
+    if (v / n_pk < J.n) te_pack_block(J.j[v / n_pk], v % n_pk, n_pk);
+    return;
+  }
+  if (b == n_ax) {                           // prep (te_len / te_scan / te_rowmap of one sequence) + E rows
+    if (tid == 0) { A.soff[0] = 0; A.soff[1] = ns; }
+    for (int t = tid; t < ns; t += TE_BLOCK) {
+      A.row_src[t] = base + t; A.row_t[t] = t; A.row_p[t] = A.p[base + t]; A.row_dp[t] = A.dp[base + t];
+      A.row_ab[t] = A.dp[base + t + 1] | (A.dq[base + t + 1] << 16);
+    }
+    constexpr int LPR = D / 4;
+    for (int e = tid; e < ns * LPR; e += TE_BLOCK) {
+      const int t = e / LPR, c = (e % LPR) * 4;
+      const float4 a = *reinterpret_cast<const float4*>(A.lt + (size_t)A.p[base + t + 1] * D + c);
+      const float4 q = *reinterpret_cast<const float4*>(A.lt + (size_t)A.q[base + t + 1] * D + c);
+      *reinterpret_cast<float4*>(A.E + (size_t)t * D + c) = make_float4(a.x - q.x, a.y - q.y, a.z - q.z, a.w - q.w);
+    }
+    return;
+  }
+  // gate rows m0 .. m0 + 15 of G for every step: thread (tm, tt) -> G[t0 + tt][m0 + tm]
+  const int m0 = 16 * b, tm = tid & 15, tt = tid >> 4;
+  for (int e = tid; e < 16 * (XW / 4); e += TE_BLOCK) {
+    const int r = e / (XW / 4), c = (e % (XW / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(A.ui + (size_t)(m0 + r) * XW + c);
+    *reinterpret_cast<float4*>(&U[r][c]) = v;
+    *reinterpret_cast<float4*>(A.uiT + (size_t)(m0 + r) * XW + c) = v;          // ui snapshot, plain layout (read by te_one_out after ui moved)
+  }
+  const float bias = A.bi[m0 + tm];
+  for (int t0 = 0; t0 < ns; t0 += 16) {
+    __syncthreads();
+    for (int e = tid; e < 16 * (XW / 4); e += TE_BLOCK) {
+      const int r = e / (XW / 4), c = (e % (XW / 4)) * 4, t = min(t0 + r, ns - 1);
+      const float* src = c < D ? A.lt + (size_t)A.p[base + t] * D + c : A.di + (size_t)A.dp[base + t] * D + (c - D);
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      *reinterpret_cast<float4*>(&Xc[r][c]) = v;
+      if (b == 0 && t0 + r < ns) *reinterpret_cast<float4*>(A.X + (size_t)(t0 + r) * XW + c) = v;       // X snapshot
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < XW; c += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(&Xc[tt][c]), u = *reinterpret_cast<const float4*>(&U[tm][c]);
+      a0 = __fmaf_rn(x.x, u.x, a0); a1 = __fmaf_rn(x.y, u.y, a1); a0 = __fmaf_rn(x.z, u.z, a0); a1 = __fmaf_rn(x.w, u.w, a1);
+    }
+    if (t0 + tt < ns) A.G[(size_t)(t0 + tt) * 3 * D + m0 + tm] = (a0 + a1) + bias;
+  }
+}
+
+// out[m][n] = sum_t Aop[t][m] * Bop[t][n] on a 16 x 64 block, then theta[m][n] -= aeff * (out + lambda * theta[m][n])
+struct OneJob { const float* a; int lda, m0, mvalid; const float* b; int ldb, n0, bshift; float* theta; int ldt; };
+__device__ __forceinline__ void one_dense_block(const OneJob& j, int ns, float aeff, float lambda, float (*As)[17], float (*Bs)[68]) {
+  const int tid = threadIdx.x, tm = tid & 15, tq = tid >> 4;
+  for (int e = tid; e < ns * 16; e += TE_BLOCK) {
+    const int t = e >> 4, m = e & 15;
+    As[t][m] = (j.m0 + m < j.mvalid) ? j.a[(size_t)t * j.lda + j.m0 + m] : 0.f;
+  }
+  for (int e = tid; e < ns * 16; e += TE_BLOCK) {
+    const int t = e >> 4, c = (e & 15) * 4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&Bs[t][c]) = (t >= j.bshift) ? *reinterpret_cast<const float4*>(j.b + (size_t)(t - j.bshift) * j.ldb + j.n0 + c) : z;
+  }
+  __syncthreads();
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < ns; ++t) {
+    const float a = As[t][tm];
+    const float4 v = *reinterpret_cast<const float4*>(&Bs[t][4 * tq]);
+    acc.x = __fmaf_rn(a, v.x, acc.x); acc.y = __fmaf_rn(a, v.y, acc.y); acc.z = __fmaf_rn(a, v.z, acc.z); acc.w = __fmaf_rn(a, v.w, acc.w);
+  }
+  if (j.m0 + tm < j.mvalid) {
+    float4* th = reinterpret_cast<float4*>(j.theta + (size_t)(j.m0 + tm) * j.ldt + j.n0 + 4 * tq);
+    float4 w = *th;
+    w.x -= aeff * (acc.x + lambda * w.x); w.y -= aeff * (acc.y + lambda * w.y);
+    w.z -= aeff * (acc.z + lambda * w.z); w.w -= aeff * (acc.w + lambda * w.w);
+    *th = w;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float alpha, float lambda, int n_hwg, int l_cap) {
+  constexpr int XW = 2 * D;
+  __shared__ __align__(16) float As[ONE_TMAX][17];
+  __shared__ __align__(16) float Bs[ONE_TMAX][68];
+  __shared__ int s_key[3 * (ONE_TMAX + 1)], s_hit[3 * (ONE_TMAX + 1)], s_cnt;
+  __shared__ float s_red[8];
+  const int tid = threadIdx.x;
+  int base, L, ns; one_header(A, base, L, ns);
+  const int NB = A.n_dist + 1, NBP = te_nbp_dev(A.n_dist);
+  const float aeff = alpha * (A.bcap < 0.f ? 1.0f : fminf(1.0f, A.bcap));       // dense rule of dense_apply_kernel at n_seq = 1
+  // ---- dense gradients + SGD step: 16 x 64 output blocks ----
+  const int nb_ui = (3 * D / 16) * (XW / 64), nb_zr = (2 * D / 16) * (D / 64), nb_c = (D / 16) * (D / 64), nb_vs = ((NB + 15) / 16) * (D / 64);
+  int b = blockIdx.x;
+  if (b < nb_ui + nb_zr + nb_c + nb_vs) {
+    OneJob j;
+    if (b < nb_ui) {                     // d ui = DA^T . X (snapshot)
+      j = OneJob{A.G, 3 * D, 16 * (b / (XW / 64)), 3 * D, A.X, XW, 64 * (b % (XW / 64)), 0, A.ui, XW};
+    } else if ((b -= nb_ui) < nb_zr) {   // d wh[z | r] = [da_z | da_r]^T . h_{t-1}
+      j = OneJob{A.G, 3 * D, 16 * (b / (D / 64)), 2 * D, A.H, D, 64 * (b % (D / 64)), 1, A.wh, D};
+    } else if ((b -= nb_zr) < nb_c) {    // d wh[c] = da_c^T . (r * h_{t-1})
+      j = OneJob{A.G + 2 * D, 3 * D, 16 * (b / (D / 64)), D, A.RH, D, 64 * (b % (D / 64)), 0, A.wh + (size_t)2 * D * D, D};
+    } else {                             // d vs = DL^T . H
+      b -= nb_c;
+      j = OneJob{A.DL, NBP, 16 * (b / (D / 64)), NB, A.H, D, 64 * (b % (D / 64)), 0, A.vs, D};
+    }
+    one_dense_block(j, ns, aeff, lambda, As, Bs);
+    return;
+  }
+  b -= nb_ui + nb_zr + nb_c + nb_vs;
+  if (b == 0) {
+    // ---- bi | bs | wd | losses | loss_weight (te_finalize + te_parts + dense_apply of one sequence) ----
+    for (int e = tid; e < 3 * D; e += TE_BLOCK) { const float w = A.bi[e]; A.bi[e] = w - aeff * (A.bi_part[e] + lambda * w); }
+    for (int e = tid; e <= NB; e += TE_BLOCK) {
+      float g = 0.f;
+      for (int k = 0; k < n_hwg; ++k) { float* p = A.hslab + (size_t)k * A.hstride + e; g += *p; *p = 0.f; }
+      float* th = e < NB ? A.bs + e : A.wd;
+      const float w = *th; *th = w - aeff * (g + lambda * w);
+    }
+    float sur = 0.f, bpr = 0.f;
+    for (int r = tid; r < ns; r += TE_BLOCK) { sur += A.rowloss[2 * (size_t)r]; bpr += A.rowloss[2 * (size_t)r + 1]; }
+    sur = block_sum(sur, s_red); bpr = block_sum(bpr, s_red);
+    if (tid == 0) {
+      const float a = A.lw[0], c = A.lw[1], m = fmaxf(a, c);
+      const float ea = expf(a - m), eb = expf(c - m);
+      const float ls0 = ea / (ea + eb), ls1 = eb / (ea + eb);
+      float* o = A.out;
+      o[0] = ls0 * sur - ls1 * bpr; o[1] = sur; o[2] = -bpr; o[3] = ls0; o[4] = ls1;
+      const float d0 = sur + lambda * ls0, d1 = -bpr + lambda * ls1, dot = d0 * ls0 + d1 * ls1;
+      A.lw[0] = a - aeff * ls0 * (d0 - dot);
+      A.lw[1] = c - aeff * ls1 * (d1 - dot);
+    }
+    return;
+  }
+  // ---- sparse write-back: one workgroup per table touch; slot e = section * L + j as te_slots ----
+  const int e = b - 1, n3 = 3 * L, pad_lt = A.n_item, pad_di = A.n_item + 1 + A.n_dist;
+  auto key_of = [&](int i) { const int sec = i / L, jj = i - sec * L; return sec == 0 ? A.p[base + jj] : sec == 1 ? A.q[base + jj] : A.n_item + 1 + A.dp[base + jj]; };
+  int key;
+  const bool padwg = e >= 3 * l_cap;                  // the two padding rows without a literal touch: analytic multiplicity only
+  if (padwg) key = e == 3 * l_cap ? pad_lt : pad_di;
+  else { if (e >= n3) return; key = key_of(e); }
+  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < n3; i += TE_BLOCK) s_key[i] = key_of(i);
+  __syncthreads();
+  int dup = 0;
+  for (int i = tid; i < n3; i += TE_BLOCK) { const bool hit = s_key[i] == key; s_hit[i] = hit; dup |= hit && (padwg || i < e); }
+  if (__syncthreads_or(dup)) return;                  // an earlier slot owns the row (or a literal touch owns the padding row)
+  int cnt = 0;
+  for (int i = 0; i < n3; ++i) cnt += s_hit[i];       // (<= 195 LDS reads)
+  const int am = key == pad_lt ? 2 * (A.len_max - L) : key == pad_di ? (A.len_max - L) : 0;
+  if (cnt + am == 0) return;
+  const int c = tid;
+  if (c >= D) return;
+  const int doff = key <= A.n_item ? 0 : D;
+  float acc = 0.f;
+  for (int i = padwg ? n3 : e; i < n3; ++i) {
+    if (!s_hit[i]) continue;
+    const int sec = i / L, jj = i - sec * L;
+    if (sec != 1 && jj < ns) {                        // + dx[jj][doff + c] = DA[jj] . ui_old[:, doff + c]
+      const float* da = A.G + (size_t)jj * 3 * D;
+      const float* u = A.uiT + doff + c;
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < 3 * D; m += 2) { d0 = __fmaf_rn(da[m], u[(size_t)m * XW], d0); d1 = __fmaf_rn(da[m + 1], u[(size_t)(m + 1) * XW], d1); }
+      acc += d0 + d1;
+    }
+    if (sec != 2 && jj >= 1) {                        // +- g h of step jj - 1
+      const float g = A.gcoef[jj - 1];
+      acc = __fmaf_rn(sec == 1 ? -g : g, A.H[(size_t)(jj - 1) * D + c], acc);
+    }
+  }
+  float sc, lm; rule_scales(alpha, lambda, 1, cnt + am, A.bcap, sc, lm);
+  float* row = key <= A.n_item ? A.lt + (size_t)key * D : A.di + (size_t)(key - A.n_item - 1) * D;
+  const float w = row[c];
+  row[c] = w - sc * (acc + lm * w);
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 int te_wgrad_jobs(int D, int n_dist, bool spatial) {
@@ -2413,6 +2615,42 @@ static void te_launch_ax(const TeArgs& A, int num_cu, hipStream_t st) {
 }
 
 template <int D>
+static hipError_t te_one_t(TeArgs& A, float alpha, float lambda, int l_cap, hipStream_t st, Timing* tm) {
+  if constexpr (D > 128) { return hipErrorInvalidValue; } else {
+  PackJobs J; te_pack_jobs(A, J, true);
+  const int n_ax = 3 * D / 16, n_pk = 8, NB = A.n_dist + 1;
+  tm->begin("te_prep", st);
+  hipLaunchKernelGGL(te_one_in_kernel<D>, dim3(n_ax + 1 + n_pk * J.n), dim3(TE_BLOCK), 0, st, A, J, n_ax, n_pk);
+  tm->end(st);
+  tm->begin("te_rec_fwd", st);
+  hipLaunchKernelGGL((te_rec_fwd1_kernel<D, false>), dim3(1), dim3(4 * D), 0, st, A);
+  tm->end(st);
+  tm->begin("te_head", st);
+  const int n_hwg = (l_cap + 30) / 32 > 0 ? (l_cap + 30) / 32 : 1;
+  hipError_t e = te_head_dispatch<D>(A, 0, n_hwg, st);
+  if (e != hipSuccess) return e;
+  tm->end(st);
+  tm->begin("te_rec_bwd", st);
+  hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(1), dim3(4 * D), 0, st, A);
+  tm->end(st);
+  tm->begin("te_tail", st);
+  const int nb = (3 * D / 16) * (2 * D / 64) + (2 * D / 16) * (D / 64) + (D / 16) * (D / 64) + ((NB + 15) / 16) * (D / 64);
+  hipLaunchKernelGGL(te_one_out_kernel<D>, dim3(nb + 1 + 3 * l_cap + 2), dim3(TE_BLOCK), 0, st, A, alpha, lambda, n_hwg, l_cap);
+  tm->end(st);
+  return hipGetLastError();
+  }
+}
+
+// The whole step of ONE Distance2Pre sequence (write-back included): launch_te_train + launch_te_scatter + launch_dense_apply in five kernels.
+// l_cap: the longest sequence of the tables (<= ONE_TMAX + 1).
+hipError_t launch_te_one(TeArgs& A, float alpha, float lambda, int l_cap, hipStream_t st, Timing* tm) {
+  if (A.dim == 64) return te_one_t<64>(A, alpha, lambda, l_cap, st, tm);
+  if (A.dim == 128) return te_one_t<128>(A, alpha, lambda, l_cap, st, tm);
+  return hipErrorInvalidValue;
+}
+bool te_one_supported(int D, bool spatial, int max_len) { return spatial && (D == 64 || D == 128) && max_len <= ONE_TMAX + 1; }
+
+template <int D>
 static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
   const int n = A.n_seq, tiles = (n + 31) / 32;
   PackJobs J; te_pack_jobs(A, J, true);
@@ -2420,7 +2658,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
-  hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+  if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   const int XW = A.xw;
   hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, XW);
   if (!A.side) { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
@@ -2579,7 +2817,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
-  hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+  if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   te_launch_ax<D>(A, num_cu, st);
   if constexpr (D >= 128) {
     if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
