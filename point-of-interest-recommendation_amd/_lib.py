@@ -55,6 +55,7 @@ SIGNATURES = {
     "poi_ctx_set_f16_rounding": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
     "poi_ctx_set_split_products": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_small_launch": (c_int, [c_void_p, c_int]),
+    "poi_ctx_set_one_sequence_path": (c_int, [c_void_p, c_int]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                              c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
     "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
@@ -203,6 +204,10 @@ class Context:
     def set_small_launch(self, max_sequences=1024):
         """Launches of at most this many sequences use the per-sequence recurrent kernels (poi_ctx_set_small_launch; 0 disables)."""
         self.check(self.lib.poi_ctx_set_small_launch(self.handle, int(max_sequences)))
+
+    def set_one_sequence_path(self, on=True):
+        """Launches of one Distance2Pre sequence through the five-kernel path (poi_ctx_set_one_sequence_path)."""
+        self.check(self.lib.poi_ctx_set_one_sequence_path(self.handle, 1 if on else 0))
 
     def unregister_f16(self, tensor):
         self.check(self.lib.poi_ctx_unregister_f16(self.handle, tensor.data_ptr()))

@@ -980,6 +980,12 @@ int poi_ctx_set_small_launch(poi_ctx* c, int max_sequences) {
   return POI_OK;
 }
 
+int poi_ctx_set_one_sequence_path(poi_ctx* c, int on) {
+  if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_one_sequence_path: on must be 0 or 1");
+  c->one_path = on;
+  return POI_OK;
+}
+
 int poi_ctx_set_topk_filter(poi_ctx* c, int on) {
   if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_topk_filter: on must be 0 or 1");
   c->topk_filter = on;

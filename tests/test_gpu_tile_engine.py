@@ -561,3 +561,46 @@ def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user):
             assert not all(np.array_equal(res[True][0][k], res[other][0][k]) for k in ("wh", "ui")), "the switch did not change the arithmetic"
     finally:
         pa._lib.context(0).set_split_products(True); pa._lib.context(0).set_small_launch(1024); pa._lib.context(0).set_engine("auto")
+
+
+@pytest.mark.parametrize("dim,n_dist,len_max", [(128, 200, 50), (64, 40, 9), (128, 1520, 12), (20, 11, 7), (128, 40, 65)])
+def test_one_sequence_path_is_the_reference_step(pa, dim, n_dist, len_max):
+    """poi_ctx_set_one_sequence_path: the five-kernel step of one sequence (te_one_*) == the reference step of the oracle, sequentially over
+    users whose sequences repeat POIs (hot = 6: the same table row as input, positive and negative target), are as short as one or two
+    positions (decay only / a single step) and as long as len_max (65: the path's limit), with the padding rows' analytic multiplicities;
+    and == the batched pipeline on the same launches (same bars).  dim 20: stored zero-padded to 64."""
+    T = toy_problem(1700 + dim + len_max, n_user=14, n_item=60, n_dist=n_dist, dim=dim, len_max=len_max, min_len=1, hot=6)
+    for u, L in ((3, 1), (5, 2)):            # a sequence of one position (decay only) and one of two (a single step)
+        T["train"][0][u, L:] = T["n_item"]; T["train"][2][u, L:] = T["n_item"]; T["train"][1][u, L:] = 0
+        T["dist"][0][u, L:] = n_dist; T["dist"][2][u, L:] = n_dist
+        T["lens"][u] = L
+    P0 = spatial_params(1700 + dim, T)
+    Pm, Qm, DPm, DQm, Mm = T["train"][0], T["train"][2], T["dist"][0], T["dist"][2], T["train"][1]
+    order = [int(np.argmin(T["lens"])), int(np.argmax(T["lens"]))] + list(range(T["n_user"]))
+    res = {}
+    try:
+        for one in (True, False):
+            model = _model(pa, T, P0)
+            model.ctx.set_engine("tile"); model.ctx.set_one_sequence_path(one)
+            model.ctx.timing(True)
+            P = P0
+            for u in order:
+                old = P
+                P, out = O.spatial_step(P, Pm[u], Qm[u], DPm[u], DQm[u], Mm[u], 0.01, 0.001)
+                los, sur, upq, ls = model.train(np.int32(u))
+                assert_close([los, sur, upq], out[:3], "losses of user %d (one-sequence path %s)" % (u, one))
+                got = _get(model)
+                # (len_max >= 50 with six hot POIs: the updates are as large as the weights, |d bi| 0.44 - the saturated float32 BPTT of
+                # tests/gpu_util.py FULL_SIZE_LT; tools/one_dbg.py: 0.7e-5 .. 1.4e-5 on EVERY engine incl. the per-sequence one)
+                kw = dict(rtol=4e-5, delta_rtol=1e-4) if len_max >= 50 else {}
+                assert_step_close(got, P, old, SP_NAMES, "after user %d (one-sequence path %s, length %d)" % (u, one, T["lens"][u]), **kw)
+                P = round_f32({**P, **got})
+            # the batched pipeline runs te_wgrad, the one-sequence path does not
+            assert (model.ctx.timing_get("te_wgrad")[1] == 0) == one, "the launches did not take the expected path"
+            model.ctx.timing(False)
+            res[one] = _get(model)
+        if len_max < 50:      # (the two runs follow their own float32 trajectories: comparable after 16 steps only where the steps are well conditioned)
+            for k in SP_NAMES:
+                assert_close(res[True][k], res[False][k], "one-sequence path vs batched pipeline " + k, rtol=3e-5)
+    finally:
+        pa._lib.context(0).set_one_sequence_path(True); pa._lib.context(0).set_engine("auto")
