@@ -516,15 +516,14 @@ def main():
 
         def ref_chunk():
             c0 = cursor[0]
-            for u in pr[c0:c0 + 500]:
-                mref.train(np.int32(u))
+            mref.train_sequence(pr[c0:c0 + 500], sync=False)        # 500 launches of one sequence each, ids staged once
             cursor[0] = (c0 + 500) % max(n_local - 500, 1)
             return 500
         n_ref, t_ref = timed_training(ref_chunk, a.reference_seconds, n_local)
         rec_ref, auc_ref = evaluate_model(mref, tab, n_local, dev)
         reference_schedule = {"seq_per_s": n_ref / t_ref, "ms_per_step": 1e3 * t_ref / n_ref, "users_trained": n_ref, "train_seconds": t_ref,
-                              "note": "model.train(uidx), one SGD step per user in shuffled order: the reference's execution model on the GPU (tile engine at "
-                                      "one sequence per launch: ~40 kernel launches around the 49-step latency chain of ONE sequence, host-synchronous)"}
+                              "note": "one SGD step per user in shuffled order, one poi_spatial_step launch per user (model.train_sequence: the reference's "
+                                      "`for uidx: model.train(uidx)` loop with the ids staged on the device once): the one-sequence path - five kernels per step"}
         del mref
 
         # (2) batched modes from the same initial parameters for --quality-seconds of training each

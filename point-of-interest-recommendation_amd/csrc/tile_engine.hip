@@ -2413,6 +2413,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
   const int nb_ui = (3 * D / 16) * (XW / 64), nb_zr = (2 * D / 16) * (D / 64), nb_c = (D / 16) * (D / 64), nb_vs = ((NB + 15) / 16) * (D / 64);
   int b = blockIdx.x;
   if (b < nb_ui + nb_zr + nb_c + nb_vs) {
+    if (A.dbg & 16) return;
     OneJob j;
     if (b < nb_ui) {                     // d ui = DA^T . X (snapshot)
       j = OneJob{A.G, 3 * D, 16 * (b / (XW / 64)), 3 * D, A.X, XW, 64 * (b % (XW / 64)), 0, A.ui, XW};
@@ -2428,6 +2429,8 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
     return;
   }
   b -= nb_ui + nb_zr + nb_c + nb_vs;
+  if (b == 0 && (A.dbg & 32)) return;
+  if (b > 0 && (A.dbg & 8)) return;
   if (b == 0) {
     // ---- bi | bs | wd | losses | loss_weight (te_finalize + te_parts + dense_apply of one sequence) ----
     for (int e = tid; e < 3 * D; e += TE_BLOCK) { const float w = A.bi[e]; A.bi[e] = w - aeff * (A.bi_part[e] + lambda * w); }
@@ -2469,26 +2472,56 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
   for (int i = 0; i < n3; ++i) cnt += s_hit[i];       // (<= 195 LDS reads)
   const int am = key == pad_lt ? 2 * (A.len_max - L) : key == pad_di ? (A.len_max - L) : 0;
   if (cnt + am == 0) return;
-  const int c = tid;
-  if (c >= D) return;
+  // thread (cq, part): columns 4 cq .. 4 cq + 3, every NP-th gate row of the dx products - 256 threads keep 3 D / NP independent
+  // 16-byte loads of the ui snapshot in flight each (one thread per column walked the 3 D rows behind a handful of loads: 40 us)
+  constexpr int CQ = D / 4, NP = TE_BLOCK / CQ;
+  const int cq = tid % CQ, part = tid / CQ;
   const int doff = key <= A.n_item ? 0 : D;
-  float acc = 0.f;
-  for (int i = padwg ? n3 : e; i < n3; ++i) {
-    if (!s_hit[i]) continue;
-    const int sec = i / L, jj = i - sec * L;
-    if (sec != 1 && jj < ns) {                        // + dx[jj][doff + c] = DA[jj] . ui_old[:, doff + c]
-      const float* da = A.G + (size_t)jj * 3 * D;
-      const float* u = A.uiT + doff + c;
-      float d0 = 0.f, d1 = 0.f;
-#pragma unroll 8
-      for (int m = 0; m < 3 * D; m += 2) { d0 = __fmaf_rn(da[m], u[(size_t)m * XW], d0); d1 = __fmaf_rn(da[m + 1], u[(size_t)(m + 1) * XW], d1); }
-      acc += d0 + d1;
+  // The row's dx sum is linear in DA: sum the DA rows of its step-input touches first (a distance-bin row can have as many as the
+  // sequence has steps - 80 % of the transitions of a user fall into a few bins), then ONE pass over the ui snapshot
+  float* Ssum = &Bs[0][0];                            // 3 D floats
+  float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    float s0 = 0.f, s1 = 0.f;                         // m = tid, tid + 256 (3 D <= 384)
+    bool any = false;
+    for (int i = padwg ? n3 : e; i < n3; ++i) {
+      if (!s_hit[i]) continue;
+      const int sec = i / L, jj = i - sec * L;
+      if (sec != 1 && jj < ns) {
+        const float* da = A.G + (size_t)jj * 3 * D;
+        s0 += da[min(tid, 3 * D - 1)]; s1 += da[min(tid + TE_BLOCK, 3 * D - 1)];
+        any = true;
+      }
+      if (sec != 2 && jj >= 1 && part == 0) {         // +- g h of step jj - 1
+        const float g0 = A.gcoef[jj - 1], g = sec == 1 ? -g0 : g0;
+        const float4 h = *reinterpret_cast<const float4*>(A.H + (size_t)(jj - 1) * D + 4 * cq);
+        a4.x = __fmaf_rn(g, h.x, a4.x); a4.y = __fmaf_rn(g, h.y, a4.y); a4.z = __fmaf_rn(g, h.z, a4.z); a4.w = __fmaf_rn(g, h.w, a4.w);
+      }
     }
-    if (sec != 2 && jj >= 1) {                        // +- g h of step jj - 1
-      const float g = A.gcoef[jj - 1];
-      acc = __fmaf_rn(sec == 1 ? -g : g, A.H[(size_t)(jj - 1) * D + c], acc);
+    if (tid < 3 * D) Ssum[tid] = s0;
+    if (tid + TE_BLOCK < 3 * D) Ssum[tid + TE_BLOCK] = s1;
+    __syncthreads();
+    if (any) {                                        // + S . ui_old[:, doff + c]     (uniform: every thread saw the same slots)
+      const float* u = A.uiT + doff + 4 * cq;
+      float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+#pragma unroll 8
+      for (int m = part; m < 3 * D; m += 2 * NP) {
+        const float w0 = Ssum[m], w1 = Ssum[m + NP];
+        const float4 v0 = *reinterpret_cast<const float4*>(u + (size_t)m * XW), v1 = *reinterpret_cast<const float4*>(u + (size_t)(m + NP) * XW);
+        d0.x = __fmaf_rn(w0, v0.x, d0.x); d0.y = __fmaf_rn(w0, v0.y, d0.y); d0.z = __fmaf_rn(w0, v0.z, d0.z); d0.w = __fmaf_rn(w0, v0.w, d0.w);
+        d1.x = __fmaf_rn(w1, v1.x, d1.x); d1.y = __fmaf_rn(w1, v1.y, d1.y); d1.z = __fmaf_rn(w1, v1.z, d1.z); d1.w = __fmaf_rn(w1, v1.w, d1.w);
+      }
+      a4.x += d0.x + d1.x; a4.y += d0.y + d1.y; a4.z += d0.z + d1.z; a4.w += d0.w + d1.w;
     }
   }
+  float* red = &As[0][0];                             // NP x D partial sums (<= 1088 floats)
+  *reinterpret_cast<float4*>(red + part * D + 4 * cq) = a4;
+  __syncthreads();
+  const int c = tid;
+  if (c >= D) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) acc += red[q * D + c];
   float sc, lm; rule_scales(alpha, lambda, 1, cnt + am, A.bcap, sc, lm);
   float* row = key <= A.n_item ? A.lt + (size_t)key * D : A.di + (size_t)(key - A.n_item - 1) * D;
   const float w = row[c];

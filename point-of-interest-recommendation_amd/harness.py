@@ -140,10 +140,11 @@ def train_valid_or_test(ds, p, device="cuda:0", log=print):
                         loss += model.train(int(uidx), [int(hp[i]), int(hq[i])])
             else:
                 loss = float(model.train_batch(u, pp, qq, mode="snapshot").sum())
-        elif B <= 1:                                                # :246-254
+        elif B <= 1 and p["gru"] == 2:                              # :246-254, one launch per user without a host round trip per step
+            loss += float(model.train_sequence(order)[:, 0].sum())
+        elif B <= 1:
             for uidx in order:
-                r = model.train(np.int32(uidx))
-                loss += r[0] if p["gru"] == 2 else r
+                loss += model.train(np.int32(uidx))
         else:
             # launches of equal size (about B users each): no tiny trailing launch
             Be = -(-U // max(1, int(round(U / float(B)))))

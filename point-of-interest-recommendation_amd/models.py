@@ -689,6 +689,23 @@ class OboSpatialGru(GruBasic):
                                                  self.alpha_lambda[0], self.alpha_lambda[1], _ptr(out), self._stream()))
         return out.cpu().numpy() if sync else out
 
+    def train_sequence(self, idxs, sync=True):
+        """The reference's epoch loop `for uidx in order: model.train(uidx)` (prog_bpr_gru_spatial.py:246-254) without a host round trip
+        per step: the ids are staged on the device once and every user is ONE poi_spatial_step launch of one sequence (sequential SGD,
+        the reference's semantics - not the batch rule), the (n, 5) loss rows [los, sur, upq, ls0, ls1] are read once at the end."""
+        ids, _ = self._ids(idxs)
+        n = ids.numel()
+        out = torch.empty((n, 5), dtype=torch.float32, device=self.device)
+        P, T = self._params(), self._tables()
+        pP, pT, st = ctypes.byref(P), ctypes.byref(T), self._stream()
+        ip, op = ids.data_ptr(), out.data_ptr()
+        step, h, a, l = self.lib.poi_spatial_step, self.ctx.handle, self.alpha_lambda[0], self.alpha_lambda[1]
+        for k in range(n):
+            rc = step(h, pP, pT, ctypes.c_void_p(ip + 4 * k), 1, a, l, ctypes.c_void_p(op + 20 * k), st)
+            if rc:
+                self.ctx.check(rc)
+        return out.cpu().numpy() if sync else out
+
     def predict(self, idxs):
         """public/GRU_Spatial.py:282-288 -> [hts (n, D), sts (n, n_dist+1)]."""
         h, s = self.predict_device(idxs)
