@@ -81,7 +81,7 @@ REGION = {"te_gather": ["te_gather_kernel"], "te_gemm_ax": ["te_gemm_nt_kernel<t
           "score_topk": ["score_kernel_packed"], "te_predict": []}
 out = {"config": "bench.py default (gowalla shape, batch_users 12500)",
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
-               "(gfx950 reports half of wide coalesced reads); counter unit KB (x 1024); per launch of the TIMED REGION (sum over its kernels)",
+               "(gfx950 reports half of wide coalesced reads); WRITE_SIZE calibrated with tools/micro/write_calib.hip (exact for the 64-byte-segment pattern of the recurrent kernels); counter unit KB (x 1024); per launch of the TIMED REGION (sum over its kernels), each pass normalised by its own launch count",
        "kernels": {}}
 for reg, pats in REGION.items():
     fk = [k for k in fa if any(k.startswith(p) for p in pats)]
@@ -91,9 +91,15 @@ for reg, pats in REGION.items():
     if reg == "te_prep":
         n_launch = fc.get("te_rowmap_kernel", n_launch)
     fetch = sum(fa[k]["FETCH_SIZE"] for k in fk)
-    write = sum(wa[k]["WRITE_SIZE"] for k in wa if any(k.startswith(p) for p in pats))
-    out["kernels"][reg] = {"launches": n_launch, "fetch_kb_raw": fetch / n_launch, "write_kb": write / n_launch,
-                           "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n_launch}
+    # the two passes are separate runs of a bench with time-based sections: each pass is normalised by ITS OWN launch count
+    # (round 3 found the write pass 1.49 x as long as the fetch pass - every write figure of r02 / the first r03 set was inflated by that)
+    wk = [k for k in wa if any(k.startswith(p) for p in pats)]
+    n_w = max([wc[k] for k in wk], default=n_launch)
+    if reg == "te_prep":
+        n_w = wc.get("te_rowmap_kernel", n_w)
+    write = sum(wa[k]["WRITE_SIZE"] for k in wk)
+    out["kernels"][reg] = {"launches": n_launch, "launches_write_pass": n_w, "fetch_kb_raw": fetch / n_launch, "write_kb": write / max(n_w, 1),
+                           "hbm_bytes_per_launch": (2.0 * fetch / n_launch + write / max(n_w, 1)) * 1024.0}
 json.dump(out, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
 
 # ---- SQ counters --------------------------------------------------------------------------------
