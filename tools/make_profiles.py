@@ -92,7 +92,7 @@ for reg, pats in REGION.items():
         n_launch = fc.get("te_rowmap_kernel", n_launch)
     fetch = sum(fa[k]["FETCH_SIZE"] for k in fk)
     # the two passes are separate runs of a bench with time-based sections: each pass is normalised by ITS OWN launch count
-    # (round 3 found the write pass 1.49 x as long as the fetch pass - every write figure of r02 / the first r03 set was inflated by that)
+    # (round 3 found the write pass 1.49 x as long as the fetch pass - every write figure of the first r03 set was inflated by that)
     wk = [k for k in wa if any(k.startswith(p) for p in pats)]
     n_w = max([wc[k] for k in wk], default=n_launch)
     if reg == "te_prep":
