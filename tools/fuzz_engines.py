@@ -67,6 +67,8 @@ def main():
             outs = []
             for _ in range(2):
                 k = int(np.random.default_rng(s).integers(1, n_user + 1))
+                if s % 5 == 2 and _ == 0:
+                    k = 1                   # a launch of ONE sequence: the one-sequence path (Distance2Pre, dim <= 128) against the per-sequence engine
                 users = np.random.default_rng(s + _).permutation(n_user)[:k].astype(np.int32)
                 outs.append(np.asarray(m.train_batch(users)))
                 if _ == 0:
