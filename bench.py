@@ -620,6 +620,27 @@ def main():
                                                  "note": "same data, dim = 20 (the reference's default): stored zero-padded to the tile engine's dim 64, exact"}
         del m3
 
+    # ---- launch_sweep: sequences/s against the launch size (what the small-launch paths of DESIGN.md section 5 buy) -------------------------
+    launch_sweep = None
+    if solo and not a.no_quality and a.shape == "gowalla":
+        ctx.set_batch_cap(a.batch_cap)
+        msw = new_model(tab, n_local, seed=7)
+        launch_sweep = {}
+        for Bs in (1, 16, 256, 1024, 1563, 4096):
+            ids_s = np.random.default_rng(Bs).permutation(n_local)[:Bs]
+            ids_s = torch.as_tensor(ids_s[np.argsort(-lens_local[ids_s], kind="stable")].astype(np.int32)).to(dev)
+            for _ in range(5):
+                msw.train_batch(ids_s, sync=False)
+            torch.cuda.synchronize(dev); t0 = time.perf_counter()
+            reps = 200 if Bs <= 256 else 60
+            for _ in range(reps):
+                msw.train_batch(ids_s, sync=False)
+            torch.cuda.synchronize(dev); ts = (time.perf_counter() - t0) / reps
+            launch_sweep["B=%d" % Bs] = {"us_per_launch": 1e6 * ts, "seq_per_s": Bs / ts}
+        launch_sweep["note"] = ("one fixed launch repeated (host loop through models.train_batch): B = 1 takes the one-sequence path, B <= 1024 the per-sequence "
+                                "recurrent kernels, above that 16-sequence tiles on split products")
+        del msw
+
     # ---- secondary_dd25: the reference's other spatial configuration (dd = 25 m: 1520 bins, public/GRU_Spatial.py:247), training only --------
     secondary_dd25 = None
     if solo and not a.no_secondary and a.shape == "gowalla" and a.dd == 200.0:
@@ -711,7 +732,7 @@ def main():
                        "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence",
                        "s_rows_per_step": rho},
             "timed_window_s": dt,
-            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_dd25": secondary_dd25, "secondary_x1": secondary_x1,
+            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_dd25": secondary_dd25, "launch_sweep": launch_sweep, "secondary_x1": secondary_x1,
             "train_step_tflops": executed_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "train_step_tflops_reference_formulation": total_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "reference_schedule": reference_schedule, "eval": eval_detail, "roofline_gather_scatter": hbm,
