@@ -359,6 +359,12 @@ int poi_sync_destroy(poi_sync* s);
 int poi_sync_begin_epoch(poi_sync* s, void* stream);                  /* theta_start <- theta */
 int poi_sync_make_delta(poi_sync* s, void* stream);                   /* flat buffer <- theta - theta_start | row flags */
 int poi_sync_buffer(poi_sync* s, float** delta_dev, int64_t* n);      /* the flat buffer to SUM-all-reduce */
+/* Segments stored as half (dtype POI_F16: config X's POI table) keep their snapshot as half - exact, the values are halves - and their
+ * deltas as half in a SECOND flat buffer (n half elements, NULL / 0 without such segments), all-reduced as float16: the combined value is
+ * rounded to half anyway, and a sum of `world` half deltas is off by at most world x 2^-11 of the DELTA (absolute) - below the 2^-11 of
+ * the value that the final rounding costs wherever an epoch moves an element by less than its own magnitude.  Config X: 10 -> 5 GB of snapshot and 10 -> 5 GB per reconciliation.  poi_sync_end_epoch all-reduces both buffers;
+ * callers that own the collective SUM-all-reduce this one too (element type float16).  The per-row touch counts stay in the float buffer. */
+int poi_sync_buffer16(poi_sync* s, void** delta16_dev, int64_t* n);
 int poi_sync_apply(poi_sync* s, int32_t world, void* stream);         /* theta <- theta_start + combine(buffer); theta_start <- theta */
 int poi_sync_end_epoch(poi_sync* s, poi_comm* comm, void* stream);
 int poi_sync_stats(poi_sync* s, double* allreduce_ms, int64_t* allreduce_bytes);   /* last end_epoch; synchronises */

@@ -102,6 +102,7 @@ SIGNATURES = {
     "poi_sync_begin_epoch": (c_int, [c_void_p, c_void_p]),
     "poi_sync_make_delta": (c_int, [c_void_p, c_void_p]),
     "poi_sync_buffer": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "poi_sync_buffer16": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
     "poi_sync_apply": (c_int, [c_void_p, c_int32, c_void_p]),
     "poi_sync_end_epoch": (c_int, [c_void_p, c_void_p, c_void_p]),
     "poi_sync_stats": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),

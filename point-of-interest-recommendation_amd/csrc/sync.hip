@@ -27,7 +27,7 @@ enum { ncclSuccess = 0 };
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef struct ncclComm* ncclComm_t;
 typedef int ncclDataType_t;
-enum { ncclFloat32 = 7 };
+enum { ncclFloat16 = 6, ncclFloat32 = 7 };
 typedef int ncclRedOp_t;
 enum { ncclSum = 0 };
 
@@ -72,38 +72,52 @@ static Rccl* rccl() {
 // rounded to half once, and the snapshot keeps exactly that rounded value so that replicas stay bit-identical)
 __device__ __forceinline__ float ldc(const float* cur, long long i, int f16) { return f16 ? __half2float(reinterpret_cast<const __half*>(cur)[i]) : cur[i]; }
 
-__global__ __launch_bounds__(256) void sync_delta_kernel(const float* __restrict__ cur, int f16, const float* __restrict__ base,
-                                                         float* __restrict__ delta, float* __restrict__ touched,
+// H (half segments, round 3): a table STORED as half keeps its snapshot as half too (exact: the values are halves) and its delta as half -
+// the combined value is rounded to half anyway, and a sum of `world` half deltas carries an error of world x 2^-11 of the DELTA, far
+// below the 2^-11 of the VALUE that rounding costs; half the snapshot memory, a quarter... half the all-reduce bytes (config X: 10 -> 5 GB).
+template <bool H> struct SyncT { typedef float T; };
+template <> struct SyncT<true> { typedef __half T; };
+__device__ __forceinline__ float sy_ld(const float* p) { return *p; }
+__device__ __forceinline__ float sy_ld(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ void sy_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void sy_st(__half* p, float v) { *p = __float2half_rn(v); }
+
+template <bool H>
+__global__ __launch_bounds__(256) void sync_delta_kernel(const float* __restrict__ cur, const typename SyncT<H>::T* __restrict__ base,
+                                                         typename SyncT<H>::T* __restrict__ delta, float* __restrict__ touched,
                                                          long long rows, long long width) {
   const int lane = lane_id();
   for (long long r = (long long)blockIdx.x * 4 + wave_id(); r < rows; r += (long long)gridDim.x * 4) {
-    const float* b = base + r * width; float* d = delta + r * width;
     bool any = false;
-    for (long long j = lane; j < width; j += 64) { const float v = ldc(cur, r * width + j, f16) - b[j]; d[j] = v; any |= (v != 0.f); }
+    for (long long j = lane; j < width; j += 64) {
+      const float c = ldc(cur, r * width + j, H ? 1 : 0), b = sy_ld(base + r * width + j);
+      sy_st(delta + r * width + j, c - b);
+      any |= (c != b);               // (the row moved - also when the half delta of a tiny step rounds to zero)
+    }
     if (touched) { const bool t = __ballot(any) != 0ull; if (lane == 0) touched[r] = t ? 1.f : 0.f; }
   }
 }
 
 // cur <- base + scale * dsum ; base <- cur.   rule 0: scale 1, 1: 1 / world, 2: 1 / max(count[row], 1)
-__global__ __launch_bounds__(256) void sync_apply_kernel(float* __restrict__ cur, int f16, float* __restrict__ base,
-                                                         const float* __restrict__ dsum, const float* __restrict__ count,
+template <bool H>
+__global__ __launch_bounds__(256) void sync_apply_kernel(float* __restrict__ cur, typename SyncT<H>::T* __restrict__ base,
+                                                         const typename SyncT<H>::T* __restrict__ dsum, const float* __restrict__ count,
                                                          long long rows, long long width, int rule, float inv_world) {
   const int lane = lane_id();
   for (long long r = (long long)blockIdx.x * 4 + wave_id(); r < rows; r += (long long)gridDim.x * 4) {
     float sc = rule == 1 ? inv_world : 1.f;
     if (rule == 2) { const float n = count[r]; sc = 1.f / fmaxf(n, 1.f); }
-    float* b = base + r * width; const float* d = dsum + r * width;
     for (long long j = lane; j < width; j += 64) {
-      float v = fmaf(sc, d[j], b[j]);
-      if (f16) { const __half hv = __float2half_rn(v); reinterpret_cast<__half*>(cur)[r * width + j] = hv; v = __half2float(hv); }
-      else cur[r * width + j] = v;
-      b[j] = v;
+      const long long i = r * width + j;
+      float v = fmaf(sc, sy_ld(dsum + i), sy_ld(base + i));
+      if (H) { const __half hv = __float2half_rn(v); reinterpret_cast<__half*>(cur)[i] = hv; base[i] = hv; }      // (the snapshot keeps exactly the rounded value)
+      else { cur[i] = v; sy_st(base + i, v); }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void sync_copy_kernel(const float* __restrict__ src, int f16, float* __restrict__ dst, long long n) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = ldc(src, i, f16);
+__global__ __launch_bounds__(256) void sync_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 
 // order-independent checksum of a float buffer: 64-bit sum of the 32-bit patterns (equal buffers <=> equal sums,
@@ -126,9 +140,10 @@ struct poi_sync {
   poi_ctx* ctx = nullptr;
   int device = 0;
   std::vector<poi_sync_seg> segs;
-  std::vector<long long> off, cnt_off;          // element offsets into the flat buffers (cnt_off < 0: no touch counts)
-  long long n_data = 0, n_total = 0;
+  std::vector<long long> off, cnt_off;          // element offsets into the flat buffers (cnt_off < 0: no touch counts); half segments: into base16 / delta16
+  long long n_data = 0, n_total = 0, n_half = 0;
   float *base = nullptr, *delta = nullptr;
+  __half *base16 = nullptr, *delta16 = nullptr; // snapshot / deltas of the segments stored as half
   hipEvent_t e0 = nullptr, e1 = nullptr;
   double last_ms = 0;
   std::string err;
@@ -199,30 +214,34 @@ int poi_sync_create(poi_ctx* ctx, int device, const poi_sync_seg* segs_host, int
   if (hipSetDevice(device) != hipSuccess) return sfail(nullptr, POI_EHIP, "hipSetDevice failed");
   poi_sync* s = new poi_sync();
   s->ctx = ctx; s->device = device;
-  long long o = 0;
+  long long o = 0, oh = 0;
   for (int i = 0; i < n_seg; ++i) {
     const poi_sync_seg& g = segs_host[i];
     if (!g.cur || g.rows <= 0 || g.width <= 0 || g.rule < POI_SYNC_SUM || g.rule > POI_SYNC_MEAN_TOUCHED || (g.dtype != POI_F32 && g.dtype != POI_F16)) { delete s; return sfail(nullptr, POI_EINVAL, "poi_sync_create: bad segment"); }
-    s->segs.push_back(g); s->off.push_back(o);
-    o += g.rows * g.width;
-    o = (o + 3) & ~3ll;
+    s->segs.push_back(g);
+    if (g.dtype == POI_F16) { s->off.push_back(oh); oh += g.rows * g.width; oh = (oh + 7) & ~7ll; }
+    else { s->off.push_back(o); o += g.rows * g.width; o = (o + 3) & ~3ll; }
   }
-  s->n_data = o;
+  s->n_data = o; s->n_half = oh;
   for (int i = 0; i < n_seg; ++i) {
     if (segs_host[i].rule == POI_SYNC_MEAN_TOUCHED) { s->cnt_off.push_back(o); o += segs_host[i].rows; o = (o + 3) & ~3ll; }
     else s->cnt_off.push_back(-1);
   }
   s->n_total = o;
-  if (hipMalloc(&s->base, sizeof(float) * (size_t)s->n_data) != hipSuccess || hipMalloc(&s->delta, sizeof(float) * (size_t)s->n_total) != hipSuccess ||
-      hipEventCreate(&s->e0) != hipSuccess || hipEventCreate(&s->e1) != hipSuccess) {
+  bool ok = hipMalloc(&s->base, sizeof(float) * (size_t)(s->n_data + 4)) == hipSuccess && hipMalloc(&s->delta, sizeof(float) * (size_t)(s->n_total + 4)) == hipSuccess &&
+            hipEventCreate(&s->e0) == hipSuccess && hipEventCreate(&s->e1) == hipSuccess;
+  if (ok && oh) ok = hipMalloc(&s->base16, sizeof(__half) * (size_t)oh) == hipSuccess && hipMalloc(&s->delta16, sizeof(__half) * (size_t)oh) == hipSuccess;
+  // the alignment gaps between the segments are never written by the kernels but travel through the all-reduce: zero them once
+  if (ok) ok = hipMemset(s->delta, 0, sizeof(float) * (size_t)(s->n_total + 4)) == hipSuccess && (!oh || hipMemset(s->delta16, 0, sizeof(__half) * (size_t)oh) == hipSuccess);
+  if (!ok) {
     (void)hipGetLastError();
     if (s->base) (void)hipFree(s->base);
     if (s->delta) (void)hipFree(s->delta);
+    if (s->base16) (void)hipFree(s->base16);
+    if (s->delta16) (void)hipFree(s->delta16);
     delete s;
     return sfail(nullptr, POI_ENOMEM, "poi_sync_create: allocation failed");
   }
-  // the alignment gaps between the segments are never written by the kernels but travel through the all-reduce: zero them once
-  if (hipMemset(s->delta, 0, sizeof(float) * (size_t)s->n_total) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(s->base); (void)hipFree(s->delta); delete s; return sfail(nullptr, POI_EHIP, "poi_sync_create: memset failed"); }
   *out = s;
   return POI_OK;
 }
@@ -233,6 +252,8 @@ int poi_sync_destroy(poi_sync* s) {
   (void)hipDeviceSynchronize();
   if (s->base) (void)hipFree(s->base);
   if (s->delta) (void)hipFree(s->delta);
+  if (s->base16) (void)hipFree(s->base16);
+  if (s->delta16) (void)hipFree(s->delta16);
   if (s->e0) (void)hipEventDestroy(s->e0);
   if (s->e1) (void)hipEventDestroy(s->e1);
   delete s;
@@ -244,8 +265,13 @@ int poi_sync_begin_epoch(poi_sync* s, void* stream) {
   if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
   for (size_t i = 0; i < s->segs.size(); ++i) {
     const long long n = s->segs[i].rows * s->segs[i].width;
+    if (s->segs[i].dtype == POI_F16) {       // the snapshot of a half table is the table (a device copy)
+      if (hipMemcpyAsync(s->base16 + s->off[i], s->segs[i].cur, sizeof(__half) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return sfail(s, POI_EHIP, "poi_sync_begin_epoch: copy failed");
+      continue;
+    }
     hipLaunchKernelGGL(poi::sync_copy_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       s->segs[i].cur, (int)s->segs[i].dtype, s->base + s->off[i], n);
+                       s->segs[i].cur, s->base + s->off[i], n);
   }
   return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_begin_epoch: launch failed");
 }
@@ -255,8 +281,13 @@ int poi_sync_make_delta(poi_sync* s, void* stream) {
   if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
   for (size_t i = 0; i < s->segs.size(); ++i) {
     const poi_sync_seg& g = s->segs[i];
-    hipLaunchKernelGGL(poi::sync_delta_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, (int)g.dtype, s->base + s->off[i],
-                       s->delta + s->off[i], s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr, (long long)g.rows, (long long)g.width);
+    float* cnt = s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr;
+    if (g.dtype == POI_F16)
+      hipLaunchKernelGGL(poi::sync_delta_kernel<true>, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base16 + s->off[i],
+                         s->delta16 + s->off[i], cnt, (long long)g.rows, (long long)g.width);
+    else
+      hipLaunchKernelGGL(poi::sync_delta_kernel<false>, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base + s->off[i],
+                         s->delta + s->off[i], cnt, (long long)g.rows, (long long)g.width);
   }
   return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_make_delta: launch failed");
 }
@@ -267,14 +298,24 @@ int poi_sync_buffer(poi_sync* s, float** delta, int64_t* n) {
   return POI_OK;
 }
 
+int poi_sync_buffer16(poi_sync* s, void** delta16_dev, int64_t* n) {
+  if (!s || !delta16_dev || !n) return sfail(s, POI_EINVAL, "poi_sync_buffer16: NULL");
+  *delta16_dev = s->delta16; *n = s->n_half;
+  return POI_OK;
+}
+
 int poi_sync_apply(poi_sync* s, int32_t world, void* stream) {
   if (!s || world < 1) return sfail(s, POI_EINVAL, "poi_sync_apply: bad argument");
   if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
   for (size_t i = 0; i < s->segs.size(); ++i) {
     const poi_sync_seg& g = s->segs[i];
-    hipLaunchKernelGGL(poi::sync_apply_kernel, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, (int)g.dtype, s->base + s->off[i],
-                       s->delta + s->off[i], s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr, (long long)g.rows, (long long)g.width,
-                       (int)g.rule, 1.0f / (float)world);
+    const float* cnt = s->cnt_off[i] >= 0 ? s->delta + s->cnt_off[i] : nullptr;
+    if (g.dtype == POI_F16)
+      hipLaunchKernelGGL(poi::sync_apply_kernel<true>, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base16 + s->off[i],
+                         s->delta16 + s->off[i], cnt, (long long)g.rows, (long long)g.width, (int)g.rule, 1.0f / (float)world);
+    else
+      hipLaunchKernelGGL(poi::sync_apply_kernel<false>, dim3(grid_rows(g.rows)), dim3(256), 0, (hipStream_t)stream, g.cur, s->base + s->off[i],
+                         s->delta + s->off[i], cnt, (long long)g.rows, (long long)g.width, (int)g.rule, 1.0f / (float)world);
   }
   return hipGetLastError() == hipSuccess ? POI_OK : sfail(s, POI_EHIP, "poi_sync_apply: launch failed");
 }
@@ -285,13 +326,18 @@ int poi_sync_end_epoch(poi_sync* s, poi_comm* comm, void* stream) {
   if (rc) return rc;
   (void)hipEventRecord(s->e0, (hipStream_t)stream);
   if ((rc = poi_allreduce_tables(s->ctx, comm, s->delta, s->n_total, stream))) return rc;
+  if (s->n_half) {       // the half segments' deltas: a second all-reduce on the same stream, half elements
+    poi::Rccl* R = poi::rccl();
+    const ncclResult_t nr = R->AllReduce(s->delta16, s->delta16, (size_t)s->n_half, ncclFloat16, ncclSum, comm->comm, (hipStream_t)stream);
+    if (nr != ncclSuccess) return sfail(s, POI_EHIP, std::string("ncclAllReduce (half): ") + R->GetErrorString(nr));
+  }
   (void)hipEventRecord(s->e1, (hipStream_t)stream);
   return poi_sync_apply(s, comm->world, stream);
 }
 
 int poi_sync_stats(poi_sync* s, double* allreduce_ms, int64_t* allreduce_bytes) {
   if (!s) return sfail(s, POI_EINVAL, "poi_sync_stats: NULL");
-  if (allreduce_bytes) *allreduce_bytes = (int64_t)s->n_total * 4;
+  if (allreduce_bytes) *allreduce_bytes = (int64_t)s->n_total * 4 + (int64_t)s->n_half * 2;
   if (allreduce_ms) {
     float ms = 0.f;
     *allreduce_ms = (hipEventSynchronize(s->e1) == hipSuccess && hipEventElapsedTime(&ms, s->e0, s->e1) == hipSuccess) ? ms : -1.0;

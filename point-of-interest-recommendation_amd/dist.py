@@ -39,8 +39,8 @@ DEFAULT_RULES = {"lt": "mean_touched", "ux": "mean_touched", "wd_table": "mean_t
 class _DevArray:
     """Zero-copy torch view of a device buffer owned by the library (__cuda_array_interface__)."""
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    def __init__(self, ptr, n, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 class HipSyncBackend:
@@ -66,6 +66,11 @@ class HipSyncBackend:
         self._check(self.lib.poi_sync_buffer(h, ctypes.byref(p), ctypes.byref(n)))
         self.n = n.value
         self.flat = torch.as_tensor(_DevArray(p.value, n.value), device=device)
+        # tables stored as half: their deltas travel as half in a second flat buffer (poi_sync_buffer16)
+        p16, n16 = ctypes.c_void_p(), ctypes.c_int64()
+        self._check(self.lib.poi_sync_buffer16(h, ctypes.byref(p16), ctypes.byref(n16)))
+        self.n16 = n16.value
+        self.flat16 = torch.as_tensor(_DevArray(p16.value, n16.value, "<f2"), device=device) if n16.value else None
         self.comm = None
 
     def _check(self, rc):
@@ -116,7 +121,7 @@ class HipSyncBackend:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.flat = None
+            self.flat = None; self.flat16 = None
             self.lib.poi_sync_destroy(self.handle); self.handle = None
         if getattr(self, "comm", None):
             self.lib.poi_comm_destroy(self.comm); self.comm = None
@@ -174,6 +179,9 @@ class ReplicaSync:
         else:
             flat = self.backend.make_delta()
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat16 = getattr(self.backend, "flat16", None)
+            if flat16 is not None:                      # half-stored tables: their deltas, as half
+                dist.all_reduce(flat16, op=dist.ReduceOp.SUM, group=self.group)
             self.backend.apply(self.world)
         self.epochs += 1
 
@@ -196,7 +204,7 @@ class ReplicaSync:
                 out["allreduce_ms_last"], out["allreduce_bytes"] = ms, nb
                 out["rccl_world_size"] = self.backend.lib.poi_comm_world(self.backend.comm)
             else:
-                out["allreduce_bytes"] = self.backend.n * 4
+                out["allreduce_bytes"] = self.backend.n * 4 + self.backend.n16 * 2
         if hasattr(self.backend, "checksum"):
             cs = self.backend.checksum()
             if dist.is_initialized():

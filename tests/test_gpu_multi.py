@@ -71,6 +71,49 @@ def test_sync_kernels_three_emulated_replicas_all_rules(pa):
     sync.close()
 
 
+def test_sync_kernels_half_table_travels_as_half(pa):
+    """A table STORED as half (config X's POI table): snapshot and deltas are half (poi_sync_buffer16: half the snapshot memory, half the
+    all-reduce bytes), the float32 tensors beside it are unaffected; three emulated replicas, rule mean_touched on the half table -
+    result == half(base + sum of the half deltas / touching replicas); the touch count sees a row whose delta is below the
+    half resolution of the DELTA buffer; the result is the next snapshot."""
+    import torch
+    ctx = pa._lib.context(0)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g, dtype=torch.float32)
+    tab0 = (rnd(5003, 256) - 0.5).half()
+    dense0 = rnd(384, 256)
+    cur = [tab0.clone(), dense0.clone()]
+    sync = pa.dist.ReplicaSync(cur, rules=["mean_touched", "mean"], ctx=ctx, force_backend=True)
+    be = sync.backend
+    assert be.flat16 is not None and be.flat16.dtype == torch.float16 and be.n16 >= tab0.numel()
+    assert be.n < dense0.numel() + 5003 + 64, "the half table's deltas must not sit in the float32 buffer as well"
+    be.begin_epoch()
+    world = 3
+    tot32, tot16 = torch.zeros_like(be.flat), torch.zeros(be.n16, device="cuda", dtype=torch.float32)
+    d16, cnt = [], torch.zeros(5003, device="cuda")
+    for r in range(world):
+        moved = torch.arange(5003, device="cuda") % (r + 2) != 0
+        new = (tab0.float() + (rnd(5003, 256) * 0.02 - 0.01) * moved[:, None]).half()
+        cur[0].copy_(new); cur[1].copy_(dense0 + 0.01 * (r + 1))
+        tot32 += be.make_delta(); tot16 += be.flat16.float()
+        d16.append((new.float() - tab0.float()).half())
+        cnt += (new != tab0).any(dim=1).float()
+    be.flat.copy_(tot32); be.flat16.copy_(tot16.half())
+    be.apply(world)
+    ssum = (d16[0].float() + d16[1].float() + d16[2].float()).half().float()          # (what was put into the half buffer)
+    exp = (tab0.float() + ssum * (1.0 / cnt.clamp(min=1.0))[:, None]).half()
+    # (the kernel fuses the multiply-add: one float32 rounding less than this expression - a half-ulp tie may fall the other way)
+    diff = (cur[0].float() - exp.float()).abs()
+    assert float((diff == 0).float().mean()) > 0.999 and bool((diff <= 1.0001 * torch.as_tensor(np.spacing(exp.abs().cpu().numpy())).cuda().float()).all())
+    assert torch.allclose(cur[1], dense0 + 0.02, rtol=0, atol=2e-7)
+    before = cur[0].clone()
+    be.make_delta()
+    assert float(be.flat16.float().abs().max()) == 0.0 and float(be.flat.abs().max()) == 0.0
+    be.apply(world)
+    assert torch.equal(cur[0], before)
+    sync.close()
+
+
 @pytest.mark.parametrize("engine,rules", [("seq", None), ("tile", None), ("tile", {"lt": "mean_touched", "di": "sum", "ui": "sum"})])
 def test_two_shards_from_one_snapshot_reconcile_to_the_oracle(pa, engine, rules):
     """Shard A and shard B are trained (batch rule, one launch each) by two model instances that start from the same
@@ -191,6 +234,22 @@ def test_rccl_entry_points_world_size_1(pa):
         assert all(torch.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(t, want))
         sync.close()
         del before
+        # a half-stored table next to a float32 tensor: the second (float16) all-reduce of poi_sync_end_epoch
+        th = [(torch.rand(1000, 256, device="cuda") - 0.5).half(), torch.rand(128, 64, device="cuda")]
+        s2 = pa.dist.ReplicaSync(th, rules=["mean_touched", "mean"], ctx=ctx, force=True)
+        assert s2.own_comm and s2.backend.flat16 is not None
+        th[0][::3] += 0.01; th[1] += 0.25
+        want = [x.clone() for x in th]
+        s2.end_epoch()
+        torch.cuda.synchronize()
+        # one rank: its own delta comes back - half(base + half(cur - base)) is cur up to the half rounding of the DELTA (2^-12 |delta|,
+        # plus the final rounding; the untouched rows are bit-identical)
+        dh = (th[0].float() - want[0].float()).abs()
+        ulp = torch.as_tensor(np.spacing(want[0].abs().cpu().numpy())).cuda().float()
+        assert bool((dh <= 0.01 * 2.0 ** -11 + ulp).all()) and float((dh == 0).float().mean()) > 0.95 and torch.equal(th[0][1::3], want[0][1::3])
+        assert torch.allclose(th[1], want[1], rtol=0, atol=1e-7)
+        assert s2.report()["allreduce_bytes"] == 4 * (128 * 64 + 1000) + 2 * 1000 * 256
+        s2.close()
     finally:
         if created:
             dist.destroy_process_group()

@@ -84,14 +84,20 @@ def main(argv=None):
             start = [getattr(model, n).t.clone() for n in names]
             sync.backend.begin_epoch()
             total = torch.zeros_like(sync.backend.flat)
+            f16 = sync.backend.flat16                           # deltas of a half-stored table (None with float32 tables)
+            total16 = torch.zeros(f16.numel(), device=f16.device) if f16 is not None else None
             for lo, hi in bounds:
                 for n, s in zip(names, start):
                     getattr(model, n).t.copy_(s)
                 run(order[(order >= lo) & (order < hi)])
                 total += sync.backend.make_delta()
+                if f16 is not None:
+                    total16 += f16.float()
             for n, s in zip(names, start):
                 getattr(model, n).t.copy_(s)
             sync.backend.flat.copy_(total)
+            if f16 is not None:
+                f16.copy_(total16.half())
             sync.backend.apply(a.world)
         torch.cuda.synchronize(); t_train += time.perf_counter() - t0
         last = epoch == a.epochs - 1 or (a.seconds and t_train >= a.seconds)
