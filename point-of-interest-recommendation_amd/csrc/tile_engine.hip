@@ -2413,7 +2413,6 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
   const int nb_ui = (3 * D / 16) * (XW / 64), nb_zr = (2 * D / 16) * (D / 64), nb_c = (D / 16) * (D / 64), nb_vs = ((NB + 15) / 16) * (D / 64);
   int b = blockIdx.x;
   if (b < nb_ui + nb_zr + nb_c + nb_vs) {
-    if (A.dbg & 16) return;
     OneJob j;
     if (b < nb_ui) {                     // d ui = DA^T . X (snapshot)
       j = OneJob{A.G, 3 * D, 16 * (b / (XW / 64)), 3 * D, A.X, XW, 64 * (b % (XW / 64)), 0, A.ui, XW};
@@ -2429,8 +2428,6 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
     return;
   }
   b -= nb_ui + nb_zr + nb_c + nb_vs;
-  if (b == 0 && (A.dbg & 32)) return;
-  if (b > 0 && (A.dbg & 8)) return;
   if (b == 0) {
     // ---- bi | bs | wd | losses | loss_weight (te_finalize + te_parts + dense_apply of one sequence) ----
     for (int e = tid; e < 3 * D; e += TE_BLOCK) { const float w = A.bi[e]; A.bi[e] = w - aeff * (A.bi_part[e] + lambda * w); }
