@@ -132,7 +132,7 @@ int poi_ctx_set_split_products(poi_ctx* ctx, int on);
  * prog_bpr_gru_spatial.py:249-250) and launches that do not fill the chip are bound by it.  Same formulas, float32 FMA chains; the
  * summation order differs from the tile kernels.  Environment override at context creation: POI_TE_REC1=<max_sequences>. */
 int poi_ctx_set_small_launch(poi_ctx* ctx, int max_sequences);
-/* One-sequence path (default on): a poi_spatial_step launch of ONE sequence - the reference schedule, prog_bpr_gru_spatial.py:249-250 -
+/* One-sequence path (default on): a poi_spatial_step / poi_gru_step launch of ONE sequence - the reference schedule, prog_bpr_gru_spatial.py:249-250 -
  * at dim 64 / 128 (stored dims below are padded), float32 tables, sequences of at most 65 positions, runs the whole step in five
  * kernels instead of the batched pipeline's ~40 dispatches (input products on the vector ALUs, per-sequence recurrences, the head,
  * and ONE kernel for every gradient product with the SGD step in its epilogue and the sparse write-back, one workgroup per table

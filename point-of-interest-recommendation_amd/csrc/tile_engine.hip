@@ -2316,9 +2316,9 @@ __device__ __forceinline__ void one_header(const TeArgs& A, int& base, int& L, i
 
 template <int D>
 __global__ __launch_bounds__(TE_BLOCK) void te_one_in_kernel(TeArgs A, PackJobs J, int n_ax, int n_pk) {
-  constexpr int XW = 2 * D, LDX = XW + 4;
+  constexpr int LDX = 2 * D + 4;
   __shared__ __align__(16) float Xc[16][LDX], U[16][LDX];
-  const int tid = threadIdx.x, b = blockIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.x, XW = A.xw;        // 2 D (Distance2Pre: POI | distance bin) or D (plain GRU)
   int base, L, ns; one_header(A, base, L, ns);
   if (b >= n_ax + 1) {                       // weight packs (te_head's vs fragments, the transposes of te_rec_bwd1)
     const int v = b - n_ax - 1;
@@ -2328,8 +2328,8 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_in_kernel(TeArgs A, PackJobs 
   if (b == n_ax) {                           // prep (te_len / te_scan / te_rowmap of one sequence) + E rows
     if (tid == 0) { A.soff[0] = 0; A.soff[1] = ns; }
     for (int t = tid; t < ns; t += TE_BLOCK) {
-      A.row_src[t] = base + t; A.row_t[t] = t; A.row_p[t] = A.p[base + t]; A.row_dp[t] = A.dp[base + t];
-      A.row_ab[t] = A.dp[base + t + 1] | (A.dq[base + t + 1] << 16);
+      A.row_src[t] = base + t; A.row_t[t] = t; A.row_p[t] = A.p[base + t];
+      if (A.spatial) { A.row_dp[t] = A.dp[base + t]; A.row_ab[t] = A.dp[base + t + 1] | (A.dq[base + t + 1] << 16); }
     }
     constexpr int LPR = D / 4;
     for (int e = tid; e < ns * LPR; e += TE_BLOCK) {
@@ -2400,7 +2400,7 @@ __device__ __forceinline__ void one_dense_block(const OneJob& j, int ns, float a
 
 template <int D>
 __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float alpha, float lambda, int n_hwg, int l_cap) {
-  constexpr int XW = 2 * D;
+  const int XW = A.xw;                               // 2 D (Distance2Pre) or D (plain GRU: no distance-bin rows, no vs / bs / wd / loss weights)
   __shared__ __align__(16) float As[ONE_TMAX][17];
   __shared__ __align__(16) float Bs[ONE_TMAX][68];
   __shared__ int s_key[3 * (ONE_TMAX + 1)], s_hit[3 * (ONE_TMAX + 1)], s_cnt;
@@ -2410,7 +2410,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
   const int NB = A.n_dist + 1, NBP = te_nbp_dev(A.n_dist);
   const float aeff = alpha * (A.bcap < 0.f ? 1.0f : fminf(1.0f, A.bcap));       // dense rule of dense_apply_kernel at n_seq = 1
   // ---- dense gradients + SGD step: 16 x 64 output blocks ----
-  const int nb_ui = (3 * D / 16) * (XW / 64), nb_zr = (2 * D / 16) * (D / 64), nb_c = (D / 16) * (D / 64), nb_vs = ((NB + 15) / 16) * (D / 64);
+  const int nb_ui = (3 * D / 16) * (XW / 64), nb_zr = (2 * D / 16) * (D / 64), nb_c = (D / 16) * (D / 64), nb_vs = A.spatial ? ((NB + 15) / 16) * (D / 64) : 0;
   int b = blockIdx.x;
   if (b < nb_ui + nb_zr + nb_c + nb_vs) {
     OneJob j;
@@ -2431,7 +2431,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
   if (b == 0) {
     // ---- bi | bs | wd | losses | loss_weight (te_finalize + te_parts + dense_apply of one sequence) ----
     for (int e = tid; e < 3 * D; e += TE_BLOCK) { const float w = A.bi[e]; A.bi[e] = w - aeff * (A.bi_part[e] + lambda * w); }
-    for (int e = tid; e <= NB; e += TE_BLOCK) {
+    for (int e = tid; A.spatial && e <= NB; e += TE_BLOCK) {
       float g = 0.f;
       for (int k = 0; k < n_hwg; ++k) { float* p = A.hslab + (size_t)k * A.hstride + e; g += *p; *p = 0.f; }
       float* th = e < NB ? A.bs + e : A.wd;
@@ -2440,7 +2440,8 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
     float sur = 0.f, bpr = 0.f;
     for (int r = tid; r < ns; r += TE_BLOCK) { sur += A.rowloss[2 * (size_t)r]; bpr += A.rowloss[2 * (size_t)r + 1]; }
     sur = block_sum(sur, s_red); bpr = block_sum(bpr, s_red);
-    if (tid == 0) {
+    if (tid == 0 && !A.spatial) A.out[0] = -(bpr + (L > 0 ? -0.69314718056f : 0.f));      // te_finalize, plain GRU (public/GRU.py:352-357,380)
+    if (tid == 0 && A.spatial) {
       const float a = A.lw[0], c = A.lw[1], m = fmaxf(a, c);
       const float ea = expf(a - m), eb = expf(c - m);
       const float ls0 = ea / (ea + eb), ls1 = eb / (ea + eb);
@@ -2453,11 +2454,12 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
     return;
   }
   // ---- sparse write-back: one workgroup per table touch; slot e = section * L + j as te_slots ----
-  const int e = b - 1, n3 = 3 * L, pad_lt = A.n_item, pad_di = A.n_item + 1 + A.n_dist;
+  const int nsec = A.spatial ? 3 : 2;                  // the plain GRU has no distance-bin section
+  const int e = b - 1, n3 = nsec * L, pad_lt = A.n_item, pad_di = A.n_item + 1 + A.n_dist;
   auto key_of = [&](int i) { const int sec = i / L, jj = i - sec * L; return sec == 0 ? A.p[base + jj] : sec == 1 ? A.q[base + jj] : A.n_item + 1 + A.dp[base + jj]; };
   int key;
   const bool padwg = e >= 3 * l_cap;                  // the two padding rows without a literal touch: analytic multiplicity only
-  if (padwg) key = e == 3 * l_cap ? pad_lt : pad_di;
+  if (padwg) { if (e > 3 * l_cap && !A.spatial) return; key = e == 3 * l_cap ? pad_lt : pad_di; }
   else { if (e >= n3) return; key = key_of(e); }
   if (tid == 0) s_cnt = 0;
   for (int i = tid; i < n3; i += TE_BLOCK) s_key[i] = key_of(i);
@@ -2467,7 +2469,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
   if (__syncthreads_or(dup)) return;                  // an earlier slot owns the row (or a literal touch owns the padding row)
   int cnt = 0;
   for (int i = 0; i < n3; ++i) cnt += s_hit[i];       // (<= 195 LDS reads)
-  const int am = key == pad_lt ? 2 * (A.len_max - L) : key == pad_di ? (A.len_max - L) : 0;
+  const int am = key == pad_lt ? 2 * (A.len_max - L) : (A.spatial && key == pad_di) ? (A.len_max - L) : 0;
   if (cnt + am == 0) return;
   // thread (cq, part): columns 4 cq .. 4 cq + 3, every NP-th gate row of the dx products - 256 threads keep 3 D / NP independent
   // 16-byte loads of the ui snapshot in flight each (one thread per column walked the 3 D rows behind a handful of loads: 40 us)
@@ -2657,28 +2659,32 @@ static hipError_t te_one_t(TeArgs& A, float alpha, float lambda, int l_cap, hipS
   tm->end(st);
   tm->begin("te_head", st);
   const int n_hwg = (l_cap + 30) / 32 > 0 ? (l_cap + 30) / 32 : 1;
-  hipError_t e = te_head_dispatch<D>(A, 0, n_hwg, st);
-  if (e != hipSuccess) return e;
+  if (A.spatial) {
+    hipError_t e = te_head_dispatch<D>(A, 0, n_hwg, st);
+    if (e != hipSuccess) return e;
+  } else {
+    hipLaunchKernelGGL(te_bpr_head_kernel<D>, dim3(8), dim3(TE_BLOCK), 0, st, A);
+  }
   tm->end(st);
   tm->begin("te_rec_bwd", st);
   hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(1), dim3(4 * D), 0, st, A);
   tm->end(st);
   tm->begin("te_tail", st);
-  const int nb = (3 * D / 16) * (2 * D / 64) + (2 * D / 16) * (D / 64) + (D / 16) * (D / 64) + ((NB + 15) / 16) * (D / 64);
+  const int nb = (3 * D / 16) * (A.xw / 64) + (2 * D / 16) * (D / 64) + (D / 16) * (D / 64) + (A.spatial ? ((NB + 15) / 16) * (D / 64) : 0);
   hipLaunchKernelGGL(te_one_out_kernel<D>, dim3(nb + 1 + 3 * l_cap + 2), dim3(TE_BLOCK), 0, st, A, alpha, lambda, n_hwg, l_cap);
   tm->end(st);
   return hipGetLastError();
   }
 }
 
-// The whole step of ONE Distance2Pre sequence (write-back included): launch_te_train + launch_te_scatter + launch_dense_apply in five kernels.
+// The whole step of ONE sequence (Distance2Pre or plain GRU + BPR; write-back included): launch_te_train + launch_te_scatter + launch_dense_apply in five kernels.
 // l_cap: the longest sequence of the tables (<= ONE_TMAX + 1).
 hipError_t launch_te_one(TeArgs& A, float alpha, float lambda, int l_cap, hipStream_t st, Timing* tm) {
   if (A.dim == 64) return te_one_t<64>(A, alpha, lambda, l_cap, st, tm);
   if (A.dim == 128) return te_one_t<128>(A, alpha, lambda, l_cap, st, tm);
   return hipErrorInvalidValue;
 }
-bool te_one_supported(int D, bool spatial, int max_len) { return spatial && (D == 64 || D == 128) && max_len <= ONE_TMAX + 1; }
+bool te_one_supported(int D, bool spatial, int max_len) { (void)spatial; return (D == 64 || D == 128) && max_len <= ONE_TMAX + 1; }
 
 template <int D>
 static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {

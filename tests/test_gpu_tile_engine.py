@@ -218,18 +218,26 @@ def test_tile_plain_gru_single_sequence_is_the_reference_step(pa, dim):
     from tests.gpu_util import gru_params
     T = toy_problem(110 + dim, n_user=5, n_item=80, dim=dim, len_max=9)
     P = gru_params(110 + dim, T)
-    model = _gru_model(pa, T, P)
-    model.ctx.set_engine("tile")
     Pm, Qm, Mm = T["train"][0], T["train"][2], T["train"][1]
-    for u in [3, 0, 3, 1]:
-        old = P
-        P, loss = O.gru_step(P, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
-        got_loss = model.train(np.int32(u))
-        assert_close(got_loss, loss, "loss")
-        got = _get_gru(model)
-        assert_step_close(got, P, old, GRU_NAMES, "after user %d" % u)
-        P = round_f32({**P, **got})
-    model.ctx.set_engine("auto")
+    P0 = P
+    try:
+        for one in (True, False):                 # the one-sequence path (dims 64 / 128) and the batched pipeline at one sequence per launch
+            model = _gru_model(pa, T, P0)
+            model.ctx.set_engine("tile"); model.ctx.set_one_sequence_path(one)
+            model.ctx.timing(True)
+            P = P0
+            for u in [3, 0, 3, 1]:
+                old = P
+                P, loss = O.gru_step(P, Pm[u], Qm[u], Mm[u], 0.01, 0.001)
+                got_loss = model.train(np.int32(u))
+                assert_close(got_loss, loss, "loss")
+                got = _get_gru(model)
+                assert_step_close(got, P, old, GRU_NAMES, "after user %d (one-sequence path %s)" % (u, one))
+                P = round_f32({**P, **got})
+            assert (model.ctx.timing_get("te_wgrad")[1] == 0) == (one and dim <= 128), "the launches did not take the expected path"
+            model.ctx.timing(False)
+    finally:
+        pa._lib.context(0).set_one_sequence_path(True); pa._lib.context(0).set_engine("auto")
 
 
 @pytest.mark.parametrize("dim,n_user", [(64, 77), (128, 150), (256, 77)])
