@@ -132,6 +132,12 @@ int poi_ctx_set_split_products(poi_ctx* ctx, int on);
  * prog_bpr_gru_spatial.py:249-250) and launches that do not fill the chip are bound by it.  Same formulas, float32 FMA chains; the
  * summation order differs from the tile kernels.  Environment override at context creation: POI_TE_REC1=<max_sequences>. */
 int poi_ctx_set_small_launch(poi_ctx* ctx, int max_sequences);
+/* Regrouped backward pass (per-bin tables, per-POI regrouping, forward table: DESIGN.md section 5) only for launches of at least
+ * min_sequences sequences (default 1280; dim >= 128, Distance2Pre): the regroupings trade matrix work for sorting / segmented-sum
+ * dispatches, which pays from ~1500 sequences per launch; smaller launches take the two-table path (the step input gathered from lt | di
+ * inside the GEMMs) - 16 users: 342 -> 277 us per launch, 256 users: 393 -> 323 us.  Same formulas, same batch rule.  0 = always regroup.
+ * Environment override at context creation: POI_TE_BINTAB_MIN=<min_sequences>. */
+int poi_ctx_set_regroup_min(poi_ctx* ctx, int min_sequences);
 /* One-sequence path (default on): a poi_spatial_step / poi_gru_step launch of ONE sequence - the reference schedule, prog_bpr_gru_spatial.py:249-250 -
  * at dim 64 / 128 (stored dims below are padded), float32 tables, sequences of at most 65 positions, runs the whole step in five
  * kernels instead of the batched pipeline's ~40 dispatches (input products on the vector ALUs, per-sequence recurrences, the head,

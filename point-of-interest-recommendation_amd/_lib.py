@@ -56,6 +56,7 @@ SIGNATURES = {
     "poi_ctx_set_split_products": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_small_launch": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_one_sequence_path": (c_int, [c_void_p, c_int]),
+    "poi_ctx_set_regroup_min": (c_int, [c_void_p, c_int]),
     "poi_bpr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                              c_int32, c_float, c_float, c_void_p, c_int, c_void_p]),
     "poi_spatial_step": (c_int, [c_void_p, POINTER(GruParams), POINTER(SeqTables), c_void_p, c_int32, c_float, c_float,
@@ -205,6 +206,10 @@ class Context:
     def set_small_launch(self, max_sequences=1024):
         """Launches of at most this many sequences use the per-sequence recurrent kernels (poi_ctx_set_small_launch; 0 disables)."""
         self.check(self.lib.poi_ctx_set_small_launch(self.handle, int(max_sequences)))
+
+    def set_regroup_min(self, min_sequences=1280):
+        """Launches below this many sequences take the two-table path instead of the regrouped backward pass (poi_ctx_set_regroup_min)."""
+        self.check(self.lib.poi_ctx_set_regroup_min(self.handle, int(min_sequences)))
 
     def set_one_sequence_path(self, on=True):
         """Launches of one Distance2Pre sequence through the five-kernel path (poi_ctx_set_one_sequence_path)."""

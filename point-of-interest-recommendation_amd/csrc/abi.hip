@@ -44,6 +44,7 @@ struct poi_ctx {
   DevBuf ptab, iota;        // forward table (te_rec_fwd16<FT>): lt . ui[:, :D]^T per table row; 0..n_item, n_item + 1
   int iota_n = -1;          // rows the iota buffer currently describes
   int fwd_tab = 1;          // POI_TE_FWDTAB=0 disables (A/B)
+  int bintab_min = 1280;    // launches below this many sequences take the two-table path (no per-bin tables / per-POI regrouping); POI_TE_BINTAB_MIN
   int one_path = 1;         // launches of ONE sequence (Distance2Pre, plain GRU) take the five-kernel path (te_one_*); POI_TE_ONE=0 -> the batched pipeline
   int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
@@ -138,6 +139,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_ONE")) c->one_path = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_BINTAB_MIN")) c->bintab_min = atoi(e);
   if (const char* e = getenv("POI_CARNN_FAST")) c->carnn_fast = atoi(e) != 0;
   if (const char* e = getenv("POI_GRAPH")) c->graph_mode = atoi(e) != 0;
   if (const char* e = getenv("POI_TOPK_FILTER")) c->topk_filter = atoi(e) != 0;
@@ -214,7 +216,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.n_item = P->n_item; A.n_dist = n_dist; A.dim = D;
   A.spatial = spatial ? 1 : 0; A.xw = spatial ? 2 * D : D;
   A.lt_f16 = is_f16(c, P->lt);
-  A.bintab = poi::te_bintab(D, spatial, n_dist) ? 1 : 0;
+  A.bintab = (poi::te_bintab(D, spatial, n_dist) && (predict || n >= c->bintab_min)) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
   A.rec_split = (!A.rec32 && c->rec_split) ? 1 : 0;
   A.rec1 = (!A.rec32 && n <= c->rec1_max) ? 1 : 0;
@@ -377,11 +379,12 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
   if (tile) {
     n_head = c->num_cu * (D >= 256 && c->head_rounds > 2 ? 2 : c->head_rounds);      // D = 256: 62 KB of LDS per te_head workgroup, two per CU
     // te_wgrad launches (output-tile jobs) x n_kc K-chunks: fill the CUs exactly (no ragged second round)
-    const int jobs = poi::te_wgrad_jobs(D, spatial ? P->n_dist : -1, spatial), nui = poi::te_wgrad_ui_jobs(D, spatial ? P->n_dist : -1, spatial);
+    const bool bt = poi::te_bintab(D, spatial, spatial ? P->n_dist : -1) && n >= c->bintab_min;
+    const int jobs = poi::te_wgrad_jobs(D, spatial ? P->n_dist : -1, spatial, bt), nui = poi::te_wgrad_ui_jobs(D, spatial ? P->n_dist : -1, spatial, bt);
     n_kc = (c->num_cu * c->wgrad_rounds) / jobs;
     if (n_kc < 1) n_kc = 1;
     n_kc_ui = n_kc;
-    if (poi::te_bintab(D, spatial, spatial ? P->n_dist : -1) && c->ppoi) {
+    if (bt && c->ppoi) {
       // per-POI regrouping: te_wgrad picks the K-chunk split on the device from the launch's own S-row count; the slabs are sized for
       // the extremes (no S rows: every slot goes to the T-row jobs; as many S rows as steps: the uniform split)
       int a, b;
@@ -417,7 +420,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.zrow = (const float*)c->zrow.p;
     E.sr_salt = (c->f16_rounding && E.lt_f16) ? (++c->sr_counter) * 0x9E3779B1u | 1u : 0u;
     E.out = out; E.bcap = bcap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
-    E.kc_dev = (poi::te_bintab(D, spatial, spatial ? P->n_dist : -1) && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
+    E.kc_dev = (E.bintab && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
@@ -446,7 +449,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
       const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
-                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1) | (c->one_path << 2) | ((unsigned)c->rec1_max << 3))};
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1) | (c->one_path << 2) | ((unsigned)c->rec1_max << 3) | ((size_t)(unsigned)c->bintab_min << 24))};
       add(bufs, sizeof bufs);
     }
     poi_ctx::StepGraph* g = nullptr;
@@ -978,6 +981,12 @@ int poi_ctx_set_split_products(poi_ctx* c, int on) {
 int poi_ctx_set_small_launch(poi_ctx* c, int max_sequences) {
   if (!c || max_sequences < 0) return fail(c, POI_EINVAL, "poi_ctx_set_small_launch: max_sequences must be >= 0");
   c->rec1_max = max_sequences;
+  return POI_OK;
+}
+
+int poi_ctx_set_regroup_min(poi_ctx* c, int min_sequences) {
+  if (!c || min_sequences < 0) return fail(c, POI_EINVAL, "poi_ctx_set_regroup_min: min_sequences must be >= 0");
+  c->bintab_min = min_sequences;
   return POI_OK;
 }
 

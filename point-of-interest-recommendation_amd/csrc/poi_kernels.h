@@ -198,10 +198,10 @@ __host__ __device__ inline int te_nbp_dev(int n_dist) {
   const int t = (n_dist + 1 + 31) / 32;
   return t <= 8 ? 32 * (t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 7 ? 7 : 8) : 256 * ((n_dist + 1 + 255) / 256);
 }
-int te_wgrad_jobs(int D, int n_dist, bool spatial);
+int te_wgrad_jobs(int D, int n_dist, bool spatial, bool bintab);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st);
-int te_wgrad_ui_jobs(int D, int n_dist, bool spatial);
+int te_wgrad_ui_jobs(int D, int n_dist, bool spatial, bool bintab);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 int te_nbp(int n_dist);
 void launch_te_iota(int* buf, int n, hipStream_t st);

@@ -2530,14 +2530,14 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_out_kernel(TeArgs A, float al
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-int te_wgrad_jobs(int D, int n_dist, bool spatial) {
-  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial, n_dist)) ? 2 * D : D;
+int te_wgrad_jobs(int D, int n_dist, bool spatial, bool bintab) {
+  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !bintab) ? 2 * D : D;
   return (3 * D / T) * (XW / T) + (2 * D / T) * (D / T) + (D / T) * (D / T) + (spatial ? ((te_nbp_dev(n_dist) + T - 1) / T) * (D / T) : 0);
 }
 
-int te_wgrad_ui_jobs(int D, int n_dist, bool spatial) {
+int te_wgrad_ui_jobs(int D, int n_dist, bool spatial, bool bintab) {
   (void)n_dist;
-  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !te_bintab(D, spatial, n_dist)) ? 2 * D : D;
+  const int T = (D % 128 == 0) ? 128 : 64, XW = (spatial && !bintab) ? 2 * D : D;
   return (3 * D / T) * (XW / T);
 }
 
@@ -2777,7 +2777,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->begin("te_wgrad", st);
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
-    const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0);
+    const int jobs = te_wgrad_jobs(D, A.n_dist, A.spatial != 0, A.bintab != 0);
     const dim3 grid(A.ppoi ? A.wg_slots : jobs * A.n_kc);
     if (A.lt_f16) hipLaunchKernelGGL((te_wgrad_kernel<D, T, true>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
     else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);

@@ -22,6 +22,17 @@ def pa():
     poi_amd._lib.context(0).set_engine("auto")
 
 
+@pytest.fixture(autouse=True, params=[0, 1280], ids=["regrouped", "default-threshold"])
+def _regroup_min(request, pa):
+    """Every test of this module runs twice: with the regrouped backward pass (per-bin tables, per-POI regrouping, forward table) forced
+    for every launch size (poi_ctx_set_regroup_min(0) - what the 12500-user launches of the bench run), and with the product's default
+    threshold, under which these small launches take the two-table path."""
+    ctx = pa._lib.context(0)
+    ctx.set_regroup_min(request.param)
+    yield
+    ctx.set_regroup_min(1280)
+
+
 def _model(pa, T, P):
     return pa.models.OboSpatialGru(train=T["train"], test=T["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001],
                                    n_user=T["n_user"], n_item=T["n_item"], n_dists=[T["n_dist"], 0.2],

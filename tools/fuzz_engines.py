@@ -64,6 +64,7 @@ def main():
                                                                                        n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P, pad_dim=(eng == "tile"))
             ctx.set_engine("tile32" if (eng == "tile" and 64 < dim <= 128 and s % 5 == 0) else eng)      # (every fifth dim-128 configuration: streaming recurrent kernels)
             ctx.set_batch_cap(float(rng.choice([1.0, 4.0, 64.0])) if eng == engines[0] else ctx.batch_cap)
+            ctx.set_regroup_min(0 if s % 2 == 0 else 1280)      # even seeds: regrouped backward pass at every launch size; odd: the default threshold
             outs = []
             for _ in range(2):
                 k = int(np.random.default_rng(s).integers(1, n_user + 1))
@@ -99,7 +100,7 @@ def main():
                     m.use_bin_matrix = True; b = m.compute_sub_topk(ids, k_top, return_scores=True)
                     sa, sb = a[1].cpu().numpy(), b[1].cpu().numpy()
                     assert np.allclose(sa, sb, rtol=0, atol=1e-5 * max(np.abs(sa).max(), 1e-30)), ("topk scores: geo vs bin matrix", s)
-        ctx.set_engine("auto"); ctx.set_batch_cap(1.0)
+        ctx.set_engine("auto"); ctx.set_batch_cap(1.0); ctx.set_regroup_min(1280)
         if len(engines) < 2:
             continue
         tol = 6e-5 if dim > 128 else 2e-5
