@@ -2311,7 +2311,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile
 #define ONE_TMAX 64
 __device__ __forceinline__ void one_header(const TeArgs& A, int& base, int& L, int& ns) {
   const int u = A.uidx[0];
-  base = A.off[u]; L = A.off[u + 1] - base; ns = L > 0 ? L - 1 : 0;
+  base = A.off[u]; L = min(A.off[u + 1] - base, ONE_TMAX + 1); ns = L > 0 ? L - 1 : 0;      // (the host checked max_len <= ONE_TMAX + 1: the clamp only guards the LDS tiles against inconsistent tables)
 }
 
 template <int D>
@@ -2603,7 +2603,7 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments (32-column ones for the streaming kernels)
   if (A.rec1) {}      // (te_rec_fwd1 reads wh directly)
   else if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
-  else if (A.rec_split && !A.fwd_tab) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table launches keep the float32 kernel)
+  else if (A.rec_split && (!A.fwd_tab || A.predict)) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table TRAINING launches keep the float32 kernel)
   else J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
   J.n = n;
 }
@@ -2811,6 +2811,7 @@ static hipError_t te_optin_lds() {
   // split-operand recurrent kernels at D = 128: 96 KB of third weight planes next to the operand planes
   auto optin = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); };
   optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, false, false, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, true, false, true>));
+  optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, true, true, true>));
   optin(reinterpret_cast<const void*>(&te_rec_bwd16_kernel<128, true>));
   done = e == hipSuccess;
   return e;
@@ -2863,6 +2864,9 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
       const dim3 g((n + 15) / 16), b(D * 4);
       const size_t ldsf = sizeof(float) * 2 * 16 * (D + 4), ldss = sizeof(short) * (2 * 3 * 16 * (D + 8) + 3 * D * D);
       if (A.rec1) hipLaunchKernelGGL((te_rec_fwd1_kernel<D, true>), dim3(n), dim3(4 * D), 0, st, A);
+      // (prediction has no per-step stores: with the forward table it is the matrix pipe that bounds it, not the memory system - split
+      // products although the table prefetch spills ~30 registers next to the planes)
+      else if (A.fwd_tab && A.rec_split) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, true, true>), g, b, ldss, st, A);
       else if (A.fwd_tab) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, true>), g, b, ldsf, st, A);
       else if (A.rec_split) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, false, true>), g, b, ldss, st, A);
       else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), g, b, ldsf, st, A);
