@@ -11,7 +11,8 @@ import bench
 
 sizes = [int(x) for x in sys.argv[1:]] or [1, 16, 64, 256, 1024, 1580, 4096, 12500]
 n_item, n_user, max_len, D = pdata.SHAPES["gowalla"]
-ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=0.8)
+DD = float(os.environ.get("LS_DD", "200"))        # LS_DD=25 LS_UD=38: the reference's 1520-bin configuration
+ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=0.8, dd=DD, ud_km=float(os.environ.get("LS_UD", "40")))
 tab = ds.shard(0, n_user)
 dev = torch.device("cuda", 0)
 m = poi_amd.models.OboSpatialGru(train=tab, test=None, dist=None, alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item,
