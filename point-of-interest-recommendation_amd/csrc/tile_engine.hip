@@ -1215,28 +1215,32 @@ template <int N> __device__ __forceinline__ float group_sum(float v) {      // s
   if (N >= 16) v += dpp_f<0x140>(v);       // row_mirror
   return v;
 }
-// a[o] += w[o][:] . x[:] for FOUR outputs sharing the LDS slice x (one 16-byte LDS read feeds 16 FMAs)
+// a[o] += w[o][:] . x[:] for FOUR outputs sharing the LDS slice x (one 16-byte LDS read feeds 16 FMAs).  The weights are held as PAIRS
+// (outputs 0|1 and 2|3) so that the products are v_pk_fma_f32 - two float32 FMAs per lane and issue slot, the only form that reaches the
+// float32 vector peak on gfx950 (a scalar v_fma_f32 stream runs at half of it); x is broadcast into both halves by op_sel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int L>
-__device__ __forceinline__ void dot4_reg_lds(const float (&w)[4][L], const float* __restrict__ x, float (&a)[4]) {
+__device__ __forceinline__ void dot4_reg_lds(const f32x2 (&w)[2][L], const float* __restrict__ x, float (&a)[4]) {
+  f32x2 p0 = {a[0], a[1]}, p1 = {a[2], a[3]};
 #pragma unroll
   for (int i = 0; i < L; i += 4) {
     const float4 u = *reinterpret_cast<const float4*>(x + i);
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      a[o] = __fmaf_rn(w[o][i], u.x, a[o]); a[o] = __fmaf_rn(w[o][i + 1], u.y, a[o]);
-      a[o] = __fmaf_rn(w[o][i + 2], u.z, a[o]); a[o] = __fmaf_rn(w[o][i + 3], u.w, a[o]);
-    }
+    p0 = __builtin_elementwise_fma(w[0][i], f32x2{u.x, u.x}, p0); p1 = __builtin_elementwise_fma(w[1][i], f32x2{u.x, u.x}, p1);
+    p0 = __builtin_elementwise_fma(w[0][i + 1], f32x2{u.y, u.y}, p0); p1 = __builtin_elementwise_fma(w[1][i + 1], f32x2{u.y, u.y}, p1);
+    p0 = __builtin_elementwise_fma(w[0][i + 2], f32x2{u.z, u.z}, p0); p1 = __builtin_elementwise_fma(w[1][i + 2], f32x2{u.z, u.z}, p1);
+    p0 = __builtin_elementwise_fma(w[0][i + 3], f32x2{u.w, u.w}, p0); p1 = __builtin_elementwise_fma(w[1][i + 3], f32x2{u.w, u.w}, p1);
   }
+  a[0] = p0.x; a[1] = p0.y; a[2] = p1.x; a[3] = p1.y;
 }
 template <int L>
-__device__ __forceinline__ void load_rows4(float (&w)[4][L], const float* __restrict__ src, int ld) {       // w[o][:] = src[o * ld + 0 .. L)
+__device__ __forceinline__ void load_rows4(f32x2 (&w)[2][L], const float* __restrict__ src, int ld) {       // w[o / 2][i][o % 2] = src[o * ld + i]
 #pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int i = 0; i < L; i += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)o * ld + i);
-      w[o][i] = v.x; w[o][i + 1] = v.y; w[o][i + 2] = v.z; w[o][i + 3] = v.w;
-    }
+  for (int i = 0; i < L; i += 4) {
+    const float4 r0 = *reinterpret_cast<const float4*>(src + i), r1 = *reinterpret_cast<const float4*>(src + (size_t)ld + i);
+    const float4 r2 = *reinterpret_cast<const float4*>(src + (size_t)2 * ld + i), r3 = *reinterpret_cast<const float4*>(src + (size_t)3 * ld + i);
+    w[0][i] = f32x2{r0.x, r1.x}; w[0][i + 1] = f32x2{r0.y, r1.y}; w[0][i + 2] = f32x2{r0.z, r1.z}; w[0][i + 3] = f32x2{r0.w, r1.w};
+    w[1][i] = f32x2{r2.x, r3.x}; w[1][i + 1] = f32x2{r2.y, r3.y}; w[1][i + 2] = f32x2{r2.z, r3.z}; w[1][i + 3] = f32x2{r2.w, r3.w};
+  }
 }
 __device__ __forceinline__ float pick4(const float (&a)[4], int o) { return o == 0 ? a[0] : o == 1 ? a[1] : o == 2 ? a[2] : a[3]; }
 
@@ -1252,7 +1256,7 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1_kernel(TeArgs A) {
   const bool isr = jz >= D;
   const int jr = isr ? jz - D : jz;
   const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
-  float wzr[4][LZ], wc[4][LC];
+  f32x2 wzr[2][LZ], wc[2][LC];
   load_rows4<LZ>(wzr, A.wh + (size_t)4 * gz * D + sz * LZ, D);
   load_rows4<LC>(wc, A.wh + (size_t)(2 * D + 4 * gc) * D + sc * LC, D);
   if (tid < D) hs[tid] = 0.f;
@@ -1260,21 +1264,30 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1_kernel(TeArgs A) {
   // pre-activations of the next step are requested a step ahead (G row r0 + t + 1 is not written before step t + 1)
   float gzr = 0.f, gcc = 0.f;
   if (ns > 0) { gzr = A.G[(size_t)r0 * 3 * D + jz]; gcc = A.G[(size_t)r0 * 3 * D + 2 * D + jc]; }
+  // Every lane issues every global store of a step - the lanes that do not own an output write their (duplicate) value into the spare
+  // packed row - so that the stores sit in straight-line code: vmcnt counts loads AND stores in order, and with the stores inside the
+  // owner branches the compiler's wait for the prefetched pre-activations also waited for the stores issued after them (a store round
+  // trip per step: 1.07 us per step instead of 0.6).
+  const size_t Tsp = (size_t)A.soff[A.n_seq];
+  const bool ownz = sz < 4, ownc = sc < 4;
+  float* const dG = A.G + Tsp * 3 * D + (tid % (3 * D));
+  float* const dH = A.H + Tsp * D + (tid % D);
+  float* const dR = A.RH + Tsp * D + (tid % D);
   for (int t = 0; t < ns; ++t) {
     const size_t row = (size_t)(r0 + t), rn = (size_t)(r0 + min(t + 1, ns - 1));
-    const float nzr = A.G[rn * 3 * D + jz], nc = A.G[rn * 3 * D + 2 * D + jc];
+    float nzr = A.G[rn * 3 * D + jz], nc = A.G[rn * 3 * D + 2 * D + jc];
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     dot4_reg_lds<LZ>(wzr, hs + sz * LZ, a);
 #pragma unroll
     for (int o = 0; o < 4; ++o) a[o] = group_sum<8>(a[o]);
-    if (sz < 4) {
-      const float v = fast_sigmoid(pick4(a, sz) + gzr);
-      if (isr) {
-        const float rh = v * hs[jr];
-        rhs[jr] = rh;
-        if (!predict) { A.G[row * 3 * D + D + jr] = v; A.RH[row * D + jr] = rh; }
-      } else {
-        zs[jr] = v;
+    {
+      const float v = fast_sigmoid(pick4(a, sz & 3) + gzr);
+      const float rh = v * hs[jr];
+      if (ownz) { if (isr) rhs[jr] = rh; else zs[jr] = v; }
+      if (!predict) {
+        const bool st = ownz && isr;
+        *(st ? A.G + row * 3 * D + D + jr : dG) = v;
+        *(st ? A.RH + row * D + jr : dR) = rh;
       }
     }
     lds_barrier();
@@ -1282,14 +1295,19 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1_kernel(TeArgs A) {
     dot4_reg_lds<LC>(wc, rhs + sc * LC, b);
 #pragma unroll
     for (int o = 0; o < 4; ++o) b[o] = group_sum<16>(b[o]);
-    if (sc < 4) {
-      const float c = fast_tanh(pick4(b, sc) + gcc);
+    {
+      const float c = fast_tanh(pick4(b, sc & 3) + gcc);
       const float z = zs[jc];
       const float hn = (1.0f - z) * hs[jc] + z * c;
-      hs[jc] = hn;                         // (the c phase reads rhs only)
-      if (!predict) { A.G[row * 3 * D + jc] = z; A.G[row * 3 * D + 2 * D + jc] = c; A.H[row * D + jc] = hn; }
+      if (ownc) hs[jc] = hn;               // (the c phase reads rhs only)
+      if (!predict) {
+        *(ownc ? A.G + row * 3 * D + jc : dG) = z;
+        *(ownc ? A.G + row * 3 * D + 2 * D + jc : dG) = c;
+        *(ownc ? A.H + row * D + jc : dH) = hn;
+      }
     }
     lds_barrier();
+    asm volatile("" : "+v"(nzr), "+v"(nc));      // the wait for the prefetch is counted HERE, behind this step's stores
     gzr = nzr; gcc = nc;
   }
   if (predict && tid < D) A.hts[(size_t)(A.out_row ? A.out_row[k] : k) * D + tid] = hs[tid];
@@ -1304,7 +1322,7 @@ __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
   const int g = tid >> 4, s = tid & 15;
   const int kk = 4 * g + (s & 3);          // the column this lane finishes (lanes s < 4)
   const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
-  float wc[4][LC], wzr[4][LZ];
+  f32x2 wc[2][LC], wzr[2][LZ];
   load_rows4<LC>(wc, reinterpret_cast<const float*>(A.pWhc16) + (size_t)4 * g * D + s * LC, D);              // Wc^T:  [k][j]
   load_rows4<LZ>(wzr, reinterpret_cast<const float*>(A.pWhzr16) + (size_t)4 * g * 2 * D + s * LZ, 2 * D);     // Wzr^T: [k][j], j < 2D
   float dhn = 0.f, sbz = 0.f, sbr = 0.f, sbc = 0.f;
@@ -1318,6 +1336,8 @@ __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
     fd = A.DH[row * D + kk];
   };
   if (ns > 0) fetch(ns - 1, z, r, c, hp, dd);
+  const bool own = s < 4;
+  float* const dG = A.G + (size_t)A.soff[A.n_seq] * 3 * D + (tid % (3 * D));      // spare packed row: see te_rec_fwd1
   for (int t = ns - 1; t >= 0; --t) {
     float nz, nr, nc, nh, nd;
     fetch(t - 1, nz, nr, nc, nh, nd);
@@ -1326,7 +1346,7 @@ __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
     const float dz = dh * (c - h);
     float dhp = dh * (1.0f - z);
     const float dacv = dh * z * (1.0f - c * c);
-    if (s < 4) dac[kk] = dacv;
+    if (own) dac[kk] = dacv;
     lds_barrier();
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     dot4_reg_lds<LC>(wc, dac + s * LC, a);
@@ -1336,11 +1356,11 @@ __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
     const float dr = m * h;
     dhp += m * r;
     const float daz = dz * z * (1.0f - z), dar = dr * r * (1.0f - r);
-    if (s < 4) {
-      dazr[kk] = daz; dazr[D + kk] = dar;
+    if (own) { dazr[kk] = daz; dazr[D + kk] = dar; }
+    {
       float* gp = A.G + (size_t)(r0 + t) * 3 * D;
-      gp[kk] = daz; gp[D + kk] = dar; gp[2 * D + kk] = dacv;
-      sbz += daz; sbr += dar; sbc += dacv;
+      *(own ? gp + kk : dG) = daz; *(own ? gp + D + kk : dG) = dar; *(own ? gp + 2 * D + kk : dG) = dacv;
+      sbz += daz; sbr += dar; sbc += dacv;      // (every lane of a column holds the same values; lanes s < 4 write them)
     }
     lds_barrier();
     float b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1348,6 +1368,7 @@ __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) b[o] = group_sum<16>(b[o]);
     dhn = dhp + pick4(b, s & 3);
+    asm volatile("" : "+v"(nz), "+v"(nr), "+v"(nc), "+v"(nh), "+v"(nd));      // (wait for the prefetch behind this step's stores)
     z = nz; r = nr; c = nc; hp = nh; dd = nd;
   }
   if (s < 4) {
