@@ -160,7 +160,10 @@ int poi_ctx_set_topk_seed(poi_ctx* ctx, const int32_t* seed_idx, int32_t k_seed)
  * MFMA sequence and distance term: the same ids AND scores, bit for bit.  The path seeds itself: unseeded calls first run the one-stage
  * kernel on the first 1/16 of the item tiles (any subset's K-th best exact score is a valid threshold); seeded calls do the same on 1/64
  * when the table has >= 2^20 items, so a useless seed costs nothing but survivors.  User tiles whose survivor lists still overflow
- * (4096 slots per user) are handed to the one-stage kernel.  poi_score_topk_geo: dims 64 / 128 / 256, bins computed on the fly. */
+ * (4096 slots per user) are handed to the one-stage kernel.  poi_score_topk_geo: dims 64 / 128 / 256, bins computed on the fly; with
+ * >= 2^20 items and <= 131072 users (config X's evaluation) its filter pass is ITEM-stationary - a workgroup keeps four item tiles in
+ * registers and walks the user tiles, whose half fragments are L2-resident, instead of every user tile walking the item table.
+ * on = 2 / 3: two-stage with the item-stationary GEO filter forced / forbidden (tests, A/B runs; POI_SF_ITEMS=1|0). */
 int poi_ctx_set_topk_filter(poi_ctx* ctx, int on);
 /* Host-side statistics of the LAST two-stage call (synchronises): users scored, pairs the filter kept (all users), 32-user tiles, and the
  * tiles whose survivor lists overflowed and were handed to the one-stage kernel.  users == 0: no two-stage call so far. */

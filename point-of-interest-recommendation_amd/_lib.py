@@ -174,8 +174,10 @@ class Context:
         self.check(self.lib.poi_ctx_set_topk_seed(self.handle, None if seed is None else seed.data_ptr(), int(k_seed)))
 
     def set_topk_filter(self, on):
-        """Two-stage fused top-K (f16 filter + exact float32 rescoring) for seeded calls: poi_ctx_set_topk_filter."""
-        self.check(self.lib.poi_ctx_set_topk_filter(self.handle, int(bool(on))))
+        """Two-stage fused top-K (f16 filter + exact float32 rescoring): poi_ctx_set_topk_filter.  on: False / True, or "items" / "users" =
+        two-stage with the item-stationary GEO filter forced / forbidden (default: chosen by shape)."""
+        mode = {"items": 2, "users": 3}.get(on, int(bool(on))) if isinstance(on, str) else int(bool(on))
+        self.check(self.lib.poi_ctx_set_topk_filter(self.handle, mode))
 
     def topk_filter_stats(self):
         """dict(users, survivors, tiles, tiles_flagged) of the last two-stage fused top-K call (poi_ctx_topk_filter_stats)."""

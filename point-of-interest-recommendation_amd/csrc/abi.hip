@@ -64,6 +64,8 @@ struct poi_ctx {
   // scoring
   DevBuf cand_s, cand_i, items_pk, gbound;
   DevBuf items_pk16, inorm, surv_cnt, surv_idx, surv_sc, tflag, pre_idx, pre_sc;      // two-stage fused top-K (score_filter.hip)
+  DevBuf users_pk16, ubound, ugeo;      // item-stationary GEO filter: users' half fragments, per-user bound terms, last-POI coordinates
+  int sf_items = -1;        // poi_ctx_set_topk_filter(ctx, 2 / 3): force / forbid the item-stationary GEO filter (-1: by shape)
   int f16_rounding = 0;     // poi_ctx_set_f16_rounding: 0 nearest, 1 stochastic (write-back of a half POI table)
   unsigned sr_counter = 0;  // launches so far (salt of the stochastic rounding)
   int topk_filter = 1;      // poi_ctx_set_topk_filter / POI_TOPK_FILTER=0: one-stage float32 kernel only
@@ -170,7 +172,7 @@ int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
   DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
-                   &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag, &c->pre_idx, &c->pre_sc};
+                   &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag, &c->pre_idx, &c->pre_sc, &c->users_pk16, &c->ubound, &c->ugeo};
   (void)hipDeviceSynchronize();
   c->tm.clear();
   drop_graphs(c);
@@ -807,6 +809,19 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     HIPCHK(c, hipMemsetAsync(c->tflag.p, 0, sizeof(int) * (size_t)n_utile, st));
     A.items_packed16 = (const uint4*)c->items_pk16.p; A.inorm = (const float2*)c->inorm.p;
     A.surv_cnt = (int*)c->surv_cnt.p; A.surv_idx = (int*)c->surv_idx.p; A.surv_sc = (float*)c->surv_sc.p; A.tile_flag = (int*)c->tflag.p;
+    // GEO with a huge item table and few users (config X's evaluation): the item-stationary filter - every user tile's own pass over the
+    // item table is 1.3 TB at 8192 users x 10 M POIs; forced (2) / forbidden (0) by POI_SF_ITEMS for tests and A/B runs
+    A.n_cu = c->num_cu;
+    {
+      int items_mode = (A.geo && n_item >= (1 << 20) && n_utile <= 4096) ? 1 : 0;
+      if (const char* e = getenv("POI_SF_ITEMS")) items_mode = A.geo ? (atoi(e) != 0) : 0;
+      if (c->sf_items >= 0) items_mode = A.geo ? c->sf_items : 0;
+      if (items_mode) {
+        if ((rc = ensure(c, c->users_pk16, sizeof(uint4) * (size_t)n_utile * kg * 64, st)) || (rc = ensure(c, c->ubound, sizeof(float) * 4 * (size_t)n_pad, st)) ||
+            (rc = ensure(c, c->ugeo, sizeof(double) * 3 * (size_t)n_pad, st))) return rc;
+        A.users_packed16 = (uint4*)c->users_pk16.p; A.ubound = (float4*)c->ubound.p; A.ugeo = (double*)c->ugeo.p;
+      }
+    }
     int nsf = ((4 * c->num_cu + n_utile - 1) / n_utile) * 4;      // >= 4 workgroups (16 waves) per CU
     if (nsf < 16) nsf = 16;      // (swept at the Gowalla shape: 8 / 16 / 32 / 64 / 128 ranges -> 3.09 / 2.84 / 2.80 / 2.86 / 3.21 ms of filter time)
     if (const char* e = getenv("POI_SF_NSPLIT")) { const int v = atoi(e); if (v >= 4) nsf = (v / 4) * 4; }      // tuning switch
@@ -997,8 +1012,9 @@ int poi_ctx_set_one_sequence_path(poi_ctx* c, int on) {
 }
 
 int poi_ctx_set_topk_filter(poi_ctx* c, int on) {
-  if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_topk_filter: on must be 0 or 1");
-  c->topk_filter = on;
+  if (!c || on < 0 || on > 3) return fail(c, POI_EINVAL, "poi_ctx_set_topk_filter: on must be 0 (one-stage only), 1 (two-stage), 2 / 3 (two-stage, item-stationary GEO filter forced / forbidden)");
+  c->topk_filter = on != 0;
+  c->sf_items = on == 2 ? 1 : on == 3 ? 0 : -1;
   return POI_OK;
 }
 

@@ -317,6 +317,9 @@ struct ScoreArgs {
   // per-user-tile overflow flags; the one-stage kernels and the merge skip every tile whose flag is clear when tile_flag is set
   const uint4* items_packed16; const float2* inorm;
   int* surv_cnt; int* surv_idx; float* surv_sc; int* tile_flag;
+  // item-stationary GEO filter (score_filter_items_kernel): the users' half fragments, per-user bound terms and last-POI coordinates
+  // (ctx scratch; users_packed16 == nullptr: the user-stationary filter), and the CU count for its persistent grid
+  uint4* users_packed16; float4* ubound; double* ugeo; int n_cu;
   int bins_ntile;           // item tiles per user-tile row of the bin matrix when the call scores only a PREFIX of the item table (0: = tiles of n_item)
 };
 bool score_two_stage_supported(const ScoreArgs& A);

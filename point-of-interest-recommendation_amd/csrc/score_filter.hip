@@ -253,6 +253,203 @@ __global__ __launch_bounds__(256, (BINS == 3 ? 2 : 3)) void score_filter_kernel(
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------------------
+// ITEM-STATIONARY filter pass for the GEO path with a huge item table and few users (config X's evaluation: 8192 users x 10 M POIs).
+// score_filter_kernel gives every user tile its own pass over the item table: 256 user tiles x 5.1 GB of half fragments = 1.3 TB per
+// call, HBM / MALL-bound (165 ms).  Here the loops are swapped: a workgroup keeps the B fragments of FOUR item tiles in registers (one
+// per wave) and walks the USER tiles, whose half fragments (4 MB in all: L2-resident) are staged through LDS once per workgroup and
+// shared by its four waves - the item table is read once, the users stream from L2 at a quarter of the volume.
+//   sf_users_prep_kernel   per user tile, once per call: the half fragments, and per user { c1 |u|_2, threshold - bound, largest distance
+//                          term }, the last-POI coordinates, and the tile flag of unseeded users - the prologue of score_filter_kernel,
+//                          the same expressions
+//   score_filter_items_kernel   the same tests as score_filter_kernel<D, 3> (coarse with the tile's largest distance term, float64
+//                          Haversine bin only for the (tile, row) pairs that pass), survivors into the same per-user lists
+// -------------------------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void sf_users_prep_kernel(ScoreArgs A, uint4* __restrict__ upk, float4* __restrict__ ub, double* __restrict__ ugeo) {
+  constexpr int KG = D / 16, CPT = D / 8;
+  __shared__ float s_n2[32], s_n1[32];
+  const int t = threadIdx.x, ut = blockIdx.x, NB = A.n_dist + 1;
+  const float wd = A.wd ? A.wd[0] : 0.f;
+  {
+    const int j = t >> 3, s = t & 7;
+    const int urow = min(ut * 32 + j, A.n - 1);
+    const float* up = A.users + (size_t)urow * D + s * CPT;
+    float n2 = 0.f, n1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < CPT / 8; ++g) {
+      const float4 v0 = *reinterpret_cast<const float4*>(up + 8 * g), v1 = *reinterpret_cast<const float4*>(up + 8 * g + 4);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      h8 hv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hv[e] = (_Float16)x[e]; n2 = fmaf(x[e], x[e], n2); n1 += fabsf(x[e]); }
+      const int col0 = s * CPT + 8 * g, m = col0 >> 4, hh = (col0 >> 3) & 1;
+      upk[((size_t)ut * KG + m) * 64 + 32 * hh + j] = __builtin_bit_cast(uint4, hv);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { n2 += __shfl_xor(n2, o, 64); n1 += __shfl_xor(n1, o, 64); }
+    if (s == 0) { s_n2[j] = n2; s_n1[j] = n1; }
+  }
+  __syncthreads();
+  bool unseeded = false;
+  if (t < 32) {
+    const int urow = ut * 32 + t, ur = min(urow, A.n - 1);
+    const float* srow = A.sts + (size_t)(ut * 32 + t) * NB;        // (sts has n_pad rows)
+    float pmax = 0.f, mx = 0.f;
+    for (int b = 0; b < NB; ++b) { const float p = srow[b]; pmax = fmaxf(pmax, fabsf(p)); mx = fmaxf(mx, wd * p); }
+    const unsigned g = urow < A.n ? A.gbound[urow] : 0u;
+    const float thr = g ? sf_ord2f(g) : -INFINITY;
+    const float nu2 = sqrtf(s_n2[t]) * 1.000002f;
+    constexpr float c1 = (9.765625e-4f * 1.0005f + (float)D * (2.38418579e-7f * 1.001f + 1.19209290e-7f) + 4.76837158e-7f) * 1.00001f;
+    const float bu = s_n1[t] * (2.98023224e-8f * 1.01f) + 4.76837158e-7f * (fabsf(wd) * pmax + (g ? fabsf(thr) : 0.f)) + 1e-30f;
+    // .w: the tile's maxima (user 0: largest c1 |u|_2, user 1: largest distance term) - what the filter's coarse test uses
+    float au = c1 * nu2, um = mx * 1.00000048f;
+    float aum = au, umm = um;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { aum = fmaxf(aum, __shfl_xor(aum, o, 64)); umm = fmaxf(umm, __shfl_xor(umm, o, 64)); }
+    ub[ut * 32 + t] = make_float4(au, urow < A.n ? thr - bu : INFINITY, um, t == 0 ? aum : t == 1 ? umm : 0.f);
+    unseeded = urow < A.n && !g;
+    const int lp = A.last_poi[ur];
+    double* gq = ugeo + (size_t)(ut * 32 + t) * 3;
+    gq[0] = A.coords[2 * lp]; gq[1] = A.coords[2 * lp + 1]; gq[2] = A.cphi[lp];
+  }
+  if (t < 64 && __any(unseeded) && t == 0) A.tile_flag[ut] = 1;      // an unseeded user: the whole tile goes to the one-stage kernel
+}
+
+// Workgroup barrier that orders LDS traffic only (tile_engine.hip's lds_barrier): __syncthreads() also waits for every outstanding GLOBAL
+// load of the wave (vmcnt(0)) - here the user tile requested two iterations ahead, i.e. a full L2 round trip per iteration: 2.7 us per
+// 32 x 32 x 256 tile product instead of 0.5.
+__device__ __forceinline__ void sf_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void score_filter_items_kernel(ScoreArgs A, const uint4* __restrict__ upk, const float4* __restrict__ ub,
+                                                                    const double* __restrict__ ugeo, int n_utile) {
+  constexpr int KG = D / 16, PF = KG * 64 / 256;      // uint4 of a user tile per thread
+  extern __shared__ __align__(16) float dyn[];
+  uint4* afb = reinterpret_cast<uint4*>(dyn);                        // [2][KG * 64]
+  float* s_cu = dyn + 2 * KG * 64 * 4;                               // [2][32] threshold - bound
+  float* s_mx = s_cu + 64;                                           // [2][2] tile maxima: c1 |u|_2, distance term
+  double* s_ug = reinterpret_cast<double*>(s_mx + 4);                // [2][32][3] last-POI latitude, longitude, cos(latitude)
+  double* s_geo = s_ug + 2 * 96;                                     // thr[n_dist]
+  int* s_flag = reinterpret_cast<int*>(s_geo + A.n_dist + 2);        // [n_utile] tile flags, read once per item group (a tile that overflows
+                                                                     // meanwhile only costs wasted work: it is redone by the one-stage kernel anyway)
+  const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, t = threadIdx.x;
+  const int N = A.n_item, NB = A.n_dist + 1, ntile = (N + 31) / 32, groups = (ntile + 3) / 4;
+  const float wd = A.wd ? A.wd[0] : 0.f;
+  const float gscale = (float)(12742.0 * 1000.0 / A.dd);
+  for (int i = t; i < A.n_dist; i += 256) s_geo[i] = A.thr[i];
+  // the next user tile is requested while the current one is multiplied (one register set; the barriers do not wait for it: sf_lds_barrier)
+  // (native vector types: an array of HIP's uint4 struct captured by the lambdas stayed in scratch memory - a store, a vmcnt(0) and a
+  // reload per iteration)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  u32x4 f0[PF]; f32x4v b0 = {0.f, INFINITY, 0.f, 0.f}; double g0 = 0.0;
+  const u32x4* upk4 = reinterpret_cast<const u32x4*>(upk);
+  const f32x4v* ub4 = reinterpret_cast<const f32x4v*>(ub);
+  u32x4* afb4 = reinterpret_cast<u32x4*>(afb);
+  auto fetch = [&](int ut) {
+    ut = min(ut, n_utile - 1);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) f0[q] = upk4[(size_t)ut * KG * 64 + t + 256 * q];
+    b0 = ub4[ut * 32 + (t & 31)];
+    g0 = ugeo[(size_t)ut * 96 + min(t, 95)];
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) afb4[buf * KG * 64 + t + 256 * q] = f0[q];
+    if (t < 32) {
+      s_cu[buf * 32 + t] = b0.y;
+      if (t < 2) s_mx[buf * 2 + t] = b0.w;           // the tile's maxima (sf_users_prep_kernel)
+    }
+    if (t < 96) s_ug[buf * 96 + t] = g0;
+  };
+  // Work unit = (chunk of user tiles, group of four item tiles), the chunk the SLOW index: every workgroup of the chip is on the same ~1 MB
+  // of user fragments at a time, which then live in the 4 MB L2 of every XCD; the item table is re-read once per chunk (x 4 at 8192 users:
+  // 20 GB from HBM).
+  const int uc = max(1, (1 << 20) / (KG * 1024)), n_chunk = (n_utile + uc - 1) / uc;
+  for (long long work = blockIdx.x; work < (long long)groups * n_chunk; work += gridDim.x) {
+    const int g = (int)(work % groups), u_lo = (int)(work / groups) * uc, u_hi = min(n_utile, u_lo + uc);
+    const int tile = min(4 * g + w, ntile - 1);
+    const bool tvalid = 4 * g + w < ntile;
+    uint4 b[KG];
+#pragma unroll
+    for (int m = 0; m < KG; ++m) b[m] = A.items_packed16[((size_t)tile * KG + m) * 64 + lane];
+    const int j = tile * 32 + li;
+    const bool jvalid = tvalid && j < N;
+    const float2 nm = A.inorm[min(j, N - 1)];
+    __syncthreads();                                 // (every wave is done with the buffers of the previous unit)
+    for (int i = t; i < u_hi - u_lo; i += 256) s_flag[i] = __hip_atomic_load(A.tile_flag + u_lo + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fetch(u_lo); put(0);
+    __syncthreads();
+    for (int ut = u_lo; ut < u_hi; ++ut) {
+      const int buf = (ut - u_lo) & 1;
+      fetch(ut + 1);
+      if (!s_flag[ut - u_lo]) {                      // (unseeded / overflowed tiles: the one-stage kernel takes them)
+        // all A fragments of the tile are requested before the first MFMA (read next to its MFMA, every product waited a full LDS round trip)
+        uint4 a[KG];
+#pragma unroll
+        for (int m = 0; m < KG; ++m) a[m] = afb[buf * KG * 64 + m * 64 + lane];
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a[0]), __builtin_bit_cast(h8, b[0]), zero, 0, 0, 0);
+#pragma unroll
+        for (int m = 1; m < KG; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a[m]), __builtin_bit_cast(h8, b[m]), acc, 0, 0, 0);
+        const float au = s_mx[buf * 2], ubt = s_mx[buf * 2 + 1];
+        const float tb = __fmaf_rn(au, nm.x, nm.y);
+        unsigned coarse = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                // rows 8 q + 4 h .. + 3 of the tile: registers 4 q .. 4 q + 3
+          const float4 c4 = *reinterpret_cast<const float4*>(s_cu + buf * 32 + 8 * q + 4 * h);
+          coarse |= !((acc[4 * q] + ubt) + tb <= c4.x) ? (1u << (4 * q)) : 0u;
+          coarse |= !((acc[4 * q + 1] + ubt) + tb <= c4.y) ? (2u << (4 * q)) : 0u;
+          coarse |= !((acc[4 * q + 2] + ubt) + tb <= c4.z) ? (4u << (4 * q)) : 0u;
+          coarse |= !((acc[4 * q + 3] + ubt) + tb <= c4.w) ? (8u << (4 * q)) : 0u;
+        }
+        if (!jvalid) coarse = 0;
+        if (__any(coarse != 0)) {
+          unsigned pass = 0;
+          const int jc = min(j, N - 1);
+          const double jlat = A.coords[2 * jc], jlon = A.coords[2 * jc + 1], jcp = A.cphi[jc];
+          const double pr = 0.017453292519943295;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (!__any((coarse >> r) & 1u)) continue;
+            const int ul = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const double* ug = s_ug + buf * 96 + 3 * ul;
+            int bin;
+            {
+#pragma clang fp contract(off)
+              const double aa = (ug[0] - jlat) * pr;
+              const double bb = (ug[1] - jlon) * pr;
+              const double c = (1.0 - cos_small(aa)) / 2 + ug[2] * jcp * (1.0 - cos_small(bb)) / 2;
+              bin = bin_of_c(c, s_geo, A.n_dist, gscale);
+            }
+            const float pv = A.sts[(size_t)(ut * 32 + ul) * NB + bin];
+            const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
+            pass |= (((coarse >> r) & 1u) && !(up <= s_cu[buf * 32 + ul])) ? (1u << r) : 0u;
+          }
+          if (__any(pass != 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (pass & (1u << r)) {
+                const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int pos = atomicAdd(A.surv_cnt + urow, 1);
+                if (pos < SF_CAP) A.surv_idx[(size_t)urow * SF_CAP + pos] = j;
+                else A.tile_flag[ut] = 1;
+              }
+            }
+          }
+        }
+      }
+      put(buf ^ 1);
+      sf_lds_barrier();
+    }
+  }
+}
+
 // 64-lane bitonic sort, best (highest score, then lowest id) first - as score_topk.hip's merge
 __device__ __forceinline__ void sf_wave_sort_desc(float& s, int& idx) {
   const int lane = lane_id();
@@ -415,6 +612,14 @@ static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStrea
     optin = true;
   }
   tm->begin("score_filter", st);
+  if (bins == 3 && A.users_packed16) {        // item-stationary (huge item table, few users): see score_filter_items_kernel
+    hipLaunchKernelGGL(sf_users_prep_kernel<D>, dim3(n_utile), dim3(256), 0, st, F, A.users_packed16, A.ubound, A.ugeo);
+    const size_t ldsi = sizeof(uint4) * 2 * (D / 16) * 64 + sizeof(float) * (64 + 4) + sizeof(double) * (2 * 96 + (size_t)A.n_dist + 2) + sizeof(int) * ((size_t)n_utile + 4);
+    const int groups = (ntile + 3) / 4;
+    const long long units = (long long)groups * ((n_utile + ((1 << 20) / ((D / 16) * 1024)) - 1) / ((1 << 20) / ((D / 16) * 1024)));
+    const int gridi = units < A.n_cu * 2 ? (int)units : A.n_cu * 2;
+    hipLaunchKernelGGL(score_filter_items_kernel<D>, dim3(gridi), dim3(256), ldsi, st, F, A.users_packed16, A.ubound, A.ugeo, n_utile);
+  } else
   if (bins == 3) hipLaunchKernelGGL((score_filter_kernel<D, 3>), grid, dim3(256), lds, st, F);
   else if constexpr (D <= 128) {
     if (bins == 1) hipLaunchKernelGGL((score_filter_kernel<D, 1>), grid, dim3(256), lds, st, F);

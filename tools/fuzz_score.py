@@ -70,7 +70,7 @@ def main():
             def run(seed=None, ks=0, two_stage=True):
                 idx = torch.empty((n, K), dtype=torch.int32, device="cuda")
                 sc = torch.empty((n, K), dtype=torch.float32, device="cuda")
-                ctx.set_topk_filter(two_stage)
+                ctx.set_topk_filter(("items" if s % 2 else "users") if (two_stage and mode == "geo") else two_stage)      # GEO: both filter loop orders
                 if seed is not None:
                     ctx.set_topk_seed(seed, ks)
                 try:
