@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-engine (float64) timing")
-    ap.add_argument("--no-x1", action="store_true", help="skip the secondary_x1 block (one GPU's slice of BASELINE.json configs[4], training only, a subprocess of ~12 s)")
+    ap.add_argument("--no-x1", action="store_true", help="skip the secondary_x1 block (one GPU's slice of BASELINE.json configs[4], training + one 8192-user evaluation, a subprocess of ~20 s)")
     ap.add_argument("--f16-rounding", default=None, choices=["nearest", "stochastic"],
                     help="write-back rounding of a half POI table (poi_ctx_set_f16_rounding); default: stochastic for --table-dtype f16 - keeps the L2 decay")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -664,12 +664,14 @@ def main():
         import subprocess
         try:
             t0 = time.perf_counter()
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape", "x1", "--steps", "8", "--warmup", "2", "--no-eval"],
-                               capture_output=True, text=True, timeout=240)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape", "x1", "--steps", "8", "--warmup", "2", "--eval-steps", "2"],
+                               capture_output=True, text=True, timeout=300)
             j = json.loads(r.stdout.strip().splitlines()[-1])
             secondary_x1 = {"workload": j["config"]["workload"], "table_storage": j["table_storage"], "f16_rounding": j["config"].get("f16_rounding"),
                             "train_seq_per_s": j["value"], "ms_per_epoch": j["ms_per_step"], "batch_users_per_launch": j["config"]["batch_users_per_launch"],
                             "dominant_kernel": j["roofline"]["kernel"], "dominant_frac": j["roofline"]["frac"], "wall_s_incl_data_generation": time.perf_counter() - t0,
+                            "eval_users_per_s": j.get("eval_users_per_s"), "eval_ms_per_8192_users_x_10M_pois": (j.get("eval") or {}).get("ms_per_eval"),
+                            "eval_filter_ms": ((j.get("eval") or {}).get("two_stage") or {}).get("ms_filter_per_eval"),
                             "tests": "tests/test_gpu_configx.py: the 10 M x 256 half table at full size (touched rows vs the float64 oracle, > 2^31-element indexing, stochastic rounding, GEO top-K over 10 M POIs)"}
         except Exception as e:          # (the block is informational: a failure must not cost the headline line)
             secondary_x1 = {"error": repr(e)[:300]}
@@ -750,7 +752,7 @@ def main():
             "reference_schedule_steps_per_s": reference_schedule and reference_schedule["seq_per_s"],
             "recall_headline_vs_reference": quality and quality["headline_vs_reference"]["recall_ratio"],
             "time_to_reference_recall_s": quality and {k: (v.get("seconds") if isinstance(v, dict) else v) for k, v in quality["time_to_recall"].items() if k.startswith("B=")},
-            "x1_train_seq_per_s": secondary_x1 and secondary_x1.get("train_seq_per_s"),
+            "x1_train_seq_per_s": secondary_x1 and secondary_x1.get("train_seq_per_s"), "x1_eval_users_per_s": secondary_x1 and secondary_x1.get("eval_users_per_s"),
             "dd25_1520_bins_train_seq_per_s": secondary_dd25 and secondary_dd25["train_seq_per_s"],
             "cpu_1core_seq_per_s": cpu and cpu["value"], "cpu_allcores_seq_per_s": cpu and cpu["all_cores"] and cpu["all_cores"]["value"],
         }
