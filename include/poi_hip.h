@@ -119,7 +119,8 @@ int poi_ctx_unregister_f16(poi_ctx* ctx, const void* ptr);
  * value is the float32 result and sub-ulp updates (the decay the reference applies at every step, public/GRU_Spatial.py:202-209) act in
  * expectation.  Counter-based: the same seed and launch sequence reproduce the same tables. */
 int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
-/* Arithmetic of the recurrent kernels of the tile engine at dim 64 / 128 (h_{t-1} . wh^T forward, da . wh backward - the contractions
+/* Arithmetic of the recurrent kernels of the tile engine (dim 64 / 128: register-resident weights; dim 256: the streaming kernels, whose
+ * weight planes are streamed from L2) (h_{t-1} . wh^T forward, da . wh backward - the contractions
  * of public/GRU_Spatial.py:127-171 that sit on the per-step dependency chain).  on = 1 (default): SPLIT products - both operands as three
  * bf16 planes (x = x1 + x2 + x3 to 2^-27), the six partial products down to 2^-16 on v_mfma_f32_16x16x32_bf16 with float32 accumulation:
  * the float32-input MFMA runs at the vector rate on gfx950, this form at 2.7x less matrix time and a product error of 2^-25 (below the

@@ -220,7 +220,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.lt_f16 = is_f16(c, P->lt);
   A.bintab = (poi::te_bintab(D, spatial, n_dist) && (predict || n >= c->bintab_min)) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
-  A.rec_split = (!A.rec32 && c->rec_split) ? 1 : 0;
+  A.rec_split = c->rec_split ? 1 : 0;          // (16-sequence tiles and the streaming kernels of dim 256 alike)
   A.rec1 = (!A.rec32 && n <= c->rec1_max) ? 1 : 0;
   A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;

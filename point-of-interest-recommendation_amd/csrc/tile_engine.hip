@@ -93,6 +93,25 @@ __device__ __forceinline__ void te_pack_block(const PackJob& j, const int vb, co
     }
     return;
   }
+  if (j.n16 == 4) {      // bf16 x 3 planes in v_mfma_f32_32x32x16_bf16 fragment order (streaming recurrent kernels <SP>): K8 field = K / 16,
+    //   P[((nt * KG + m) * 3 + plane) * 64 + lane] = 8 x bf16 { B_plane[16m + 8h + c][32 nt + j], c = 0..7 },  lane = 32 h + j
+    const int total4 = j.NT * j.K8 * 3 * 64;
+    for (int e = vb * TE_BLOCK + threadIdx.x; e < total4; e += nvb * TE_BLOCK) {
+      const int lane = e & 63, f = e >> 6, pl = f % 3, m = (f / 3) % j.K8, nt = (f / 3) / j.K8;
+      const int n = nt * 32 + (lane & 31), k0 = 16 * m + 8 * (lane >> 5);
+      unsigned h[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int k = k0 + c;
+        const float v = (k < j.K && n < j.N) ? j.src[(size_t)k * j.sk + (size_t)n * j.sn] : 0.f;
+        unsigned u[3];
+        split3(v, u[0], u[1], u[2]);
+        h[c] = (pl == 0 ? u[0] : pl == 1 ? u[1] : u[2]) >> 16;
+      }
+      reinterpret_cast<uint4*>(j.dst)[e] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    }
+    return;
+  }
   if (j.n16 == 2) {
     const int total3 = j.NT * j.K8 * 3 * 64;
     for (int e = vb * TE_BLOCK + threadIdx.x; e < total3; e += nvb * TE_BLOCK) {
@@ -281,6 +300,53 @@ __device__ __forceinline__ void mma16s_g1(f32x4& h, f32x4& l, f32x4& l2, const u
     l = mfma16b(a1, b[m][1], l); l2 = mfma16b(a2, b[m][0], l2);
     l = mfma16b(a3, b[m][0], l); l2 = mfma16b(a2, b[m][1], l2);
     l = mfma16b(a1, b3, l);
+  }
+}
+
+// Split products for the STREAMING recurrent kernels (te_rec_fwd32 / bwd32 <SP>: D = 256): A planes (bf16, 32 rows) in LDS, B planes streamed
+// from L2 in v_mfma_f32_32x32x16_bf16 fragment order (te_pack n16 == 4), one k group of prefetch as mma_lds_packed.  Six products per k group
+// into ONE accumulator per n tile (float32-level accuracy; the register file has no room for a second set).
+__device__ __forceinline__ f32x16 mfma32b(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int NTW, int KG>
+__device__ __forceinline__ void mma_lds_packed_s3(f32x16 (&acc)[1][NTW], const unsigned short* __restrict__ ldsA, int ldh,
+                                                  const float4* __restrict__ bp, const int (&nt)[NTW]) {
+  const int lane = lane_id(), li = lane & 31, h = lane >> 5, ps = 32 * ldh;
+  const unsigned short* arow = ldsA + li * ldh + 8 * h;
+  const uint4* bj[NTW];
+  uint4 bc[NTW][3], bn[NTW][3], ac[3], an[3];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    bj[j] = reinterpret_cast<const uint4*>(bp) + ((size_t)nt[j] * KG) * 3 * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bc[j][p] = bj[j][p * 64];
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) ac[p] = *reinterpret_cast<const uint4*>(arow + p * ps);
+#pragma unroll 2
+  for (int m = 0; m < KG; ++m) {
+    const int mn = m + 1 < KG ? m + 1 : m;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bn[j][p] = bj[j][((size_t)mn * 3 + p) * 64];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) an[p] = *reinterpret_cast<const uint4*>(arow + p * ps + 16 * mn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      acc[0][j] = mfma32b(ac[0], bc[j][2], acc[0][j]); acc[0][j] = mfma32b(ac[1], bc[j][1], acc[0][j]); acc[0][j] = mfma32b(ac[2], bc[j][0], acc[0][j]);
+      acc[0][j] = mfma32b(ac[0], bc[j][1], acc[0][j]); acc[0][j] = mfma32b(ac[1], bc[j][0], acc[0][j]);
+      acc[0][j] = mfma32b(ac[0], bc[j][0], acc[0][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bc[j][p] = bn[j][p];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) ac[p] = an[p];
   }
 }
 
@@ -1386,12 +1452,15 @@ __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
 // hides behind the 32x32x2 MFMAs.  Wave w owns hidden columns [D/4 * w, D/4 * (w + 1)) of all three gates, i.e.
 // TPW = D/128 n-tiles per gate: the state update is lane-local in the MFMA C layout.  Two barriers per step.
 // -------------------------------------------------------------------------------------------------
-template <int D, bool predict, int NWV>      // NWV waves per workgroup: wave w owns hidden columns [D / NWV * w, D / NWV * (w + 1))
+template <int D, bool predict, int NWV, bool SP = false>      // NWV waves per workgroup: wave w owns hidden columns [D / NWV * w, D / NWV * (w + 1)); SP: split products
 __global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int K8 = D / 8, LDA = D + 4, TPW = D / 32 / NWV, NTG = D / 32;       // NTG: n-tiles per gate
+  constexpr int LDH = D + 8, PS = 32 * LDH;
   float* Hb = lds;                       // h_{t-1}, overwritten by h_t   32 x LDA
   float* RHb = Hb + 32 * LDA;            // r * h_{t-1}
+  unsigned short* Hs = reinterpret_cast<unsigned short*>(lds);      // SP: 3 bf16 planes x 32 x LDH
+  unsigned short* RHs = Hs + 3 * PS;
   __shared__ int s_r0[32], s_ns[32];
   const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
   const int tile = blockIdx.x;
@@ -1401,7 +1470,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
     if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
   }
-  for (int e = tid; e < 32 * LDA; e += NWV * 64) Hb[e] = 0.f;
+  if constexpr (SP) { for (int e = tid; e < 3 * PS; e += NWV * 64) Hs[e] = 0; }
+  else { for (int e = tid; e < 32 * LDA; e += NWV * 64) Hb[e] = 0.f; }
   lds_barrier();
   int ns_max = 0;
   for (int i = 0; i < 32; ++i) ns_max = max(ns_max, s_ns[i]);
@@ -1433,7 +1503,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
     for (int j = 0; j < 2 * TPW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) azr[0][j][r] = 0.f;
-    mma_lds_packed<1, 2 * TPW, K8>(azr, Hb, LDA, A.pWhT16, ntzr);
+    if constexpr (SP) mma_lds_packed_s3<2 * TPW, D / 16>(azr, Hs, LDH, A.pWhT16, ntzr);
+    else mma_lds_packed<1, 2 * TPW, K8>(azr, Hb, LDA, A.pWhT16, ntzr);
     float zv[TPW][16];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
@@ -1443,7 +1514,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
         zv[i][r] = fast_sigmoid(azr[0][i][r] + gz[i][r]);
         const float rv = fast_sigmoid(azr[0][TPW + i][r] + gr[i][r]);
         const float rh = rv * hcur[i][r];
-        RHb[c_row(r, lane) * LDA + col] = rh;
+        if constexpr (SP) split3_store(RHs + c_row(r, lane) * LDH + col, PS, rh);
+        else RHb[c_row(r, lane) * LDA + col] = rh;
         if (!predict) { A.G[grow[r] * 3 * D + D + col] = rv; A.RH[grow[r] * D + col] = rh; }
       }
     float gc[TPW][16];
@@ -1457,7 +1529,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
     for (int j = 0; j < TPW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ac[0][j][r] = 0.f;
-    mma_lds_packed<1, TPW, K8>(ac, RHb, LDA, A.pWhT16, ntc);
+    if constexpr (SP) mma_lds_packed_s3<TPW, D / 16>(ac, RHs, LDH, A.pWhT16, ntc);
+    else mma_lds_packed<1, TPW, K8>(ac, RHb, LDA, A.pWhT16, ntc);
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -1465,7 +1538,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
         const int col = (w * TPW + i) * 32 + li;
         const float c = fast_tanh(ac[0][i][r] + gc[i][r]);
         const float hn = on[r] ? (1.0f - zv[i][r]) * hcur[i][r] + zv[i][r] * c : hcur[i][r];
-        Hb[c_row(r, lane) * LDA + col] = hn;          // nobody reads Hb between the two barriers of a step
+        if constexpr (SP) split3_store(Hs + c_row(r, lane) * LDH + col, PS, hn);
+        else Hb[c_row(r, lane) * LDA + col] = hn;     // nobody reads Hb between the two barriers of a step
         hcur[i][r] = hn;
         if (!predict) { A.G[grow[r] * 3 * D + col] = zv[i][r]; A.G[grow[r] * 3 * D + 2 * D + col] = c; A.H[grow[r] * D + col] = hn; }
       }
@@ -1482,12 +1556,15 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_fwd32_kernel(TeArgs A) {
   }
 }
 
-template <int D, int NWV>
+template <int D, int NWV, bool SP = false>
 __global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int K8 = D / 8, LDA = D + 4, LDB = 2 * D + 4, TPW = D / 32 / NWV;
+  constexpr int LHA = D + 8, LHB = 2 * D + 8;
   float* Ac = lds;                       // da_c           32 x LDA
   float* Azr = Ac + 32 * LDA;            // da_z | da_r    32 x LDB
+  unsigned short* Acs = reinterpret_cast<unsigned short*>(lds);      // SP: 3 bf16 planes x 32 x LHA
+  unsigned short* Azrs = Acs + 3 * 32 * LHA;                         //     3 planes x 32 x LHB
   __shared__ int s_r0[32], s_ns[32];
   const int lane = lane_id(), w = wave_id(), li = lane & 31, tid = threadIdx.x;
   const int tile = blockIdx.x;
@@ -1533,7 +1610,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
         daz[i][r] = dh * (c - h) * z * (1.0f - z);
         dhp[i][r] = dh * (1.0f - z);
         dacv[i][r] = dh * z * (1.0f - c * c);
-        Ac[c_row(r, lane) * LDA + col] = dacv[i][r];
+        if constexpr (SP) split3_store(Acs + c_row(r, lane) * LHA + col, 32 * LHA, dacv[i][r]);
+        else Ac[c_row(r, lane) * LDA + col] = dacv[i][r];
       }
     lds_barrier();
     f32x16 m[1][TPW];
@@ -1541,7 +1619,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
     for (int j = 0; j < TPW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) m[0][j][r] = 0.f;
-    mma_lds_packed<1, TPW, K8>(m, Ac, LDA, A.pWhc16, ntw);
+    if constexpr (SP) mma_lds_packed_s3<TPW, D / 16>(m, Acs, LHA, A.pWhc16, ntw);
+    else mma_lds_packed<1, TPW, K8>(m, Ac, LDA, A.pWhc16, ntw);
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -1551,8 +1630,13 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
         const float dr = mv * hp[i][r];
         dhp[i][r] += mv * rv[i][r];
         const float dar = dr * rv[i][r] * (1.0f - rv[i][r]);
-        Azr[ri * LDB + col] = daz[i][r];
-        Azr[ri * LDB + D + col] = dar;
+        if constexpr (SP) {
+          split3_store(Azrs + ri * LHB + col, 32 * LHB, daz[i][r]);
+          split3_store(Azrs + ri * LHB + D + col, 32 * LHB, dar);
+        } else {
+          Azr[ri * LDB + col] = daz[i][r];
+          Azr[ri * LDB + D + col] = dar;
+        }
         float* g = A.G + grow[r] * 3 * D + col;
         g[0] = daz[i][r]; g[D] = dar; g[2 * D] = dacv[i][r];
         sbz[i] += daz[i][r]; sbr[i] += dar; sbc[i] += dacv[i][r];        // zero for inactive steps (dh == 0)
@@ -1563,7 +1647,8 @@ __global__ __launch_bounds__(NWV * 64) void te_rec_bwd32_kernel(TeArgs A) {
     for (int j = 0; j < TPW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-    mma_lds_packed<1, TPW, 2 * K8>(acc, Azr, LDB, A.pWhzr16, ntw);
+    if constexpr (SP) mma_lds_packed_s3<TPW, 2 * D / 16>(acc, Azrs, LHB, A.pWhzr16, ntw);
+    else mma_lds_packed<1, TPW, 2 * K8>(acc, Azr, LDB, A.pWhzr16, ntw);
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -2610,6 +2695,9 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     if (A.rec1) {       // per-sequence kernels: plain transposes (the forward kernel reads wh itself)
       J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, 0, 0, A.pWhc16, 3};
       J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 0, 0, A.pWhzr16, 3};
+    } else if (A.rec32 && A.rec_split) {      // streaming kernels on split products: bf16 x 3 planes, 32x32x16 fragments
+      J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 16, D / 32, A.pWhc16, 4};
+      J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 16, D / 32, A.pWhzr16, 4};
     } else if (A.rec32) {      // 32-column fragments of the streaming recurrent kernels (same buffers)
       J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, D / 8, D / 32, A.pWhc16, 0};
       J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 2 * D / 8, D / 32, A.pWhzr16, 0};
@@ -2623,6 +2711,7 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   }
   // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments (32-column ones for the streaming kernels)
   if (A.rec1) {}      // (te_rec_fwd1 reads wh directly)
+  else if (A.rec32 && A.rec_split) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 32, A.pWhT16, 4};
   else if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
   else if (A.rec_split && (!A.fwd_tab || A.predict)) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table TRAINING launches keep the float32 kernel)
   else J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
@@ -2737,7 +2826,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   tm->begin("te_rec_fwd", st);
   if constexpr (D >= 128) {
-    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
+    if (A.rec32 && A.rec_split) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false, D / 32, true>), dim3((n + 31) / 32), dim3(D * 2), sizeof(short) * 2 * 3 * 32 * (D + 8), st, A);
+    else if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
@@ -2763,7 +2853,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->end(st);
   tm->begin("te_rec_bwd", st);
   if constexpr (D >= 128) {
-    if (A.rec32) hipLaunchKernelGGL((te_rec_bwd32_kernel<D, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
+    if (A.rec32 && A.rec_split) hipLaunchKernelGGL((te_rec_bwd32_kernel<D, D / 32, true>), dim3((n + 31) / 32), dim3(D * 2), sizeof(short) * 3 * 32 * (3 * D + 16), st, A);
+    else if (A.rec32) hipLaunchKernelGGL((te_rec_bwd32_kernel<D, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * (32 * (D + 4) + 32 * (2 * D + 4)), st, A);
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
@@ -2830,10 +2921,15 @@ static hipError_t te_optin_lds() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   // split-operand recurrent kernels at D = 128: 96 KB of third weight planes next to the operand planes
-  auto optin = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); };
+  auto optin = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); };
   optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, false, false, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, true, false, true>));
   optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, true, true, true>));
   optin(reinterpret_cast<const void*>(&te_rec_bwd16_kernel<128, true>));
+  // streaming kernels on split products: three bf16 planes per operand tile (101 KB forward, 147 KB backward at D = 256)
+  optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, false, 8, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true, 8, true>));
+  optin(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<256, 8, true>));
+  optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<128, false, 4, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<128, true, 4, true>));
+  optin(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<128, 4, true>));
   done = e == hipSuccess;
   return e;
 }
@@ -2878,7 +2974,8 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   te_launch_ax<D>(A, num_cu, st);
   if constexpr (D >= 128) {
-    if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
+    if (A.rec32 && A.rec_split) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true, D / 32, true>), dim3((n + 31) / 32), dim3(D * 2), sizeof(short) * 2 * 3 * 32 * (D + 8), st, A);
+    else if (A.rec32) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true, D / 32>), dim3((n + 31) / 32), dim3(D * 2), sizeof(float) * 2 * 32 * (D + 4), st, A);
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
