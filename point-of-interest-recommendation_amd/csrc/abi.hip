@@ -221,6 +221,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.bintab = (poi::te_bintab(D, spatial, n_dist) && (predict || n >= c->bintab_min)) ? 1 : 0;
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
   A.rec_split = c->rec_split ? 1 : 0;          // (16-sequence tiles and the streaming kernels of dim 256 alike)
+  A.head_split = (c->rec_split && A.spatial && P->n_dist + 1 > 256) ? 1 : 0;
   A.rec1 = (!A.rec32 && n <= c->rec1_max) ? 1 : 0;
   A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
@@ -264,7 +265,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
   A.RH = take(Tcap * D); A.DH = take(Tcap * D); A.rowloss = take(Tcap * 2);
   A.uiT = take((size_t)6 * D * D); A.uiP = take((size_t)3 * D * D);
-  A.pVsT = (float4*)take((size_t)NBP * D); A.pVs = (float4*)take((size_t)NBP * D);
+  A.pVsT = (float4*)take((size_t)NBP * D * 3 / 2); A.pVs = (float4*)take((size_t)NBP * D * 3 / 2);      // (x 1.5: te_head_big3 reads bf16 x 3 planes)
   // (x 1.5: the split-operand recurrent kernels keep every weight as three bf16 planes)
   A.pWhT16 = (float4*)take((size_t)9 * D * D / 2); A.pWhc16 = (float4*)take((size_t)3 * D * D / 2); A.pWhzr16 = (float4*)take((size_t)3 * D * D);
   if (A.bintab) {

@@ -137,6 +137,7 @@ struct TeArgs {
   float* uiT;                         // ui transposed (2D x 3D), K-contiguous B operand of te_gemm_dx
   float4 *pWhT16, *pWhc16, *pWhzr16;  // 16-column fragments (16x16x4 MFMA) for the recurrent kernels
   int rec_split;                      // recurrent kernels on bf16 x 3 split operands (te_rec_fwd16 / bwd16 <SP>)
+  int head_split;                     // chunked head (more than 256 bins) on split products: pVsT / pVs hold bf16 x 3 fragments
   int rec1;                           // per-sequence recurrent kernels on the vector ALUs (te_rec_fwd1 / bwd1): small launches
   float* slab;
   int n_slab, n_head, n_kc;

@@ -311,14 +311,15 @@ __device__ __forceinline__ f32x16 mfma32b(const uint4& a, const uint4& b, f32x16
 }
 template <int NTW, int KG>
 __device__ __forceinline__ void mma_lds_packed_s3(f32x16 (&acc)[1][NTW], const unsigned short* __restrict__ ldsA, int ldh,
-                                                  const float4* __restrict__ bp, const int (&nt)[NTW]) {
+                                                  const float4* __restrict__ bp, const int (&nt)[NTW], const int kstride = KG) {
+  // (kstride: k groups per n tile of the packed operand - more than KG when this call contracts over a K slice of it)
   const int lane = lane_id(), li = lane & 31, h = lane >> 5, ps = 32 * ldh;
   const unsigned short* arow = ldsA + li * ldh + 8 * h;
   const uint4* bj[NTW];
   uint4 bc[NTW][3], bn[NTW][3], ac[3], an[3];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
-    bj[j] = reinterpret_cast<const uint4*>(bp) + ((size_t)nt[j] * KG) * 3 * 64 + lane;
+    bj[j] = reinterpret_cast<const uint4*>(bp) + ((size_t)nt[j] * kstride) * 3 * 64 + lane;
 #pragma unroll
     for (int p = 0; p < 3; ++p) bc[j][p] = bj[j][p * 64];
   }
@@ -347,6 +348,52 @@ __device__ __forceinline__ void mma_lds_packed_s3(f32x16 (&acc)[1][NTW], const u
       for (int p = 0; p < 3; ++p) bc[j][p] = bn[j][p];
 #pragma unroll
     for (int p = 0; p < 3; ++p) ac[p] = an[p];
+  }
+}
+
+// The same with the B fragments of PF k groups in flight (a ring of PF + 1 register sets): for callers whose
+// B stream comes from L2 at ~1 us under load while one k group is 0.16 us of MFMA work (te_head_big3).
+template <int NTW, int KG, int PF>
+__device__ __forceinline__ void mma_lds_packed_s3p(f32x16 (&acc)[1][NTW], const unsigned short* __restrict__ ldsA, int ldh,
+                                                   const float4* __restrict__ bp, const int (&nt)[NTW], const int kstride = KG) {
+  constexpr int R = PF + 1;
+  const int lane = lane_id(), li = lane & 31, h = lane >> 5, ps = 32 * ldh;
+  const unsigned short* arow = ldsA + li * ldh + 8 * h;
+  const uint4* bj[NTW];
+  uint4 bq[R][NTW][3], ac[3], an[3];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) bj[j] = reinterpret_cast<const uint4*>(bp) + ((size_t)nt[j] * kstride) * 3 * 64 + lane;
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[u][j][p] = bj[j][((size_t)u * 3 + p) * 64];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) ac[p] = *reinterpret_cast<const uint4*>(arow + p * ps);
+  for (int m0 = 0; m0 < KG; m0 += R) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int m = m0 + u, ml = min(m + PF, KG - 1), mn = min(m + 1, KG - 1);
+      if (KG % R != 0 && m >= KG) break;
+      // (ring slot of group m + PF = the slot group m - 1 has just left)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[(u + PF) % R][j][p] = bj[j][((size_t)ml * 3 + p) * 64];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) an[p] = *reinterpret_cast<const uint4*>(arow + p * ps + 16 * mn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        acc[0][j] = mfma32b(ac[0], bq[u][j][2], acc[0][j]); acc[0][j] = mfma32b(ac[1], bq[u][j][1], acc[0][j]); acc[0][j] = mfma32b(ac[2], bq[u][j][0], acc[0][j]);
+        acc[0][j] = mfma32b(ac[0], bq[u][j][1], acc[0][j]); acc[0][j] = mfma32b(ac[1], bq[u][j][0], acc[0][j]);
+        acc[0][j] = mfma32b(ac[0], bq[u][j][0], acc[0][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ac[p] = an[p];
+    }
   }
 }
 
@@ -2157,6 +2204,253 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_big_kern
   }
 }
 
+// exp(x) for x <= 0 in six instructions: x log2(e) as a head and a tail (the fma recovers the product's rounding error, the second term
+// log2(e)'s), v_exp_f32 on the head, first-order correction for the tail; ~1 ulp like expf, without its range reduction and denormal
+// scaling - results below 2^-126 flush to zero (softmax terms), -inf and anything below -150 give exactly 0.
+__device__ __forceinline__ float exp_neg(float x) {
+  x = fmaxf(x, -150.f);
+  const float hi = x * 1.44269502162933349609375f;
+  const float lo = fmaf(x, 1.925963033500e-8f, fmaf(x, 1.44269502162933349609375f, -hi));
+  const float r = __builtin_amdgcn_exp2f(hi);
+  return fmaf(r, lo * 0.693147182464599609375f, r);
+}
+// te_head_big on split products (poi_ctx_set_split_products, the default): the same two passes, every float32 product formed from three
+// bf16 planes per operand (six v_mfma_f32_32x32x16_bf16 per 16 k, float32 accumulate: 2.7x the float32 matrix rate).  h is split when
+// the tile is staged; the d-logits chunk is split by the thread that computes it, into three bf16 planes that ALIAS the float32
+// logits chunk (every thread has its 32 logits in registers by then; one more barrier) - 77 KB per workgroup at D = 128, two
+// workgroups per CU.  The d-logits go to DL from registers (32-byte segments per row), d bs is summed from the planes (their sum is
+// the float32 value to 2^-24) straight into the workgroup's slab.  vs packed as te_pack n16 == 4 in both orientations.
+#ifndef TE_HB3_PFL
+#define TE_HB3_PFL 2      // k groups of B in flight: logits (two n tiles per wave), DH (one)
+#define TE_HB3_PFD 3
+#endif
+template <int D, int MODE>
+__global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 1 : 2)) void te_head_big3_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int KG = D / 16, LDH = D + 8, CH = 256, LDO = CH + 4, LDP = CH + 8, NTD = D / 32, DTW = (NTD + 3) / 4, LPR = D / 4;
+  const int NB = A.n_dist + 1, NBP = te_nbp_dev(A.n_dist), NCH = NBP / CH, KBG = NBP / 16;
+  unsigned short* Hp = reinterpret_cast<unsigned short*>(lds);      // 3 planes x 32 x LDH
+  float* Ot = reinterpret_cast<float*>(Hp + 3 * 32 * LDH);          // 32 x LDO: one 256-bin chunk of logits ...
+  unsigned short* Op = reinterpret_cast<unsigned short*>(Ot);        // ... then 3 planes x 32 x LDP of d logits
+  __shared__ float s_g[32], s_he[32], s_red[8];
+  __shared__ int s_a[32], s_b[32];
+  const int T = MODE ? A.n_seq : A.soff[A.n_seq];
+  const float* __restrict__ Hsrc = MODE ? A.hts : A.H;
+  const float* __restrict__ Esrc = A.E;
+  const int w = wave_id();
+  int tid = threadIdx.x, lane = tid & 63, li = tid & 31;
+  if ((int)blockIdx.x * 32 >= T) return;
+  float ls0 = 0.f, ls1 = 1.f, wd = 0.f;
+  {
+    const float a = A.lw[0], b = A.lw[1], m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    ls0 = ea / (ea + eb); ls1 = eb / (ea + eb); wd = A.wd[0];
+  }
+  float* hs = A.hslab + (size_t)blockIdx.x * A.hstride;
+  float dwd_acc = 0.f;
+  constexpr int SF4 = 32 * LPR / TE_BLOCK;
+  float4 ph[SF4], pe[SF4];
+  int pab = 0;
+  auto prefetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
+      const size_t gr = (size_t)min(r0 + r, T - 1);
+      ph[q] = *reinterpret_cast<const float4*>(Hsrc + gr * D + c);
+      if (!MODE) pe[q] = *reinterpret_cast<const float4*>(Esrc + gr * D + c);
+    }
+    if (!MODE) pab = A.row_ab[min(r0 + (tid & 31), T - 1)];
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
+      unsigned u[4][3];
+      split3(ph[q].x, u[0][0], u[0][1], u[0][2]); split3(ph[q].y, u[1][0], u[1][1], u[1][2]);
+      split3(ph[q].z, u[2][0], u[2][1], u[2][2]); split3(ph[q].w, u[3][0], u[3][1], u[3][2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint2*>(Hp + (p * 32 + r) * LDH + c) = make_uint2((u[0][p] >> 16) | (u[1][p] & 0xFFFF0000u), (u[2][p] >> 16) | (u[3][p] & 0xFFFF0000u));
+      if (!MODE) {
+        float d = (ph[q].x * pe[q].x + ph[q].y * pe[q].y) + (ph[q].z * pe[q].z + ph[q].w * pe[q].w);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+        if ((tid % LPR) == 0) s_he[r] = d;
+      }
+    }
+    if (!MODE && tid < 32) { s_a[tid] = pab & 0xffff; s_b[tid] = (pab >> 16) & 0xffff; }
+  };
+  auto logits = [&](int c) {
+    int nto[2];
+    float bsv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      nto[j] = c * 8 + w + 4 * j;
+      const int bin = nto[j] * 32 + li;
+      bsv[j] = A.bs[min(bin, NB - 1)];
+      bsv[j] = bin < NB ? bsv[j] : -INFINITY;
+    }
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    mma_lds_packed_s3p<2, KG, TE_HB3_PFL>(acc, Hp, LDH, A.pVsT, nto);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (w + 4 * j) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + col] = acc[0][j][r] + bsv[j];
+    }
+  };
+  HP_INIT
+  prefetch(blockIdx.x * 32);
+  stage();
+  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63; li = tid & 31;
+    lds_barrier();
+    HP(0)
+    const int row = tid >> 3, sub = tid & 7, gr = r0 + row;
+    const int a = MODE ? 0 : s_a[row], b = MODE ? 0 : s_b[row];
+    const float* o = Ot + row * LDO;
+    // ---- pass A: online softmax statistics of this lane's bins (k = sub mod 8) ----
+    float m_l = -INFINITY, S_l = 0.f, C_l = 0.f, la = 0.f, lb = 0.f;
+    for (int c = 0; c < NCH; ++c) {
+      logits(c);
+      HP(1)
+      lds_barrier();
+      HP(2)
+      float mc = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < CH / 8; ++i) mc = fmaxf(mc, o[sub + 8 * i]);
+      const float mn = fmaxf(m_l, mc);
+      if (mn > -INFINITY) {
+        const float sc = exp_neg(m_l - mn);     // exp(-inf) = 0 on the first chunk
+        float s = 0.f, cs = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH / 8; ++i) {
+          const int k = c * CH + sub + 8 * i;
+          const float e = exp_neg(o[sub + 8 * i] - mn);
+          s += e; cs += k <= a ? e : 0.f;
+        }
+        S_l = S_l * sc + s; C_l = C_l * sc + cs; m_l = mn;
+      }
+      if (!MODE) {                              // the two target logits, read by every lane of the row
+        if ((unsigned)(a - c * CH) < (unsigned)CH) la = o[a - c * CH];
+        if ((unsigned)(b - c * CH) < (unsigned)CH) lb = o[b - c * CH];
+      }
+      HP(3)
+      lds_barrier();
+      HP(4)
+    }
+    float mx = m_l;
+    mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx));
+    const float rs = m_l > -INFINITY ? exp_neg(m_l - mx) : 0.f;
+    float sum = S_l * rs, cum = C_l * rs;
+    sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
+    cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
+    const float inv = 1.0f / sum;
+    float g = 0.f, dot = 0.f, sa = 1.f;
+    const bool live = gr < T;
+    if (!MODE) {
+      cum *= inv;
+      sa = expf(la - mx) * inv;
+      const float sb = expf(lb - mx) * inv;
+      const float he = s_he[row];
+      const float u = he + wd * (sa - sb);
+      g = live ? -ls1 * sigmoidf_(-u) : 0.f;
+      dot = ls0 * cum - ls0 + g * wd * (sa - sb);
+      {
+        const size_t rsx = (size_t)min(gr, T);
+        A.rowloss[2 * rsx] = cum - logf(sa);
+        A.rowloss[2 * rsx + 1] = log_sigmoidf_(u);
+        A.gcoef[rsx] = g;
+      }
+      dwd_acc += sub == 0 ? g * (sa - sb) : 0.f;
+      if (sub == 0) s_g[row] = g;
+    }
+    // ---- pass B ----
+    int ntd[DTW];
+#pragma unroll
+    for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
+    prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
+    f32x16 dh[1][DTW];
+#pragma unroll
+    for (int j = 0; j < DTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[0][j][r] = 0.f;
+    for (int c = 0; c < NCH; ++c) {
+      logits(c);
+      lds_barrier();
+      HP(5)
+      float v[CH / 8];
+#pragma unroll
+      for (int i = 0; i < CH / 8; ++i) v[i] = o[sub + 8 * i];
+#pragma unroll
+      for (int i = 0; i < CH / 8; ++i) {
+        const int k = c * CH + sub + 8 * i;
+        const float s = exp_neg(v[i] - mx) * inv;
+        if (MODE) {
+          if (live && k < NB) A.sts[(size_t)gr * NB + k] = s;
+        } else {
+          float ds = (k <= a ? ls0 : 0.f);
+          if (k == a) ds += g * wd - ls0 / sa;
+          if (k == b) ds -= g * wd;
+          v[i] = (live && k < NB) ? s * (ds - dot) : 0.f;
+        }
+      }
+      lds_barrier();                              // every thread holds its logits: the planes may overwrite the chunk
+      HP(6)
+      if (!MODE) {
+        float* dl = A.DL + (size_t)min(gr, T) * NBP + c * CH + sub;
+        unsigned short* op = Op + row * LDP + sub;
+#pragma unroll
+        for (int i = 0; i < CH / 8; ++i) {
+          split3_store(op + 8 * i, 32 * LDP, v[i]);
+          dl[8 * i] = v[i];
+        }
+        lds_barrier();
+        HP(7)
+        {
+          float sd = 0.f;                         // (thread tid owns bin c * 256 + tid)
+#pragma unroll 8
+          for (int r = 0; r < 32; ++r) {
+            const unsigned short* q = Op + r * LDP + tid;
+            sd += (__uint_as_float((unsigned)q[0] << 16) + __uint_as_float((unsigned)q[32 * LDP] << 16)) + __uint_as_float((unsigned)q[64 * LDP] << 16);
+          }
+          const int k = c * CH + tid;
+          if (k < NB) hs[k] += sd;
+        }
+        mma_lds_packed_s3p<DTW, CH / 16, (DTW > 1 ? 1 : TE_HB3_PFD)>(dh, Op, LDP, A.pVs + (size_t)c * (CH / 16) * 3 * 64, ntd, KBG);
+        lds_barrier();                            // the next chunk's logits overwrite the planes
+        HP(8)
+      }
+    }
+    if (!MODE) {
+#pragma unroll
+      for (int j = 0; j < DTW; ++j) {
+        if (w + 4 * j >= NTD) continue;
+        const int col = ntd[j] * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = c_row(r, lane);
+          const float ge = Esrc[(size_t)min(r0 + i, T - 1) * D + col];
+          A.DH[(size_t)min(r0 + i, T) * D + col] = dh[0][j][r] + s_g[i] * ge;
+        }
+      }
+    }
+    stage();
+    HP(9)
+  }
+  HP_END
+  if (!MODE) {
+    const float dw = block_sum(dwd_acc, s_red);
+    if (tid == 0) hs[NB] += dw;
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // te_wgrad: split-K transposed GEMMs  out[m][n] = sum_r DA[r][m0+m] * Bsrc[r][n0+n]  on TxT output
 // blocks (T = 128 when D % 128 == 0, else 64); K-chunk c covers packed rows [c*chunk, (c+1)*chunk).
@@ -2667,6 +2961,12 @@ static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_
 
 template <int D>
 static hipError_t te_head_dispatch(const TeArgs& A, int mode, int grid, hipStream_t st) {
+  if (A.n_dist + 1 > 256 && A.head_split) {      // chunked head on split products
+    const size_t lds = sizeof(short) * 3 * 32 * (D + 8) + sizeof(short) * 3 * 32 * (256 + 8);
+    if (mode) hipLaunchKernelGGL((te_head_big3_kernel<D, 1>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
+    else hipLaunchKernelGGL((te_head_big3_kernel<D, 0>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
+    return hipGetLastError();
+  }
   if (A.n_dist + 1 > 256) {      // chunked head (te_head_big_kernel)
     const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (256 + 4) + te_nbp_dev(A.n_dist));
     if (mode) hipLaunchKernelGGL((te_head_big_kernel<D, 1>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
@@ -2686,10 +2986,12 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   const int D = A.dim, NBP = nbt_for(A.n_dist + 1) * 32, NB = A.n_dist + 1;
   int n = 0;
   // B[k][n] = vs[n][k]   (K = D, N = NB -> NBP)
-  if (A.spatial) J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 8, NBP / 32, A.pVsT};
+  if (A.spatial && A.head_split) J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 16, NBP / 32, A.pVsT, 4};
+  else if (A.spatial) J.j[n++] = PackJob{A.vs, 1, D, D, NB, D / 8, NBP / 32, A.pVsT};
   if (train) {
     // B[k][n] = vs[k][n]   (K = NB -> NBP, N = D)
-    if (A.spatial) J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
+    if (A.spatial && A.head_split) J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 16, D / 32, A.pVs, 4};
+    else if (A.spatial) J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
     // 16-column fragments of the recurrent kernels (16x16x4 MFMA): B[k][n] = wh[2][k][n] (K = D, N = D) and
     // B[k][n] = wh_flat[k][n], k < 2D (K = 2D, N = D)
     if (A.rec1) {       // per-sequence kernels: plain transposes (the forward kernel reads wh itself)
@@ -2930,6 +3232,10 @@ static hipError_t te_optin_lds() {
   optin(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<256, 8, true>));
   optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<128, false, 4, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<128, true, 4, true>));
   optin(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<128, 4, true>));
+  // chunked head on split products: 77 KB at D = 128, 101 KB at D = 256
+  optin(reinterpret_cast<const void*>(&te_head_big3_kernel<128, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<128, 1>));
+  optin(reinterpret_cast<const void*>(&te_head_big3_kernel<256, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<256, 1>));
+  optin(reinterpret_cast<const void*>(&te_head_big3_kernel<64, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<64, 1>));
   done = e == hipSuccess;
   return e;
 }
@@ -2938,12 +3244,12 @@ static hipError_t te_optin_lds() {
 static void te_head_prof_dump(const char* what) {
   unsigned long long h[4][10];
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_head_prof), sizeof(h)) != hipSuccess) return;
-  static const char* nm[10] = {"wait top barrier", "logits mfma + Ot write", "wait barrier 2", "prefetch + softmax", "wait barrier 3", "ge loads, DL copy, d bs", "DH mfma", "DH store", "stage", "-"};
+  static const char* nm[10] = {"wait top barrier", "logits mfma + Ot write", "wait barrier 2", "prefetch + softmax", "wait barrier 3", "ge loads, DL copy, d bs", "DH mfma", "DH store", "stage", "(te_head_big3: stage)"};
   for (int w = 0; w < 4; ++w) {
     unsigned long long tot = 0;
-    for (int i = 0; i < 9; ++i) tot += h[w][i];
+    for (int i = 0; i < 10; ++i) tot += h[w][i];
     fprintf(stderr, "[te_head prof %s] wave %d: total %.3e cycles;", what, w, (double)tot);
-    for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%;", nm[i], 100.0 * (double)h[w][i] / (double)(tot ? tot : 1));
+    for (int i = 0; i < 10; ++i) fprintf(stderr, " %s %.1f%%;", nm[i], 100.0 * (double)h[w][i] / (double)(tot ? tot : 1));
     fprintf(stderr, "\n");
   }
   unsigned long long z[4][10] = {};

@@ -546,14 +546,15 @@ def test_forked_write_back_is_bitwise_the_serial_one(pa, monkeypatch):
         assert np.array_equal(res["fork"][k], res["serial"][k]), k
 
 
-@pytest.mark.parametrize("dim,n_item,n_user", [(128, 120, 150), (128, 5000, 150), (64, 120, 70)])
-def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user):
+@pytest.mark.parametrize("dim,n_item,n_user,n_dist", [(128, 120, 150, 40), (128, 5000, 150, 40), (64, 120, 70, 40), (128, 300, 150, 1520), (256, 300, 40, 1520)])
+def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user, n_dist):
     """The three arithmetic forms of the recurrence - 16-sequence MFMA tiles on bf16 x 3 split products (poi_ctx_set_split_products, default
     for launches above the small-launch threshold), on float32-input MFMAs, and one sequence per workgroup on the vector ALUs
     (poi_ctx_set_small_launch, default for launches of <= 1024 sequences) - with the forward table (n_item small against the launch) and
     without (n_item 5000): training launch against the oracle's mean rule at the usual bars, predict against the oracle, and the
-    variants against each other (same bars: float32-accurate evaluations of the same step)."""
-    T = toy_problem(900 + dim + n_item, n_user=n_user, n_item=n_item, n_dist=40, dim=dim, len_max=11, hot=60)
+    variants against each other (same bars: float32-accurate evaluations of the same step).  1520 bins: the chunked head on split products
+    (te_head_big3) against the float32-input one (te_head_big); dim 256: the streaming recurrent kernels in both forms (no per-sequence form)."""
+    T = toy_problem(900 + dim + n_item, n_user=n_user, n_item=n_item, n_dist=n_dist, dim=dim, len_max=11, hot=60)
     P = spatial_params(900 + dim, T)
     users = np.random.default_rng(5).permutation(n_user)[: n_user - 5].astype(np.int32)
     exp, outs = _oracle_batch(P, T, users)
