@@ -71,29 +71,44 @@ __global__ __launch_bounds__(256) void pack_items_f16_kernel(const float* __rest
 // stage 1.  BINS: 0 = no distance term, 1 / 2 = resident bin matrix (uint8 / uint16, misc.hip::ulptai_kernel) + the users' bin probabilities,
 // 3 = GEO: bins computed on the fly from the coordinates (poi_score_topk_geo: no U x N matrix; config X) - only for the pairs whose
 // approximate score + bound + the LARGEST possible distance term of the user can exceed the threshold (as score_kernel_geo_stream)
-template <int D, int BINS>
-__global__ __launch_bounds__(256, (BINS == 3 ? 2 : 3)) void score_filter_kernel(ScoreArgs A) {
+// UT = 2 (resident bin matrix / no distance term): the workgroup holds TWO user tiles and every wave scores both against each item tile it
+// loads - the kernel's time is proportional to the item fragments it pulls out of L2 (loading them twice doubles it: 2.8 -> 5.3 ms at the
+// Gowalla shape), so one load now feeds sixteen MFMAs instead of eight.  68 KB of LDS and ~190 registers: two workgroups per CU.
+template <int D, int BINS, int UT>
+__global__ __launch_bounds__(256, ((BINS == 3 || UT == 2) ? 2 : 3)) void score_filter_kernel(ScoreArgs A) {
   constexpr int KG = D / 16, CPT = D / 8, QN = (BINS == 1 || BINS == 2) ? BINS : 1;
   constexpr bool GEO = BINS == 3;
+  static_assert(!(GEO && UT != 1), "the GEO filter keeps one user tile per workgroup");
   extern __shared__ __align__(16) float dyn[];
-  uint4* af = reinterpret_cast<uint4*>(dyn);               // [KG][64] half fragments of the user tile
-  float* s_au = dyn + KG * 64 * 4;                         // 32: c1 |u|_2
-  float* s_c = s_au + 32;                                  // 32: threshold - user part of the bound
-  float* s_n2 = s_c + 32; float* s_n1 = s_n2 + 32;         // 32 + 32
-  float* s_sts = s_n1 + 32;                                // 32 x NB (BINS)
   const int lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5, t = threadIdx.x;
   const int N = A.n_item, NB = A.n_dist + 1;
+  // per user tile: [KG][64] half fragments | 32: c1 |u|_2 | 32: threshold - user part of the bound | 32 + 32 | 32 x NB (BINS)
+  const int ustride = KG * 64 * 4 + 128 + (BINS ? ((32 * NB + 3) & ~3) : 0);
+  auto af_of = [&](int u) { return reinterpret_cast<uint4*>(dyn + u * ustride); };
+  auto au_of = [&](int u) { return dyn + u * ustride + KG * 64 * 4; };
+  auto c_of = [&](int u) { return au_of(u) + 32; };
+  auto n2_of = [&](int u) { return au_of(u) + 64; };
+  auto n1_of = [&](int u) { return au_of(u) + 96; };
+  auto sts_of = [&](int u) { return au_of(u) + 128; };
+  float* s_sts = sts_of(0);
   // GEO: thr[n_dist] | user lat[32] | lon[32] | cos(lat)[32] (doubles, 8-byte aligned behind the float block) | ub[32]
   double* s_geo = reinterpret_cast<double*>(s_sts + ((32 * NB + 1) & ~1));
   double* s_ulat = s_geo + A.n_dist; double* s_ulon = s_ulat + 32; double* s_ucp = s_ulon + 32;
   float* s_ub = reinterpret_cast<float*>(s_ucp + 32);
-  const int ut = blockIdx.x;
+  const int n_utile = (A.n + 31) / 32;
+  int utv[UT];                                             // (a workgroup past the last user tile scores the last one again and drops the result)
+#pragma unroll
+  for (int u = 0; u < UT; ++u) utv[u] = min((int)blockIdx.x * UT + u, n_utile - 1);
+  const bool phantom = UT == 2 && (int)blockIdx.x * UT + 1 >= n_utile;
   const int split = blockIdx.y * POI_NWAVE + w;
   const int ntile = (N + 31) / 32;
   const int tps = (ntile + A.n_split - 1) / A.n_split;
   const int t_begin = split * tps, t_end = min(ntile, t_begin + tps);
   const float wd = (BINS && A.wd) ? A.wd[0] : 0.f;
-  {
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const int ut = utv[u];
+    uint4* af = af_of(u);
     const int j = t >> 3, s = t & 7;
     const int urow = min(ut * 32 + j, A.n - 1);
     const float* up = A.users + (size_t)urow * D + s * CPT;
@@ -110,8 +125,8 @@ __global__ __launch_bounds__(256, (BINS == 3 ? 2 : 3)) void score_filter_kernel(
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) { n2 += __shfl_xor(n2, o, 64); n1 += __shfl_xor(n1, o, 64); }
-    if (s == 0) { s_n2[j] = n2; s_n1[j] = n1; }
-    if (BINS) for (int i = t; i < 32 * NB; i += 256) s_sts[i] = A.sts[(size_t)ut * 32 * NB + i];
+    if (s == 0) { n2_of(u)[j] = n2; n1_of(u)[j] = n1; }
+    if (BINS) for (int i = t; i < 32 * NB; i += 256) sts_of(u)[i] = A.sts[(size_t)ut * 32 * NB + i];
     if (GEO) {
       for (int i = t; i < A.n_dist; i += 256) s_geo[i] = A.thr[i];
       if (t < 32) {
@@ -121,135 +136,166 @@ __global__ __launch_bounds__(256, (BINS == 3 ? 2 : 3)) void score_filter_kernel(
     }
   }
   __syncthreads();
-  if (t < 32) {
-    const int urow = ut * 32 + t;
+  if (t < 32 * UT) {
+    const int u = t >> 5, tt = t & 31;
+    const float* sts = sts_of(u);
+    const int urow = utv[u] * 32 + tt;
     float pmax = 0.f;
-    if (BINS) for (int b = 0; b < NB; ++b) pmax = fmaxf(pmax, fabsf(s_sts[t * NB + b]));
+    if (BINS) for (int b = 0; b < NB; ++b) pmax = fmaxf(pmax, fabsf(sts[tt * NB + b]));
     const unsigned g = urow < A.n ? A.gbound[urow] : 0u;
     const float thr = g ? sf_ord2f(g) : -INFINITY;
-    const float nu2 = sqrtf(s_n2[t]) * 1.000002f;
+    const float nu2 = sqrtf(n2_of(u)[tt]) * 1.000002f;
     constexpr float c1 = (9.765625e-4f * 1.0005f + (float)D * (2.38418579e-7f * 1.001f + 1.19209290e-7f) + 4.76837158e-7f) * 1.00001f;
-    const float bu = s_n1[t] * (2.98023224e-8f * 1.01f) + 4.76837158e-7f * (fabsf(wd) * pmax + (g ? fabsf(thr) : 0.f)) + 1e-30f;
-    s_au[t] = c1 * nu2;
-    s_c[t] = urow < A.n ? thr - bu : INFINITY;             // rows past n: nothing survives
-    s_n2[t] = (urow < A.n && !g) ? 1.f : 0.f;              // an unseeded user (no bound: malformed / missing seed row)
+    const float bu = n1_of(u)[tt] * (2.98023224e-8f * 1.01f) + 4.76837158e-7f * (fabsf(wd) * pmax + (g ? fabsf(thr) : 0.f)) + 1e-30f;
+    au_of(u)[tt] = c1 * nu2;
+    c_of(u)[tt] = urow < A.n ? thr - bu : INFINITY;        // rows past n: nothing survives
+    n2_of(u)[tt] = (urow < A.n && !g) ? 1.f : 0.f;         // an unseeded user (no bound: malformed / missing seed row)
     if (GEO) {                                             // ub = max_b wd sts[b] (>= 0: column n_dist is zero), widened: >= every exact product
       float mx = 0.f;
-      for (int b = 0; b < NB; ++b) mx = fmaxf(mx, wd * s_sts[t * NB + b]);
-      s_ub[t] = mx * 1.00000048f;
+      for (int b = 0; b < NB; ++b) mx = fmaxf(mx, wd * sts[tt * NB + b]);
+      s_ub[tt] = mx * 1.00000048f;
     }
   }
   __syncthreads();
+  bool dead[UT];
   {
     // a tile with an unseeded user would keep every pair of that user: it goes to the one-stage kernel as a whole, at once
-    bool unseeded = false;
-    for (int i = 0; i < 32; ++i) unseeded |= s_n2[i] != 0.f;
-    if (unseeded) { if (t == 0) A.tile_flag[ut] = 1; return; }
+    bool all_dead = true;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      bool unseeded = false;
+      for (int i = 0; i < 32; ++i) unseeded |= n2_of(u)[i] != 0.f;
+      if (unseeded && t == 0 && !(u == 1 && phantom)) A.tile_flag[utv[u]] = 1;
+      dead[u] = unseeded || (u == 1 && phantom);
+      all_dead &= dead[u];
+    }
+    if (all_dead) return;
   }
   // (the norm part of the bound uses the LARGEST c1 |u|_2 of the tile's 32 users: one fma per lane and tile instead of one per pair and
   // sixteen registers less - the hidden states of a model have similar norms, so the bound loosens by a few per cent at most)
-  float cc[16], au = 0.f;
+  float cc[UT][16], au[UT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) cc[r] = s_c[(r & 3) + 8 * (r >> 2) + 4 * h];
-  for (int i = 0; i < 32; ++i) au = fmaxf(au, s_au[i]);
+  for (int u = 0; u < UT; ++u) {
+    au[u] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cc[u][r] = c_of(u)[(r & 3) + 8 * (r >> 2) + 4 * h];
+    for (int i = 0; i < 32; ++i) au[u] = fmaxf(au[u], au_of(u)[i]);
+  }
   float ubt = 0.f;                 // GEO: the largest distance term any user of the tile can get (one register instead of sixteen)
   if (GEO) for (int i = 0; i < 32; ++i) ubt = fmaxf(ubt, s_ub[i]);
   const float gscale = GEO ? (float)(12742.0 * 1000.0 / A.dd) : 0.f;
   const uint4* bp = A.items_packed16 + lane;
-  const uint4* qp = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)ut * ntile * 64 + lane) * QN;
+  const uint4* qp[UT];
+#pragma unroll
+  for (int u = 0; u < UT; ++u) qp[u] = reinterpret_cast<const uint4*>(A.ulptai) + ((size_t)utv[u] * ntile * 64 + lane) * QN;
   const int sbase = 4 * h * NB;
-  uint4 b[KG], qn[QN];
+  uint4 b[KG], qn[UT][QN];
   float2 nm = make_float2(0.f, 0.f);
   if (t_begin < t_end) {
 #pragma unroll
     for (int m = 0; m < KG; ++m) b[m] = bp[((size_t)t_begin * KG + m) * 64];
     if (BINS == 1 || BINS == 2) {
 #pragma unroll
-      for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)t_begin * 64 * QN + q];
+      for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int q = 0; q < QN; ++q) qn[u][q] = qp[u][(size_t)t_begin * 64 * QN + q];
     }
     nm = A.inorm[min(t_begin * 32 + li, N - 1)];
   }
-  int flagv = 0;
+  int flagv[UT];
+#pragma unroll
+  for (int u = 0; u < UT; ++u) flagv[u] = 0;
   for (int tile = t_begin; tile < t_end; ++tile) {
     // a tile whose survivor lists overflowed (useless seeds: thresholds far below the final ones) is rescored by the one-stage kernel
     // anyway: the flag is polled every 16 item tiles, one poll period ahead (no wait on the load), and the wave stops
     if (((tile - t_begin) & 15) == 0) {
-      if (flagv) break;
-      flagv = __hip_atomic_load(A.tile_flag + ut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool all_dead = true;
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        dead[u] |= flagv[u] != 0;
+        all_dead &= dead[u];
+        flagv[u] = __hip_atomic_load(A.tile_flag + utv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (all_dead) break;
     }
     const int nt = min(tile + 1, t_end - 1);               // (branch-free: the last tile reloads itself)
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int m = 0; m < KG; ++m) {
-      const h8 a = __builtin_bit_cast(h8, af[m * 64 + lane]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(h8, b[m]), acc, 0, 0, 0);
-      b[m] = bp[((size_t)nt * KG + m) * 64];               // this k-group of the NEXT tile
-    }
     const int j = tile * 32 + li;
     const bool jvalid = j < N;
-    const float tb = __fmaf_rn(au, nm.x, nm.y);
-    unsigned pass = 0;
-    if constexpr (GEO) {
-      // coarse test with the largest distance term the user can get; the float64 Haversine bin only for the (tile, row) pairs that pass
-      unsigned coarse = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) coarse |= !((acc[r] + ubt) + tb <= cc[r]) ? (1u << r) : 0u;
-      if (!jvalid) coarse = 0;
-      if (__any(coarse != 0)) {
-        const int jc = min(j, N - 1);
-        const double jlat = A.coords[2 * jc], jlon = A.coords[2 * jc + 1], jcp = A.cphi[jc];
-        const double pr = 0.017453292519943295;
+    for (int u = 0; u < UT; ++u) {
+      const uint4* af = af_of(u);
+      const float* sts = sts_of(u);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int m = 0; m < KG; ++m) {
+        const h8 a = __builtin_bit_cast(h8, af[m * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(h8, b[m]), acc, 0, 0, 0);
+        if (u == UT - 1) b[m] = bp[((size_t)nt * KG + m) * 64];               // this k-group of the NEXT tile
+      }
+      const float tb = __fmaf_rn(au[u], nm.x, nm.y);
+      unsigned pass = 0;
+      if constexpr (GEO) {
+        // coarse test with the largest distance term the user can get; the float64 Haversine bin only for the (tile, row) pairs that pass
+        unsigned coarse = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) coarse |= !((acc[r] + ubt) + tb <= cc[u][r]) ? (1u << r) : 0u;
+        if (!jvalid) coarse = 0;
+        if (__any(coarse != 0)) {
+          const int jc = min(j, N - 1);
+          const double jlat = A.coords[2 * jc], jlon = A.coords[2 * jc + 1], jcp = A.cphi[jc];
+          const double pr = 0.017453292519943295;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (!__any((coarse >> r) & 1u)) continue;
+            const int ul = (r & 3) + 8 * (r >> 2) + 4 * h;
+            int bin;
+            {
+#pragma clang fp contract(off)
+              const double a = (s_ulat[ul] - jlat) * pr;
+              const double bb = (s_ulon[ul] - jlon) * pr;
+              const double c = (1.0 - cos_small(a)) / 2 + s_ucp[ul] * jcp * (1.0 - cos_small(bb)) / 2;
+              bin = bin_of_c(c, s_geo, A.n_dist, gscale);
+            }
+            const float pv = sts[ul * NB + bin];
+            const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
+            pass |= (((coarse >> r) & 1u) && !(up <= cc[u][r])) ? (1u << r) : 0u;
+          }
+        }
+      } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (!__any((coarse >> r) & 1u)) continue;
-          const int ul = (r & 3) + 8 * (r >> 2) + 4 * h;
-          int bin;
-          {
-#pragma clang fp contract(off)
-            const double a = (s_ulat[ul] - jlat) * pr;
-            const double bb = (s_ulon[ul] - jlon) * pr;
-            const double c = (1.0 - cos_small(a)) / 2 + s_ucp[ul] * jcp * (1.0 - cos_small(bb)) / 2;
-            bin = bin_of_c(c, s_geo, A.n_dist, gscale);
+          if (r == 8) __builtin_amdgcn_sched_barrier(0);     // two batches of eight gathers: sixteen in flight cost the occupancy
+          float pv = 0.f;
+          if (BINS) {
+            int bin;
+            if (BINS == 1) { const unsigned wv = r < 4 ? qn[u][0].x : r < 8 ? qn[u][0].y : r < 12 ? qn[u][0].z : qn[u][0].w; bin = (wv >> (8 * (r & 3))) & 255u; }
+            else { const uint4 qq = qn[u][(r >> 3) & (QN - 1)]; const int e = r & 7; const unsigned wv = e < 2 ? qq.x : e < 4 ? qq.y : e < 6 ? qq.z : qq.w; bin = (wv >> (16 * (e & 1))) & 65535u; }
+            pv = sts[sbase + ((r & 3) + 8 * (r >> 2)) * NB + bin];
           }
-          const float pv = s_sts[ul * NB + bin];
           const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
-          pass |= (((coarse >> r) & 1u) && !(up <= cc[r])) ? (1u << r) : 0u;
+          pass |= !(up <= cc[u][r]) ? (1u << r) : 0u;        // (a NaN survives)
         }
       }
-    } else {
+      if (BINS == 1 || BINS == 2) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r == 8) __builtin_amdgcn_sched_barrier(0);       // two batches of eight gathers: sixteen in flight cost the occupancy
-      float pv = 0.f;
-      if (BINS) {
-        int bin;
-        if (BINS == 1) { const unsigned wv = r < 4 ? qn[0].x : r < 8 ? qn[0].y : r < 12 ? qn[0].z : qn[0].w; bin = (wv >> (8 * (r & 3))) & 255u; }
-        else { const uint4 qq = qn[(r >> 3) & (QN - 1)]; const int e = r & 7; const unsigned wv = e < 2 ? qq.x : e < 4 ? qq.y : e < 6 ? qq.z : qq.w; bin = (wv >> (16 * (e & 1))) & 65535u; }
-        pv = s_sts[sbase + ((r & 3) + 8 * (r >> 2)) * NB + bin];
+        for (int q = 0; q < QN; ++q) qn[u][q] = qp[u][(size_t)nt * 64 * QN + q];
       }
-      const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
-      pass |= !(up <= cc[r]) ? (1u << r) : 0u;             // (a NaN survives)
-    }
-    }
-    if (BINS == 1 || BINS == 2) {
+      if (!jvalid || dead[u]) pass = 0;
+      if (__any(pass != 0)) {
 #pragma unroll
-      for (int q = 0; q < QN; ++q) qn[q] = qp[(size_t)nt * 64 * QN + q];
+        for (int r = 0; r < 16; ++r) {
+          if (pass & (1u << r)) {
+            const int urow = utv[u] * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int pos = atomicAdd(A.surv_cnt + urow, 1);
+            if (pos < SF_CAP) A.surv_idx[(size_t)urow * SF_CAP + pos] = j;
+            else A.tile_flag[utv[u]] = 1;
+          }
+        }
+      }
     }
     nm = A.inorm[min(nt * 32 + li, N - 1)];
-    if (!jvalid) pass = 0;
-    if (__any(pass != 0)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (pass & (1u << r)) {
-          const int urow = ut * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int pos = atomicAdd(A.surv_cnt + urow, 1);
-          if (pos < SF_CAP) A.surv_idx[(size_t)urow * SF_CAP + pos] = j;
-          else A.tile_flag[ut] = 1;
-        }
-      }
-    }
   }
 }
 
@@ -586,8 +632,14 @@ bool score_two_stage_supported(const ScoreArgs& A) {
   return A.geo ? (A.dim == 64 || A.dim == 128 || A.dim == 256) : (A.dim == 64 || A.dim == 128);      // (the users' bin probabilities live in LDS: 32 x (n_dist + 1) floats)
 }
 
+// user tiles per workgroup: two while both fit twice into a CU's LDS (two workgroups per CU), else one
+static int score_filter_ut(int dim, int n_dist, bool bins, bool geo) {
+  const size_t per_tile = sizeof(float) * ((size_t)(dim / 16) * 64 * 4 + 128 + (bins ? ((32 * (size_t)(n_dist + 1) + 3) & ~(size_t)3) : 0));
+  return (!geo && 2 * per_tile <= 79 * 1024) ? 2 : 1;
+}
 size_t score_filter_lds(int dim, int n_dist, bool bins, bool geo) {
-  return sizeof(float) * ((size_t)(dim / 16) * 64 * 4 + 128 + (bins ? ((32 * (size_t)(n_dist + 1) + 1) & ~(size_t)1) : 0)) + (geo ? sizeof(double) * (size_t)(n_dist + 96) + sizeof(float) * 32 : 0);
+  const size_t per_tile = sizeof(float) * ((size_t)(dim / 16) * 64 * 4 + 128 + (bins ? ((32 * (size_t)(n_dist + 1) + 3) & ~(size_t)3) : 0));
+  return score_filter_ut(dim, n_dist, bins, geo) * per_tile + (geo ? sizeof(double) * (size_t)(n_dist + 96) + sizeof(float) * 32 : 0);
 }
 
 template <int D>
@@ -599,13 +651,17 @@ static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStrea
   tm->end(st);
   ScoreArgs F = A; F.n_split = n_split_f;
   const size_t lds = score_filter_lds(D, A.n_dist, bins != 0, bins == 3);
-  const dim3 grid(n_utile, n_split_f / POI_NWAVE);
+  const int ut = score_filter_ut(D, A.n_dist, bins != 0, bins == 3);
+  const dim3 grid((n_utile + ut - 1) / ut, n_split_f / POI_NWAVE);
   static bool optin = false;
   if (!optin) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipSuccess;
+    auto big = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    big(reinterpret_cast<const void*>(&score_filter_kernel<D, 3, 1>));
     if constexpr (D <= 128) {
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_filter_kernel<D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      big(reinterpret_cast<const void*>(&score_filter_kernel<D, 2, 1>)); big(reinterpret_cast<const void*>(&score_filter_kernel<D, 1, 1>));
+      big(reinterpret_cast<const void*>(&score_filter_kernel<D, 2, 2>)); big(reinterpret_cast<const void*>(&score_filter_kernel<D, 1, 2>));
+      big(reinterpret_cast<const void*>(&score_filter_kernel<D, 0, 2>));
     }
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_rescore_kernel<D / 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
@@ -620,11 +676,13 @@ static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStrea
     const int gridi = units < A.n_cu * 2 ? (int)units : A.n_cu * 2;
     hipLaunchKernelGGL(score_filter_items_kernel<D>, dim3(gridi), dim3(256), ldsi, st, F, A.users_packed16, A.ubound, A.ugeo, n_utile);
   } else
-  if (bins == 3) hipLaunchKernelGGL((score_filter_kernel<D, 3>), grid, dim3(256), lds, st, F);
+  if (bins == 3) hipLaunchKernelGGL((score_filter_kernel<D, 3, 1>), grid, dim3(256), lds, st, F);
   else if constexpr (D <= 128) {
-    if (bins == 1) hipLaunchKernelGGL((score_filter_kernel<D, 1>), grid, dim3(256), lds, st, F);
-    else if (bins == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2>), grid, dim3(256), lds, st, F);
-    else hipLaunchKernelGGL((score_filter_kernel<D, 0>), grid, dim3(256), lds, st, F);
+    if (bins == 1 && ut == 2) hipLaunchKernelGGL((score_filter_kernel<D, 1, 2>), grid, dim3(256), lds, st, F);
+    else if (bins == 1) hipLaunchKernelGGL((score_filter_kernel<D, 1, 1>), grid, dim3(256), lds, st, F);
+    else if (bins == 2 && ut == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2, 2>), grid, dim3(256), lds, st, F);
+    else if (bins == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2, 1>), grid, dim3(256), lds, st, F);
+    else hipLaunchKernelGGL((score_filter_kernel<D, 0, 2>), grid, dim3(256), lds, st, F);
   } else return hipErrorInvalidValue;
   tm->end(st);
   constexpr int D8 = D / 8;

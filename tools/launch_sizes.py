@@ -19,6 +19,8 @@ m = poi_amd.models.OboSpatialGru(train=tab, test=None, dist=None, alpha_lambda=[
                                  n_dists=[ds.dist_num, ds.dd / 1000.0], n_in=D, n_hidden=D, device=dev, seed=7, coords=ds.coords)
 ctx = m.ctx
 ctx.set_batch_cap(64.0)
+if os.environ.get("LS_GRAPH"):      # hipGraph replay of the launches (poi_ctx_set_graph)
+    ctx.set_graph(True)
 lens = np.diff(tab.off.astype(np.int64))
 KN = ["te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_psum", "te_wgrad", "te_gemm_dx", "te_finalize", "te_dsum", "te_bin_gemm",
       "te_scatter", "te_tail", "dense_apply"]
