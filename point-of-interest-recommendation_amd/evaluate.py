@@ -45,10 +45,11 @@ def rank_metrics(all_ranks, tes_buys_masks, tes_masks, at_nums):
     return out
 
 
-def coalesce_ranges(starts_ends, target=16384):
+def coalesce_ranges(starts_ends, target=65536):
     """Merge consecutive contiguous id ranges into calls of up to `target` users.  The reference evaluates in
     batch_size_test users per call (Params.compute_start_end); the metrics are sums over users, so the grouping is
-    free - and the scoring kernel is at its best at 16384 users per call (call sizes)."""
+    free - and the two-stage scoring path is at its best with as many users per call as there are (INTEGRATION.md, call sizes;
+    the cap bounds the per-call survivor lists: 32 KB per user)."""
     out, cur = [], None
     for se in starts_ends:
         se = np.asarray(se)
