@@ -128,6 +128,7 @@ struct TeArgs {
   int *dch0, *dch1;                   // first 64-entry chunk / first super-chunk of each bin (+ total)
   float* dpart2; int *dnf, *dnf2, *dbn;   // super-chunk partial sums; distinct-sequence counts per chunk / super-chunk / bin
   int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
+  int early_bins; float bin_alpha, bin_lambda;      // the distance-bin chain of the write-back starts on the side stream behind te_wgrad (launch_te_train)
   // packed-row workspace
   int *soff, *row_src, *row_t, *row_p, *row_dp, *row_ab;   // packed row -> CSR position, step index, input table rows (lt, di)
   float *X, *E, *G, *H, *RH, *DH, *DL, *rowloss;   // DL: d logits (T x padded bins)
@@ -204,6 +205,7 @@ hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st);
 int te_wgrad_ui_jobs(int D, int n_dist, bool spatial, bool bintab);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
+hipError_t launch_te_bins(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm);      // te_scatter.hip: per-bin sums of DA -> d di, d ui[:, D:]
 int te_nbp(int n_dist);
 void launch_te_iota(int* buf, int n, hipStream_t st);
 hipError_t launch_te_one(TeArgs& A, float alpha, float lambda, int l_cap, hipStream_t st, Timing* tm);      // n_seq == 1, whole step

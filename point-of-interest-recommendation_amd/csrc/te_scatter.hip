@@ -732,35 +732,51 @@ __global__ __launch_bounds__(4 * D) void te_dui_kernel(TeArgs A) {
   if (qtr == 0) A.slab[A.dl.ui + (size_t)k * 2 * D + D + c] = (qp[0][c] + qp[1][c]) + (qp[2][c] + qp[3][c]);
 }
 
+// The distance-bin chain: per-bin sums of DA -> the two small dense products -> the bin rows' write-back.  It needs DA (te_rec_bwd), the
+// sorted entries and the OLD ui / di, and writes only its own buffers, the di rows and the di half of slab 0's d ui.
+template <int D>
+static hipError_t te_bins_t(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm) {
+  // the per-bin reduction of DA rows is scatter traffic (te_dsum: one pass over DA at HBM speed); the two small
+  // dense products that follow (S . ui[:, D:], S^T . di) are timed on their own
+  tm->begin("te_dsum", sb);
+  hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(TE_DPREP_T), 0, sb, A);
+  hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, sb, A);
+  tm->end(sb);
+  tm->begin("te_bin_gemm", sb);
+  hipLaunchKernelGGL(te_dred_kernel<D>, dim3(num_cu * 2), dim3(3 * D), 0, sb, A);
+  hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, sb, A);
+  hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(4 * D), 0, sb, A);
+  hipLaunchKernelGGL(te_dapply_kernel<D>, dim3(A.n_dist + 1), dim3(D), 0, sb, A, alpha, lambda);
+  tm->end(sb);
+  return hipGetLastError();
+}
+hipError_t launch_te_bins(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm) {
+  if (A.dim == 64) return te_bins_t<64>(A, alpha, lambda, num_cu, sb, tm);
+  if (A.dim == 128) return te_bins_t<128>(A, alpha, lambda, num_cu, sb, tm);
+  if (A.dim == 256) return te_bins_t<256>(A, alpha, lambda, num_cu, sb, tm);
+  return hipErrorInvalidValue;
+}
+
 template <int D>
 static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm) {
   const int R = A.n_item + 1 + A.n_dist + 1;
   int grid = (R + 3) / 4;
   if (grid > num_cu * 32) grid = num_cu * 32;
   if (A.side && hipStreamWaitEvent(st, A.ev_sorted, 0) != hipSuccess) return hipGetLastError();     // the sorted entries
-  // The distance-bin chain (per-bin sums of DA -> the two small dense products -> the bin rows' write-back) and the POI rows' reduction
-  // below touch disjoint rows and share only read-only inputs (the sorted entries, DA, H): with a side stream they run next to each
-  // other - te_dsum streams DA at HBM speed while te_reduce is a chain of dependent loads, and the five small kernels of the bin chain
-  // hide behind the reduction.  (The events of the training phase are free again: both streams passed them in launch_te_train.)
-  // Timing: the regions te_dsum / te_bin_gemm (side stream) and te_scatter then OVERLAP and stretch each other; `te_tail` spans fork to join.
-  // (large launches only: the two cross-stream dependencies cost ~35 us, more than the whole tail of a one-sequence launch)
-  const bool fork = A.bintab && A.side && !(A.dbg & 1) && A.n_seq >= 2048;
+  // The distance-bin chain and the POI rows' reduction below touch disjoint rows and share only read-only inputs (the sorted entries,
+  // DA, H): with a side stream they run next to each other - te_dsum streams DA at HBM speed while te_reduce is a chain of dependent
+  // loads, and the five small kernels of the bin chain hide behind the reduction.  Large launches (A.early_bins): launch_te_train has
+  // already started the chain on the side stream, next to te_gemm_dx, and only the join is left here.  Otherwise it forks here
+  // (>= 2048 sequences) or runs inline (the two cross-stream dependencies cost ~35 us, more than the whole tail of a one-sequence launch).
+  // Timing: forked regions OVERLAP the main stream's and stretch each other; `te_tail` spans this function's fork to join.
+  const bool early = A.bintab && A.early_bins;
+  const bool fork = !early && A.bintab && A.side && !(A.dbg & 1) && A.n_seq >= 2048;
   hipStream_t sb = fork ? A.side : st;
   const long tail = tm->span_begin("te_tail", st);
   if (fork && (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(sb, A.ev_bwd, 0) != hipSuccess)) return hipGetLastError();
-  if (A.bintab) {
-    // the per-bin reduction of DA rows is scatter traffic (te_dsum: one pass over DA at HBM speed); the two small
-    // dense products that follow (S . ui[:, D:], S^T . di) are timed on their own
-    tm->begin("te_dsum", sb);
-    hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(TE_DPREP_T), 0, sb, A);
-    hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, sb, A);
-    tm->end(sb);
-    tm->begin("te_bin_gemm", sb);
-    hipLaunchKernelGGL(te_dred_kernel<D>, dim3(num_cu * 2), dim3(3 * D), 0, sb, A);
-    hipLaunchKernelGGL(te_dfin_kernel<D>, dim3(A.n_dist + 1), dim3(3 * D), 0, sb, A);
-    hipLaunchKernelGGL(te_dui_kernel<D>, dim3(3 * D), dim3(4 * D), 0, sb, A);
-    hipLaunchKernelGGL(te_dapply_kernel<D>, dim3(A.n_dist + 1), dim3(D), 0, sb, A, alpha, lambda);
-    tm->end(sb);
+  if (A.bintab && !early) {
+    hipError_t be = te_bins_t<D>(A, alpha, lambda, num_cu, sb, tm);
+    if (be != hipSuccess) return be;
   }
   if (fork && hipEventRecord(A.ev_fin, sb) != hipSuccess) return hipGetLastError();
   tm->begin("te_scatter", st);
@@ -770,6 +786,7 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu), dim3(256), 0, st, A, alpha, lambda);
   tm->end(st);
   if (fork && hipStreamWaitEvent(st, A.ev_fin, 0) != hipSuccess) return hipGetLastError();       // join: dense_apply reads te_dui's slab
+  if (early && hipStreamWaitEvent(st, A.ev_slots, 0) != hipSuccess) return hipGetLastError();     // (recorded behind the chain by launch_te_train)
   tm->span_end(tail, st);
   return hipGetLastError();
 }

@@ -3197,6 +3197,15 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
+  if (A.side && A.early_bins && A.bintab) {
+    // the distance-bin chain of the write-back needs nothing the main stream still has to produce: it starts here, next to te_gemm_dx
+    // (350 tiles on 512 workgroup slots), instead of at the fork in launch_te_scatter, which joins on ev_slots (ev_bwd / ev_slots: both
+    // streams passed them long ago)
+    if (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_bwd, 0) != hipSuccess) return hipGetLastError();
+    hipError_t be = launch_te_bins(A, A.bin_alpha, A.bin_lambda, num_cu, A.side, tm);
+    if (be != hipSuccess) return be;
+    if (hipEventRecord(A.ev_slots, A.side) != hipSuccess) return hipGetLastError();
+  }
   tm->begin("te_gemm_dx", st);
   {
     // dx = DA . ui: K = 3D is always wide enough for the compile-time-K kernel.  With the per-bin table only the

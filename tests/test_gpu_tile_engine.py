@@ -426,7 +426,7 @@ def test_fp16_poi_table_float32_math(pa, dim, n_user):
     assert abs(model.l2.eval() - O.l2_value({**Pn, "loss_weight": got["loss_weight"]}, 0.001, SP_NAMES)) <= 1e-5 * model.l2.eval()
 
 
-@pytest.mark.parametrize("dim,n_user,batch", [(128, 96, 32), (64, 40, 1), (256, 48, 16)])
+@pytest.mark.parametrize("dim,n_user,batch", [(128, 96, 32), (64, 40, 1), (256, 48, 16), (128, 2200, 2200)])      # (2200: the side-stream forks of large launches)
 def test_graph_replay_is_bitwise_the_eager_launch(pa, dim, n_user, batch):
     """poi_ctx_set_graph: the captured launch replays the same kernels in the same order - parameters and per-sequence outputs are
     bitwise those of eager launches, whatever uidx / out pointers the caller hands over (they are staged)."""
