@@ -440,10 +440,12 @@ def main():
         if k == "te_finalize":
             ent["note"] = "runs on the side stream next to te_wgrad / te_gemm_dx: its span overlaps them and is not part of the serial sum"
         if k in ("te_dsum", "te_bin_gemm", "te_scatter") and kt["te_tail"][1]:
-            ent["note"] = ("the distance-bin chain (te_dsum, te_bin_gemm; side stream) and te_scatter (POI rows) run CONCURRENTLY: their spans overlap and "
-                           "stretch each other (stand-alone: 0.37 / 0.14 / 0.44 ms per epoch, POI_TE_DBG=1) - te_tail is the fork-to-join span that counts")
+            ent["note"] = ("the distance-bin chain (te_dsum, te_bin_gemm) runs on the side stream from the end of te_wgrad on, next to te_gemm_dx and "
+                           "te_scatter (POI rows): the spans overlap and stretch each other (stand-alone: 0.37 / 0.14 / 0.44 ms per epoch, POI_TE_DBG=1) - "
+                           "te_tail, te_scatter's start to the join, is the span that counts")
         if k == "te_tail":
-            ent["note"] = "fork-to-join span of te_dsum + te_bin_gemm (side stream) next to te_scatter; the serial sums below use it instead of the three"
+            ent["note"] = ("te_scatter's start to the join with the side stream's distance-bin chain (te_dsum + te_bin_gemm, started behind te_wgrad); "
+                           "the serial sums below use it instead of the three")
         kernels[k] = ent
     dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
     # HBM traffic per launch from the COMMITTED PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
