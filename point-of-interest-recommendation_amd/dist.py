@@ -158,7 +158,22 @@ class ReplicaSync:
             if own_comm is None:
                 own_comm = self.active and dist.get_backend(group) == "nccl"
             if own_comm and self.active:
-                backend.init_comm(group)
+                # every rank must end up on the SAME collective: a rank whose communicator could not be built (or whose peers' could
+                # not) falls back, with all the others, to torch.distributed.all_reduce on the same buffers
+                err = None
+                try:
+                    backend.init_comm(group)
+                except Exception as e:      # noqa: BLE001 - reported below, then agreed on across ranks
+                    err = e
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.tensors[0].device if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0:
+                    import warnings
+                    warnings.warn("poi_comm_init_rank failed on at least one rank (%s): replica reconciliation falls back to "
+                                  "torch.distributed.all_reduce" % (err if err else "a peer"))
+                    if getattr(backend, "comm", None):
+                        backend.lib.poi_comm_destroy(backend.comm)
+                    backend.comm = None
         if isinstance(backend, HipSyncBackend) and own_comm is None:
             own_comm = False
         self.backend = backend
