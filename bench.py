@@ -300,7 +300,12 @@ def main():
 
         def eval_epoch():
             model.update_trained_items(); model.update_trained_dists()
-            hts, sts = model.predict_device(all_ids)
+            if n_eval < n_local:      # (--eval-users: predict the users that are scored, the other rows of the snapshots stay zero)
+                h_e, s_e = model.predict_device(all_ids[:n_eval])
+                hts = torch.zeros((n_local, h_e.shape[1]), dtype=h_e.dtype, device=dev); hts[:n_eval] = h_e
+                sts = torch.zeros((n_local, s_e.shape[1]), dtype=s_e.dtype, device=dev); sts[:n_eval] = s_e
+            else:
+                hts, sts = model.predict_device(all_ids)
             model.update_trained_users(hts); model.update_trained_sus(sts)
             hits = torch.zeros((), dtype=torch.int64, device=dev)
             for c0 in range(0, n_eval, a.eval_chunk):
@@ -347,7 +352,7 @@ def main():
         eval_users_per_s = (n_user if n_eval == n_local else n_eval) * a.eval_steps / dte
         fl = 2.0 * n_eval * n_item * D * a.eval_steps
         eval_detail = {"ms_per_eval": 1e3 * dte / a.eval_steps, "recall_at_20_after_timed_training": float(hits.item()) / n_eval,
-                       "users_scored_per_eval": n_eval, "users_predicted_per_eval": n_local,
+                       "users_scored_per_eval": n_eval, "users_predicted_per_eval": n_eval,
                        "distance_term": "resident bin matrix" if getattr(model, "_ulptai", None) is not None else "bins on the fly (poi_score_topk_geo)",
                        # 2 U N D over the time of ALL scoring kernels of a timed evaluation (filter + rescoring + pre-pass / fallback): an EQUIVALENT rate - the
                        # two-stage path does most of these flops on the f16 matrix pipe (see two_stage.filter_frac_of_f16_mfma_peak), so it may exceed the f32 peak
