@@ -2214,12 +2214,13 @@ __device__ __forceinline__ float exp_neg(float x) {
   const float r = __builtin_amdgcn_exp2f(hi);
   return fmaf(r, lo * 0.693147182464599609375f, r);
 }
-// te_head_big on split products (poi_ctx_set_split_products, the default): the same two passes, every float32 product formed from three
-// bf16 planes per operand (six v_mfma_f32_32x32x16_bf16 per 16 k, float32 accumulate: 2.7x the float32 matrix rate).  h is split when
-// the tile is staged; the d-logits chunk is split by the thread that computes it, into three bf16 planes that ALIAS the float32
-// logits chunk (every thread has its 32 logits in registers by then; one more barrier) - 77 KB per workgroup at D = 128, two
-// workgroups per CU.  The d-logits go to DL from registers (32-byte segments per row), d bs is summed from the planes (their sum is
-// the float32 value to 2^-24) straight into the workgroup's slab.  vs packed as te_pack n16 == 4 in both orientations.
+// te_head_big on split products (poi_ctx_set_split_products, the default): every float32 product formed from three bf16 planes per
+// operand (six v_mfma_f32_32x32x16_bf16 per 16 k, float32 accumulate: 2.7x the float32 matrix rate).  h is split when the tile is
+// staged.  Training: pass A leaves every logits chunk in DL, pass B reads it back (same thread: four adjacent bins x eight), turns it
+// into d logits in place and splits them into three bf16 planes that ALIAS pass A's float32 chunk - 77 KB per workgroup at D = 128,
+// two workgroups per CU - for the d h product; d bs is summed from the planes (their sum is the float32 value to 2^-24) straight
+// into the workgroup's slab.  Predict: the logits are recomputed for the probabilities.  vs packed as te_pack n16 == 4 in both
+// orientations.
 #ifndef TE_HB3_PFL
 #define TE_HB3_PFL 2      // k groups of B in flight: logits (two n tiles per wave), DH (one)
 #define TE_HB3_PFD 3
@@ -2340,6 +2341,11 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 1 : 2)) void te_head_big3_ker
       if (!MODE) {                              // the two target logits, read by every lane of the row
         if ((unsigned)(a - c * CH) < (unsigned)CH) la = o[a - c * CH];
         if ((unsigned)(b - c * CH) < (unsigned)CH) lb = o[b - c * CH];
+        // the chunk's logits wait in DL for pass B (the thread that stores them reads them back: no visibility question), which
+        // overwrites them with the d logits - a 2 x 6 KB round trip per row instead of a third pass over vs
+        float* dlr = A.DL + (size_t)min(gr, T) * NBP + c * CH + 4 * sub;
+#pragma unroll
+        for (int i = 0; i < CH / 32; ++i) *reinterpret_cast<float4*>(dlr + 32 * i) = *reinterpret_cast<const float4*>(o + 4 * sub + 32 * i);
       }
       HP(3)
       lds_barrier();
@@ -2381,35 +2387,45 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 1 : 2)) void te_head_big3_ker
     for (int j = 0; j < DTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[0][j][r] = 0.f;
-    for (int c = 0; c < NCH; ++c) {
-      logits(c);
-      lds_barrier();
-      HP(5)
-      float v[CH / 8];
-#pragma unroll
-      for (int i = 0; i < CH / 8; ++i) v[i] = o[sub + 8 * i];
-#pragma unroll
-      for (int i = 0; i < CH / 8; ++i) {
-        const int k = c * CH + sub + 8 * i;
-        const float s = exp_neg(v[i] - mx) * inv;
-        if (MODE) {
-          if (live && k < NB) A.sts[(size_t)gr * NB + k] = s;
-        } else {
-          float ds = (k <= a ? ls0 : 0.f);
-          if (k == a) ds += g * wd - ls0 / sa;
-          if (k == b) ds -= g * wd;
-          v[i] = (live && k < NB) ? s * (ds - dot) : 0.f;
-        }
-      }
-      lds_barrier();                              // every thread holds its logits: the planes may overwrite the chunk
-      HP(6)
-      if (!MODE) {
-        float* dl = A.DL + (size_t)min(gr, T) * NBP + c * CH + sub;
-        unsigned short* op = Op + row * LDP + sub;
+    if constexpr (MODE) {
+      for (int c = 0; c < NCH; ++c) {             // predict: logits again -> probabilities
+        logits(c);
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < CH / 8; ++i) {
-          split3_store(op + 8 * i, 32 * LDP, v[i]);
-          dl[8 * i] = v[i];
+          const int k = c * CH + sub + 8 * i;
+          const float s = exp_neg(o[sub + 8 * i] - mx) * inv;
+          if (live && k < NB) A.sts[(size_t)gr * NB + k] = s;
+        }
+        lds_barrier();
+      }
+    } else {
+      for (int c = 0; c < NCH; ++c) {
+        // this thread's 32 logits of the chunk, as pass A left them: bins 32 i + 4 sub + e
+        float* dlr = A.DL + (size_t)min(gr, T) * NBP + c * CH + 4 * sub;
+        float4 lv[CH / 32];
+#pragma unroll
+        for (int i = 0; i < CH / 32; ++i) lv[i] = *reinterpret_cast<const float4*>(dlr + 32 * i);
+        HP(5)
+        unsigned short* op = Op + row * LDP + 4 * sub;
+#pragma unroll
+        for (int i = 0; i < CH / 32; ++i) {
+          float v[4] = {lv[i].x, lv[i].y, lv[i].z, lv[i].w};
+          unsigned u[4][3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = c * CH + 32 * i + 4 * sub + e;
+            const float s = exp_neg(v[e] - mx) * inv;
+            float ds = (k <= a ? ls0 : 0.f);
+            if (k == a) ds += g * wd - ls0 / sa;
+            if (k == b) ds -= g * wd;
+            v[e] = (live && k < NB) ? s * (ds - dot) : 0.f;
+            split3(v[e], u[e][0], u[e][1], u[e][2]);
+          }
+          *reinterpret_cast<float4*>(dlr + 32 * i) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint2*>(op + p * 32 * LDP + 32 * i) = make_uint2((u[0][p] >> 16) | (u[1][p] & 0xFFFF0000u), (u[2][p] >> 16) | (u[3][p] & 0xFFFF0000u));
         }
         lds_barrier();
         HP(7)
@@ -2424,7 +2440,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 1 : 2)) void te_head_big3_ker
           if (k < NB) hs[k] += sd;
         }
         mma_lds_packed_s3p<DTW, CH / 16, (DTW > 1 ? 1 : TE_HB3_PFD)>(dh, Op, LDP, A.pVs + (size_t)c * (CH / 16) * 3 * 64, ntd, KBG);
-        lds_barrier();                            // the next chunk's logits overwrite the planes
+        lds_barrier();                            // the next chunk's planes overwrite these
         HP(8)
       }
     }
