@@ -2430,14 +2430,21 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 1 : 2)) void te_head_big3_ker
         lds_barrier();
         HP(7)
         {
-          float sd = 0.f;                         // (thread tid owns bin c * 256 + tid)
+          // (thread tid owns bin c * 256 + tid: two rows of a plane per v_dot2c_f32_bf16 against (1, 1) - the bf16 pair goes in as it is)
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+          float sd[3] = {0.f, 0.f, 0.f};
 #pragma unroll 8
-          for (int r = 0; r < 32; ++r) {
+          for (int r = 0; r < 32; r += 2) {
             const unsigned short* q = Op + r * LDP + tid;
-            sd += (__uint_as_float((unsigned)q[0] << 16) + __uint_as_float((unsigned)q[32 * LDP] << 16)) + __uint_as_float((unsigned)q[64 * LDP] << 16);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+              const unsigned pk = (unsigned)q[pl * 32 * LDP] | ((unsigned)q[pl * 32 * LDP + LDP] << 16);
+              sd[pl] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), ones, sd[pl], false);
+            }
           }
           const int k = c * CH + tid;
-          if (k < NB) hs[k] += sd;
+          if (k < NB) hs[k] += (sd[0] + sd[1]) + sd[2];
         }
         mma_lds_packed_s3p<DTW, CH / 16, (DTW > 1 ? 1 : TE_HB3_PFD)>(dh, Op, LDP, A.pVs + (size_t)c * (CH / 16) * 3 * 64, ntd, KBG);
         lds_barrier();                            // the next chunk's planes overwrite these
