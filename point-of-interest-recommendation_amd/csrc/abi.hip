@@ -231,7 +231,8 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
   A.dl = poi::dense_layout(D, A.xw, n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 192;   // + spare rows: row T and the rest of the last 128-row tile
-  const size_t pk = (size_t)12 * D * D + (size_t)9 * D * D + (size_t)2 * NBP * D + (size_t)12 * D * D + 64;
+  // uiT 6 + uiP 3 + pWhT16 4.5 + pWhc16 1.5 + pWhzr16 3 + pUiP3 4.5 + pUiT3 4.5 (x D^2), pVsT + pVs 2 x 1.5 NBP D, + the rounding of each carve
+  const size_t pk = (size_t)27 * D * D + (size_t)3 * NBP * D + 64;
   // sorted scatter (training): 3 slots per sequence position
   const bool sorted = !predict;
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
