@@ -125,7 +125,8 @@ int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
  * bf16 planes (x = x1 + x2 + x3 to 2^-27), the six partial products down to 2^-16 on v_mfma_f32_16x16x32_bf16 with float32 accumulation:
  * the float32-input MFMA runs at the vector rate on gfx950, this form at 2.7x less matrix time and a product error of 2^-25 (below the
  * float32 accumulation noise; the timed Gowalla launch measures 4.7e-6 against the float64 oracle, 5.7e-6 with on = 0).
- * The switch also covers the softmax head of configurations with more than 256 distance bins (the reference's dd = 25 m: 1520 bins,
+ * The switch also covers the forward table of large launches (every POI row times the POI half of ui: te_ptab_s3, dim 128) and
+ * the softmax head of configurations with more than 256 distance bins (the reference's dd = 25 m: 1520 bins,
  * public/GRU_Spatial.py:247): logits and d h of the chunked head on the same split products (te_head_big3) instead of float32-input MFMAs.
  * on = 0: float32-input v_mfma_f32_16x16x4_f32 (rounds 1 - 2).  Environment override at context creation: POI_TE_SPLIT=0|1. */
 int poi_ctx_set_split_products(poi_ctx* ctx, int on);

@@ -231,7 +231,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (const char* e = getenv("POI_TE_DBG")) A.dbg = atoi(e);
   A.dl = poi::dense_layout(D, A.xw, n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 192;   // + spare rows: row T and the rest of the last 128-row tile
-  // uiT 6 + uiP 3 + pWhT16 4.5 + pWhc16 1.5 + pWhzr16 3 + pUiP3 4.5 + pUiT3 4.5 (x D^2), pVsT + pVs 2 x 1.5 NBP D, + the rounding of each carve
+  // uiT 6 + uiP 3 + pWhT16 4.5 + pWhc16 1.5 + pWhzr16 3 + pUiP3 4.5 (x D^2) + spare, pVsT + pVs 2 x 1.5 NBP D, + the rounding of each carve
   const size_t pk = (size_t)27 * D * D + (size_t)3 * NBP * D + 64;
   // sorted scatter (training): 3 slots per sequence position
   const bool sorted = !predict;
@@ -268,6 +268,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.X = take(Tcap * 2 * D); A.E = take(Tcap * D); A.G = take(Tcap * 3 * D); A.H = take(Tcap * D);
   A.RH = take(Tcap * D); A.DH = take(Tcap * D); A.rowloss = take(Tcap * 2);
   A.uiT = take((size_t)6 * D * D); A.uiP = take((size_t)3 * D * D);
+  A.pUiP3 = (float4*)take((size_t)9 * D * D / 2);
   A.pVsT = (float4*)take((size_t)NBP * D * 3 / 2); A.pVs = (float4*)take((size_t)NBP * D * 3 / 2);      // (x 1.5: te_head_big3 reads bf16 x 3 planes)
   // (x 1.5: the split-operand recurrent kernels keep every weight as three bf16 planes)
   A.pWhT16 = (float4*)take((size_t)9 * D * D / 2); A.pWhc16 = (float4*)take((size_t)3 * D * D / 2); A.pWhzr16 = (float4*)take((size_t)3 * D * D);

@@ -135,6 +135,7 @@ struct TeArgs {
   float4 *pVsT, *pVs;
   // forward table (te_rec_fwd16<FT>): ptab = lt . ui[:, :D]^T over all n_item + 1 table rows; iota = 0..n_item, then n_item + 1
   float* ptab; const int* iota; int fwd_tab; float* uiP;       // uiP: ui's POI half with gate-interleaved rows
+  float4* pUiP3;                      // uiP as bf16 x 3 fragments (te_pack n16 == 4): B operand of te_ptab_s3 (the forward table on split products)
   float* uiT;                         // ui transposed (2D x 3D), K-contiguous B operand of te_gemm_dx
   float4 *pWhT16, *pWhc16, *pWhzr16;  // 16-column fragments (16x16x4 MFMA) for the recurrent kernels
   int rec_split;                      // recurrent kernels on bf16 x 3 split operands (te_rec_fwd16 / bwd16 <SP>)

@@ -93,17 +93,19 @@ __device__ __forceinline__ void te_pack_block(const PackJob& j, const int vb, co
     }
     return;
   }
-  if (j.n16 == 4) {      // bf16 x 3 planes in v_mfma_f32_32x32x16_bf16 fragment order (streaming recurrent kernels <SP>): K8 field = K / 16,
+  if (j.n16 == 4 || j.n16 == 5) {      // bf16 x 3 planes in v_mfma_f32_32x32x16_bf16 fragment order (streaming recurrent kernels <SP>): K8 field = K / 16,
+    // (n16 == 5: column n of B is row (n % 3) * (N / 3) + n / 3 of the source - the gate-interleaved columns of the forward table, te_uiperm's order)
     //   P[((nt * KG + m) * 3 + plane) * 64 + lane] = 8 x bf16 { B_plane[16m + 8h + c][32 nt + j], c = 0..7 },  lane = 32 h + j
     const int total4 = j.NT * j.K8 * 3 * 64;
     for (int e = vb * TE_BLOCK + threadIdx.x; e < total4; e += nvb * TE_BLOCK) {
       const int lane = e & 63, f = e >> 6, pl = f % 3, m = (f / 3) % j.K8, nt = (f / 3) / j.K8;
       const int n = nt * 32 + (lane & 31), k0 = 16 * m + 8 * (lane >> 5);
+      const int ns = j.n16 == 5 ? (n % 3) * (j.N / 3) + n / 3 : n;
       unsigned h[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int k = k0 + c;
-        const float v = (k < j.K && n < j.N) ? j.src[(size_t)k * j.sk + (size_t)n * j.sn] : 0.f;
+        const float v = (k < j.K && n < j.N) ? j.src[(size_t)k * j.sk + (size_t)ns * j.sn] : 0.f;
         unsigned u[3];
         split3(v, u[0], u[1], u[2]);
         h[c] = (pl == 0 ? u[0] : pl == 1 ? u[1] : u[2]) >> 16;
@@ -3040,7 +3042,94 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
   else if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
   else if (A.rec_split && (!A.fwd_tab || A.predict)) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table TRAINING launches keep the float32 kernel)
   else J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 16, A.pWhT16, 1};
+  // forward table on split products (te_ptab_s3): B[k][n] = ui[(n % 3) D + n / 3][k], k < D - the POI half of ui, gate-interleaved columns
+  if (A.fwd_tab && A.rec_split && D == 128) J.j[n++] = PackJob{A.ui, 1, A.xw, D, 3 * D, D / 16, 3 * D / 32, A.pUiP3, 5};
   J.n = n;
+}
+
+// The forward table on split products (poi_ctx_set_split_products): ptab[r][n] = sum_k lt[r][k] uiP[n][k] over the n_item + 1 table rows,
+// dim 128.  A workgroup takes 128 table rows; a wave keeps ITS 32 rows as resident A fragments - float32 (or half) rows fetched straight
+// into the fragment layout, split into three bf16 planes in registers (96 registers) - and walks the twelve 32-column tiles of uiP, whose
+// bf16 x 3 fragments (te_pack n16 == 4: 24 KB per column tile, already in lane order) all four waves read from LDS: one pass over uiP per
+// 128 rows out of L2 (a 32-row tile per pass would ask L2 for 0.9 GB per launch).  The fragments come in by LDS DMA
+// (global_load_lds_dwordx4: no staging registers - the kernel sits at the register cap) into a ring of three buffers, two column tiles
+// ahead of the one the MFMAs read: an L2 round trip is ~3 column tiles of matrix work.  The DMA is issued from inline asm, so the
+// waits are counted here (s_waitcnt vmcnt(N): the queue retires in order, N = what was issued behind the awaited tile - the C stores
+// of the tiles in between and the next tile's six requests) and the barriers are raw (no vmcnt(0) in front of them).  Six
+// v_mfma_f32_32x32x16_bf16 per 16 k, the leading product in its own accumulator.  Rows past the table's last go to the spare row
+// behind it, as in te_gemm_ntk.
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {      // lds_dst: the WAVE's destination (lane l lands at + 16 l)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int D, bool F16>
+__global__ __launch_bounds__(TE_BLOCK, 2) void te_ptab_s3_kernel(const void* __restrict__ tab, const int* __restrict__ n_ptr, const float4* __restrict__ Bp,
+                                                                 float* __restrict__ C) {
+  constexpr int KG = D / 16, N = 3 * D, NT = N / 32, FR = KG * 3 * 64, PT = FR / TE_BLOCK;      // uint4 fragments per column tile; per thread
+  static_assert(FR % TE_BLOCK == 0 && NT >= 4, "te_ptab_s3: fragment block per thread");
+  extern __shared__ __align__(16) float lds[];
+  uint4* s_b = reinterpret_cast<uint4*>(lds);                 // [3][FR]
+  const int n_rows = *n_ptr;
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
+  const uint4* bsrc = reinterpret_cast<const uint4*>(Bp);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)s_b;
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(w * 64) * 16u);
+  auto request = [&](int j) {                                  // column tile j -> ring slot j % 3: PT requests per thread
+    const unsigned dst = wbase + (unsigned)((j % 3) * FR) * 16u;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) glds16(bsrc + (size_t)j * FR + tid + q * TE_BLOCK, dst + (unsigned)(q * TE_BLOCK) * 16u);
+  };
+  const int n_tile = (n_rows + 127) / 128;
+  for (int t = blockIdx.x; t < n_tile; t += gridDim.x) {
+    uint4 a[KG][3];
+    {
+      const size_t row = (size_t)min(t * 128 + w * 32 + li, n_rows - 1);
+#pragma unroll
+      for (int m = 0; m < KG; ++m) {
+        const float4 x0 = ld4t(tab, row * D + 16 * m + 8 * h, F16), x1 = ld4t(tab, row * D + 16 * m + 8 * h + 4, F16);
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        unsigned u[8][3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3(x[e], u[e][0], u[e][1], u[e][2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[m][p] = make_uint4((u[0][p] >> 16) | (u[1][p] & 0xFFFF0000u), (u[2][p] >> 16) | (u[3][p] & 0xFFFF0000u),
+                               (u[4][p] >> 16) | (u[5][p] & 0xFFFF0000u), (u[6][p] >> 16) | (u[7][p] & 0xFFFF0000u));
+      }
+    }
+    // (the compiler has waited for the row loads above: nothing of this tile is in the queue yet; the previous tile's ring slots were
+    // released by its last barrier)
+    request(0); request(1);
+    for (int j = 0; j < NT; ++j) {
+      // tile j has landed when at most the requests / stores issued behind it are outstanding
+      if (j == 0) wait_vm<PT>();                               // behind tile 0: tile 1
+      else if (j == 1) wait_vm<PT + 16>();                     // tile 2, C stores of tile 0
+      else if (j == NT - 1) wait_vm<32>();                     // C stores of tiles NT - 3, NT - 2
+      else wait_vm<16 + PT + 16>();                            // C stores of j - 2, tile j + 1, C stores of j - 1
+      lds_barrier();                                           // every wave's part of tile j is in; slot (j + 2) % 3 (tile j - 1) has been read
+      if (j + 2 < NT) request(j + 2);
+      const uint4* cur = s_b + (j % 3) * FR + lane;
+      f32x16 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hi[r] = 0.f; lo[r] = 0.f; }
+#pragma unroll
+      for (int m = 0; m < KG; ++m) {
+        const uint4 b1 = cur[(m * 3 + 0) * 64], b2 = cur[(m * 3 + 1) * 64], b3 = cur[(m * 3 + 2) * 64];
+        hi = mfma32b(a[m][0], b1, hi);
+        lo = mfma32b(a[m][0], b3, lo); lo = mfma32b(a[m][1], b2, lo); lo = mfma32b(a[m][2], b1, lo);
+        lo = mfma32b(a[m][0], b2, lo); lo = mfma32b(a[m][1], b1, lo);
+      }
+      const int col = j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = min(t * 128 + w * 32 + c_row(r, lane), n_rows);
+        C[(size_t)rr * N + col] = hi[r] + lo[r];
+      }
+    }
+    lds_barrier();                                             // the last column tile has been read: the ring is free
+  }
 }
 
 // ax = x . ui^T + bi.  Spatial: POI half through the GEMM (K = D, B = the first D columns of ui), distance-bin
@@ -3055,6 +3144,12 @@ static void te_launch_ax_t(const TeArgs& A, int num_cu, hipStream_t st) {
       if (A.fwd_tab) {
         // forward table: ptab = lt . ui[:, :D]^T over the n_item + 1 table rows (identity "gather": the same kernel reads the rows of a
         // half table too), columns gate-interleaved like ztab's; te_rec_fwd16<FT> gathers ptab[p_t] + ztab[dp_t]
+        if constexpr (D == 128) {
+          if (A.rec_split) {      // split products: te_pack has left the gate-interleaved POI half of ui as bf16 x 3 fragments (te_pack_jobs)
+            hipLaunchKernelGGL((te_ptab_s3_kernel<D, F16>), dim3(num_cu * 2), block, sizeof(uint4) * 3 * (D / 16) * 3 * 64, st, A.lt, A.iota + A.n_item + 1, A.pUiP3, A.ptab);
+            return;
+          }
+        }
         hipLaunchKernelGGL(te_uiperm_kernel, dim3(3 * D * D / 1024), dim3(256), 0, st, A);
         NtArgs P{nullptr, 0, A.lt, nullptr, A.iota, nullptr, D, A.uiP, D, A.ptab, 3 * D, nullptr, A.iota + A.n_item + 1, 3 * D, D, nullptr, nullptr};
         hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, D, 3 * D, false, F16>), grid, block, 0, st, P);
@@ -3268,6 +3363,8 @@ static hipError_t te_optin_lds() {
   optin(reinterpret_cast<const void*>(&te_head_big3_kernel<128, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<128, 1>));
   optin(reinterpret_cast<const void*>(&te_head_big3_kernel<256, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<256, 1>));
   optin(reinterpret_cast<const void*>(&te_head_big3_kernel<64, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<64, 1>));
+  // forward table on split products: three 24 KB ring slots
+  optin(reinterpret_cast<const void*>(&te_ptab_s3_kernel<128, false>)); optin(reinterpret_cast<const void*>(&te_ptab_s3_kernel<128, true>));
   done = e == hipSuccess;
   return e;
 }

@@ -17,7 +17,8 @@ HOT = ["te_head_kernel<128, 7, 0>", "te_wgrad_kernel<128, 128, false>", "te_wgra
        "te_rec_fwd16_kernel<128, false, false, true>",       # split products
        "te_rec_bwd16_kernel<128, false>", "te_rec_bwd16_kernel<128, true>",
        "te_rec_fwd1_kernel<128, false>", "te_rec_bwd1_kernel<128>", "te_one_in_kernel<128>", "te_one_out_kernel<128>",
-       "te_head_big3_kernel<128, 0>",                        # chunked head (1520 bins) on split products: 247 registers, two workgroups per CU
+       "te_head_big3_kernel<128, 0>",                        # chunked head (1520 bins) on split products, two workgroups per CU
+       "te_ptab_s3_kernel<128, false>",                      # forward table on split products: 96 registers of resident A planes, LDS-DMA ring
        "te_gemm_ntk_kernel<false, true, 128, 128, 384, 128, 384, false, false>",
        "te_gemm_ntk_kernel<false, false, 384, 0, 128, 384, 256, false, false>"]
 # te_rec_bwd16<SP>: 96 registers of resident weight planes + two sets of operand prefetch + the split temporaries exceed the 256 registers of
