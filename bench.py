@@ -740,9 +740,11 @@ def main():
                        "replica_schedule": a.replica_schedule if (world > 1 or a.emulate_world) else None, "launches_per_epoch_per_replica": len(batches),
                        "f16_rounding": a.f16_rounding if a.table_dtype == "f16" else None,
                        "alpha": 0.01, "lambda": 0.001, "engine": "tile" if "te_rec_fwd" in kernels else "per-sequence",
-                       "arithmetic": "f32 results throughout; the recurrent kernels of launches above the small-launch bound form their f32 "
-                                     "products from three bf16 planes per operand (six MFMA partial products, f32 accumulate; <=5.1e-6 of the "
-                                     "f64 oracle, same bar as the f32 MFMA path -- tests/test_gpu_tile_engine.py); te_wgrad/te_head use the f32 MFMA",
+                       "arithmetic": "f32 results throughout; the recurrent kernels of launches above the small-launch bound and the forward table "
+                                     "(te_gemm_ax of large launches: te_ptab_s3) form their f32 products from three bf16 planes per operand (six MFMA "
+                                     "partial products, f32 accumulate; <=5.1e-6 of the f64 oracle, same bar as the f32 MFMA path -- "
+                                     "tests/test_gpu_tile_engine.py): their `frac` entries under `kernels` are f32-equivalent flops over the f32 "
+                                     "matrix peak; te_wgrad / te_head / te_gemm_dx use the f32 MFMA",
                        "s_rows_per_step": rho},
             "timed_window_s": dt,
             "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_dd25": secondary_dd25, "launch_sweep": launch_sweep, "secondary_x1": secondary_x1,
