@@ -41,6 +41,7 @@ struct poi_ctx {
   DevBuf pmark;             // per-POI regrouping: per lt row, S row + 1 of a step-input POI of this launch (te_passign; all-zero between launches)
   int ppoi = 1;             // POI_TE_PPOI=0 disables the regrouping (A/B)
   int early_bins = 1;       // distance-bin chain of the write-back starts next to te_gemm_dx on the side stream; POI_TE_EARLY_BINS=0: at the tail (A/B)
+  int early_min = 1024;     // ... for launches of at least this many sequences (POI_TE_EARLY_MIN; 1300 .. 2000 users: -5 % per launch against the inline chain)
   DevBuf kc_dev;            // te_wgrad's K-chunk split, chosen on the device per launch
   DevBuf ptab, iota;        // forward table (te_rec_fwd16<FT>): lt . ui[:, :D]^T per table row; 0..n_item, n_item + 1
   int iota_n = -1;          // rows the iota buffer currently describes
@@ -139,6 +140,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_EARLY_BINS")) c->early_bins = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_EARLY_MIN")) c->early_min = atoi(e);
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
@@ -430,7 +432,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.kc_dev = (E.bintab && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
-    E.early_bins = (c->early_bins && E.bintab && c->side && n >= 2048) ? 1 : 0; E.bin_alpha = alpha; E.bin_lambda = lambda;
+    E.early_bins = (c->early_bins && E.bintab && c->side && n >= c->early_min) ? 1 : 0; E.bin_alpha = alpha; E.bin_lambda = lambda;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)
     // one sequence (the reference schedule): the whole step in five kernels (tile_engine.hip, te_one_*)

@@ -766,7 +766,7 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   // The distance-bin chain and the POI rows' reduction below touch disjoint rows and share only read-only inputs (the sorted entries,
   // DA, H): with a side stream they run next to each other - te_dsum streams DA at HBM speed while te_reduce is a chain of dependent
   // loads, and the five small kernels of the bin chain hide behind the reduction.  Large launches (A.early_bins): launch_te_train has
-  // already started the chain on the side stream, next to te_gemm_dx, and only the join is left here.  Otherwise it forks here
+  // already started the chain on the side stream, next to te_gemm_dx, and only the join is left here.  Otherwise (early_bins off) it forks here
   // (>= 2048 sequences) or runs inline (the two cross-stream dependencies cost ~35 us, more than the whole tail of a one-sequence launch).
   // Timing: forked regions OVERLAP the main stream's and stretch each other; `te_tail` spans this function's fork to join.
   const bool early = A.bintab && A.early_bins;
