@@ -440,8 +440,16 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     auto run = [&](hipStream_t s) -> hipError_t {
       if (one) return poi::launch_te_one(E, alpha, lambda, T->max_len, s, &c->tm);
       hipError_t e = poi::launch_te_train(E, c->num_cu, s, &c->tm);
+      // early distance-bin chain (launch_te_train started it on the side stream behind te_wgrad): the dense write-back needs te_wgrad's slabs,
+      // te_finalize's parts and te_dui's - all of them older on the side stream - and nothing the POI rows' reduction on `s` reads: it
+      // follows the chain there, and launch_te_scatter's join (ev_slots) waits for both
+      const bool dense_side = E.early_bins && E.bintab && E.side;
+      if (e == hipSuccess && dense_side) {
+        e = poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, E.side, &c->tm);
+        if (e == hipSuccess) e = hipEventRecord(E.ev_slots, E.side);
+      }
       if (e == hipSuccess) e = poi::launch_te_scatter(E, alpha, lambda, c->num_cu, s, &c->tm);
-      if (e == hipSuccess) e = poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, s, &c->tm);
+      if (e == hipSuccess && !dense_side) e = poi::launch_dense_apply(A, spatial, n_slab, n_slab, alpha, lambda, s, &c->tm);
       return e;
     };
     const size_t out_bytes = sizeof(float) * (size_t)n * (spatial ? 5 : 1);

@@ -3322,7 +3322,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_bwd, 0) != hipSuccess) return hipGetLastError();
     hipError_t be = launch_te_bins(A, A.bin_alpha, A.bin_lambda, num_cu, A.side, tm);
     if (be != hipSuccess) return be;
-    if (hipEventRecord(A.ev_slots, A.side) != hipSuccess) return hipGetLastError();
+    // (the caller puts the dense write-back behind the chain on the side stream and records ev_slots: abi.hip)
   }
   tm->begin("te_gemm_dx", st);
   {
