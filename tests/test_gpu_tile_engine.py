@@ -457,28 +457,32 @@ def test_graph_replay_is_bitwise_the_eager_launch(pa, dim, n_user, batch):
 
 @pytest.mark.parametrize("n_item", [127, 128, 129, 255, 400, 641])
 def test_forward_table_any_table_size(pa, n_item):
-    """Forward table (te_gemm_ax over the n_item + 1 table rows, te_rec_fwd16 gathers): table sizes around the 128-row GEMM tile
-    boundaries, training batch against the oracle's mean rule and predict against the oracle - a table whose last tile is partial
-    once wrote its spare rows behind a too-small buffer."""
+    """Forward table (the n_item + 1 table rows times the POI half of ui - te_ptab_s3 on split products, te_gemm_ntk on float32-input
+    MFMAs -, te_rec_fwd16 gathers): table sizes around the 128-row tile boundaries, training batch against the oracle's mean rule and
+    predict against the oracle - a table whose last tile is partial once wrote its spare rows behind a too-small buffer.  (The 16-sequence
+    tile kernels are forced: launches this small otherwise take the per-sequence kernels, which read no forward table.)"""
     T = toy_problem(500 + n_item, n_user=160, n_item=n_item, n_dist=40, dim=128, len_max=11, hot=min(60, n_item // 2))
     P = spatial_params(500 + n_item, T)
-    model = _model(pa, T, P)
-    model.ctx.set_engine("tile")
     users = np.random.default_rng(3).permutation(160)[:150].astype(np.int32)
     exp, outs = _oracle_batch(P, T, users)
-    got_out = model.train_batch(users)
-    for k, out in enumerate(outs):
-        assert_close(got_out[k][:3], out[:3], "losses[%d]" % k, rtol=2e-5)
-    got = _get(model)
-    assert_step_close(got, exp, P, SP_NAMES, "forward table, n_item %d" % n_item)
-    model.update_trained_items(); model.update_trained_dists()
-    ids = np.arange(160, dtype=np.int32)
-    hts, sts = model.predict(ids)
-    Pn = {k: (np.asarray(v, np.float64) if k != "wd" else float(v)) for k, v in got.items()}
-    Pn["h0"] = np.zeros(128)
-    eh, es = O.spatial_predict(Pn, Pn["lt"], Pn["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
-    assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
-    model.ctx.set_engine("auto")
+    try:
+        for split in (True, False):
+            model = _model(pa, T, P)
+            model.ctx.set_engine("tile"); model.ctx.set_small_launch(0); model.ctx.set_split_products(split)
+            got_out = model.train_batch(users)
+            for k, out in enumerate(outs):
+                assert_close(got_out[k][:3], out[:3], "losses[%d]" % k, rtol=2e-5)
+            got = _get(model)
+            assert_step_close(got, exp, P, SP_NAMES, "forward table, n_item %d, split %s" % (n_item, split))
+            model.update_trained_items(); model.update_trained_dists()
+            ids = np.arange(160, dtype=np.int32)
+            hts, sts = model.predict(ids)
+            Pn = {k: (np.asarray(v, np.float64) if k != "wd" else float(v)) for k, v in got.items()}
+            Pn["h0"] = np.zeros(128)
+            eh, es = O.spatial_predict(Pn, Pn["lt"], Pn["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
+            assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
+    finally:
+        pa._lib.context(0).set_engine("auto"); pa._lib.context(0).set_small_launch(1024); pa._lib.context(0).set_split_products(True)
 
 
 @pytest.mark.parametrize("dim,n_dist,spatial", [(64, 11, True), (128, 255, True), (128, 300, True), (256, 40, True), (64, 0, False), (128, 0, False)])
