@@ -449,7 +449,8 @@ def main():
                            "te_scatter (POI rows): the spans overlap and stretch each other (stand-alone: 0.37 / 0.14 / 0.44 ms per epoch, POI_TE_DBG=1) - "
                            "te_tail, te_scatter's start to the join, is the span that counts")
         if k == "te_tail":
-            ent["note"] = ("te_scatter's start to the join with the side stream's distance-bin chain (te_dsum + te_bin_gemm, started behind te_wgrad); "
+            ent["note"] = ("te_scatter's start to the join with the side stream's distance-bin chain (te_dsum + te_bin_gemm, started behind te_wgrad) "
+                           "and the dense write-back that follows it there (dense_apply: its time is inside this span on launches of >= 1024 users); "
                            "the serial sums below use it instead of the three")
         kernels[k] = ent
     dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
