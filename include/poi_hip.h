@@ -130,6 +130,16 @@ int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
  * public/GRU_Spatial.py:247): logits and d h of the chunked head on the same split products (te_head_big3) instead of float32-input MFMAs.
  * on = 0: float32-input v_mfma_f32_16x16x4_f32 (rounds 1 - 2).  Environment override at context creation: POI_TE_SPLIT=0|1. */
 int poi_ctx_set_split_products(poi_ctx* ctx, int on);
+/* Exact forward pass of the tile engine's TRAINING launches (dims 64 / 128; default on).  The reference computes in float64 (Theano
+ * floatX: public/GRU.py:57, public/GRU_Spatial.py:52) and with its uniform(-0.5, 0.5) init the forward recurrence h_{t-1} -> h_t
+ * (public/GRU_Spatial.py:170-178) EXPANDS perturbations: a float32 forward pass, whatever its summation order, leaves a 50-position
+ * sequence 1e-5 off the float64 result, and the whole update with it; the backward pass is linear in its carry and is not affected.
+ * on = 1: the input product ui . x_t + bi and the recurrent products are computed in ~40-bit fixed point on the INT8 matrix cores
+ * (five signed base-256 digit planes per operand, exact int32 accumulation, digit pairs combined in float64: te_xfwd.hip), the gates
+ * and the state in float64; everything behind the forward pass (head, BPTT, gradients, write-back) stays float32 and reads the
+ * float32 roundings of z, r, c, h.  on = 0: the float32 forward kernels of rounds 1 - 3 (split products / per-sequence / forward table).
+ * Environment override at context creation: POI_TE_XFWD=0|1. */
+int poi_ctx_set_exact_forward(poi_ctx* ctx, int on);
 /* Small launches: launches of at most max_sequences sequences (default 1024; 0 disables; dim 64 / 128) run the recurrence of every
  * sequence in its own workgroup on the vector ALUs (te_rec_fwd1 / bwd1, weights resident in registers) instead of 16-sequence MFMA
  * tiles - a tile step costs the same whether it holds 16 sequences or one, so the reference schedule (one user per step,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
     "poi_ctx_set_f16_rounding": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
     "poi_ctx_set_split_products": (c_int, [c_void_p, c_int]),
+    "poi_ctx_set_exact_forward": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_small_launch": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_one_sequence_path": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_regroup_min": (c_int, [c_void_p, c_int]),
@@ -204,6 +205,10 @@ class Context:
     def set_split_products(self, on=True):
         """Recurrent kernels of the tile engine on bf16 x 3 split products (default) or float32-input MFMAs (poi_ctx_set_split_products)."""
         self.check(self.lib.poi_ctx_set_split_products(self.handle, 1 if on else 0))
+
+    def set_exact_forward(self, on=True):
+        """Training launches run the forward pass in fixed point on the int8 matrix cores + float64 gates (poi_ctx_set_exact_forward, default on)."""
+        self.check(self.lib.poi_ctx_set_exact_forward(self.handle, 1 if on else 0))
 
     def set_small_launch(self, max_sequences=1024):
         """Launches of at most this many sequences use the per-sequence recurrent kernels (poi_ctx_set_small_launch; 0 disables)."""

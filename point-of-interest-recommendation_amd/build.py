@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpoi_hip.so")
-SOURCES = ["abi.hip", "seq_engine.hip", "exact_engine.hip", "tile_engine.hip", "te_scatter.hip", "te_small.hip", "bpr.hip", "score_topk.hip", "score_filter.hip",
+SOURCES = ["abi.hip", "seq_engine.hip", "exact_engine.hip", "tile_engine.hip", "te_scatter.hip", "te_xfwd.hip", "bpr.hip", "score_topk.hip", "score_filter.hip",
            "misc.hip", "sync.hip", "carnn.hip"]
 HEADERS = ["poi_common.h", "poi_kernels.h", "seq_common.h", os.path.join("..", "..", "include", "poi_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]

@@ -50,6 +50,8 @@ struct poi_ctx {
   int one_path = 1;         // launches of ONE sequence (Distance2Pre, plain GRU) take the five-kernel path (te_one_*); POI_TE_ONE=0 -> the batched pipeline
   int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
+  int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores + float64 gates) for dims 64 / 128; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
+  DevBuf xw, xg;            // its digit fragments, scales and per-bin table | per-step pre-activations or the forward table (float64)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
   // A launch is captured the second time its key (every pointer / size / scalar the kernels receive) is seen; the caller's uidx /
   // out are staged through context buffers so that the key does not depend on them.
@@ -143,6 +145,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_EARLY_MIN")) c->early_min = atoi(e);
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_XFWD")) c->xfwd = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_ONE")) c->one_path = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_BINTAB_MIN")) c->bintab_min = atoi(e);
@@ -174,7 +177,7 @@ static void drop_graphs(poi_ctx* c) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota,
+  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota, &c->xw, &c->xg,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
                    &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag, &c->pre_idx, &c->pre_sc, &c->users_pk16, &c->ubound, &c->ugeo};
   (void)hipDeviceSynchronize();
@@ -258,12 +261,32 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (A.ppoi && (rc = ensure(c, c->pmark, sizeof(int) * (size_t)(P->n_item + 2), st))) return rc;
   // forward table: worth it when the table has clearly fewer rows than the launch has steps (Tcap is the upper bound: sequences
   // average ~40 % of the longest) - te_gemm_ax then multiplies n_item + 1 rows instead of one row per step
-  A.fwd_tab = (c->fwd_tab && A.bintab && !A.rec32 && !A.rec1 && 2 * (size_t)(P->n_item + 1) <= Tcap) ? 1 : 0;      // (the per-sequence kernels read G)
+  // exact forward (training launches, dims 64 / 128): input product and forward recurrence in fixed point / float64 (te_xfwd.hip)
+  A.xfwd = (c->xfwd && !predict && !A.rec32 && poi::te_xfwd_supported(D)) ? 1 : 0;
+  const bool want_ft = c->fwd_tab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap;
+  A.fwd_tab = (!A.xfwd && want_ft && A.bintab && !A.rec1) ? 1 : 0;      // (the per-sequence kernels read G)
+  A.xft = (A.xfwd && want_ft) ? 1 : 0;
+  if (A.fwd_tab || A.xft) {
+    if ((rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
+    if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }
+    A.iota = (const int*)c->iota.p;
+  }
   if (A.fwd_tab) {
     // (+ spare rows: te_gemm_ntk writes whole 128-row tiles - rows past the table's last land behind it, as in G)
-    if ((rc = ensure(c, c->ptab, sizeof(float) * ((size_t)(P->n_item + 1 + 127) / 128 * 128 + 128) * 3 * D, st)) || (rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
-    if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }
-    A.ptab = (float*)c->ptab.p; A.iota = (const int*)c->iota.p;
+    if ((rc = ensure(c, c->ptab, sizeof(float) * ((size_t)(P->n_item + 1 + 127) / 128 * 128 + 128) * 3 * D, st))) return rc;
+    A.ptab = (float*)c->ptab.p;
+  }
+  if (A.xfwd) {
+    const size_t frag = (size_t)3 * D * D * 5, nz = (size_t)(spatial ? n_dist + 1 : 1) * 3 * D;      // five int8 digit planes per weight
+    if ((rc = ensure(c, c->xw, 2 * frag + 64 + sizeof(double) * (6 * (size_t)D + nz + 8), st))) return rc;
+    const size_t xrows = A.xft ? (size_t)P->n_item + 1 + 2 : Tcap;
+    if ((rc = ensure(c, c->xg, sizeof(double) * xrows * 3 * D, st))) return rc;
+    char* xp = (char*)c->xw.p;
+    A.xWh8 = (uint4*)xp; A.xUi8 = (uint4*)(xp + ((frag + 15) & ~(size_t)15));
+    double* xd = (double*)(xp + 2 * ((frag + 15) & ~(size_t)15));
+    A.xWhS = xd; A.xUiS = xd + 3 * D; A.ztabx = xd + 6 * D;
+    if (A.xft) A.ptabx = (double*)c->xg.p; else A.gx = (double*)c->xg.p;
+    A.x_rows_est = (int)(Tcap < (size_t)1 << 30 ? Tcap : (size_t)1 << 30);
   }
   float* f = (float*)c->te_ws.p;
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
@@ -1006,6 +1029,13 @@ int poi_ctx_set_f16_rounding(poi_ctx* c, int mode, uint32_t seed) {
 int poi_ctx_set_split_products(poi_ctx* c, int on) {
   if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_split_products: on must be 0 or 1");
   c->rec_split = on;
+  return POI_OK;
+}
+
+int poi_ctx_set_exact_forward(poi_ctx* c, int on) {
+  if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_exact_forward: on must be 0 or 1");
+  c->xfwd = on;
+  drop_graphs(c);
   return POI_OK;
 }
 

@@ -182,6 +182,11 @@ struct TeArgs {
                                       // (te_wgrad_split) - the split-K order is a function of the launch alone, not of its history
   unsigned sr_salt;                   // != 0: a half POI table is written back with stochastic rounding (poi_ctx_set_f16_rounding), salt of this launch
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
+  // exact forward (te_xfwd.hip): input product + forward recurrence in ~40-bit fixed point on the int8 matrix cores, float64 gate math
+  int xfwd, xft;                      // on; pre-activations from the forward table ptabx[p_t] + ztabx[dp_t] (else gx[row])
+  double *gx, *ptabx, *ztabx;         // (T + spare) x 3D per step | (n_item + 1 + spare) x 3D | (n_dist + 1) x 3D, gate-interleaved columns
+  uint4 *xWh8, *xUi8; double *xWhS, *xUiS;      // digit fragments + row scales of wh (16x16x64 order) and of ui's POI half (32x32x32 order, gate-interleaved rows)
+  int x_rows_est;                     // host-side bound of the packed row count (grid sizing of te_gemmx)
 };
 // entry code: packed-row index of the position (28 bits) + what the position contributes
 #define TE_ENT_ROW 0x0FFFFFFF
@@ -213,6 +218,8 @@ hipError_t launch_te_one(TeArgs& A, float alpha, float lambda, int l_cap, hipStr
 bool te_one_supported(int D, bool spatial, int max_len);
 hipError_t launch_te_train(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_te_predict(TeArgs& A, int num_cu, hipStream_t st, Timing* tm);
+bool te_xfwd_supported(int D);
+hipError_t launch_te_xfwd(const TeArgs& A, int num_cu, hipStream_t st, Timing* tm, int phase);      // te_xfwd.hip: phase 0 = input product, 1 = recurrence
 hipError_t launch_rows_apply(const SeqArgs& A, bool spatial, int grid, float alpha, float lambda, hipStream_t st, Timing* tm);
 hipError_t launch_dense_apply(const SeqArgs& A, bool spatial, int n_slab, int n_slab_head, float alpha, float lambda, hipStream_t st, Timing* tm);
 

@@ -1,0 +1,507 @@
+// Exact forward pass of the tile engine ("x" kernels): the forward recurrence of the GRU and its input product in ~40-bit fixed point
+// on the INT8 matrix cores (v_mfma_i32_16x16x64_i8 / 32x32x32_i8: exact products, exact int32 accumulation), gate math in float64.
+//
+// Why: the reference runs float64 (Theano floatX, public/GRU.py:57, public/GRU_Spatial.py:52) and BASELINE.json asks for weights
+// within 1e-5 after one step.  At dim 128 / 50 positions with the reference's uniform(-0.5, 0.5) init the GRU is saturated and the
+// forward map h_{t-1} -> h_t EXPANDS perturbations: a float32 forward pass (any summation order, libm-exact gates) leaves the late
+// hidden states 1e-5 off, and the whole update inherits that (tools/precision_split.py: float32 forward + float64 everything else
+// 2e-5 of the max-norm; float64 forward + float32 everything else 2e-7).  The backward pass is LINEAR in its carry - its rounding
+// errors are amplified exactly like the signal - and stays float32.  So only two things need more than float32: the input product
+// G_t = ui . x_t + bi and the chain h_t = GRU(G_t, h_{t-1}).
+//
+// How (the Ozaki scheme on integer matrix cores): an operand row is scaled by a power of two to |Q| <= 2^38 and cut into five signed
+// base-256 digits (int8 planes); the product of two rows is sum_{i + j <= 4} 256^-(i+j) (d_i . e_j) with every digit product summed
+// EXACTLY in int32 by the matrix core (|d e| <= 2^14, K <= 256 terms, <= 5 digit pairs per accumulator: < 2^25); the five
+// accumulators are combined in float64.  Dropped: digit pairs with i + j >= 5, <= 2^-39 of the row scales - the result carries ~2e-9
+// of relative error where float32 accumulation carries 1e-7, at 15 int8 MFMAs of 16 cycles per 64 k against 16 float32 ones of 32
+// (the int8 matrix rate is 32x the float32 one on gfx950; a v_mfma_f64_16x16x4_f64 path would cost 4.3x the matrix time of this one).
+// h and r * h lie in [-1, 1]: their scale is a constant (2^-38), no exponent search on the chain.
+//
+// Kernels: te_xpack (weights -> digit planes in MFMA fragment order + per-row scales, once per launch), te_xztab (distance-bin half
+// of the input product + bias per bin, float64 FMAs), te_gemmx (POI half of the input product: table rows or gathered step rows),
+// te_rec_fwdx (the recurrence, 16-sequence tiles as te_rec_fwd16; same outputs: G := z | r | c, H, RH in float32 for the head and BPTT).
+#include "poi_common.h"
+#include "poi_kernels.h"
+
+namespace poi {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#define XS 5                       // signed base-256 digits per operand
+#define XQB (8 * XS - 2)           // |Q| <= 2^XQB: the leading digit stays inside [-64, 64] (+ carry)
+
+__device__ __forceinline__ void x_lds_barrier() {      // orders LDS traffic only (tile_engine.hip: lds_barrier)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ double x_pow2(int e) { return __longlong_as_double((long long)(1023 + e) << 52); }
+// exponent e with |m| < 2^e (m = 0 and subnormals: -126)
+__device__ __forceinline__ int x_exponent(float m) { return (int)((__float_as_uint(m) >> 23) & 255u) - 126; }
+
+// Signed base-256 digits of rint(t), |t| <= 2^XQB: adding 1.5 * 2^52 leaves rint(t) in the low mantissa bits (two's complement);
+// adding 0x80 to every digit position makes the digits unsigned bytes u_i = d_i + 128, and u_i ^ 0x80 is d_i as int8.
+// lo: digits 4 (byte 0, least significant) .. 1 (byte 3); hi: digit 0 in byte 0.
+__device__ __forceinline__ void x_digits(double t, unsigned& lo, unsigned& hi) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(t + 0x1.8p52) + 0x8080808080ull;
+  lo = (unsigned)b ^ 0x80808080u;
+  hi = ((unsigned)(b >> 32) ^ 0x80u) & 0xFFu;
+}
+__device__ __forceinline__ unsigned x_digit(unsigned lo, unsigned hi, int s) { return s == 0 ? hi : (lo >> (8 * (XS - 1 - s))) & 0xFFu; }
+
+// sum_w acc_w 256^-w in float64 (exact: every acc is an integer below 2^25, the sum has < 53 significant bits)
+__device__ __forceinline__ double x_combine(const i32x4 (&acc)[XS], int r) {
+  double t = (double)acc[XS - 1][r];
+#pragma unroll
+  for (int w = XS - 2; w >= 0; --w) t = __builtin_fma(t, 0x1p-8, (double)acc[w][r]);
+  return t;
+}
+
+// float64 exp / sigmoid / tanh, branch-free (the gate math sits on the per-step chain): Cody-Waite reduction, degree-12 Taylor
+// polynomial on |r| <= ln2 / 2 (truncation 2e-16), v_ldexp_f64; 1 / d by v_rcp_f64 + two Newton steps.  ~1e-15 relative.
+__device__ __forceinline__ double x_exp(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 479001600.0;
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+__device__ __forceinline__ double x_rcp(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  return y;
+}
+__device__ __forceinline__ double x_sigmoid(double x) {
+  x = __builtin_fmin(__builtin_fmax(x, -700.0), 700.0);
+  return x_rcp(1.0 + x_exp(-x));
+}
+__device__ __forceinline__ double x_tanh(double x) {
+  x = __builtin_fmin(__builtin_fmax(x, -350.0), 350.0);
+  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * x)), 1.0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_xpack: rows of a float32 weight matrix -> digit planes in MFMA B-fragment order + the row scales 2^(e - 12)
+// (product of two scaled rows: 2^(e_a - 38) 2^(e_b - 38) 256^8 sum_w 256^-w acc_w = 2^(e_a + e_b - 12) sum_w ...; the A side
+// contributes 2^e_a - or 2^0 for the fixed-point chain operands h, r * h, whose Q = rint(h 2^38)).
+//   frag32 == 0 (te_rec_fwdx, v_mfma_i32_16x16x64_i8): dst[((nt KB + kb) XS + s) 64 + 16 g + j] byte b = digit s of row 16 nt + j, k = 64 kb + 16 g + b
+//   frag32 == 1 (te_gemmx,    v_mfma_i32_32x32x32_i8): dst[((nt KB + kb) XS + s) 64 + 32 h + j] byte b = digit s of row 32 nt + j, k = 32 kb + 16 h + b
+// A and B fragments use the SAME (lane group, byte) -> k assignment, which is all the contraction needs.
+// inter: destination row n = 3 c + g is source row g (rows / 3) + c (the gate-interleaved columns of the forward table).
+// -------------------------------------------------------------------------------------------------
+struct XPackJob { const float* src; int ld, koff, rows, K, inter, frag32; unsigned char* dst; double* scale; };
+struct XPackJobs { XPackJob j[2]; int n; };
+
+__global__ __launch_bounds__(256) void te_xpack_kernel(XPackJobs J) {
+  const XPackJob j = J.j[blockIdx.y];
+  const int lane = lane_id();
+  for (int n = blockIdx.x * 4 + wave_id(); n < j.rows; n += gridDim.x * 4) {
+    const int sr = j.inter ? (n % 3) * (j.rows / 3) + n / 3 : n;
+    const float* src = j.src + (size_t)sr * j.ld + j.koff;
+    float v[4], m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int k = lane + 64 * i; v[i] = k < j.K ? src[k] : 0.f; m = fmaxf(m, fabsf(v[i])); }
+    m = wave_max(m);
+    const int e = x_exponent(m);
+    const double sc = x_pow2(XQB - e);
+    if (lane == 0) j.scale[n] = x_pow2(e - 12);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = lane + 64 * i;
+      if (k >= j.K) break;
+      unsigned lo, hi;
+      x_digits((double)v[i] * sc, lo, hi);
+#pragma unroll
+      for (int s = 0; s < XS; ++s) {
+        size_t at;
+        if (j.frag32) { const int KB = j.K / 32; at = ((((size_t)(n / 32) * KB + k / 32) * XS + s) * 64 + 32 * ((k % 32) / 16) + n % 32) * 16 + k % 16; }
+        else { const int KB = j.K / 64; at = ((((size_t)(n / 16) * KB + k / 64) * XS + s) * 64 + 16 * ((k % 64) / 16) + n % 16) * 16 + k % 16; }
+        j.dst[at] = (unsigned char)x_digit(lo, hi, s);
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_xztab: ztabx[b][3 c + g] = di[b] . ui[g D + c][D:] + bi[g D + c] in float64 (products of float32 values are exact in float64).
+// Plain GRU (no distance-bin table): one row, the bias.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void te_xztab_kernel(TeArgs A) {
+  __shared__ float drow[256];
+  const int D = A.dim, XW = A.xw, b = blockIdx.x, n = threadIdx.x;
+  if (A.spatial && n < D) drow[n] = A.di[(size_t)b * D + n];
+  __syncthreads();
+  if (n >= 3 * D) return;
+  const int c = n / 3, g = n % 3, r = g * D + c;
+  double a0 = (double)A.bi[r], a1 = 0.0;
+  if (A.spatial) {
+    const float* u = A.ui + (size_t)r * XW + D;
+    for (int k = 0; k < D; k += 4) {
+      const float4 uv = *reinterpret_cast<const float4*>(u + k);
+      a0 = __builtin_fma((double)drow[k], (double)uv.x, a0); a1 = __builtin_fma((double)drow[k + 1], (double)uv.y, a1);
+      a0 = __builtin_fma((double)drow[k + 2], (double)uv.z, a0); a1 = __builtin_fma((double)drow[k + 3], (double)uv.w, a1);
+    }
+  }
+  A.ztabx[(size_t)b * 3 * D + n] = a0 + a1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_gemmx: C[r][n] = lt[idx[r]] . uiP[n]  (+ ztabx[zidx[r]][n]),  n = 3 c + g < 3 D, in float64 from the digit products.
+// A workgroup item = 128 rows x a group of 32-column tiles; a wave keeps ITS 32 rows as resident digit planes (rows fetched straight
+// into the fragment layout, row scale = the row's largest exponent, digits cut in registers) and walks the column tiles, whose digit
+// fragments (te_xpack, frag32) are staged through LDS once per workgroup.  Rows past the end land in the spare row behind C.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ i32x16 x_mfma32(const i32x4& a, const i32x4& b, i32x16 c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ i32x4 x_mfma16(const i32x4& a, const i32x4& b, i32x4 c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int x_crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }      // C/D layout of the 32x32 tile
+// byte `b` of four words -> one word
+__device__ __forceinline__ unsigned x_gather_byte(unsigned w0, unsigned w1, unsigned w2, unsigned w3, int b) {
+  const unsigned sel = (unsigned)b | ((unsigned)(4 + b) << 8);
+  const unsigned t01 = __builtin_amdgcn_perm(w1, w0, sel), t23 = __builtin_amdgcn_perm(w3, w2, sel);
+  return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+}
+
+struct XGemmArgs {
+  const void* tab; int f16;                 // POI table (float32 or IEEE half)
+  const int* idx;                           // row r of C <- table row idx[r] (null: r)
+  const int* n_ptr; int idx_max;            // number of rows (device); idx clamp
+  const uint4* B8; const double* Bs;        // digit fragments + scales of uiP (te_xpack, frag32)
+  const double* ztabx; const int* zidx; int z_max;      // epilogue: + ztabx[min(zidx[r], z_max)] (null: nothing)
+  double* C;
+  int ncg;                                  // column groups per row tile (work items = row tiles x ncg)
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
+  constexpr int KB = D / 32, N = 3 * D, NT = N / 32, FR = KB * XS * 64;      // uint4 fragments per column tile
+  __shared__ uint4 s_b[FR];
+  __shared__ double s_rs[4][32];
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
+  const int n_rows = *P.n_ptr;
+  const int n_tile = (n_rows + 127) / 128, ncg = P.ncg, tpg = NT / ncg;
+  for (int it = blockIdx.x; it < n_tile * ncg; it += gridDim.x) {
+    const int t = it / ncg, j0 = (it % ncg) * tpg;
+    // ---- this wave's 32 rows -> digit planes a[kb][s] (lane: row li, k = 32 kb + 16 h + 0..15) ----
+    i32x4 a[KB][XS];
+    {
+      const int row = min(t * 128 + w * 32 + li, n_rows - 1);
+      const size_t src = (size_t)(P.idx ? min((unsigned)P.idx[row], (unsigned)P.idx_max) : row) * D;
+      float4 x[KB][4];
+      float m = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x[kb][q] = ld4t(P.tab, src + 32 * kb + 16 * h + 4 * q, P.f16);
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(x[kb][q].x), fabsf(x[kb][q].y))), fmaxf(fabsf(x[kb][q].z), fabsf(x[kb][q].w)));
+        }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const int e = x_exponent(m);
+      const double sc = x_pow2(XQB - e);
+      if (h == 0) s_rs[w][li] = x_pow2(e);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        unsigned lo[16], hi[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x_digits((double)x[kb][q].x * sc, lo[4 * q], hi[4 * q]); x_digits((double)x[kb][q].y * sc, lo[4 * q + 1], hi[4 * q + 1]);
+          x_digits((double)x[kb][q].z * sc, lo[4 * q + 2], hi[4 * q + 2]); x_digits((double)x[kb][q].w * sc, lo[4 * q + 3], hi[4 * q + 3]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[kb][0][q] = (int)x_gather_byte(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3], 0);
+#pragma unroll
+          for (int s = 1; s < XS; ++s) a[kb][s][q] = (int)x_gather_byte(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3], XS - 1 - s);
+        }
+      }
+    }
+    for (int j = j0; j < j0 + tpg; ++j) {
+      __syncthreads();                                         // the previous column tile has been read (and s_rs is visible)
+      for (int e = tid; e < FR; e += 256) s_b[e] = P.B8[(size_t)j * FR + e];
+      __syncthreads();
+      i32x16 acc[XS];
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        i32x4 b[XS];
+#pragma unroll
+        for (int s = 0; s < XS; ++s) b[s] = __builtin_bit_cast(i32x4, s_b[(kb * XS + s) * 64 + lane]);
+#pragma unroll
+        for (int sa = 0; sa < XS; ++sa)
+#pragma unroll
+          for (int sb = 0; sb < XS - sa; ++sb) acc[sa + sb] = x_mfma32(a[kb][sa], b[sb], acc[sa + sb]);
+      }
+      const int col = j * 32 + li;
+      const double cs = P.Bs[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = x_crow(r, lane), grow = t * 128 + w * 32 + rr;
+        double v = (double)acc[XS - 1][r];
+#pragma unroll
+        for (int s = XS - 2; s >= 0; --s) v = __builtin_fma(v, 0x1p-8, (double)acc[s][r]);
+        v *= s_rs[w][rr] * cs;
+        const int orow = min(grow, n_rows);
+        if (P.ztabx) v += P.ztabx[(size_t)(P.zidx ? min((unsigned)P.zidx[min(grow, n_rows - 1)], (unsigned)P.z_max) : 0) * N + col];
+        P.C[(size_t)orow * N + col] = v;
+      }
+    }
+    __syncthreads();                                           // s_rs is rewritten by the next item
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// te_rec_fwdx: te_rec_fwd16's tiling (one workgroup of D / 16 waves per 16 sequences, wave w owns hidden columns [16 w, 16 w + 16)
+// of z, r, c and h; two barriers per step), with h_{t-1} / r * h_{t-1} in LDS as five int8 digit planes (fixed point, scale 2^-38),
+// the recurrent weights resident as digit fragments (digits 0 - 2 in registers, 3 - 4 - three MFMAs in fifteen - in LDS), the
+// pre-activations and the state in float64.  FT: pre-activations = ptabx[p_t] + ztabx[dp_t] (forward table); else gx[row].
+// Outputs exactly as te_rec_fwd16: G := z | r | c, H, RH (float32 roundings of the float64 values).
+// -------------------------------------------------------------------------------------------------
+struct XG3 { double z, r, c; };
+
+template <int D, bool FT>
+__global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
+  constexpr int KB = D / 64, NW = D / 16, SR = 3, SL = XS - SR, LDP = D + 16, PSZ = 16 * LDP;
+  extern __shared__ __align__(16) unsigned char xlds[];
+  unsigned char* Hq = xlds;                          // XS planes x 16 rows x LDP bytes
+  unsigned char* RHq = Hq + XS * PSZ;
+  uint4* Bl = reinterpret_cast<uint4*>(RHq + XS * PSZ) + (size_t)wave_id() * (3 * KB * SL * 64);      // this wave's low digit fragments [gate][kb][sl]
+  __shared__ int s_r0[16], s_ns[16];
+  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, g4 = 4 * (lane >> 4);
+  const int col = 16 * w + (lane & 15);
+  const int tile = blockIdx.x;
+  if (tid < 16) {
+    const int k = tile * 16 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  for (int e = tid; e < 2 * XS * PSZ / 4; e += blockDim.x) reinterpret_cast<unsigned*>(xlds)[e] = 0u;      // h_0 = 0: all digits zero
+  i32x4 bw[3][KB][SR];
+  double cn[3];
+#pragma unroll
+  for (int gt = 0; gt < 3; ++gt) {
+    const int nt = gt * NW + w;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int s = 0; s < XS; ++s) {
+        const uint4 v = A.xWh8[((size_t)(nt * KB + kb) * XS + s) * 64 + lane];
+        if (s < SR) bw[gt][kb][s] = __builtin_bit_cast(i32x4, v);
+        else Bl[((gt * KB + kb) * SL + (s - SR)) * 64 + lane] = v;
+      }
+    cn[gt] = A.xWhS[gt * D + col];
+  }
+  __syncthreads();
+  int ns_max = 0;
+  for (int i = 0; i < 16; ++i) ns_max = max(ns_max, s_ns[i]);
+  int rowb[4], nsr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { rowb[r] = s_r0[g4 + r]; nsr[r] = s_ns[g4 + r]; }
+  const int Tsp = A.soff[A.n_seq];                   // spare packed row: finished sequences read / write it unconditionally
+  double hcur[4] = {0.0, 0.0, 0.0, 0.0};
+  XG3 gc[4];                                         // pre-activations of the current step
+
+  const unsigned char* arow = Hq + (lane & 15) * LDP + 16 * (lane >> 4);
+  const unsigned char* rrow = RHq + (lane & 15) * LDP + 16 * (lane >> 4);
+  auto put_digits = [&](unsigned char* plane0, int i, double v) {       // v in [-1, 1] -> the five planes at (row i, col)
+    unsigned lo, hi;
+    x_digits(v * 0x1p38, lo, hi);
+    unsigned char* at = plane0 + i * LDP + col;
+    at[0] = (unsigned char)hi; at[PSZ] = (unsigned char)(lo >> 24); at[2 * PSZ] = (unsigned char)(lo >> 16);
+    at[3 * PSZ] = (unsigned char)(lo >> 8); at[4 * PSZ] = (unsigned char)lo;
+  };
+  auto compute = [&](int t) {
+    i32x4 az[XS], ar[XS];
+#pragma unroll
+    for (int s = 0; s < XS; ++s) { az[s] = i32x4{0, 0, 0, 0}; ar[s] = i32x4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      i32x4 a[XS], lz[SL], lr[SL];
+#pragma unroll
+      for (int s = 0; s < XS; ++s) a[s] = *reinterpret_cast<const i32x4*>(arow + s * PSZ + 64 * kb);
+#pragma unroll
+      for (int s = 0; s < SL; ++s) {
+        lz[s] = __builtin_bit_cast(i32x4, Bl[((0 * KB + kb) * SL + s) * 64 + lane]);
+        lr[s] = __builtin_bit_cast(i32x4, Bl[((1 * KB + kb) * SL + s) * 64 + lane]);
+      }
+#pragma unroll
+      for (int sa = 0; sa < XS; ++sa)
+#pragma unroll
+        for (int sb = 0; sb < XS - sa; ++sb) {
+          az[sa + sb] = x_mfma16(a[sa], sb < SR ? bw[0][kb][sb < SR ? sb : 0] : lz[sb >= SR ? sb - SR : 0], az[sa + sb]);
+          ar[sa + sb] = x_mfma16(a[sa], sb < SR ? bw[1][kb][sb < SR ? sb : 0] : lr[sb >= SR ? sb - SR : 0], ar[sa + sb]);
+        }
+    }
+    double zv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = g4 + r;
+      const double rv = x_sigmoid(__builtin_fma(x_combine(ar, r), cn[1], gc[r].r));
+      zv[r] = x_sigmoid(__builtin_fma(x_combine(az, r), cn[0], gc[r].z));
+      const double rh = rv * hcur[r];
+      put_digits(RHq, i, rh);
+      const size_t row = (size_t)(t < nsr[r] ? rowb[r] + t : Tsp);
+      A.G[row * 3 * D + D + col] = (float)rv; A.RH[row * D + col] = (float)rh;
+    }
+    x_lds_barrier();
+    i32x4 ac[XS];
+#pragma unroll
+    for (int s = 0; s < XS; ++s) ac[s] = i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      i32x4 a[XS], lc[SL];
+#pragma unroll
+      for (int s = 0; s < XS; ++s) a[s] = *reinterpret_cast<const i32x4*>(rrow + s * PSZ + 64 * kb);
+#pragma unroll
+      for (int s = 0; s < SL; ++s) lc[s] = __builtin_bit_cast(i32x4, Bl[((2 * KB + kb) * SL + s) * 64 + lane]);
+#pragma unroll
+      for (int sa = 0; sa < XS; ++sa)
+#pragma unroll
+        for (int sb = 0; sb < XS - sa; ++sb)
+          ac[sa + sb] = x_mfma16(a[sa], sb < SR ? bw[2][kb][sb < SR ? sb : 0] : lc[sb >= SR ? sb - SR : 0], ac[sa + sb]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = g4 + r;
+      const bool on = t < nsr[r];
+      const double c = x_tanh(__builtin_fma(x_combine(ac, r), cn[2], gc[r].c));
+      const double hn = on ? __builtin_fma(zv[r], c - hcur[r], hcur[r]) : hcur[r];
+      put_digits(Hq, i, hn);
+      hcur[r] = hn;
+      const size_t row = (size_t)(on ? rowb[r] + t : Tsp);
+      A.G[row * 3 * D + col] = (float)zv[r]; A.G[row * 3 * D + 2 * D + col] = (float)c;
+      A.H[row * D + col] = (float)hn;
+    }
+    x_lds_barrier();
+  };
+
+  if constexpr (!FT) {
+    auto fetch = [&](int t, XG3 (&n)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n[q] = *reinterpret_cast<const XG3*>(A.gx + (size_t)(t < nsr[q] ? rowb[q] + t : Tsp) * 3 * D + 3 * col);
+    };
+    XG3 nx[4];
+    fetch(0, gc);
+    for (int t = 0; t < ns_max; ++t) {
+      fetch(t + 1, nx);
+      compute(t);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("" : "+v"(nx[q].z), "+v"(nx[q].r), "+v"(nx[q].c));      // the wait for the prefetch is counted here, behind the step's stores
+        gc[q] = nx[q];
+      }
+    }
+  } else {
+    // forward table: the row ids of step t + 2 and the table rows of step t + 1 are requested at the top of step t
+    int rp[4], rz[4];
+    auto ids = [&](int t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int rr = t < nsr[q] ? rowb[q] + t : Tsp; rp[q] = A.row_p[rr]; rz[q] = A.spatial ? A.row_dp[rr] : 0; }
+    };
+    auto rows = [&](XG3 (&pp)[4], XG3 (&zz)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p1 = (int)min((unsigned)rp[q], (unsigned)A.n_item), z1 = A.spatial ? (int)min((unsigned)rz[q], (unsigned)A.n_dist) : 0;
+        pp[q] = *reinterpret_cast<const XG3*>(A.ptabx + (size_t)p1 * 3 * D + 3 * col);
+        zz[q] = *reinterpret_cast<const XG3*>(A.ztabx + (size_t)z1 * 3 * D + 3 * col);
+      }
+    };
+    XG3 pn[4], zn[4];
+    ids(0); rows(pn, zn);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { gc[q].z = pn[q].z + zn[q].z; gc[q].r = pn[q].r + zn[q].r; gc[q].c = pn[q].c + zn[q].c; }
+    ids(1);
+    for (int t = 0; t < ns_max; ++t) {
+      rows(pn, zn);                            // step t + 1 (ids loaded a step ago)
+      ids(t + 2);
+      compute(t);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("" : "+v"(pn[q].z), "+v"(pn[q].r), "+v"(pn[q].c), "+v"(zn[q].z), "+v"(zn[q].r), "+v"(zn[q].c));
+        gc[q].z = pn[q].z + zn[q].z; gc[q].r = pn[q].r + zn[q].r; gc[q].c = pn[q].c + zn[q].c;
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+bool te_xfwd_supported(int D) { return D == 64 || D == 128; }
+
+size_t te_xfwd_lds(int D) {
+  const int KB = D / 64, NW = D / 16, SL = XS - 3;
+  return (size_t)2 * XS * 16 * (D + 16) + (size_t)NW * 3 * KB * SL * 64 * 16;
+}
+
+// bytes of the digit fragments / doubles of the scales for a (rows x K) operand
+size_t te_xfrag_bytes(int rows, int K) { return (size_t)rows * K * XS; }
+
+template <int D>
+static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing* tm, int phase) {
+  static bool optin = false;
+  if (!optin) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e != hipSuccess) return e;
+    optin = true;
+  }
+  const int n = A.n_seq;
+  if (phase == 0) {
+  tm->begin("te_gemm_ax", st);
+  {
+    XPackJobs J;
+    J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
+    J.j[1] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 1, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS};
+    J.n = 2;
+    hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 2), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(te_xztab_kernel, dim3(A.spatial ? A.n_dist + 1 : 1), dim3(3 * D), 0, st, A);
+    XGemmArgs P;
+    P.tab = A.lt; P.f16 = A.lt_f16; P.idx_max = A.n_item; P.B8 = A.xUi8; P.Bs = A.xUiS; P.z_max = A.spatial ? A.n_dist : 0;
+    int rows_est;
+    if (A.xft) { P.idx = nullptr; P.n_ptr = A.iota + A.n_item + 1; P.ztabx = nullptr; P.zidx = nullptr; P.C = A.ptabx; rows_est = A.n_item + 1; }
+    else { P.idx = A.row_p; P.n_ptr = A.soff + n; P.ztabx = A.ztabx; P.zidx = A.spatial ? A.row_dp : nullptr; P.C = A.gx; rows_est = A.x_rows_est; }
+    // few row tiles: split the column tiles of a row tile over several workgroups (the slicing of the rows is repeated, it is cheap)
+    const int n_tile_est = (rows_est + 127) / 128, NT = 3 * D / 32;
+    int ncg = 1;
+    while (ncg < NT && n_tile_est * ncg < num_cu && NT % (ncg * 2) == 0) ncg *= 2;
+    if (ncg * 2 <= NT && NT % (ncg * 3) == 0 && n_tile_est * ncg < num_cu) ncg *= 3;
+    P.ncg = ncg;
+    const int grid = min(num_cu * 2, n_tile_est * ncg > 0 ? n_tile_est * ncg : 1);
+    hipLaunchKernelGGL(te_gemmx_kernel<D>, dim3(grid), dim3(256), 0, st, P);
+  }
+  tm->end(st);
+  return hipGetLastError();
+  }
+  tm->begin("te_rec_fwd", st);
+  if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
+  else hipLaunchKernelGGL((te_rec_fwdx_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
+  tm->end(st);
+  return hipGetLastError();
+}
+
+// te_gemm_ax (phase 0) / te_rec_fwd (phase 1) of a training launch in the exact-forward mode (TeArgs.xfwd)
+hipError_t launch_te_xfwd(const TeArgs& A, int num_cu, hipStream_t st, Timing* tm, int phase) {
+  if (A.dim == 64) return te_xfwd_t<64>(A, num_cu, st, tm, phase);
+  if (A.dim == 128) return te_xfwd_t<128>(A, num_cu, st, tm, phase);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace poi

@@ -3037,7 +3037,7 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     }
   }
   // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments (32-column ones for the streaming kernels)
-  if (A.rec1) {}      // (te_rec_fwd1 reads wh directly)
+  if (A.rec1 || (A.xfwd && train)) {}      // (te_rec_fwd1 reads wh directly; the exact forward has its own digit fragments: te_xpack)
   else if (A.rec32 && A.rec_split) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 32, A.pWhT16, 4};
   else if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
   else if (A.rec_split && (!A.fwd_tab || A.predict)) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table TRAINING launches keep the float32 kernel)
@@ -3184,9 +3184,15 @@ static hipError_t te_one_t(TeArgs& A, float alpha, float lambda, int l_cap, hipS
   tm->begin("te_prep", st);
   hipLaunchKernelGGL(te_one_in_kernel<D>, dim3(n_ax + 1 + n_pk * J.n), dim3(TE_BLOCK), 0, st, A, J, n_ax, n_pk);
   tm->end(st);
+  if (A.xfwd) {      // exact forward: input product + recurrence of the one sequence through the fixed-point kernels (te_one_in has set soff / row_p / row_dp)
+    hipError_t xe = launch_te_xfwd(A, 64, st, tm, 0);
+    if (xe == hipSuccess) xe = launch_te_xfwd(A, 64, st, tm, 1);
+    if (xe != hipSuccess) return xe;
+  } else {
   tm->begin("te_rec_fwd", st);
   hipLaunchKernelGGL((te_rec_fwd1_kernel<D, false>), dim3(1), dim3(4 * D), 0, st, A);
   tm->end(st);
+  }
   tm->begin("te_head", st);
   const int n_hwg = (l_cap + 30) / 32 > 0 ? (l_cap + 30) / 32 : 1;
   if (A.spatial) {
@@ -3232,9 +3238,14 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
   tm->end(st);
+  if (A.xfwd) {      // exact forward (te_xfwd.hip): the input product in fixed point on the int8 matrix cores, float64 tables
+    hipError_t xe = launch_te_xfwd(A, num_cu, st, tm, 0);
+    if (xe != hipSuccess) return xe;
+  } else {
   tm->begin("te_gemm_ax", st);
   te_launch_ax<D>(A, num_cu, st);
   tm->end(st);
+  }
   if (A.side) {
     // The slot sort is needed only by te_scatter, so it runs on the side stream - next to te_rec_fwd, a
     // latency chain that leaves most of the chip idle.  NOT next to the GEMMs: their grids are exactly two
@@ -3244,6 +3255,10 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
     if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
   }
+  if (A.xfwd) {
+    hipError_t xe = launch_te_xfwd(A, num_cu, st, tm, 1);
+    if (xe != hipSuccess) return xe;
+  } else {
   tm->begin("te_rec_fwd", st);
   if constexpr (D >= 128) {
     if (A.rec32 && A.rec_split) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, false, D / 32, true>), dim3((n + 31) / 32), dim3(D * 2), sizeof(short) * 2 * 3 * 32 * (D + 8), st, A);
@@ -3263,6 +3278,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     }
   }
   tm->end(st);
+  }
   tm->begin("te_head", st);
   if (A.spatial) {
     hipError_t e = te_head_dispatch<D>(A, 0, A.n_head, st);
