@@ -23,6 +23,8 @@
 #include "poi_common.h"
 #include "poi_kernels.h"
 
+#include <type_traits>
+
 namespace poi {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -50,34 +52,27 @@ __device__ __forceinline__ void x_digits(double t, unsigned& lo, unsigned& hi) {
 }
 __device__ __forceinline__ unsigned x_digit(unsigned lo, unsigned hi, int s) { return s == 0 ? hi : (lo >> (8 * (XS - 1 - s))) & 0xFFu; }
 
-// sum_w acc_w 256^-w in float64 (exact: every acc is an integer below 2^25, the sum has < 53 significant bits)
+// 256 sum_w acc_w 256^-w in float64: the digit-pair classes 0|1 and 2|3 are merged in int32 first ((a0 << 8) + a1 and (a2 << 8) + a3 stay
+// below 2^31 for K <= 128: |a0| <= 65^2 K, |a2| <= 2^15 K + 2^14 K), then three conversions and two FMAs (every step exact: < 53 bits).
 __device__ __forceinline__ double x_combine(const i32x4 (&acc)[XS], int r) {
-  double t = (double)acc[XS - 1][r];
-#pragma unroll
-  for (int w = XS - 2; w >= 0; --w) t = __builtin_fma(t, 0x1p-8, (double)acc[w][r]);
-  return t;
+  const int m01 = (acc[0][r] << 8) + acc[1][r], m23 = (acc[2][r] << 8) + acc[3][r];
+  return __builtin_fma(__builtin_fma((double)acc[4][r], 0x1p-8, (double)m23), 0x1p-16, (double)m01);
 }
 
-// float64 exp / sigmoid / tanh, branch-free (the gate math sits on the per-step chain): Cody-Waite reduction, degree-12 Taylor
-// polynomial on |r| <= ln2 / 2 (truncation 2e-16), v_ldexp_f64; 1 / d by v_rcp_f64 + two Newton steps.  ~1e-15 relative.
-__device__ __forceinline__ double x_exp(double x) {
-  const double n = __builtin_rint(x * 1.4426950408889634074);
-  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 479001600.0;
-  p = __builtin_fma(p, r, 1.0 / 39916800.0);
-  p = __builtin_fma(p, r, 1.0 / 3628800.0);
-  p = __builtin_fma(p, r, 1.0 / 362880.0);
-  p = __builtin_fma(p, r, 1.0 / 40320.0);
-  p = __builtin_fma(p, r, 1.0 / 5040.0);
-  p = __builtin_fma(p, r, 1.0 / 720.0);
-  p = __builtin_fma(p, r, 1.0 / 120.0);
-  p = __builtin_fma(p, r, 1.0 / 24.0);
-  p = __builtin_fma(p, r, 1.0 / 6.0);
+// float64 exp / sigmoid / tanh, branch-free (the gate math sits on the per-step chain): e^x = 2^m T[j] p(r) with n = rint(64 x / ln 2) =
+// 64 m + j, T[j] = 2^(j / 64) (64 doubles in LDS), r = x - n ln2 / 64 (Cody-Waite, |r| <= 0.0055) and the degree-4 Taylor polynomial
+// (truncation 4e-14 relative); 1 / d by v_rcp_f64 + two Newton steps.  ~1e-13 relative: the chain needs ~1e-10 (see the header).
+__device__ __forceinline__ double x_exp(double x, const double* __restrict__ T) {
+  const double n = __builtin_rint(x * 0x1.71547652b82fep+6);
+  double r = __builtin_fma(n, -0x1.62e42fee00000p-7, x);
+  r = __builtin_fma(n, -2.9815858269852933e-12, r);
+  const int ni = (int)n;
+  const double tj = T[ni & 63];
+  double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)n);
+  return __builtin_amdgcn_ldexp(tj * p, ni >> 6);
 }
 __device__ __forceinline__ double x_rcp(double d) {
   double y = __builtin_amdgcn_rcp(d);
@@ -85,13 +80,13 @@ __device__ __forceinline__ double x_rcp(double d) {
   y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
   return y;
 }
-__device__ __forceinline__ double x_sigmoid(double x) {
+__device__ __forceinline__ double x_sigmoid(double x, const double* __restrict__ T) {
   x = __builtin_fmin(__builtin_fmax(x, -700.0), 700.0);
-  return x_rcp(1.0 + x_exp(-x));
+  return x_rcp(1.0 + x_exp(-x, T));
 }
-__device__ __forceinline__ double x_tanh(double x) {
+__device__ __forceinline__ double x_tanh(double x, const double* __restrict__ T) {
   x = __builtin_fmin(__builtin_fmax(x, -350.0), 350.0);
-  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * x)), 1.0);
+  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * x, T)), 1.0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -267,13 +262,17 @@ __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// te_rec_fwdx: te_rec_fwd16's tiling (one workgroup of D / 16 waves per 16 sequences, wave w owns hidden columns [16 w, 16 w + 16)
-// of z, r, c and h; two barriers per step), with h_{t-1} / r * h_{t-1} in LDS as five int8 digit planes (fixed point, scale 2^-38),
-// the recurrent weights resident as digit fragments (digits 0 - 2 in registers, 3 - 4 - three MFMAs in fifteen - in LDS), the
-// pre-activations and the state in float64.  FT: pre-activations = ptabx[p_t] + ztabx[dp_t] (forward table); else gx[row].
+// te_rec_fwdx: te_rec_fwd16's tiling (one workgroup of D / 16 waves per 16 sequences, wave w owns hidden units [16 w, 16 w + 16) of
+// z, r, c and h; two barriers per step), with h_{t-1} / r * h_{t-1} in LDS as five int8 digit planes (fixed point, scale 2^-38), the
+// recurrent weights resident as digit fragments (digits 0 - 2 in registers, 3 - 4 - three MFMAs in fifteen - in LDS), the
+// pre-activations and the state in float64.  The products are formed TRANSPOSED - the weights are the MFMA's A operand (16 hidden
+// units), the state its B operand (16 sequences) - so that a lane holds FOUR CONSECUTIVE hidden units of ONE sequence: the digits of
+// its four state values are one 4-byte LDS write per plane (per-value byte writes conflicted four ways and were a microsecond per
+// step), its outputs 16-byte stores, its pre-activations 96 contiguous bytes.
+// FT: pre-activations = ptabx[p_t] + ztabx[dp_t] (forward table); else gx[row].
 // Outputs exactly as te_rec_fwd16: G := z | r | c, H, RH (float32 roundings of the float64 values).
 // -------------------------------------------------------------------------------------------------
-struct XG3 { double z, r, c; };
+struct XG12 { double v[12]; };      // z | r | c of four consecutive hidden units (gate-interleaved columns)
 
 template <int D, bool FT>
 __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
@@ -283,8 +282,10 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
   unsigned char* RHq = Hq + XS * PSZ;
   uint4* Bl = reinterpret_cast<uint4*>(RHq + XS * PSZ) + (size_t)wave_id() * (3 * KB * SL * 64);      // this wave's low digit fragments [gate][kb][sl]
   __shared__ int s_r0[16], s_ns[16];
-  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, g4 = 4 * (lane >> 4);
-  const int col = 16 * w + (lane & 15);
+  __shared__ double s_t64[64];                       // 2^(j / 64): x_exp
+  __shared__ __align__(16) double s_cn[3 * D];       // weight-row scales x 2^-8 (x_combine returns 256 x the digit-pair sum)
+  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, i = lane & 15;
+  const int u0 = 16 * w + 4 * (lane >> 4);           // this lane: hidden units u0 .. u0 + 3 of sequence i
   const int tile = blockIdx.x;
   if (tid < 16) {
     const int k = tile * 16 + tid;
@@ -292,9 +293,10 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
     if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
   }
+  if (tid >= 64 && tid < 128) s_t64[tid - 64] = exp2((double)(tid - 64) * (1.0 / 64.0));
+  for (int e = tid; e < 3 * D; e += blockDim.x) s_cn[e] = A.xWhS[e] * 0x1p-8;
   for (int e = tid; e < 2 * XS * PSZ / 4; e += blockDim.x) reinterpret_cast<unsigned*>(xlds)[e] = 0u;      // h_0 = 0: all digits zero
   i32x4 bw[3][KB][SR];
-  double cn[3];
 #pragma unroll
   for (int gt = 0; gt < 3; ++gt) {
     const int nt = gt * NW + w;
@@ -306,136 +308,127 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
         if (s < SR) bw[gt][kb][s] = __builtin_bit_cast(i32x4, v);
         else Bl[((gt * KB + kb) * SL + (s - SR)) * 64 + lane] = v;
       }
-    cn[gt] = A.xWhS[gt * D + col];
   }
   __syncthreads();
   int ns_max = 0;
-  for (int i = 0; i < 16; ++i) ns_max = max(ns_max, s_ns[i]);
-  int rowb[4], nsr[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { rowb[r] = s_r0[g4 + r]; nsr[r] = s_ns[g4 + r]; }
+  for (int q = 0; q < 16; ++q) ns_max = max(ns_max, s_ns[q]);
+  const int rowb = s_r0[i], nsr = s_ns[i];
   const int Tsp = A.soff[A.n_seq];                   // spare packed row: finished sequences read / write it unconditionally
   double hcur[4] = {0.0, 0.0, 0.0, 0.0};
-  XG3 gc[4];                                         // pre-activations of the current step
+  XG12 gc;                                           // pre-activations of the current step
 
-  const unsigned char* arow = Hq + (lane & 15) * LDP + 16 * (lane >> 4);
-  const unsigned char* rrow = RHq + (lane & 15) * LDP + 16 * (lane >> 4);
-  auto put_digits = [&](unsigned char* plane0, int i, double v) {       // v in [-1, 1] -> the five planes at (row i, col)
-    unsigned lo, hi;
-    x_digits(v * 0x1p38, lo, hi);
-    unsigned char* at = plane0 + i * LDP + col;
-    at[0] = (unsigned char)hi; at[PSZ] = (unsigned char)(lo >> 24); at[2 * PSZ] = (unsigned char)(lo >> 16);
-    at[3 * PSZ] = (unsigned char)(lo >> 8); at[4 * PSZ] = (unsigned char)lo;
+  const unsigned char* hrow = Hq + i * LDP + 16 * (lane >> 4);       // B fragments: sequence i, k = 64 kb + 16 (lane >> 4) + 0 .. 15
+  const unsigned char* rrow = RHq + i * LDP + 16 * (lane >> 4);
+  auto put_digits = [&](unsigned char* plane0, const double (&v)[4]) {       // four values in [-1, 1] -> 4 bytes per plane at (row i, units u0 ..)
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x_digits(v[r] * 0x1p38, lo[r], hi[r]);
+    unsigned* at = reinterpret_cast<unsigned*>(plane0 + i * LDP + u0);
+    at[0] = x_gather_byte(hi[0], hi[1], hi[2], hi[3], 0);
+#pragma unroll
+    for (int s = 1; s < XS; ++s) at[s * (PSZ / 4)] = x_gather_byte(lo[0], lo[1], lo[2], lo[3], XS - 1 - s);
   };
-  auto compute = [&](int t) {
-    i32x4 az[XS], ar[XS];
+  // digit products of NG gates that share the state operand, transposed: acc[g][w][r] = sum over the digit pairs (sa, sb), sa + sb = w,
+  // of W_sb[gate gt0 + g, unit u0 + r] . H_sa[sequence i]  (15 MFMAs per gate and 64 k; consecutive MFMAs go to different accumulators)
+  auto mma = [&](auto& acc, const unsigned char* __restrict__ h0, const int gt0, auto ng) {
+    constexpr int NG = decltype(ng)::value;
 #pragma unroll
-    for (int s = 0; s < XS; ++s) { az[s] = i32x4{0, 0, 0, 0}; ar[s] = i32x4{0, 0, 0, 0}; }
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      i32x4 a[XS], lz[SL], lr[SL];
-#pragma unroll
-      for (int s = 0; s < XS; ++s) a[s] = *reinterpret_cast<const i32x4*>(arow + s * PSZ + 64 * kb);
-#pragma unroll
-      for (int s = 0; s < SL; ++s) {
-        lz[s] = __builtin_bit_cast(i32x4, Bl[((0 * KB + kb) * SL + s) * 64 + lane]);
-        lr[s] = __builtin_bit_cast(i32x4, Bl[((1 * KB + kb) * SL + s) * 64 + lane]);
-      }
-#pragma unroll
-      for (int sa = 0; sa < XS; ++sa)
-#pragma unroll
-        for (int sb = 0; sb < XS - sa; ++sb) {
-          az[sa + sb] = x_mfma16(a[sa], sb < SR ? bw[0][kb][sb < SR ? sb : 0] : lz[sb >= SR ? sb - SR : 0], az[sa + sb]);
-          ar[sa + sb] = x_mfma16(a[sa], sb < SR ? bw[1][kb][sb < SR ? sb : 0] : lr[sb >= SR ? sb - SR : 0], ar[sa + sb]);
-        }
-    }
-    double zv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = g4 + r;
-      const double rv = x_sigmoid(__builtin_fma(x_combine(ar, r), cn[1], gc[r].r));
-      zv[r] = x_sigmoid(__builtin_fma(x_combine(az, r), cn[0], gc[r].z));
-      const double rh = rv * hcur[r];
-      put_digits(RHq, i, rh);
-      const size_t row = (size_t)(t < nsr[r] ? rowb[r] + t : Tsp);
-      A.G[row * 3 * D + D + col] = (float)rv; A.RH[row * D + col] = (float)rh;
-    }
-    x_lds_barrier();
-    i32x4 ac[XS];
-#pragma unroll
-    for (int s = 0; s < XS; ++s) ac[s] = i32x4{0, 0, 0, 0};
+      for (int s = 0; s < XS; ++s) acc[g][s] = i32x4{0, 0, 0, 0};
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      i32x4 a[XS], lc[SL];
+      i32x4 a[XS], lb[NG][SL];
 #pragma unroll
-      for (int s = 0; s < XS; ++s) a[s] = *reinterpret_cast<const i32x4*>(rrow + s * PSZ + 64 * kb);
+      for (int s = 0; s < XS; ++s) a[s] = *reinterpret_cast<const i32x4*>(h0 + s * PSZ + 64 * kb);
 #pragma unroll
-      for (int s = 0; s < SL; ++s) lc[s] = __builtin_bit_cast(i32x4, Bl[((2 * KB + kb) * SL + s) * 64 + lane]);
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int s = 0; s < SL; ++s) lb[g][s] = __builtin_bit_cast(i32x4, Bl[(((gt0 + g) * KB + kb) * SL + s) * 64 + lane]);
 #pragma unroll
       for (int sa = 0; sa < XS; ++sa)
 #pragma unroll
         for (int sb = 0; sb < XS - sa; ++sb)
-          ac[sa + sb] = x_mfma16(a[sa], sb < SR ? bw[2][kb][sb < SR ? sb : 0] : lc[sb >= SR ? sb - SR : 0], ac[sa + sb]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[g][sa + sb] = x_mfma16(sb < SR ? bw[gt0 + g][kb][sb < SR ? sb : 0] : lb[g][sb >= SR ? sb - SR : 0], a[sa], acc[g][sa + sb]);
     }
+  };
+  // one step: z | r products (they share the state's digit fragments: one LDS read) -> r gate, r * h digits -> barrier -> c products,
+  // z gate (off the chain: behind the c products' issue), c gate, h, h digits -> barrier
+  auto compute = [&](int t) {
+    i32x4 azr[2][XS], ac[1][XS];
+    const bool on = t < nsr;
+    const size_t row = (size_t)(on ? rowb + t : Tsp);
+    mma(azr, hrow, 0, std::integral_constant<int, 2>());
+    {
+      double rh[4];
+      float rv4[4], rh4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double rv = x_sigmoid(__builtin_fma(x_combine(azr[1], r), s_cn[D + u0 + r], gc.v[3 * r + 1]), s_t64);
+        rh[r] = rv * hcur[r];
+        rv4[r] = (float)rv; rh4[r] = (float)rh[r];
+      }
+      put_digits(RHq, rh);
+      *reinterpret_cast<float4*>(A.G + row * 3 * D + D + u0) = make_float4(rv4[0], rv4[1], rv4[2], rv4[3]);
+      *reinterpret_cast<float4*>(A.RH + row * D + u0) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
+    }
+    x_lds_barrier();
+    mma(ac, rrow, 2, std::integral_constant<int, 1>());
+    double zv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zv[r] = x_sigmoid(__builtin_fma(x_combine(azr[0], r), s_cn[u0 + r], gc.v[3 * r]), s_t64);
+    float z4[4], c4[4], h4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = g4 + r;
-      const bool on = t < nsr[r];
-      const double c = x_tanh(__builtin_fma(x_combine(ac, r), cn[2], gc[r].c));
+      const double c = x_tanh(__builtin_fma(x_combine(ac[0], r), s_cn[2 * D + u0 + r], gc.v[3 * r + 2]), s_t64);
       const double hn = on ? __builtin_fma(zv[r], c - hcur[r], hcur[r]) : hcur[r];
-      put_digits(Hq, i, hn);
       hcur[r] = hn;
-      const size_t row = (size_t)(on ? rowb[r] + t : Tsp);
-      A.G[row * 3 * D + col] = (float)zv[r]; A.G[row * 3 * D + 2 * D + col] = (float)c;
-      A.H[row * D + col] = (float)hn;
+      z4[r] = (float)zv[r]; c4[r] = (float)c; h4[r] = (float)hn;
     }
+    put_digits(Hq, hcur);
+    *reinterpret_cast<float4*>(A.G + row * 3 * D + u0) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+    *reinterpret_cast<float4*>(A.G + row * 3 * D + 2 * D + u0) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+    *reinterpret_cast<float4*>(A.H + row * D + u0) = make_float4(h4[0], h4[1], h4[2], h4[3]);
     x_lds_barrier();
   };
 
   if constexpr (!FT) {
-    auto fetch = [&](int t, XG3 (&n)[4]) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) n[q] = *reinterpret_cast<const XG3*>(A.gx + (size_t)(t < nsr[q] ? rowb[q] + t : Tsp) * 3 * D + 3 * col);
-    };
-    XG3 nx[4];
+    auto fetch = [&](int t, XG12& n) { n = *reinterpret_cast<const XG12*>(A.gx + (size_t)(t < nsr ? rowb + t : Tsp) * 3 * D + 3 * u0); };
+    XG12 nx;
     fetch(0, gc);
     for (int t = 0; t < ns_max; ++t) {
       fetch(t + 1, nx);
       compute(t);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        asm volatile("" : "+v"(nx[q].z), "+v"(nx[q].r), "+v"(nx[q].c));      // the wait for the prefetch is counted here, behind the step's stores
-        gc[q] = nx[q];
+      for (int q = 0; q < 12; ++q) {
+        asm volatile("" : "+v"(nx.v[q]));      // the wait for the prefetch is counted here, behind the step's stores
+        gc.v[q] = nx.v[q];
       }
     }
   } else {
     // forward table: the row ids of step t + 2 and the table rows of step t + 1 are requested at the top of step t
-    int rp[4], rz[4];
-    auto ids = [&](int t) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int rr = t < nsr[q] ? rowb[q] + t : Tsp; rp[q] = A.row_p[rr]; rz[q] = A.spatial ? A.row_dp[rr] : 0; }
+    int rp = 0, rz = 0;
+    auto ids = [&](int t) { const int rr = t < nsr ? rowb + t : Tsp; rp = A.row_p[rr]; rz = A.spatial ? A.row_dp[rr] : 0; };
+    auto rows = [&](XG12& pp, XG12& zz) {
+      const int p1 = (int)min((unsigned)rp, (unsigned)A.n_item), z1 = A.spatial ? (int)min((unsigned)rz, (unsigned)A.n_dist) : 0;
+      pp = *reinterpret_cast<const XG12*>(A.ptabx + (size_t)p1 * 3 * D + 3 * u0);
+      zz = *reinterpret_cast<const XG12*>(A.ztabx + (size_t)z1 * 3 * D + 3 * u0);
     };
-    auto rows = [&](XG3 (&pp)[4], XG3 (&zz)[4]) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int p1 = (int)min((unsigned)rp[q], (unsigned)A.n_item), z1 = A.spatial ? (int)min((unsigned)rz[q], (unsigned)A.n_dist) : 0;
-        pp[q] = *reinterpret_cast<const XG3*>(A.ptabx + (size_t)p1 * 3 * D + 3 * col);
-        zz[q] = *reinterpret_cast<const XG3*>(A.ztabx + (size_t)z1 * 3 * D + 3 * col);
-      }
-    };
-    XG3 pn[4], zn[4];
+    XG12 pn, zn;
     ids(0); rows(pn, zn);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { gc[q].z = pn[q].z + zn[q].z; gc[q].r = pn[q].r + zn[q].r; gc[q].c = pn[q].c + zn[q].c; }
+    for (int q = 0; q < 12; ++q) gc.v[q] = pn.v[q] + zn.v[q];
     ids(1);
     for (int t = 0; t < ns_max; ++t) {
       rows(pn, zn);                            // step t + 1 (ids loaded a step ago)
       ids(t + 2);
       compute(t);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        asm volatile("" : "+v"(pn[q].z), "+v"(pn[q].r), "+v"(pn[q].c), "+v"(zn[q].z), "+v"(zn[q].r), "+v"(zn[q].c));
-        gc[q].z = pn[q].z + zn[q].z; gc[q].r = pn[q].r + zn[q].r; gc[q].c = pn[q].c + zn[q].c;
+      for (int q = 0; q < 12; ++q) {
+        asm volatile("" : "+v"(pn.v[q]), "+v"(zn.v[q]));
+        gc.v[q] = pn.v[q] + zn.v[q];
       }
     }
   }
