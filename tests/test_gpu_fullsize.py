@@ -3,10 +3,9 @@ Gowalla shape in EXACTLY bench.py's configuration (configs[2]: data with 80 % lo
 bins -, batch cap 64, users sorted by length) and the whole-shard launch + a sequential reference-schedule
 run of the Foursquare shape (configs[1]) are compared with the plain-C float64 restatement of the batch rule /
 the sequential epoch (oracle/poi_oracle_c.c, threaded over the launch), all nine tensors, weights within 1e-5
-AND updates within 1e-4 of every ROW's own absolute mass (tests/gpu_util.delta_excess with absmass) - for the float32
-tile engine with the documented loosening of the POI table (FULL_SIZE_LT), and for the EXACT engine (float64 arithmetic,
-poi_ctx_set_engine(4)) with no loosening at all: every row of every tensor inside 1e-5, every update inside 1e-6 of its mass,
-300 sequential steps inside 1e-5.  (2) Size-independent properties at the Gowalla shape (100 k POIs, 50 k users,
+AND updates within 1e-4 of every ROW's own absolute mass (tests/gpu_util.delta_excess with absmass) - for the timed
+tile engine (exact forward pass, float32 behind it) with no loosening of any tensor, 300 sequential steps inside 1e-5, and for the
+EXACT engine (float64 arithmetic, poi_ctx_set_engine(4)): every update inside 1e-6 of its mass.  (2) Size-independent properties at the Gowalla shape (100 k POIs, 50 k users,
 L <= 50, D = 128, 200 bins):
   * a 12500-user launch leaves every table row that no sequence of the launch touches bit-identical,
     moves every touched row, keeps everything finite and is bitwise reproducible (lt / di);
@@ -138,16 +137,16 @@ _CACHE = {}
 
 
 def test_gowalla_timed_launch_matches_the_oracle_batch_rule(setup):
-    """The float32 tile engine (per-bin tables, per-POI regrouping, three-level per-bin sums, sorted scatter, te_dapply) on the TIMED
-    configuration against the float64 oracle of the capped-sum rule: per-sequence losses, the nine tensors to 1e-5 of their
-    max-norm (lt: FULL_SIZE_LT) and every row's UPDATE to 1e-4 of the row's own absolute mass."""
-    from tests.gpu_util import FULL_SIZE_LT, assert_close, assert_step_close, rows_within
+    """The tile engine (exact forward pass, per-bin tables, per-POI regrouping, three-level per-bin sums, sorted scatter, te_dapply) on the
+    TIMED configuration against the float64 oracle of the capped-sum rule: per-sequence losses to 1e-5, ALL nine tensors to 1e-5 of their
+    max-norm - every row of the POI table - and every row's UPDATE to 1e-4 of the row's own absolute mass."""
+    from tests.gpu_util import assert_close, assert_step_close, rows_within
     P, out, got, exp, eout, touched = _gowalla_launch(setup, "auto")
-    assert_close(out[:, :3], eout[:, :3], "losses of the launch", rtol=2e-5)
-    worst = assert_step_close(got, exp, P, SP_NAMES, "gowalla 12500-user launch", loose=FULL_SIZE_LT, absmass=touched["absmass"])
-    assert rows_within(got["lt"], exp["lt"]) >= 0.999, "more than 0.1 % of the POI rows miss the 1e-5 bar"
+    assert_close(out[:, :3], eout[:, :3], "losses of the launch")
+    worst = assert_step_close(got, exp, P, SP_NAMES, "gowalla 12500-user launch", absmass=touched["absmass"])
+    assert rows_within(got["lt"], exp["lt"]) == 1.0, "POI rows miss the 1e-5 bar"
     assert np.array_equal((got["lt"] != P["lt"]).any(axis=1), touched["lt"])
-    print("gowalla launch vs oracle (float32 tile engine): worst weight rel err %.2e" % worst)
+    print("gowalla launch vs oracle (tile engine, exact forward): worst weight rel err %.2e" % worst)
 
 
 def test_gowalla_timed_launch_exact_engine_meets_the_contract_on_every_row(setup):
@@ -189,16 +188,15 @@ def test_delta_bar_catches_a_padding_multiplicity_off_by_one_at_the_gowalla_shap
 def test_foursquare_shape_full_size_against_the_oracle():
     """configs[1] (10 k POIs, 5 k users, L <= 20, D = 64 - the two-table path of the tile engine) at FULL size:
     (a) the whole shard in one launch == the oracle's batch rule; (b) the reference schedule (one user per step,
-    prog_bpr_gru_spatial.py:249-250) over 300 users of the shuffled order == the sequential float64 epoch (float32 engine:
-    errors compound over the steps, 2e-4); (a') / (b') the same on the EXACT engine with no loosening - every row of the nine
-    tensors inside 1e-5 after the launch AND after the 300 sequential steps, predict to 2e-7;
+    prog_bpr_gru_spatial.py:249-250) over 300 users of the shuffled order == the sequential float64 epoch, every tensor inside
+    1e-5 after the 300 steps; (a') / (b') the same on the EXACT engine - updates inside 1e-6 of their mass, predict to 2e-7;
     (c) predict + all-POI top-20 == float64 scores' ranks on gap-checked rows."""
     import torch
     import poi_amd
     from oracle import c_oracle as C
     from oracle import poi_oracle as O
     from poi_amd import data as pdata
-    from tests.gpu_util import EXACT_DELTA_RTOL, FULL_SIZE_LT, assert_close, assert_step_close, rows_within
+    from tests.gpu_util import EXACT_DELTA_RTOL, assert_close, assert_step_close, rows_within
     n_item, n_user, max_len, D = pdata.SHAPES["foursquare"]
     ds = pdata.make_synthetic(n_user, n_item, max_len, seed=78, local=0.8)
     tab = ds.shard(0, n_user)
@@ -212,9 +210,9 @@ def test_foursquare_shape_full_size_against_the_oracle():
     out = np.asarray(m.train_batch(users))
     got = _state(m)
     exp, eout, tch = C.spatial_batch_mean(P, tab.off, tab.p, tab.q, tab.dp, tab.dq, users, tab.len_max, 0.01, 0.001, absmass=True)
-    assert_close(out[:, :3], eout[:, :3], "losses", rtol=2e-5)
-    assert_step_close(got, exp, P, SP_NAMES, "foursquare whole-shard launch", loose=FULL_SIZE_LT, absmass=tch["absmass"])
-    assert rows_within(got["lt"], exp["lt"]) >= 0.999
+    assert_close(out[:, :3], eout[:, :3], "losses")
+    assert_step_close(got, exp, P, SP_NAMES, "foursquare whole-shard launch", absmass=tch["absmass"])
+    assert rows_within(got["lt"], exp["lt"]) == 1.0
     # (a') the same launch on the exact engine: the contract on every row, no loosening
     m = make()
     m.ctx.set_engine("exact")
@@ -244,15 +242,15 @@ def test_foursquare_shape_full_size_against_the_oracle():
     masks = [np.r_[np.ones(off[u + 1] - off[u], int), np.zeros(max_len - (off[u + 1] - off[u]), int)] for u in sub]
     eh, es = O.spatial_predict(got_x | {"h0": np.zeros(D)}, got_x["lt"], got_x["di"], rows(tab.p, n_item), rows(tab.dp, ds.dist_num), masks)
     assert_close(hx, eh, "hts (exact)", rtol=2e-7); assert_close(sx, es, "sts (exact)", rtol=2e-7)
-    # (b) reference schedule, float32 tile engine
+    # (b) reference schedule on the timed engine (exact forward pass): 300 sequential steps stay inside the ONE-step bar
     m = make()
     Pc = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in P.items()}
     eo = C.spatial_epoch(Pc, tab.off, tab.p, tab.q, tab.dp, tab.dq, order, tab.len_max, 0.01, 0.001)
     go = np.array([[r[0], r[1], r[2]] for r in (m.train(np.int32(u)) for u in order)])
-    assert_close(go, eo[:, :3], "sequential losses", rtol=2e-4)
+    assert_close(go, eo[:, :3], "sequential losses")
     got = _state(m)
     for k in SP_NAMES:
-        assert_close(got[k], Pc[k], "after 300 sequential steps: " + k, rtol=2e-4)
+        assert_close(got[k], Pc[k], "after 300 sequential steps: " + k)
     # (c) predict + score + top-K at full size
     m.update_trained_items(); m.update_trained_dists()
     ids = np.arange(n_user, dtype=np.int32)
