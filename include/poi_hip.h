@@ -41,7 +41,10 @@
 extern "C" {
 #endif
 
-#define POI_ABI_VERSION 2
+/* 3 (round 4): poi_sync_buffer no longer carries the deltas of POI_F16 segments - they travel in poi_sync_buffer16, and poi_sync_apply
+ * refuses to combine half segments whose buffer the caller never asked for; new entry points since 2: poi_sync_buffer16,
+ * poi_ctx_set_split_products / _small_launch / _one_sequence_path / _regroup_min / _f16_rounding / _topk_filter(_stats), poi_ctx_set_exact_forward. */
+#define POI_ABI_VERSION 3
 
 enum {
   POI_OK = 0,

@@ -6,7 +6,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpoi_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 BPR_SNAPSHOT, BPR_HOGWILD = 0, 1
 

@@ -476,7 +476,8 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       return e;
     };
     const size_t out_bytes = sizeof(float) * (size_t)n * (spatial ? 5 : 1);
-    if (!c->graph_mode || c->tm.on || !c->side || n < c->graph_min_n || n > c->graph_max_n || E.sr_salt) { HIPCHK(c, run(st)); return POI_OK; }
+    // (timing: only the SAMPLED launches carry event pairs - the others replay; a sampled launch runs eagerly)
+    if (!c->graph_mode || (c->tm.on && c->tm.active) || !c->side || n < c->graph_min_n || n > c->graph_max_n || E.sr_salt) { HIPCHK(c, run(st)); return POI_OK; }
     // ---- graph replay ----
     if ((rc = ensure(c, c->uidx_stage, sizeof(int32_t) * (size_t)n, st)) || (rc = ensure(c, c->out_stage, out_bytes, st))) return rc;
     std::vector<uint64_t> key;
@@ -490,8 +491,14 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
       const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
-                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, (const void*)(size_t)(c->fwd_tab | (c->rec_split << 1) | (c->one_path << 2) | ((unsigned)c->rec1_max << 3) | ((size_t)(unsigned)c->bintab_min << 24) | ((size_t)c->early_bins << 60))};
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, c->xw.p, c->xg.p};
       add(bufs, sizeof bufs);
+      // every switch that decides which kernels / which stream topology the launch takes, each in its own word (packed into one
+      // word they overlapped and early_min was missing), plus what te_setup derived from them for THIS launch
+      const uint64_t sw[] = {(uint64_t)c->fwd_tab, (uint64_t)c->rec_split, (uint64_t)c->one_path, (uint64_t)(unsigned)c->rec1_max, (uint64_t)(unsigned)c->bintab_min,
+                             (uint64_t)c->early_bins, (uint64_t)(unsigned)c->early_min, (uint64_t)c->xfwd, (uint64_t)E.early_bins, (uint64_t)E.bintab, (uint64_t)E.rec1,
+                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.ppoi, (uint64_t)one};
+      add(sw, sizeof sw);
     }
     poi_ctx::StepGraph* g = nullptr;
     for (auto& e : c->graphs) if (e.key == key) { g = &e; break; }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void pack_items_f16_kernel(const float* __rest
   if (s == 0 && valid) inorm[gi] = make_float2(bad ? INFINITY : sqrtf(n2) * 1.000002f, n1 * (2.98023224e-8f * 1.01f));
 }
 
-#define SF_CAP 4096       // survivor slots per user in global memory (good seeds leave ~K + 1 of them; an overflow flags the tile)
+#define SF_CAP 2048       // survivor slots per user in global memory (good seeds leave ~K + 1 of them, the self-seeding pre-pass ~16 K; an overflow flags the tile).  8 bytes per slot: a 65536-user call pins 1 GB of grow-only context memory
 
 // stage 1.  BINS: 0 = no distance term, 1 / 2 = resident bin matrix (uint8 / uint16, misc.hip::ulptai_kernel) + the users' bin probabilities,
 // 3 = GEO: bins computed on the fly from the coordinates (poi_score_topk_geo: no U x N matrix; config X) - only for the pairs whose
@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256, ((BINS == 3 || UT == 2) ? 2 : 3)) void score_f
     const float bu = n1_of(u)[tt] * (2.98023224e-8f * 1.01f) + 4.76837158e-7f * (fabsf(wd) * pmax + (g ? fabsf(thr) : 0.f)) + 1e-30f;
     au_of(u)[tt] = c1 * nu2;
     c_of(u)[tt] = urow < A.n ? thr - bu : INFINITY;        // rows past n: nothing survives
-    n2_of(u)[tt] = (urow < A.n && !g) ? 1.f : 0.f;         // an unseeded user (no bound: malformed / missing seed row)
+    // an unseeded user (no bound: malformed / missing seed row) - or one whose row may not survive the rounding to half: an element
+    // beyond the half range becomes +-inf, an all-(-inf) product sum would DROP a pair whose float32 score is finite (|x| > 65000 implies
+    // |u|_2^2 > 4e9; the converse costs only speed) - hands its tile to the one-stage kernel
+    n2_of(u)[tt] = (urow < A.n && (!g || !(n2_of(u)[tt] < 4.0e9f))) ? 1.f : 0.f;
     if (GEO) {                                             // ub = max_b wd sts[b] (>= 0: column n_dist is zero), widened: >= every exact product
       float mx = 0.f;
       for (int b = 0; b < NB; ++b) mx = fmaxf(mx, wd * sts[tt * NB + b]);
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void sf_users_prep_kernel(ScoreArgs A, uint4* 
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) { aum = fmaxf(aum, __shfl_xor(aum, o, 64)); umm = fmaxf(umm, __shfl_xor(umm, o, 64)); }
     ub[ut * 32 + t] = make_float4(au, urow < A.n ? thr - bu : INFINITY, um, t == 0 ? aum : t == 1 ? umm : 0.f);
-    unseeded = urow < A.n && !g;
+    unseeded = urow < A.n && (!g || !(s_n2[t] < 4.0e9f));      // (no bound, or a row that may overflow the half range: see score_filter_kernel)
     const int lp = A.last_poi[ur];
     double* gq = ugeo + (size_t)(ut * 32 + t) * 3;
     gq[0] = A.coords[2 * lp]; gq[1] = A.coords[2 * lp + 1]; gq[2] = A.cphi[lp];

@@ -142,6 +142,7 @@ struct poi_sync {
   std::vector<poi_sync_seg> segs;
   std::vector<long long> off, cnt_off;          // element offsets into the flat buffers (cnt_off < 0: no touch counts); half segments: into base16 / delta16
   long long n_data = 0, n_total = 0, n_half = 0;
+  bool asked16 = false;                         // the caller has seen poi_sync_buffer16 (a caller that owns the collective must all-reduce it too)
   float *base = nullptr, *delta = nullptr;
   __half *base16 = nullptr, *delta16 = nullptr; // snapshot / deltas of the segments stored as half
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -301,11 +302,16 @@ int poi_sync_buffer(poi_sync* s, float** delta, int64_t* n) {
 int poi_sync_buffer16(poi_sync* s, void** delta16_dev, int64_t* n) {
   if (!s || !delta16_dev || !n) return sfail(s, POI_EINVAL, "poi_sync_buffer16: NULL");
   *delta16_dev = s->delta16; *n = s->n_half;
+  s->asked16 = true;
   return POI_OK;
 }
 
 int poi_sync_apply(poi_sync* s, int32_t world, void* stream) {
   if (!s || world < 1) return sfail(s, POI_EINVAL, "poi_sync_apply: bad argument");
+  // A caller written against ABI 2 all-reduces poi_sync_buffer only: the half segments would then combine each replica's OWN delta with
+  // the global touch counts and diverge silently.  (poi_sync_end_epoch reduces both buffers itself.)
+  if (s->n_half > 0 && world > 1 && !s->asked16)
+    return sfail(s, POI_EINVAL, "poi_sync_apply: the set has IEEE-half segments whose deltas live in poi_sync_buffer16, which was never queried - all-reduce it as well (ABI 3)");
   if (hipSetDevice(s->device) != hipSuccess) return sfail(s, POI_EHIP, "hipSetDevice failed");
   for (size_t i = 0; i < s->segs.size(); ++i) {
     const poi_sync_seg& g = s->segs[i];
@@ -332,6 +338,7 @@ int poi_sync_end_epoch(poi_sync* s, poi_comm* comm, void* stream) {
     if (nr != ncclSuccess) return sfail(s, POI_EHIP, std::string("ncclAllReduce (half): ") + R->GetErrorString(nr));
   }
   (void)hipEventRecord(s->e1, (hipStream_t)stream);
+  s->asked16 = true;      // (both buffers were reduced above)
   return poi_sync_apply(s, comm->world, stream);
 }
 

@@ -81,18 +81,38 @@ class HipSyncBackend:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def init_comm(self, group=None):
-        """The library's own RCCL communicator: rank 0 draws the id, one broadcast hands it to the others."""
+        """The library's own RCCL communicator: rank 0 draws the id, one broadcast hands it to the others.  Returns True when every rank
+        holds a communicator, False when the ranks AGREED not to build one.  The collective sequence is the same on every rank whatever
+        fails locally: (1) every rank probes that the library can bind librccl (poi_comm_unique_id into a scratch buffer - rank 0's
+        draw is the id), (2) ONE broadcast of the id (zeros if rank 0 could not draw it), (3) ONE all-reduce (MIN) of the probe results,
+        and only if all ranks passed (4) the collective poi_comm_init_rank, followed by (5) a second MIN all-reduce of its outcome."""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+        on_dev = dist.get_backend(group) == "nccl"
         buf = (ctypes.c_char * 128)()
-        if rank == 0:
+        ok = 1
+        try:
             self._check(self.lib.poi_comm_unique_id(buf))
+        except Exception:      # noqa: BLE001 - agreed on across ranks below
+            ok = 0
+            buf = (ctypes.c_char * 128)()
         t = torch.tensor(list(buf.raw), dtype=torch.uint8)
-        t = t.to(self.device) if dist.get_backend(group) == "nccl" else t
+        t = t.to(self.device) if on_dev else t
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if on_dev else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            return False
         raw = bytes(t.cpu().tolist())
         h = ctypes.c_void_p()
-        self._check(self.lib.poi_comm_init_rank(raw, world, rank, self.device.index, ctypes.byref(h)))
+        rc = self.lib.poi_comm_init_rank(raw, world, rank, self.device.index, ctypes.byref(h))
+        flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            if rc == 0 and h:
+                self.lib.poi_comm_destroy(h)
+            return False
         self.comm = h
+        return True
 
     def begin_epoch(self):
         self._check(self.lib.poi_sync_begin_epoch(self.handle, self._stream()))
@@ -158,21 +178,12 @@ class ReplicaSync:
             if own_comm is None:
                 own_comm = self.active and dist.get_backend(group) == "nccl"
             if own_comm and self.active:
-                # every rank must end up on the SAME collective: a rank whose communicator could not be built (or whose peers' could
-                # not) falls back, with all the others, to torch.distributed.all_reduce on the same buffers
-                err = None
-                try:
-                    backend.init_comm(group)
-                except Exception as e:      # noqa: BLE001 - reported below, then agreed on across ranks
-                    err = e
-                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.tensors[0].device if dist.get_backend(group) == "nccl" else "cpu")
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-                if int(ok.item()) == 0:
+                # every rank ends up on the SAME collective: init_comm runs one fixed sequence of collectives and returns the ranks'
+                # common verdict; without a communicator all of them use torch.distributed.all_reduce on the same buffers
+                if not backend.init_comm(group):
                     import warnings
-                    warnings.warn("poi_comm_init_rank failed on at least one rank (%s): replica reconciliation falls back to "
-                                  "torch.distributed.all_reduce" % (err if err else "a peer"))
-                    if getattr(backend, "comm", None):
-                        backend.lib.poi_comm_destroy(backend.comm)
+                    warnings.warn("the library's RCCL communicator could not be built on at least one rank: replica reconciliation falls back to "
+                                  "torch.distributed.all_reduce")
                     backend.comm = None
         if isinstance(backend, HipSyncBackend) and own_comm is None:
             own_comm = False
