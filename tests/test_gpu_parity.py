@@ -239,10 +239,10 @@ def test_topk_golden_bit_exact(pa, golden_dir):
     dev = torch.as_tensor(scores).cuda()
     for k, key in ((20, "ranks"), (5, "ranks5")):
         exp = O.topk_desc(scores, k)
-        if np.array_equal(exp, g[key]):      # float32 rounding kept the float64 order
-            pass
+        assert np.array_equal(exp, g[key]), "float32 rounding changed the float64 order of the golden scores"
         idx = torch.empty((scores.shape[0], k), dtype=torch.int32, device="cuda")
         ctx.check(ctx.lib.poi_topk(ctx.handle, dev.data_ptr(), scores.shape[0], scores.shape[1], k, idx.data_ptr(), None, None))
+        assert np.array_equal(idx.cpu().numpy(), g[key]), "HIP top-K differs from the ranks of the reference's own helpers"
         assert np.array_equal(idx.cpu().numpy(), exp)
     assert np.array_equal(O.topk_desc(g["scores"], 20), g["ranks"])
 
