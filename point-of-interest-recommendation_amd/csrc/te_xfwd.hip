@@ -23,6 +23,7 @@
 #include "poi_common.h"
 #include "poi_kernels.h"
 
+#include <stdio.h>
 #include <type_traits>
 
 namespace poi {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void te_xpack_kernel(XPackJobs J) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// te_xztab: ztabx[b][3 c + g] = di[b] . ui[g D + c][D:] + bi[g D + c] in float64 (products of float32 values are exact in float64).
+// te_xztab: ztabx[b][g D + c] = di[b] . ui[g D + c][D:] + bi[g D + c] in float64 (products of float32 values are exact in float64).
 // Plain GRU (no distance-bin table): one row, the bias.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(768) void te_xztab_kernel(TeArgs A) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(768) void te_xztab_kernel(TeArgs A) {
   if (A.spatial && n < D) drow[n] = A.di[(size_t)b * D + n];
   __syncthreads();
   if (n >= 3 * D) return;
-  const int c = n / 3, g = n % 3, r = g * D + c;
+  const int r = n;                                  // gate-major columns: n = g D + c, the row of ui / bi itself
   double a0 = (double)A.bi[r], a1 = 0.0;
   if (A.spatial) {
     const float* u = A.ui + (size_t)r * XW + D;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(768) void te_xztab_kernel(TeArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// te_gemmx: C[r][n] = lt[idx[r]] . uiP[n]  (+ ztabx[zidx[r]][n]),  n = 3 c + g < 3 D, in float64 from the digit products.
+// te_gemmx: C[r][n] = lt[idx[r]] . uiP[n]  (+ ztabx[zidx[r]][n]),  n = g D + c < 3 D (gate-major columns), in float64 from the digit products.
 // A workgroup item = 128 rows x a group of 32-column tiles; a wave keeps ITS 32 rows as resident digit planes (rows fetched straight
 // into the fragment layout, row scale = the row's largest exponent, digits cut in registers) and walks the column tiles, whose digit
 // fragments (te_xpack, frag32) are staged through LDS once per workgroup.  Rows past the end land in the spare row behind C.
@@ -272,7 +273,21 @@ __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
 // FT: pre-activations = ptabx[p_t] + ztabx[dp_t] (forward table); else gx[row].
 // Outputs exactly as te_rec_fwd16: G := z | r | c, H, RH (float32 roundings of the float64 values).
 // -------------------------------------------------------------------------------------------------
-struct XG12 { double v[12]; };      // z | r | c of four consecutive hidden units (gate-interleaved columns)
+#ifdef TE_XPROF
+// -DTE_XPROF (never in the product build): clock64() stamps between the phases of a step, summed per wave over all workgroups
+__device__ unsigned long long g_xprof[8][10];
+#define XP_INIT long long xp_t = clock64(); long long xp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define XP(i) { const long long xp_n = clock64(); xp[i] += xp_n - xp_t; xp_t = xp_n; }
+#define XP_END if (lane_id() == 0) { for (int q_ = 0; q_ < 10; ++q_) atomicAdd(&g_xprof[wave_id() & 7][q_], (unsigned long long)xp[q_]); }
+#else
+#define XP_INIT
+#define XP(i)
+#define XP_END
+#endif
+// z | r | c of four consecutive hidden units: v[4 g + r] = gate g of unit u0 + r.  The float64 tables are GATE-MAJOR (column g D + u): a lane's
+// 32 bytes per gate sit next to its neighbours' - the 16 lanes of a row read one 128-byte line per wave and gate.  (Gate-interleaved
+// columns, 96 bytes per lane, made every 16-byte load instruction of a wave touch 48 lines: the kernel was bound by the address path.)
+struct XG12 { double v[12]; };
 
 template <int D, bool FT>
 __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
@@ -316,6 +331,16 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
   const int Tsp = A.soff[A.n_seq];                   // spare packed row: finished sequences read / write it unconditionally
   double hcur[4] = {0.0, 0.0, 0.0, 0.0};
   XG12 gc;                                           // pre-activations of the current step
+  struct XG4 { double v[4]; };
+  auto load3 = [&](XG12& o, const double* __restrict__ rowp) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const XG4 q = *reinterpret_cast<const XG4*>(rowp + g * D + u0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o.v[4 * g + r] = q.v[r];
+    }
+  };
+  XP_INIT
 
   const unsigned char* hrow = Hq + i * LDP + 16 * (lane >> 4);       // B fragments: sequence i, k = 64 kb + 16 (lane >> 4) + 0 .. 15
   const unsigned char* rrow = RHq + i * LDP + 16 * (lane >> 4);
@@ -360,13 +385,15 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
     i32x4 azr[2][XS], ac[1][XS];
     const bool on = t < nsr;
     const size_t row = (size_t)(on ? rowb + t : Tsp);
+    XP(0)
     mma(azr, hrow, 0, std::integral_constant<int, 2>());
+    XP(1)
     {
       double rh[4];
       float rv4[4], rh4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double rv = x_sigmoid(__builtin_fma(x_combine(azr[1], r), s_cn[D + u0 + r], gc.v[3 * r + 1]), s_t64);
+        const double rv = x_sigmoid(__builtin_fma(x_combine(azr[1], r), s_cn[D + u0 + r], gc.v[4 + r]), s_t64);
         rh[r] = rv * hcur[r];
         rv4[r] = (float)rv; rh4[r] = (float)rh[r];
       }
@@ -374,15 +401,19 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
       *reinterpret_cast<float4*>(A.G + row * 3 * D + D + u0) = make_float4(rv4[0], rv4[1], rv4[2], rv4[3]);
       *reinterpret_cast<float4*>(A.RH + row * D + u0) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
     }
+    XP(2)
     x_lds_barrier();
+    XP(3)
     mma(ac, rrow, 2, std::integral_constant<int, 1>());
+    XP(4)
     double zv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zv[r] = x_sigmoid(__builtin_fma(x_combine(azr[0], r), s_cn[u0 + r], gc.v[3 * r]), s_t64);
+    for (int r = 0; r < 4; ++r) zv[r] = x_sigmoid(__builtin_fma(x_combine(azr[0], r), s_cn[u0 + r], gc.v[r]), s_t64);
+    XP(5)
     float z4[4], c4[4], h4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double c = x_tanh(__builtin_fma(x_combine(ac[0], r), s_cn[2 * D + u0 + r], gc.v[3 * r + 2]), s_t64);
+      const double c = x_tanh(__builtin_fma(x_combine(ac[0], r), s_cn[2 * D + u0 + r], gc.v[8 + r]), s_t64);
       const double hn = on ? __builtin_fma(zv[r], c - hcur[r], hcur[r]) : hcur[r];
       hcur[r] = hn;
       z4[r] = (float)zv[r]; c4[r] = (float)c; h4[r] = (float)hn;
@@ -391,11 +422,13 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
     *reinterpret_cast<float4*>(A.G + row * 3 * D + u0) = make_float4(z4[0], z4[1], z4[2], z4[3]);
     *reinterpret_cast<float4*>(A.G + row * 3 * D + 2 * D + u0) = make_float4(c4[0], c4[1], c4[2], c4[3]);
     *reinterpret_cast<float4*>(A.H + row * D + u0) = make_float4(h4[0], h4[1], h4[2], h4[3]);
+    XP(6)
     x_lds_barrier();
+    XP(7)
   };
 
   if constexpr (!FT) {
-    auto fetch = [&](int t, XG12& n) { n = *reinterpret_cast<const XG12*>(A.gx + (size_t)(t < nsr ? rowb + t : Tsp) * 3 * D + 3 * u0); };
+    auto fetch = [&](int t, XG12& n) { load3(n, A.gx + (size_t)(t < nsr ? rowb + t : Tsp) * 3 * D); };
     XG12 nx;
     fetch(0, gc);
     for (int t = 0; t < ns_max; ++t) {
@@ -408,13 +441,15 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
       }
     }
   } else {
-    // forward table: the row ids of step t + 2 and the table rows of step t + 1 are requested at the top of step t
+    // forward table: the row ids of step t + 2 and the table rows of step t + 1 are requested at the top of step t.  (Measured and not
+    // kept: touching the lines of the row of step t + 3 - one dword per 128-byte line, at the top or at the very end of a step - to bring
+    // them to L2 two steps early: 412 -> 444 .. 481 us per 12500-user launch; vmcnt retires in order, a far prefetch sits in every wait.)
     int rp = 0, rz = 0;
     auto ids = [&](int t) { const int rr = t < nsr ? rowb + t : Tsp; rp = A.row_p[rr]; rz = A.spatial ? A.row_dp[rr] : 0; };
     auto rows = [&](XG12& pp, XG12& zz) {
       const int p1 = (int)min((unsigned)rp, (unsigned)A.n_item), z1 = A.spatial ? (int)min((unsigned)rz, (unsigned)A.n_dist) : 0;
-      pp = *reinterpret_cast<const XG12*>(A.ptabx + (size_t)p1 * 3 * D + 3 * u0);
-      zz = *reinterpret_cast<const XG12*>(A.ztabx + (size_t)z1 * 3 * D + 3 * u0);
+      load3(pp, A.ptabx + (size_t)p1 * 3 * D);
+      load3(zz, A.ztabx + (size_t)z1 * 3 * D);
     };
     XG12 pn, zn;
     ids(0); rows(pn, zn);
@@ -432,6 +467,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
       }
     }
   }
+  XP_END
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -462,7 +498,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   {
     XPackJobs J;
     J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
-    J.j[1] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 1, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS};
+    J.j[1] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 0, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS};
     J.n = 2;
     hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 2), dim3(256), 0, st, J);
     hipLaunchKernelGGL(te_xztab_kernel, dim3(A.spatial ? A.n_dist + 1 : 1), dim3(3 * D), 0, st, A);
@@ -483,6 +519,23 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   tm->end(st);
   return hipGetLastError();
   }
+#ifdef TE_XPROF
+  struct Dump { ~Dump() {
+    unsigned long long h[8][10];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_xprof), sizeof(h)) != hipSuccess) return;
+    static const char* nm[10] = {"prefetch issue / loop", "z|r products", "r gate, digits, stores", "barrier 1", "c products", "z gate", "c gate, h, digits, stores", "barrier 2", "", ""};
+    for (int w = 0; w < 8; ++w) {
+      unsigned long long tot = 0;
+      for (int i = 0; i < 10; ++i) tot += h[w][i];
+      if (!tot) continue;
+      fprintf(stderr, "[te_rec_fwdx prof] wave %d: total %.3e cycles;", w, (double)tot);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%;", nm[i], 100.0 * (double)h[w][i] / (double)tot);
+      fprintf(stderr, "\n");
+    }
+    unsigned long long z[8][10] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xprof), z, sizeof(z));
+  } } dump_at_exit;
+#endif
   tm->begin("te_rec_fwd", st);
   if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
   else hipLaunchKernelGGL((te_rec_fwdx_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
