@@ -51,6 +51,12 @@ __device__ __forceinline__ void x_digits(double t, unsigned& lo, unsigned& hi) {
   lo = (unsigned)b ^ 0x80808080u;
   hi = ((unsigned)(b >> 32) ^ 0x80u) & 0xFFu;
 }
+// the same for v in [-1, 1] at the chain's fixed scale 2^38 (one FMA: v 2^38 is exact, the sum rounds once)
+__device__ __forceinline__ void x_digits38(double v, unsigned& lo, unsigned& hi) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(__builtin_fma(v, 0x1p38, 0x1.8p52)) + 0x8080808080ull;
+  lo = (unsigned)b ^ 0x80808080u;
+  hi = ((unsigned)(b >> 32) ^ 0x80u) & 0xFFu;
+}
 __device__ __forceinline__ unsigned x_digit(unsigned lo, unsigned hi, int s) { return s == 0 ? hi : (lo >> (8 * (XS - 1 - s))) & 0xFFu; }
 
 // 256 sum_w acc_w 256^-w in float64: the digit-pair classes 0|1 and 2|3 are merged in int32 first ((a0 << 8) + a1 and (a2 << 8) + a3 stay
@@ -62,7 +68,7 @@ __device__ __forceinline__ double x_combine(const i32x4 (&acc)[XS], int r) {
 
 // float64 exp / sigmoid / tanh, branch-free (the gate math sits on the per-step chain): e^x = 2^m T[j] p(r) with n = rint(64 x / ln 2) =
 // 64 m + j, T[j] = 2^(j / 64) (64 doubles in LDS), r = x - n ln2 / 64 (Cody-Waite, |r| <= 0.0055) and the degree-4 Taylor polynomial
-// (truncation 4e-14 relative); 1 / d by v_rcp_f64 + two Newton steps.  ~1e-13 relative: the chain needs ~1e-10 (see the header).
+// (truncation 4e-14 relative); 1 / d by v_rcp_f64 + one Newton step.  ~1e-13 relative: the chain needs ~1e-10 (see the header).
 __device__ __forceinline__ double x_exp(double x, const double* __restrict__ T) {
   const double n = __builtin_rint(x * 0x1.71547652b82fep+6);
   double r = __builtin_fma(n, -0x1.62e42fee00000p-7, x);
@@ -75,19 +81,15 @@ __device__ __forceinline__ double x_exp(double x, const double* __restrict__ T) 
   p = __builtin_fma(p, r, 1.0);
   return __builtin_amdgcn_ldexp(tj * p, ni >> 6);
 }
-__device__ __forceinline__ double x_rcp(double d) {
-  double y = __builtin_amdgcn_rcp(d);
-  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
-  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
-  return y;
+__device__ __forceinline__ double x_rcp(double d) {       // v_rcp_f64 is good to 4.6e-8 (tools/micro/i8_f64_overlap.hip): one Newton step -> 2e-15
+  const double y = __builtin_amdgcn_rcp(d);
+  return __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
 }
 __device__ __forceinline__ double x_sigmoid(double x, const double* __restrict__ T) {
-  x = __builtin_fmin(__builtin_fmax(x, -700.0), 700.0);
-  return x_rcp(1.0 + x_exp(-x, T));
+  return x_rcp(1.0 + x_exp(-__builtin_fmax(x, -700.0), T));      // (only e^-x can overflow; e^-x -> 0 gives 1)
 }
 __device__ __forceinline__ double x_tanh(double x, const double* __restrict__ T) {
-  x = __builtin_fmin(__builtin_fmax(x, -350.0), 350.0);
-  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * x, T)), 1.0);
+  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * __builtin_fmin(x, 350.0), T)), 1.0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
   auto put_digits = [&](unsigned char* plane0, const double (&v)[4]) {       // four values in [-1, 1] -> 4 bytes per plane at (row i, units u0 ..)
     unsigned lo[4], hi[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x_digits(v[r] * 0x1p38, lo[r], hi[r]);
+    for (int r = 0; r < 4; ++r) x_digits38(v[r], lo[r], hi[r]);
     unsigned* at = reinterpret_cast<unsigned*>(plane0 + i * LDP + u0);
     at[0] = x_gather_byte(hi[0], hi[1], hi[2], hi[3], 0);
 #pragma unroll

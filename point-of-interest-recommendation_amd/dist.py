@@ -204,12 +204,21 @@ class ReplicaSync:
             self.backend.end_epoch_rccl()
         else:
             flat = self.backend.make_delta()
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce_chunked(flat)
             flat16 = getattr(self.backend, "flat16", None)
             if flat16 is not None:                      # half-stored tables: their deltas, as half
-                dist.all_reduce(flat16, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce_chunked(flat16)
             self.backend.apply(self.world)
         self.epochs += 1
+
+    CHUNK_BYTES = 256 << 20
+
+    def _all_reduce_chunked(self, flat):
+        """One all-reduce per 256 MB slice of the flat buffer (config X's half table is 5 GB per replica: a single call would need the
+        collective's staging for all of it at once, and a slice that has been reduced can be consumed while the next one is in flight)."""
+        n = flat.numel(); step = max(1, self.CHUNK_BYTES // flat.element_size())
+        for o in range(0, n, step):
+            dist.all_reduce(flat[o:o + step], op=dist.ReduceOp.SUM, group=self.group)
 
     def report(self):
         """Self-validation block for bench.py: what the collective saw and whether the replicas agree bit for bit."""

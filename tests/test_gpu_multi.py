@@ -289,3 +289,24 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     mg = d["multi_gpu"]
     assert mg["world_size"] == 2 and mg["world_size_seen_by_all_gather"] == 2 and mg["replica_checksums_equal"] and mg["epochs_synced"] >= 5
     assert d["config"]["replica_schedule"] == "quality" and mg["throughput_schedule"]["launches_per_epoch_per_replica"] >= 1
+
+
+def test_half_table_reconciliation_across_two_processes():
+    """poi_sync_buffer16 across REAL processes at config X's scale per call: two ranks (gloo, both on this GPU) reconcile a 1 GB half table
+    (4 M x 128) + a float32 tensor - the library's delta / touch-count / combine kernels around cross-process all-reduces of the float32
+    buffer and of the 1 GB half buffer in 256 MB slices (dist.ReplicaSync._all_reduce_chunked).  Every rank checks
+    half(base + half(d_0 + d_1) / touching replicas) element by element, untouched rows bit-identical, replica checksums equal
+    (tests/_sync16_worker.py)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "_sync16_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    res = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("[")][-1])
+    assert len(res) == 2 and all(x["ok_table"] and x["ok_untouched"] and x["ok_dense"] and x["checksums_equal"] for x in res)
+    assert res[0]["allreduce_bytes"] >= (1 << 30) and res[0]["rows_moved_by_both"] > 1000 and res[0]["rows_moved_by_one"] > 1000

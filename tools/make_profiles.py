@@ -72,8 +72,8 @@ def counters(sub):
 fa, fc = counters("fetch")
 wa, wc = counters("write")
 # timed regions of bench.py -> kernels
-REGION = {"te_gather": ["te_gather_kernel"], "te_gemm_ax": ["te_gemm_nt_kernel<true", "te_gemm_ntk_kernel<true", "te_gemm_ntk_kernel<false, true", "te_ptab_s3_kernel", "te_ztab_kernel"], "te_gemm_dx": ["te_gemm_nt_kernel<false", "te_gemm_ntk_kernel<false, false"],
-          "te_rec_fwd": ["te_rec_fwd16_kernel"], "te_rec_bwd": ["te_rec_bwd16_kernel"], "te_head": ["te_head_kernel", "te_head_big", "te_bpr_head_kernel"],
+REGION = {"te_gather": ["te_gather_kernel"], "te_gemm_ax": ["te_gemm_nt_kernel<true", "te_gemm_ntk_kernel<true", "te_gemm_ntk_kernel<false, true", "te_ptab_s3_kernel", "te_ztab_kernel", "te_xpack_kernel", "te_xztab_kernel", "te_gemmx_kernel"], "te_gemm_dx": ["te_gemm_nt_kernel<false", "te_gemm_ntk_kernel<false, false"],
+          "te_rec_fwd": ["te_rec_fwd16_kernel", "te_rec_fwdx_kernel"], "te_rec_bwd": ["te_rec_bwd16_kernel"], "te_head": ["te_head_kernel", "te_head_big", "te_bpr_head_kernel"],
           "te_wgrad": ["te_wgrad_kernel"], "te_psum": ["te_pcount_kernel", "te_passign_kernel", "te_psum_kernel", "te_pfin_kernel"], "te_scatter": ["te_reduce_kernel", "te_hot_reduce_kernel", "te_hot_apply_kernel"], "te_dsum": ["te_dprep_kernel", "te_dsum_kernel"], "te_bin_gemm": ["te_dred_kernel", "te_dfin_kernel", "te_dui_kernel", "te_dapply_kernel"],
           "dense_apply": ["dense_apply_kernel"], "te_finalize": ["te_finalize_kernel", "te_parts_kernel"],
           "te_prep": ["te_len_kernel", "te_scan_kernel", "te_rowmap_kernel", "te_pack_kernel", "te_transpose_kernel", "rs_hist_kernel",

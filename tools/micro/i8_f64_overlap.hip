@@ -73,7 +73,18 @@ static void test(const char* name, double* out, int grid) {
   printf("%-28s one stream (2 waves / SIMD, 1 MFMA + 8 VALU alternating): MFMA only %.3f ms, with VALU %.3f ms = %.1f cycles per (MFMA + 8 VALU) pair of both waves\n", "", a0, a1,
          a1 * 1e-3 * 2.4e9 / ((double)N1 * 16));
 }
+// accuracy of v_rcp_f64 (the seed of te_xfwd.hip's 1 / (1 + e^x)): max relative error over 2^20 arguments in [1, 2^40]
+__global__ void rcp_err(double* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const double d = (1.0 + (double)i * 9.5367431640625e-7) * (double)(1ull << (i % 41));
+  const double y = __builtin_amdgcn_rcp(d), e0 = fabs(__builtin_fma(-d, y, 1.0));
+  const double y1 = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y), e1 = fabs(__builtin_fma(-d, y1, 1.0));
+  atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(e0));
+  atomicMax((unsigned long long*)out + 1, (unsigned long long)__double_as_longlong(e1));
+}
 int main() {
+  { double* o; hipMalloc(&o, 16); hipMemset(o, 0, 16); rcp_err<<<4096, 256>>>(o); double h[2]; hipMemcpy(h, o, 16, hipMemcpyDeviceToHost);
+    printf("v_rcp_f64: max |1 - d rcp(d)| = %.3e; after one Newton step %.3e\n", h[0], h[1]); }
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int grid = p.multiProcessorCount;
   double* out; hipMalloc(&out, sizeof(double) * grid * 512);
