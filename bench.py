@@ -368,6 +368,7 @@ def main():
         barrier()
         dte_cold = rank_max(time.perf_counter() - t0)
         model.topk_seeding = True
+        dte_first = dte_cold
         eval_epoch()                       # fills the seeds
         # timed passes at the reference driver's cadence - one training epoch, then one evaluation (prog_bpr_gru_spatial.py:249-290):
         # the top-K lists of the previous evaluation seed the thresholds of this one, under a model that has moved by an epoch.
@@ -391,12 +392,14 @@ def main():
         ms_pred = ctx.timing_get("seq_predict")[0] + ctx.timing_get("te_predict")[0]
         ms_dist = ctx.timing_get("dist_prob")[0]
         ctx.timing(False)
-        # (with the per-epoch refresh, the default, the headline evaluation rate is the UNSEEDED pass - nothing carried over from an earlier
-        # evaluation; the seeded steady state of a training loop that evaluates every epoch is reported beside it)
+        # (with the per-epoch refresh, the default, the headline evaluation rate is the FIRST evaluation of a run - nothing carried over from an
+        # earlier evaluation; the seeded steady state of a training loop that evaluates every epoch and the pass without any seed are beside it)
         eval_users_per_s_seeded = (n_user if n_eval == n_local else n_eval) * a.eval_steps / dte
-        eval_users_per_s = ((n_user if n_eval == n_local else n_eval) / dte_cold) if refresh else eval_users_per_s_seeded
+        eval_users_per_s = ((n_user if n_eval == n_local else n_eval) / dte_first) if refresh else eval_users_per_s_seeded
         fl = 2.0 * n_eval * n_item * D * a.eval_steps
-        eval_detail = {"ms_per_eval": 1e3 * dte_cold if refresh else 1e3 * dte / a.eval_steps, "recall_at_20_after_timed_training": float(hits.item()) / n_eval,
+        eval_detail = {"ms_per_eval": 1e3 * dte_first if refresh else 1e3 * dte / a.eval_steps,
+                       "headline_is": "the first evaluation of a run, unseeded" if refresh else "the seeded steady state",
+                       "ms_per_eval_first": 1e3 * dte_first, "recall_at_20_after_timed_training": float(hits.item()) / n_eval,
                        "users_scored_per_eval": n_eval, "users_predicted_per_eval": n_eval,
                        "distance_term": "resident bin matrix" if getattr(model, "_ulptai", None) is not None else "bins on the fly (poi_score_topk_geo)",
                        # 2 U N D over the time of ALL scoring kernels of a timed evaluation (filter + rescoring + pre-pass / fallback): an EQUIVALENT rate - the
@@ -643,7 +646,7 @@ def main():
             return {"batch_users_per_launch": Bq_, "batch_cap": cap, "seconds": None, "epochs": ep, "best_recall_at_20_in_budget": best, "budget_s": budget}
         ttr = {"target_recall_at_20": rec_ref, "what": "training seconds until recall@20 reaches what the reference schedule (one user per step) has after %.1f s" % t_ref,
                "B=1 (reference schedule)": {"seconds": t_ref, "recall_at_20": rec_ref},
-               "B=256": time_to_recall(256, 16.0, rec_ref), "B=1563": time_to_recall(1563, 32.0, rec_ref), "B=12500": time_to_recall(a.batch_users, a.batch_cap, rec_ref)}
+               "B=256": time_to_recall(256, 16.0, rec_ref), "B=1563": time_to_recall(1563, 32.0, rec_ref), "B=12500": time_to_recall(a.batch_users, a.batch_cap, rec_ref, budget=6.0)}
         modes = {"headline": batched(a.batch_users, a.batch_cap, a.quality_seconds),
                  "headline_mean_rule": batched(a.batch_users, 1.0, a.quality_seconds),
                  "small_launches": batched(256, 16.0, a.quality_seconds)}

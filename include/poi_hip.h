@@ -141,8 +141,11 @@ int poi_ctx_set_split_products(poi_ctx* ctx, int on);
  * (five signed base-256 digit planes per operand, exact int32 accumulation, digit pairs combined in float64: te_xfwd.hip), the gates
  * and the state in float64; everything behind the forward pass (head, BPTT, gradients, write-back) stays float32 and reads the
  * float32 roundings of z, r, c, h.  on = 0: the float32 forward kernels of rounds 1 - 3 (split products / per-sequence / forward table).
- * Environment override at context creation: POI_TE_XFWD=0|1. */
-int poi_ctx_set_exact_forward(poi_ctx* ctx, int on);
+ * per_sequence_max (>= 0; < 0 keeps the current value, default 512): launches of at most this many sequences run the recurrence of every
+ * sequence in its own workgroup in float64 on the vector ALUs (te_rec_fwd1x: ~1 us per step and sequence; the reference's schedule - one
+ * user per step, prog_bpr_gru_spatial.py:249-250 - takes this form), larger ones in 16-sequence tiles on the int8 matrix cores
+ * (te_rec_fwdx: 3.6 us per step and tile).  Environment overrides at context creation: POI_TE_XFWD=0|1, POI_TE_XREC1=<per_sequence_max>. */
+int poi_ctx_set_exact_forward(poi_ctx* ctx, int on, int per_sequence_max);
 /* Small launches: launches of at most max_sequences sequences (default 1024; 0 disables; dim 64 / 128) run the recurrence of every
  * sequence in its own workgroup on the vector ALUs (te_rec_fwd1 / bwd1, weights resident in registers) instead of 16-sequence MFMA
  * tiles - a tile step costs the same whether it holds 16 sequences or one, so the reference schedule (one user per step,

@@ -54,7 +54,7 @@ SIGNATURES = {
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
     "poi_ctx_set_f16_rounding": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
     "poi_ctx_set_split_products": (c_int, [c_void_p, c_int]),
-    "poi_ctx_set_exact_forward": (c_int, [c_void_p, c_int]),
+    "poi_ctx_set_exact_forward": (c_int, [c_void_p, c_int, c_int]),
     "poi_ctx_set_small_launch": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_one_sequence_path": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_regroup_min": (c_int, [c_void_p, c_int]),
@@ -206,9 +206,10 @@ class Context:
         """Recurrent kernels of the tile engine on bf16 x 3 split products (default) or float32-input MFMAs (poi_ctx_set_split_products)."""
         self.check(self.lib.poi_ctx_set_split_products(self.handle, 1 if on else 0))
 
-    def set_exact_forward(self, on=True):
-        """Training launches run the forward pass in fixed point on the int8 matrix cores + float64 gates (poi_ctx_set_exact_forward, default on)."""
-        self.check(self.lib.poi_ctx_set_exact_forward(self.handle, 1 if on else 0))
+    def set_exact_forward(self, on=True, per_sequence_max=-1):
+        """Training launches run the forward pass in fixed point on the int8 matrix cores + float64 gates (poi_ctx_set_exact_forward, default
+        on); per_sequence_max: launches of at most this many sequences use the per-sequence float64 kernel (default 512; -1 keeps it)."""
+        self.check(self.lib.poi_ctx_set_exact_forward(self.handle, 1 if on else 0, int(per_sequence_max)))
 
     def set_small_launch(self, max_sequences=1024):
         """Launches of at most this many sequences use the per-sequence recurrent kernels (poi_ctx_set_small_launch; 0 disables)."""

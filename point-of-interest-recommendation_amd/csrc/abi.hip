@@ -51,6 +51,7 @@ struct poi_ctx {
   int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
   int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores + float64 gates) for dims 64 / 128; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
+  int xrec1_max = 512;      // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
   DevBuf xw, xg;            // its digit fragments, scales and per-bin table | per-step pre-activations or the forward table (float64)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
   // A launch is captured the second time its key (every pointer / size / scalar the kernels receive) is seen; the caller's uidx /
@@ -146,6 +147,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_XFWD")) c->xfwd = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_XREC1")) c->xrec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_ONE")) c->one_path = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_BINTAB_MIN")) c->bintab_min = atoi(e);
@@ -265,7 +267,8 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.xfwd = (c->xfwd && !predict && !A.rec32 && poi::te_xfwd_supported(D)) ? 1 : 0;
   const bool want_ft = c->fwd_tab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap;
   A.fwd_tab = (!A.xfwd && want_ft && A.bintab && !A.rec1) ? 1 : 0;      // (the per-sequence kernels read G)
-  A.xft = (A.xfwd && want_ft) ? 1 : 0;
+  A.xrec1 = (A.xfwd && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
+  A.xft = (A.xfwd && want_ft && !A.xrec1) ? 1 : 0;
   if (A.fwd_tab || A.xft) {
     if ((rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
     if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }
@@ -497,7 +500,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       // word they overlapped and early_min was missing), plus what te_setup derived from them for THIS launch
       const uint64_t sw[] = {(uint64_t)c->fwd_tab, (uint64_t)c->rec_split, (uint64_t)c->one_path, (uint64_t)(unsigned)c->rec1_max, (uint64_t)(unsigned)c->bintab_min,
                              (uint64_t)c->early_bins, (uint64_t)(unsigned)c->early_min, (uint64_t)c->xfwd, (uint64_t)E.early_bins, (uint64_t)E.bintab, (uint64_t)E.rec1,
-                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.ppoi, (uint64_t)one};
+                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one};
       add(sw, sizeof sw);
     }
     poi_ctx::StepGraph* g = nullptr;
@@ -1039,9 +1042,10 @@ int poi_ctx_set_split_products(poi_ctx* c, int on) {
   return POI_OK;
 }
 
-int poi_ctx_set_exact_forward(poi_ctx* c, int on) {
+int poi_ctx_set_exact_forward(poi_ctx* c, int on, int per_sequence_max) {
   if (!c || on < 0 || on > 1) return fail(c, POI_EINVAL, "poi_ctx_set_exact_forward: on must be 0 or 1");
   c->xfwd = on;
+  if (per_sequence_max >= 0) c->xrec1_max = per_sequence_max;
   drop_graphs(c);
   return POI_OK;
 }

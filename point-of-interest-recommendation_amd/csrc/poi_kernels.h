@@ -183,6 +183,7 @@ struct TeArgs {
   unsigned sr_salt;                   // != 0: a half POI table is written back with stochastic rounding (poi_ctx_set_f16_rounding), salt of this launch
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
   // exact forward (te_xfwd.hip): input product + forward recurrence in ~40-bit fixed point on the int8 matrix cores, float64 gate math
+  int xrec1;                          // the recurrence of every sequence in its own workgroup on the float64 vector ALUs (te_rec_fwd1x): small launches
   int xfwd, xft;                      // on; pre-activations from the forward table ptabx[p_t] + ztabx[dp_t] (else gx[row])
   double *gx, *ptabx, *ztabx;         // (T + spare) x 3D per step | (n_item + 1 + spare) x 3D | (n_dist + 1) x 3D, gate-major columns (g D + unit)
   uint4 *xWh8, *xUi8; double *xWhS, *xUiS;      // digit fragments + row scales of wh (16x16x64 order) and of ui's POI half (32x32x32 order)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void pack_items_f16_kernel(const float* __rest
   if (s == 0 && valid) inorm[gi] = make_float2(bad ? INFINITY : sqrtf(n2) * 1.000002f, n1 * (2.98023224e-8f * 1.01f));
 }
 
-#define SF_CAP 2048       // survivor slots per user in global memory (good seeds leave ~K + 1 of them, the self-seeding pre-pass ~16 K; an overflow flags the tile).  8 bytes per slot: a 65536-user call pins 1 GB of grow-only context memory
+#define SF_CAP 4096       // survivor slots per user in global memory (good seeds leave ~K + 1 of them, the self-seeding pre-pass ~16 K; an overflow flags the tile).  8 bytes per slot: a 65536-user call pins 2 GB of grow-only context memory
 
 // stage 1.  BINS: 0 = no distance term, 1 / 2 = resident bin matrix (uint8 / uint16, misc.hip::ulptai_kernel) + the users' bin probabilities,
 // 3 = GEO: bins computed on the fly from the coordinates (poi_score_topk_geo: no U x N matrix; config X) - only for the pairs whose

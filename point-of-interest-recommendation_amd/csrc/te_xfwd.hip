@@ -473,6 +473,111 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// te_rec_fwd1x: the exact forward recurrence of ONE sequence per workgroup on the vector ALUs, in float64 - small launches (at most one
+// workgroup per CU or two) and the one-sequence path (the reference's schedule).  te_rec_fwd1's tiling: 4 D threads, a thread owns FOUR
+// outputs and one k-slice (z | r phase: 8 slices of D / 8, c phase: 16 slices of D / 16; adjacent lanes, DPP sums), the recurrent weights
+// RESIDENT in registers as float64 (96 per thread at dim 128: converted once - float32 -> float64 is exact), h / r h broadcast from LDS.
+// A 16-row tile step of te_rec_fwdx costs 3.6 us whether the tile holds 16 sequences or one (float64 gate math for 16 x 3 D values);
+// here a step is 96 FMAs + two gate values per thread: ~1 us.  Same inputs (gx, gate-major) and outputs as te_rec_fwdx.
+// -------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double x_dpp(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int N> __device__ __forceinline__ double x_group_sum(double v) {      // sum over N = 8 / 16 adjacent lanes, in every lane
+  v += x_dpp<0xB1>(v);                     // quad_perm [1,0,3,2]
+  v += x_dpp<0x4E>(v);                     // quad_perm [2,3,0,1]
+  v += x_dpp<0x141>(v);                    // row_half_mirror
+  if (N >= 16) v += x_dpp<0x140>(v);       // row_mirror
+  return v;
+}
+__device__ __forceinline__ double x_pick4(const double (&a)[4], int o) { return o == 0 ? a[0] : o == 1 ? a[1] : o == 2 ? a[2] : a[3]; }
+
+template <int D>
+__global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
+  constexpr int LZ = D / 8, LC = D / 16;
+  __shared__ __align__(16) double hs[D], rhs[D], zs[D];
+  __shared__ double s_t64[64];
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int gz = tid >> 3, sz = tid & 7, gc = tid >> 4, sc = tid & 15;
+  const int jz = 4 * gz + (sz & 3), jc = 4 * gc + (sc & 3);        // the output this lane finishes (lanes sz / sc < 4)
+  const bool isr = jz >= D;
+  const int jr = isr ? jz - D : jz;
+  const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
+  double wzr[4][LZ], wc[4][LC];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+#pragma unroll
+    for (int i = 0; i < LZ; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(A.wh + (size_t)(4 * gz + o) * D + sz * LZ + i);
+      wzr[o][i] = (double)v.x; wzr[o][i + 1] = (double)v.y; wzr[o][i + 2] = (double)v.z; wzr[o][i + 3] = (double)v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < LC; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(A.wh + (size_t)(2 * D + 4 * gc + o) * D + sc * LC + i);
+      wc[o][i] = (double)v.x; wc[o][i + 1] = (double)v.y; wc[o][i + 2] = (double)v.z; wc[o][i + 3] = (double)v.w;
+    }
+  }
+  if (tid < D) hs[tid] = 0.0;
+  if (tid >= 64 && tid < 128) s_t64[tid - 64] = exp2((double)(tid - 64) * (1.0 / 64.0));
+  __syncthreads();
+  double gzr = 0.0, gcc = 0.0;
+  if (ns > 0) { gzr = A.gx[(size_t)r0 * 3 * D + jz]; gcc = A.gx[(size_t)r0 * 3 * D + 2 * D + jc]; }
+  // every lane issues every global store of a step (non-owners write their duplicate into the spare packed row): straight-line code,
+  // exact vmcnt waits (te_rec_fwd1)
+  const size_t Tsp = (size_t)A.soff[A.n_seq];
+  const bool ownz = sz < 4, ownc = sc < 4;
+  float* const dG = A.G + Tsp * 3 * D + (tid % (3 * D));
+  float* const dH = A.H + Tsp * D + (tid % D);
+  float* const dR = A.RH + Tsp * D + (tid % D);
+  for (int t = 0; t < ns; ++t) {
+    const size_t row = (size_t)(r0 + t), rn = (size_t)(r0 + min(t + 1, ns - 1));
+    double nzr = A.gx[rn * 3 * D + jz], nc = A.gx[rn * 3 * D + 2 * D + jc];
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < LZ; i += 2) {
+      const double2 x = *reinterpret_cast<const double2*>(hs + sz * LZ + i);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) a[o] = __builtin_fma(wzr[o][i + 1], x.y, __builtin_fma(wzr[o][i], x.x, a[o]));
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) a[o] = x_group_sum<8>(a[o]);
+    {
+      const double v = x_sigmoid(x_pick4(a, sz & 3) + gzr, s_t64);
+      const double rh = v * hs[jr];
+      if (ownz) { if (isr) rhs[jr] = rh; else zs[jr] = v; }
+      const bool st = ownz && isr;
+      *(st ? A.G + row * 3 * D + D + jr : dG) = (float)v;
+      *(st ? A.RH + row * D + jr : dR) = (float)rh;
+    }
+    x_lds_barrier();
+    double b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < LC; i += 2) {
+      const double2 x = *reinterpret_cast<const double2*>(rhs + sc * LC + i);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) b[o] = __builtin_fma(wc[o][i + 1], x.y, __builtin_fma(wc[o][i], x.x, b[o]));
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) b[o] = x_group_sum<16>(b[o]);
+    {
+      const double c = x_tanh(x_pick4(b, sc & 3) + gcc, s_t64);
+      const double z = zs[jc], hp = hs[jc];
+      const double hn = __builtin_fma(z, c - hp, hp);
+      if (ownc) hs[jc] = hn;               // (the c phase reads rhs only; the lanes that share jc are in one wave)
+      *(ownc ? A.G + row * 3 * D + jc : dG) = (float)z;
+      *(ownc ? A.G + row * 3 * D + 2 * D + jc : dG) = (float)c;
+      *(ownc ? A.H + row * D + jc : dH) = (float)hn;
+    }
+    x_lds_barrier();
+    asm volatile("" : "+v"(nzr), "+v"(nc));      // the wait for the prefetch is counted HERE, behind this step's stores
+    gzr = nzr; gcc = nc;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 bool te_xfwd_supported(int D) { return D == 64 || D == 128; }
@@ -539,7 +644,8 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   } } dump_at_exit;
 #endif
   tm->begin("te_rec_fwd", st);
-  if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
+  if (A.xrec1) hipLaunchKernelGGL(te_rec_fwd1x_kernel<D>, dim3(n), dim3(4 * D), 0, st, A);
+  else if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
   else hipLaunchKernelGGL((te_rec_fwdx_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
   tm->end(st);
   return hipGetLastError();

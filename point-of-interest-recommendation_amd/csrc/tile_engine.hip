@@ -2784,6 +2784,17 @@ __global__ __launch_bounds__(TE_BLOCK) void te_one_in_kernel(TeArgs A, PackJobs 
       if (b == 0 && t0 + r < ns) *reinterpret_cast<float4*>(A.X + (size_t)(t0 + r) * XW + c) = v;       // X snapshot
     }
     __syncthreads();
+    if (A.xfwd) {      // exact forward: the input product in float64 (products of float32 values are exact), gate-major row of gx
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < XW; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(&Xc[tt][c]), u = *reinterpret_cast<const float4*>(&U[tm][c]);
+        a0 = __builtin_fma((double)x.x, (double)u.x, a0); a1 = __builtin_fma((double)x.y, (double)u.y, a1);
+        a0 = __builtin_fma((double)x.z, (double)u.z, a0); a1 = __builtin_fma((double)x.w, (double)u.w, a1);
+      }
+      if (t0 + tt < ns) A.gx[(size_t)(t0 + tt) * 3 * D + m0 + tm] = (a0 + a1) + (double)bias;
+      continue;
+    }
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll 8
     for (int c = 0; c < XW; c += 4) {
@@ -3184,9 +3195,8 @@ static hipError_t te_one_t(TeArgs& A, float alpha, float lambda, int l_cap, hipS
   tm->begin("te_prep", st);
   hipLaunchKernelGGL(te_one_in_kernel<D>, dim3(n_ax + 1 + n_pk * J.n), dim3(TE_BLOCK), 0, st, A, J, n_ax, n_pk);
   tm->end(st);
-  if (A.xfwd) {      // exact forward: input product + recurrence of the one sequence through the fixed-point kernels (te_one_in has set soff / row_p / row_dp)
-    hipError_t xe = launch_te_xfwd(A, 64, st, tm, 0);
-    if (xe == hipSuccess) xe = launch_te_xfwd(A, 64, st, tm, 1);
+  if (A.xfwd) {      // exact forward: the recurrence of the one sequence in float64 on the vector ALUs (te_rec_fwd1x)
+    hipError_t xe = launch_te_xfwd(A, 64, st, tm, 1);      // (te_one_in has written gx: the input product in float64)
     if (xe != hipSuccess) return xe;
   } else {
   tm->begin("te_rec_fwd", st);

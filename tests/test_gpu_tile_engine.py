@@ -29,8 +29,11 @@ def _regroup_min(request, pa):
     threshold, under which these small launches take the two-table path."""
     ctx = pa._lib.context(0)
     ctx.set_regroup_min(request.param)
+    # (the exact forward pass likewise: 16-sequence int8 tiles for every launch size under "regrouped", the per-sequence float64 kernel for
+    # these small launches under the default)
+    ctx.set_exact_forward(True, 0 if request.param == 0 else 512)
     yield
-    ctx.set_regroup_min(1280)
+    ctx.set_regroup_min(1280); ctx.set_exact_forward(True, 512)
 
 
 def _model(pa, T, P):
@@ -629,13 +632,15 @@ def test_one_sequence_path_is_the_reference_step(pa, dim, n_dist, len_max):
         pa._lib.context(0).set_one_sequence_path(True); pa._lib.context(0).set_engine("auto")
 
 
+@pytest.mark.parametrize("per_seq", [512, 0], ids=["per-sequence-f64", "int8-tiles"])
 @pytest.mark.parametrize("dim,len_max", [(128, 50), (64, 20)])
-def test_exact_forward_pass_is_far_inside_the_bar_and_the_switch_changes_the_arithmetic(pa, dim, len_max):
+def test_exact_forward_pass_is_far_inside_the_bar_and_the_switch_changes_the_arithmetic(pa, dim, len_max, per_seq):
     """poi_ctx_set_exact_forward (default on): input product + forward recurrence in fixed point on the int8 matrix cores, float64 gates
     (te_xfwd.hip).  On the step the float32 forward passes miss - one sequence of 50 positions at dim 128, six hot POIs: updates as large
     as the weights - every tensor lands within 2e-6 of the float64 oracle (measured 5e-7: what is left is the float32 BPTT and the
     float32 roundings of z, r, c, h), on the one-sequence path, the batched pipeline and a 70-user launch; with the switch off the same
-    launches run the float32 forward kernels (different bits, same toy-size bar)."""
+    launches run the float32 forward kernels (different bits, same toy-size bar).  Both forms of the exact recurrence: one workgroup per sequence
+    in float64 on the vector ALUs (te_rec_fwd1x, the default for these launch sizes) and 16-sequence tiles on the int8 matrix cores (te_rec_fwdx)."""
     T = toy_problem(1700 + dim + 50, n_user=80, n_item=60, n_dist=200, dim=dim, len_max=len_max, min_len=1, hot=6)
     P0 = spatial_params(1700 + dim, T)
     users = np.arange(70, dtype=np.int32)
@@ -648,7 +653,7 @@ def test_exact_forward_pass_is_far_inside_the_bar_and_the_switch_changes_the_ari
         for xf in (True, False):
             for mode in ("one", "batched", "batch-70"):
                 model = _model(pa, T, P0)
-                ctx.set_engine("tile"); ctx.set_exact_forward(xf); ctx.set_one_sequence_path(mode == "one")
+                ctx.set_engine("tile"); ctx.set_exact_forward(xf, per_seq); ctx.set_one_sequence_path(mode == "one")
                 if mode == "batch-70":
                     model.train_batch(users); exp = exp_b
                 else:
@@ -660,4 +665,4 @@ def test_exact_forward_pass_is_far_inside_the_bar_and_the_switch_changes_the_ari
         for mode in ("one", "batched", "batch-70"):
             assert not all(np.array_equal(res[(True, mode)][0][k], res[(False, mode)][0][k]) for k in ("wh", "ui", "lt")), "the switch did not change the arithmetic"
     finally:
-        ctx.set_exact_forward(True); ctx.set_one_sequence_path(True); ctx.set_engine("auto")
+        ctx.set_exact_forward(True, 512); ctx.set_one_sequence_path(True); ctx.set_engine("auto")
