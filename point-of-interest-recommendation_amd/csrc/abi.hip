@@ -268,7 +268,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const bool want_ft = c->fwd_tab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap;
   A.fwd_tab = (!A.xfwd && want_ft && A.bintab && !A.rec1) ? 1 : 0;      // (the per-sequence kernels read G)
   A.xrec1 = (A.xfwd && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
-  A.xft = (A.xfwd && want_ft && !A.xrec1) ? 1 : 0;
+  A.xft = (A.xfwd && want_ft && !A.xrec1 && n > 1) ? 1 : 0;      // (n == 1: the one-sequence path writes gx itself, te_one_in)
   if (A.fwd_tab || A.xft) {
     if ((rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
     if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }

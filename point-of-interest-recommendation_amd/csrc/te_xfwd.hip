@@ -183,16 +183,35 @@ struct XGemmArgs {
   int ncg;                                  // column groups per row tile (work items = row tiles x ncg)
 };
 
+// LDS DMA (tile_engine.hip: te_ptab_s3): 16 bytes per lane straight from global memory into LDS, no staging registers; lane l of the
+// wave lands at lds_dst + 16 l.  Issued from inline asm: the waits are counted by hand (s_waitcnt vmcnt(N), the queue retires in order).
+template <int N>
+__device__ __forceinline__ void x_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void x_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 template <int D>
 __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
   constexpr int KB = D / 32, N = 3 * D, NT = N / 32, FR = KB * XS * 64;      // uint4 fragments per column tile
-  __shared__ uint4 s_b[FR];
+  constexpr int PT = (FR + 255) / 256;
+  __shared__ uint4 s_b[2][FR];                                 // two column tiles: tile j + 1 lands while tile j is multiplied
   __shared__ double s_rs[4][32];
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
   const int n_rows = *P.n_ptr;
   const int n_tile = (n_rows + 127) / 128, ncg = P.ncg, tpg = NT / ncg;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&s_b[0][0];
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(w * 64) * 16u);
+  auto request = [&](int j, int slot) {                        // column tile j -> slot: every wave its 64-fragment pieces
+#pragma unroll
+    for (int q = 0; q < PT; ++q)
+      if (FR % 256 == 0 || (w * 64 + q * 256) < FR)            // (wave-uniform: a wave's piece lies inside the tile or not)
+        x_glds16(P.B8 + (size_t)j * FR + tid + q * 256, wbase + (unsigned)(slot * FR + q * 256) * 16u);
+  };
   for (int it = blockIdx.x; it < n_tile * ncg; it += gridDim.x) {
     const int t = it / ncg, j0 = (it % ncg) * tpg;
+    request(j0, 0);
     // ---- this wave's 32 rows -> digit planes a[kb][s] (lane: row li, k = 32 kb + 16 h + 0..15) ----
     i32x4 a[KB][XS];
     {
@@ -228,9 +247,13 @@ __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
       }
     }
     for (int j = j0; j < j0 + tpg; ++j) {
-      __syncthreads();                                         // the previous column tile has been read (and s_rs is visible)
-      for (int e = tid; e < FR; e += 256) s_b[e] = P.B8[(size_t)j * FR + e];
-      __syncthreads();
+      const int slot = (j - j0) & 1;
+      // tile j has landed when at most what was issued behind its request is outstanding: the 16 C stores of tile j - 1 (first tile: the
+      // compiler has already waited for the row loads that followed the request - nothing younger is in flight)
+      if (j == j0) x_wait_vm<0>(); else x_wait_vm<16>();
+      x_lds_barrier();                                         // every wave's pieces are in; the other slot (tile j - 1) has been read; s_rs is visible
+      if (j + 1 < j0 + tpg) request(j + 1, slot ^ 1);
+      const uint4* cur = s_b[slot];
       i32x16 acc[XS];
 #pragma unroll
       for (int s = 0; s < XS; ++s)
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
       for (int kb = 0; kb < KB; ++kb) {
         i32x4 b[XS];
 #pragma unroll
-        for (int s = 0; s < XS; ++s) b[s] = __builtin_bit_cast(i32x4, s_b[(kb * XS + s) * 64 + lane]);
+        for (int s = 0; s < XS; ++s) b[s] = __builtin_bit_cast(i32x4, cur[(kb * XS + s) * 64 + lane]);
 #pragma unroll
         for (int sa = 0; sa < XS; ++sa)
 #pragma unroll
@@ -248,19 +271,22 @@ __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
       }
       const int col = j * 32 + li;
       const double cs = P.Bs[col];
+      double zadd[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int grow = t * 128 + w * 32 + x_crow(r, lane);
+        zadd[r] = P.ztabx ? P.ztabx[(size_t)(P.zidx ? min((unsigned)P.zidx[min(grow, n_rows - 1)], (unsigned)P.z_max) : 0) * N + col] : 0.0;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = x_crow(r, lane), grow = t * 128 + w * 32 + rr;
-        double v = (double)acc[XS - 1][r];
-#pragma unroll
-        for (int s = XS - 2; s >= 0; --s) v = __builtin_fma(v, 0x1p-8, (double)acc[s][r]);
-        v *= s_rs[w][rr] * cs;
-        const int orow = min(grow, n_rows);
-        if (P.ztabx) v += P.ztabx[(size_t)(P.zidx ? min((unsigned)P.zidx[min(grow, n_rows - 1)], (unsigned)P.z_max) : 0) * N + col];
-        P.C[(size_t)orow * N + col] = v;
+        const int m01 = (acc[0][r] << 8) + acc[1][r], m23 = (acc[2][r] << 8) + acc[3][r];
+        const double v = __builtin_fma(__builtin_fma((double)acc[4][r], 0x1p-8, (double)m23), 0x1p-16, (double)m01);
+        P.C[(size_t)min(grow, n_rows) * N + col] = __builtin_fma(v, s_rs[w][rr] * (cs * 0x1p-8), zadd[r]);      // (exactly 16 stores, last in the tile)
       }
     }
-    __syncthreads();                                           // s_rs is rewritten by the next item
+    x_wait_vm<0>();
+    x_lds_barrier();                                           // both slots and s_rs are free for the next item
   }
 }
 
@@ -600,6 +626,13 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     optin = true;
   }
   const int n = A.n_seq;
+  if (phase == 2) {      // digit fragments of the recurrent weights only (one-sequence path with the tile recurrence: te_one_in forms gx itself)
+    XPackJobs J;
+    J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
+    J.n = 1;
+    hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 1), dim3(256), 0, st, J);
+    return hipGetLastError();
+  }
   if (phase == 0) {
   tm->begin("te_gemm_ax", st);
   {
@@ -615,6 +648,8 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     if (A.xft) { P.idx = nullptr; P.n_ptr = A.iota + A.n_item + 1; P.ztabx = nullptr; P.zidx = nullptr; P.C = A.ptabx; rows_est = A.n_item + 1; }
     else { P.idx = A.row_p; P.n_ptr = A.soff + n; P.ztabx = A.ztabx; P.zidx = A.spatial ? A.row_dp : nullptr; P.C = A.gx; rows_est = A.x_rows_est; }
     // few row tiles: split the column tiles of a row tile over several workgroups (the slicing of the rows is repeated, it is cheap)
+    // (per-step rows: the host only knows the launch's step CAPACITY; sequences average ~40 % of the longest)
+    if (!A.xft) rows_est = rows_est * 2 / 5 + 1;
     const int n_tile_est = (rows_est + 127) / 128, NT = 3 * D / 32;
     int ncg = 1;
     while (ncg < NT && n_tile_est * ncg < num_cu && NT % (ncg * 2) == 0) ncg *= 2;
@@ -651,7 +686,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   return hipGetLastError();
 }
 
-// te_gemm_ax (phase 0) / te_rec_fwd (phase 1) of a training launch in the exact-forward mode (TeArgs.xfwd)
+// te_gemm_ax (phase 0) / te_rec_fwd (phase 1) of a training launch in the exact-forward mode (TeArgs.xfwd); phase 2: the recurrent weights' digit fragments only
 hipError_t launch_te_xfwd(const TeArgs& A, int num_cu, hipStream_t st, Timing* tm, int phase) {
   if (A.dim == 64) return te_xfwd_t<64>(A, num_cu, st, tm, phase);
   if (A.dim == 128) return te_xfwd_t<128>(A, num_cu, st, tm, phase);

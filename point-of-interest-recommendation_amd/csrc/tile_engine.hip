@@ -3196,7 +3196,8 @@ static hipError_t te_one_t(TeArgs& A, float alpha, float lambda, int l_cap, hipS
   hipLaunchKernelGGL(te_one_in_kernel<D>, dim3(n_ax + 1 + n_pk * J.n), dim3(TE_BLOCK), 0, st, A, J, n_ax, n_pk);
   tm->end(st);
   if (A.xfwd) {      // exact forward: the recurrence of the one sequence in float64 on the vector ALUs (te_rec_fwd1x)
-    hipError_t xe = launch_te_xfwd(A, 64, st, tm, 1);      // (te_one_in has written gx: the input product in float64)
+    hipError_t xe = A.xrec1 ? hipSuccess : launch_te_xfwd(A, 64, st, tm, 2);      // (16-row tile recurrence forced: it needs wh's digit fragments)
+    if (xe == hipSuccess) xe = launch_te_xfwd(A, 64, st, tm, 1);      // (te_one_in has written gx: the input product in float64)
     if (xe != hipSuccess) return xe;
   } else {
   tm->begin("te_rec_fwd", st);
