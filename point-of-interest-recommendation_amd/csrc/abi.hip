@@ -803,7 +803,7 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     if (k > 0) HIPCHK(c, poi::launch_topk_merge(X, X.n_split, n_pad, st));
     return POI_OK;
   };
-  bool two_stage = false;
+  bool two_stage = false, use_maxpass = false;
   if (k > 0) {
     const size_t cand = (size_t)n_split * n_pad * k;
     if ((rc = ensure(c, c->cand_s, sizeof(float) * cand, st))) return rc;
@@ -832,7 +832,11 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
       c->tm.end(st);
       A.seeded = 1;
     }
-    if (two_stage && sub_tiles > 0) {
+    // unseeded, resident bin matrix / no distance term, dims 64 / 128: thresholds from the block maxima of the f16 lower bounds instead
+    // (score_filter.hip, MAXP: one f16 pass over ALL items, ~1.3 K survivors per user against ~17 K of the float32 prefix pre-pass)
+    use_maxpass = two_stage && !seeded && sub_tiles > 0 && poi::score_maxpass_supported(A);
+    if (const char* e = getenv("POI_SF_MAXPASS")) use_maxpass = use_maxpass && atoi(e) != 0;
+    if (two_stage && sub_tiles > 0 && !use_maxpass) {
       if ((rc = ensure(c, c->pre_idx, sizeof(int) * (size_t)n_pad * k, st)) || (rc = ensure(c, c->pre_sc, sizeof(float) * (size_t)n_pad * k, st))) return rc;
       poi::ScoreArgs S = A;
       S.n_item = sub_tiles * 32; S.bins_ntile = ntile; S.n_split = splits_for(sub_tiles);
@@ -876,6 +880,10 @@ static int score_common(poi_ctx* c, const float* users, const float* items, int3
     if (const char* e = getenv("POI_SF_NSPLIT")) { const int v = atoi(e); if (v >= 4) nsf = (v / 4) * 4; }      // tuning switch
     if (nsf > (ntile / 4) * 4) nsf = (ntile / 4) * 4;
     if (nsf < 4) nsf = 4;
+    if (use_maxpass) {
+      HIPCHK(c, poi::launch_score_maxpass(A, nsf, st, &c->tm));
+      A.seeded = 1;
+    }
     HIPCHK(c, poi::launch_score_two_stage(A, nsf, st, &c->tm));
     c->last_two_n = n; c->last_two_tiles = n_utile;
   }

@@ -336,6 +336,8 @@ struct ScoreArgs {
 };
 bool score_two_stage_supported(const ScoreArgs& A);
 hipError_t launch_score_two_stage(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm);
+bool score_maxpass_supported(const ScoreArgs& A);
+hipError_t launch_score_maxpass(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm);      // unseeded calls: thresholds from block maxima of the f16 lower bounds
 int score_filter_cap();
 hipError_t launch_topk_bound(const float* score_k, int n, int k, unsigned* gbound, hipStream_t st);
 hipError_t launch_ulptai(const double* coords, const double* cphi, const double* thr, const int* last_poi, int n, int n_item,

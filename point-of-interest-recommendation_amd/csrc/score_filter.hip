@@ -74,7 +74,12 @@ __global__ __launch_bounds__(256) void pack_items_f16_kernel(const float* __rest
 // UT = 2 (resident bin matrix / no distance term): the workgroup holds TWO user tiles and every wave scores both against each item tile it
 // loads - the kernel's time is proportional to the item fragments it pulls out of L2 (loading them twice doubles it: 2.8 -> 5.3 ms at the
 // Gowalla shape), so one load now feeds sixteen MFMAs instead of eight.  68 KB of LDS and ~190 registers: two workgroups per CU.
-template <int D, int BINS, int UT>
+// MAXP (the self-seeding pass of an UNSEEDED call, round 4): no thresholds, no survivors - every lane keeps, per user of its 16 rows, the
+// running maximum of (approximate score - the pair's bound) over the items it sees: item range `split`, items = lane (mod 32).  These
+// n_split x 32 item BLOCKS are disjoint, so the K-th largest block maximum of a user is a rigorous lower bound of his K-th best exact
+// score (sf_select_kernel turns it into the filter's threshold) - and with 512+ blocks the 20 best items almost always sit in 20 different
+// blocks: ~1.3 K survivors per user where the float32 one-stage pre-pass over 1/16 of the items left 17 K (and cost 2.6 ms).
+template <int D, int BINS, int UT, bool MAXP = false>
 __global__ __launch_bounds__(256, ((BINS == 3 || UT == 2) ? 2 : 3)) void score_filter_kernel(ScoreArgs A) {
   constexpr int KG = D / 16, CPT = D / 8, QN = (BINS == 1 || BINS == 2) ? BINS : 1;
   constexpr bool GEO = BINS == 3;
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, ((BINS == 3 || UT == 2) ? 2 : 3)) void score_f
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
       bool unseeded = false;
-      for (int i = 0; i < 32; ++i) unseeded |= n2_of(u)[i] != 0.f;
+      if (!MAXP) for (int i = 0; i < 32; ++i) unseeded |= n2_of(u)[i] != 0.f;
       if (unseeded && t == 0 && !(u == 1 && phantom)) A.tile_flag[utv[u]] = 1;
       dead[u] = unseeded || (u == 1 && phantom);
       all_dead &= dead[u];
@@ -206,12 +211,17 @@ __global__ __launch_bounds__(256, ((BINS == 3 || UT == 2) ? 2 : 3)) void score_f
     nm = A.inorm[min(t_begin * 32 + li, N - 1)];
   }
   int flagv[UT];
+  float mx[UT][MAXP ? 16 : 1];
 #pragma unroll
-  for (int u = 0; u < UT; ++u) flagv[u] = 0;
+  for (int u = 0; u < UT; ++u) {
+    flagv[u] = 0;
+#pragma unroll
+    for (int r = 0; r < (MAXP ? 16 : 1); ++r) mx[u][r] = -INFINITY;
+  }
   for (int tile = t_begin; tile < t_end; ++tile) {
     // a tile whose survivor lists overflowed (useless seeds: thresholds far below the final ones) is rescored by the one-stage kernel
     // anyway: the flag is polled every 16 item tiles, one poll period ahead (no wait on the load), and the wave stops
-    if (((tile - t_begin) & 15) == 0) {
+    if (!MAXP && ((tile - t_begin) & 15) == 0) {
       bool all_dead = true;
 #pragma unroll
       for (int u = 0; u < UT; ++u) {
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(256, ((BINS == 3 || UT == 2) ? 2 : 3)) void score_f
             else { const uint4 qq = qn[u][(r >> 3) & (QN - 1)]; const int e = r & 7; const unsigned wv = e < 2 ? qq.x : e < 4 ? qq.y : e < 6 ? qq.z : qq.w; bin = (wv >> (16 * (e & 1))) & 65535u; }
             pv = sts[sbase + ((r & 3) + 8 * (r >> 2)) * NB + bin];
           }
+          if constexpr (MAXP) { mx[u][r] = fmaxf(mx[u][r], jvalid ? __fmaf_rn(wd, pv, acc[r]) - tb : -INFINITY); continue; }      // (a NaN is ignored: lower)
           const float up = __fmaf_rn(wd, pv, acc[r]) + tb;
           pass |= !(up <= cc[u][r]) ? (1u << r) : 0u;        // (a NaN survives)
         }
@@ -299,6 +310,59 @@ __global__ __launch_bounds__(256, ((BINS == 3 || UT == 2) ? 2 : 3)) void score_f
       }
     }
     nm = A.inorm[min(nt * 32 + li, N - 1)];
+  }
+  if constexpr (MAXP) {      // block maxima -> surv_sc as scratch: [user][n_split x 32], one 128-byte line per (user, item range)
+    const int bw = A.n_split * 32;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (u == 1 && phantom) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int urow = utv[u] * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        A.surv_sc[(size_t)urow * bw + split * 32 + li] = mx[u][r];
+      }
+    }
+  }
+}
+
+// K-th largest of a user's block maxima (score_filter_kernel<MAXP>) -> the filter's threshold gbound[u].  One wave per user, the BWL * 64
+// values in registers, K rounds of (wave maximum, its first owner drops it).  What is subtracted on top of the per-pair bound the maxima
+// already carry: the user part of the filter's bound (2^-25 |u|_1) and the float32 evaluation of the comparison itself, both doubled.
+template <int BWL>
+__global__ __launch_bounds__(256) void sf_select_kernel(ScoreArgs A, int k) {
+  const int u = blockIdx.x * POI_NWAVE + wave_id(), lane = lane_id();
+  if (u >= A.n) return;
+  const float* bm = A.surv_sc + (size_t)u * (BWL * 64);
+  float v[BWL];
+#pragma unroll
+  for (int i = 0; i < BWL; ++i) v[i] = bm[lane + 64 * i];
+  float kth = -INFINITY;
+  for (int it = 0; it < k; ++it) {
+    float m = v[0];
+#pragma unroll
+    for (int i = 1; i < BWL; ++i) m = fmaxf(m, v[i]);
+    const float wm = wave_max(m);
+    kth = wm;
+    if (!(wm > -INFINITY)) break;                              // fewer than K finite blocks: no bound
+    const unsigned long long own = __ballot(m == wm);
+    if (lane == __ffsll((long long)own) - 1) {                 // the first owner drops ONE instance
+      bool done = false;
+#pragma unroll
+      for (int i = 0; i < BWL; ++i) { const bool hit = !done && v[i] == wm; v[i] = hit ? -INFINITY : v[i]; done |= hit; }
+    }
+  }
+  if (!(kth > -INFINITY)) return;
+  float n1 = 0.f, pmax = 0.f;
+  for (int i = lane; i < A.dim; i += 64) n1 += fabsf(A.users[(size_t)u * A.dim + i]);
+  n1 = wave_sum(n1);
+  const bool bins = A.ulptai != nullptr || A.geo;
+  if (bins && A.sts) { for (int b = lane; b <= A.n_dist; b += 64) pmax = fmaxf(pmax, fabsf(A.sts[(size_t)u * (A.n_dist + 1) + b])); pmax = wave_max(pmax); }
+  const float wd = (bins && A.wd) ? A.wd[0] : 0.f;
+  const float slack = 2.f * (n1 * (2.98023224e-8f * 1.01f) + 4.76837158e-7f * (fabsf(wd) * pmax + fabsf(kth))) + 1e-30f;
+  const float thr = kth - slack;
+  if (lane == 0 && thr > -INFINITY) {
+    const unsigned o = sf_f2ord(thr);
+    if (o > 1u && o - 1u > A.gbound[u]) A.gbound[u] = o - 1u;
   }
 }
 
@@ -699,6 +763,52 @@ static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStrea
   }
   tm->end(st);
   return hipGetLastError();
+}
+
+// self-seeding of an unseeded call (resident bin matrix or no distance term, dims 64 / 128): block maxima of the approximate lower bounds +
+// K-th largest per user -> gbound.  Uses surv_sc as scratch and leaves the packed items / norms for the filter pass.
+template <int D>
+static hipError_t launch_maxpass_t(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm) {
+  if constexpr (D > 128) { return hipErrorInvalidValue; } else {
+  const int ntile = (A.n_item + 31) / 32, n_utile = (A.n + 31) / 32;
+  const int bins = A.ulptai ? (A.bin_bytes == 1 ? 1 : 2) : 0;
+  const int nsm = n_split_f >= 64 ? 64 : n_split_f >= 32 ? 32 : 16;      // 512 .. 2048 blocks per user
+  tm->begin("pack_items", st);
+  hipLaunchKernelGGL(pack_items_f16_kernel<D>, dim3(ntile), dim3(256), 0, st, A.items, A.items_f16, A.n_item, const_cast<uint4*>(A.items_packed16), const_cast<float2*>(A.inorm));
+  tm->end(st);
+  ScoreArgs F = A; F.n_split = nsm;
+  const size_t lds = score_filter_lds(D, A.n_dist, bins != 0, false);
+  const int ut = score_filter_ut(D, A.n_dist, bins != 0, false);
+  const dim3 grid((n_utile + ut - 1) / ut, nsm / POI_NWAVE);
+  static bool optin = false;
+  if (!optin) {
+    hipError_t e = hipSuccess;
+    auto big = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    big(reinterpret_cast<const void*>(&score_filter_kernel<D, 2, 1, true>)); big(reinterpret_cast<const void*>(&score_filter_kernel<D, 1, 1, true>));
+    big(reinterpret_cast<const void*>(&score_filter_kernel<D, 2, 2, true>)); big(reinterpret_cast<const void*>(&score_filter_kernel<D, 1, 2, true>));
+    big(reinterpret_cast<const void*>(&score_filter_kernel<D, 0, 2, true>));
+    if (e != hipSuccess) return e;
+    optin = true;
+  }
+  tm->begin("score_maxpass", st);
+  if (bins == 1 && ut == 2) hipLaunchKernelGGL((score_filter_kernel<D, 1, 2, true>), grid, dim3(256), lds, st, F);
+  else if (bins == 1) hipLaunchKernelGGL((score_filter_kernel<D, 1, 1, true>), grid, dim3(256), lds, st, F);
+  else if (bins == 2 && ut == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2, 2, true>), grid, dim3(256), lds, st, F);
+  else if (bins == 2) hipLaunchKernelGGL((score_filter_kernel<D, 2, 1, true>), grid, dim3(256), lds, st, F);
+  else hipLaunchKernelGGL((score_filter_kernel<D, 0, 2, true>), grid, dim3(256), lds, st, F);
+  const dim3 gs((A.n + POI_NWAVE - 1) / POI_NWAVE);
+  if (nsm == 64) hipLaunchKernelGGL(sf_select_kernel<32>, gs, dim3(256), 0, st, F, A.k);
+  else if (nsm == 32) hipLaunchKernelGGL(sf_select_kernel<16>, gs, dim3(256), 0, st, F, A.k);
+  else hipLaunchKernelGGL(sf_select_kernel<8>, gs, dim3(256), 0, st, F, A.k);
+  tm->end(st);
+  return hipGetLastError();
+  }
+}
+bool score_maxpass_supported(const ScoreArgs& A) { return !A.geo && (A.dim == 64 || A.dim == 128) && A.k > 0 && A.k <= 64 && (A.n_item + 31) / 32 >= 64 * 4; }
+hipError_t launch_score_maxpass(const ScoreArgs& A, int n_split_f, hipStream_t st, Timing* tm) {
+  if (A.dim == 64) return launch_maxpass_t<64>(A, n_split_f, st, tm);
+  if (A.dim == 128) return launch_maxpass_t<128>(A, n_split_f, st, tm);
+  return hipErrorInvalidValue;
 }
 
 // stage 1 + stage 2; the caller then runs the one-stage kernel + merge with A.tile_flag set (they skip every tile that is not flagged)
