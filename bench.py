@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 PEAK_I8_TOPS = 5000.0       # MI355X_MICROARCH.md / cdna_hip_programming.md: int8 MFMA = 2 x the 2.5 PF bf16 dense peak (measured 3.9 - 4.4 POP/s)
-PROFILE_TAG = "r03"         # profiles/<tag>_pmc_traffic.json: committed rocprofv3 PMC passes of this command
+PROFILE_TAG = "r04"         # profiles/<tag>_pmc_traffic.json: committed rocprofv3 PMC passes of this command
 
 
 def parse():
