@@ -133,7 +133,7 @@ int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
  * public/GRU_Spatial.py:247): logits and d h of the chunked head on the same split products (te_head_big3) instead of float32-input MFMAs.
  * on = 0: float32-input v_mfma_f32_16x16x4_f32 (rounds 1 - 2).  Environment override at context creation: POI_TE_SPLIT=0|1. */
 int poi_ctx_set_split_products(poi_ctx* ctx, int on);
-/* Exact forward pass of the tile engine's TRAINING launches (dims 64 / 128; default on).  The reference computes in float64 (Theano
+/* Exact forward pass of the tile engine's training launches AND of poi_gru_predict (dims 64 / 128; default on).  The reference computes in float64 (Theano
  * floatX: public/GRU.py:57, public/GRU_Spatial.py:52) and with its uniform(-0.5, 0.5) init the forward recurrence h_{t-1} -> h_t
  * (public/GRU_Spatial.py:170-178) EXPANDS perturbations: a float32 forward pass, whatever its summation order, leaves a 50-position
  * sequence 1e-5 off the float64 result, and the whole update with it; the backward pass is linear in its carry and is not affected.

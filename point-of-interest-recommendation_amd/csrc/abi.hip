@@ -263,8 +263,8 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (A.ppoi && (rc = ensure(c, c->pmark, sizeof(int) * (size_t)(P->n_item + 2), st))) return rc;
   // forward table: worth it when the table has clearly fewer rows than the launch has steps (Tcap is the upper bound: sequences
   // average ~40 % of the longest) - te_gemm_ax then multiplies n_item + 1 rows instead of one row per step
-  // exact forward (training launches, dims 64 / 128): input product and forward recurrence in fixed point / float64 (te_xfwd.hip)
-  A.xfwd = (c->xfwd && !predict && !A.rec32 && poi::te_xfwd_supported(D)) ? 1 : 0;
+  // exact forward (dims 64 / 128): input product and forward recurrence in fixed point / float64 (te_xfwd.hip)
+  A.xfwd = (c->xfwd && !A.rec32 && poi::te_xfwd_supported(D)) ? 1 : 0;      // (training launches and predict alike)
   const bool want_ft = c->fwd_tab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap;
   A.fwd_tab = (!A.xfwd && want_ft && A.bintab && !A.rec1) ? 1 : 0;      // (the per-sequence kernels read G)
   A.xrec1 = (A.xfwd && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)

@@ -86,10 +86,10 @@ __device__ __forceinline__ double x_rcp(double d) {       // v_rcp_f64 is good t
   return __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
 }
 __device__ __forceinline__ double x_sigmoid(double x, const double* __restrict__ T) {
-  return x_rcp(1.0 + x_exp(-__builtin_fmax(x, -700.0), T));      // (only e^-x can overflow; e^-x -> 0 gives 1)
+  return x_rcp(1.0 + x_exp(-__builtin_fmin(__builtin_fmax(x, -700.0), 700.0), T));      // (clamped: the reduction of x_exp needs |x| < 2^31 ln2 / 64)
 }
 __device__ __forceinline__ double x_tanh(double x, const double* __restrict__ T) {
-  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * __builtin_fmin(x, 350.0), T)), 1.0);
+  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * __builtin_fmin(__builtin_fmax(x, -350.0), 350.0), T)), 1.0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -317,7 +317,7 @@ __device__ unsigned long long g_xprof[8][10];
 // columns, 96 bytes per lane, made every 16-byte load instruction of a wave touch 48 lines: the kernel was bound by the address path.)
 struct XG12 { double v[12]; };
 
-template <int D, bool FT>
+template <int D, bool FT, bool PRED = false>      // PRED: poi_gru_predict - all L positions, no per-step stores, the final state -> hts
 __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
   constexpr int KB = D / 64, NW = D / 16, SR = 3, SL = XS - SR, LDP = D + 16, PSZ = 16 * LDP;
   extern __shared__ __align__(16) unsigned char xlds[];
@@ -426,8 +426,10 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
         rv4[r] = (float)rv; rh4[r] = (float)rh[r];
       }
       put_digits(RHq, rh);
-      *reinterpret_cast<float4*>(A.G + row * 3 * D + D + u0) = make_float4(rv4[0], rv4[1], rv4[2], rv4[3]);
-      *reinterpret_cast<float4*>(A.RH + row * D + u0) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
+      if constexpr (!PRED) {
+        *reinterpret_cast<float4*>(A.G + row * 3 * D + D + u0) = make_float4(rv4[0], rv4[1], rv4[2], rv4[3]);
+        *reinterpret_cast<float4*>(A.RH + row * D + u0) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
+      }
     }
     XP(2)
     x_lds_barrier();
@@ -447,9 +449,11 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
       z4[r] = (float)zv[r]; c4[r] = (float)c; h4[r] = (float)hn;
     }
     put_digits(Hq, hcur);
-    *reinterpret_cast<float4*>(A.G + row * 3 * D + u0) = make_float4(z4[0], z4[1], z4[2], z4[3]);
-    *reinterpret_cast<float4*>(A.G + row * 3 * D + 2 * D + u0) = make_float4(c4[0], c4[1], c4[2], c4[3]);
-    *reinterpret_cast<float4*>(A.H + row * D + u0) = make_float4(h4[0], h4[1], h4[2], h4[3]);
+    if constexpr (!PRED) {
+      *reinterpret_cast<float4*>(A.G + row * 3 * D + u0) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+      *reinterpret_cast<float4*>(A.G + row * 3 * D + 2 * D + u0) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+      *reinterpret_cast<float4*>(A.H + row * D + u0) = make_float4(h4[0], h4[1], h4[2], h4[3]);
+    }
     XP(6)
     x_lds_barrier();
     XP(7)
@@ -495,6 +499,11 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
       }
     }
   }
+  if constexpr (PRED) {
+    const int k = tile * 16 + i;
+    if (k < A.n_seq)
+      *reinterpret_cast<float4*>(A.hts + (size_t)(A.out_row ? A.out_row[k] : k) * D + u0) = make_float4((float)hcur[0], (float)hcur[1], (float)hcur[2], (float)hcur[3]);
+  }
   XP_END
 }
 
@@ -521,7 +530,7 @@ template <int N> __device__ __forceinline__ double x_group_sum(double v) {      
 }
 __device__ __forceinline__ double x_pick4(const double (&a)[4], int o) { return o == 0 ? a[0] : o == 1 ? a[1] : o == 2 ? a[2] : a[3]; }
 
-template <int D>
+template <int D, bool PRED = false>
 __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
   constexpr int LZ = D / 8, LC = D / 16;
   __shared__ __align__(16) double hs[D], rhs[D], zs[D];
@@ -575,8 +584,10 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
       const double rh = v * hs[jr];
       if (ownz) { if (isr) rhs[jr] = rh; else zs[jr] = v; }
       const bool st = ownz && isr;
-      *(st ? A.G + row * 3 * D + D + jr : dG) = (float)v;
-      *(st ? A.RH + row * D + jr : dR) = (float)rh;
+      if constexpr (!PRED) {
+        *(st ? A.G + row * 3 * D + D + jr : dG) = (float)v;
+        *(st ? A.RH + row * D + jr : dR) = (float)rh;
+      }
     }
     x_lds_barrier();
     double b[4] = {0.0, 0.0, 0.0, 0.0};
@@ -593,14 +604,17 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
       const double z = zs[jc], hp = hs[jc];
       const double hn = __builtin_fma(z, c - hp, hp);
       if (ownc) hs[jc] = hn;               // (the c phase reads rhs only; the lanes that share jc are in one wave)
-      *(ownc ? A.G + row * 3 * D + jc : dG) = (float)z;
-      *(ownc ? A.G + row * 3 * D + 2 * D + jc : dG) = (float)c;
-      *(ownc ? A.H + row * D + jc : dH) = (float)hn;
+      if constexpr (!PRED) {
+        *(ownc ? A.G + row * 3 * D + jc : dG) = (float)z;
+        *(ownc ? A.G + row * 3 * D + 2 * D + jc : dG) = (float)c;
+        *(ownc ? A.H + row * D + jc : dH) = (float)hn;
+      }
     }
     x_lds_barrier();
     asm volatile("" : "+v"(nzr), "+v"(nc));      // the wait for the prefetch is counted HERE, behind this step's stores
     gzr = nzr; gcc = nc;
   }
+  if (PRED && tid < D) A.hts[(size_t)(A.out_row ? A.out_row[k] : k) * D + tid] = (float)hs[tid];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -622,6 +636,8 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   if (!optin) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     if (e != hipSuccess) return e;
     optin = true;
   }
@@ -634,7 +650,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     return hipGetLastError();
   }
   if (phase == 0) {
-  tm->begin("te_gemm_ax", st);
+  if (!A.predict) tm->begin("te_gemm_ax", st);
   {
     XPackJobs J;
     J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
@@ -658,7 +674,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     const int grid = min(num_cu * 2, n_tile_est * ncg > 0 ? n_tile_est * ncg : 1);
     hipLaunchKernelGGL(te_gemmx_kernel<D>, dim3(grid), dim3(256), 0, st, P);
   }
-  tm->end(st);
+  if (!A.predict) tm->end(st);
   return hipGetLastError();
   }
 #ifdef TE_XPROF
@@ -678,6 +694,12 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xprof), z, sizeof(z));
   } } dump_at_exit;
 #endif
+  if (A.predict) {      // (inside the caller's te_predict region)
+    if (A.xrec1) hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, true>), dim3(n), dim3(4 * D), 0, st, A);
+    else if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
+    else hipLaunchKernelGGL((te_rec_fwdx_kernel<D, false, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
+    return hipGetLastError();
+  }
   tm->begin("te_rec_fwd", st);
   if (A.xrec1) hipLaunchKernelGGL(te_rec_fwd1x_kernel<D>, dim3(n), dim3(4 * D), 0, st, A);
   else if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);

@@ -3048,7 +3048,7 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     }
   }
   // B[k][n] = wh_flat[n][k]   (K = D, N = 3D), 16-column fragments (32-column ones for the streaming kernels)
-  if (A.rec1 || (A.xfwd && train)) {}      // (te_rec_fwd1 reads wh directly; the exact forward has its own digit fragments: te_xpack)
+  if (A.rec1 || A.xfwd) {}      // (te_rec_fwd1 reads wh directly; the exact forward has its own digit fragments: te_xpack)
   else if (A.rec32 && A.rec_split) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 16, 3 * D / 32, A.pWhT16, 4};
   else if (A.rec32) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 8, 3 * D / 32, A.pWhT16, 0};
   else if (A.rec_split && (!A.fwd_tab || A.predict)) J.j[n++] = PackJob{A.wh, 1, D, D, 3 * D, D / 32, 3 * D / 16, A.pWhT16, 2};      // (forward-table TRAINING launches keep the float32 kernel)
@@ -3434,6 +3434,11 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+  if (A.xfwd) {      // exact forward (te_xfwd.hip): the same input product and recurrence as the training launches, final state -> hts
+    hipError_t xe = launch_te_xfwd(A, num_cu, st, tm, 0);
+    if (xe == hipSuccess) xe = launch_te_xfwd(A, num_cu, st, tm, 1);
+    if (xe != hipSuccess) return xe;
+  } else {
   te_launch_ax<D>(A, num_cu, st);
   if constexpr (D >= 128) {
     if (A.rec32 && A.rec_split) hipLaunchKernelGGL((te_rec_fwd32_kernel<D, true, D / 32, true>), dim3((n + 31) / 32), dim3(D * 2), sizeof(short) * 2 * 3 * 32 * (D + 8), st, A);
@@ -3451,6 +3456,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
       else if (A.rec_split) hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true, false, true>), g, b, ldss, st, A);
       else hipLaunchKernelGGL((te_rec_fwd16_kernel<D, true>), g, b, ldsf, st, A);
     }
+  }
   }
   hipError_t e = hipSuccess;
   if (A.sts) e = te_head_dispatch<D>(A, 1, num_cu * 2 < tiles ? num_cu * 2 : tiles, st);

@@ -662,6 +662,15 @@ def test_exact_forward_pass_is_far_inside_the_bar_and_the_switch_changes_the_ari
                 worst = assert_step_close(got, exp, P0, SP_NAMES, "exact forward %s, %s" % (xf, mode), rtol=2e-6 if xf else (1e-5 if len_max < 50 else 4e-5),
                                           delta_rtol=1e-4)
                 res[(xf, mode)] = (got, worst)
+                if mode == "batch-70":      # predict runs the same exact forward pass: hts of the 50-position sequences to 2e-6 (float32 forward: 1e-5 class)
+                    model.update_trained_items(); model.update_trained_dists()
+                    ids = np.arange(T["n_user"], dtype=np.int32)
+                    hts, sts = model.predict(ids)
+                    Pn = {k: (np.asarray(v, np.float64) if k != "wd" else float(v)) for k, v in got.items()}
+                    Pn["h0"] = np.zeros(dim)
+                    eh, es = O.spatial_predict(Pn, Pn["lt"], Pn["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
+                    assert_close(hts, eh, "hts (exact forward %s)" % xf, rtol=2e-6 if xf else 4e-5)
+                    assert_close(sts, es, "sts (exact forward %s)" % xf, rtol=2e-6 if xf else 4e-5)
         for mode in ("one", "batched", "batch-70"):
             assert not all(np.array_equal(res[(True, mode)][0][k], res[(False, mode)][0][k]) for k in ("wh", "ui", "lt")), "the switch did not change the arithmetic"
     finally:
