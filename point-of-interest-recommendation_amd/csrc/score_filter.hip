@@ -21,6 +21,7 @@
 #include "poi_common.h"
 #include "poi_kernels.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace poi {
 
@@ -772,7 +773,8 @@ static hipError_t launch_maxpass_t(const ScoreArgs& A, int n_split_f, hipStream_
   if constexpr (D > 128) { return hipErrorInvalidValue; } else {
   const int ntile = (A.n_item + 31) / 32, n_utile = (A.n + 31) / 32;
   const int bins = A.ulptai ? (A.bin_bytes == 1 ? 1 : 2) : 0;
-  const int nsm = n_split_f >= 64 ? 64 : n_split_f >= 32 ? 32 : 16;      // 512 .. 2048 blocks per user
+  int nsm = n_split_f >= 64 ? 64 : n_split_f >= 32 ? 32 : 16;      // 512 .. 2048 blocks per user
+  if (const char* e = getenv("POI_SF_NSM")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) nsm = v; }      // tuning switch
   tm->begin("pack_items", st);
   hipLaunchKernelGGL(pack_items_f16_kernel<D>, dim3(ntile), dim3(256), 0, st, A.items, A.items_f16, A.n_item, const_cast<uint4*>(A.items_packed16), const_cast<float2*>(A.inorm));
   tm->end(st);
