@@ -159,7 +159,7 @@ int poi_ctx_set_small_launch(poi_ctx* ctx, int max_sequences);
  * Environment override at context creation: POI_TE_BINTAB_MIN=<min_sequences>. */
 int poi_ctx_set_regroup_min(poi_ctx* ctx, int min_sequences);
 /* One-sequence path (default on): a poi_spatial_step / poi_gru_step launch of ONE sequence - the reference schedule, prog_bpr_gru_spatial.py:249-250 -
- * at dim 64 / 128 (stored dims below are padded), float32 tables, sequences of at most 65 positions, runs the whole step in five
+ * at dim 64 / 128 (stored dims below are padded), float32 tables, sequences of at most 161 positions (the reference mentions len_max 157 for Foursquare), runs the whole step in five
  * kernels instead of the batched pipeline's ~40 dispatches (input products on the vector ALUs, per-sequence recurrences, the head,
  * and ONE kernel for every gradient product with the SGD step in its epilogue and the sparse write-back, one workgroup per table
  * touch).  Same formulas and write-back rule (public/GRU_Spatial.py:127-229); on = 0 sends such launches through the batched

@@ -2733,7 +2733,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile
 //               ui snapshot, +- g h - and applies the step; the padding rows' analytic multiplicities as in te_rowmap).
 // Same formulas and batch rule (n_seq = 1) as te_scatter / dense_apply; T <= 64 steps.
 // -------------------------------------------------------------------------------------------------
-#define ONE_TMAX 64
+#define ONE_TMAX 160      // steps of the one-sequence path (te_one_out keeps a 16 x ONE_TMAX and a 64 x ONE_TMAX operand tile in LDS: 54 KB); 161 positions cover the len_max 157 the reference mentions for Foursquare (public/GRU.py:171)
 __device__ __forceinline__ void one_header(const TeArgs& A, int& base, int& L, int& ns) {
   const int u = A.uidx[0];
   base = A.off[u]; L = min(A.off[u + 1] - base, ONE_TMAX + 1); ns = L > 0 ? L - 1 : 0;      // (the host checked max_len <= ONE_TMAX + 1: the clamp only guards the LDS tiles against inconsistent tables)

@@ -590,11 +590,11 @@ def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user, 
         pa._lib.context(0).set_split_products(True); pa._lib.context(0).set_small_launch(1024); pa._lib.context(0).set_engine("auto")
 
 
-@pytest.mark.parametrize("dim,n_dist,len_max", [(128, 200, 50), (64, 40, 9), (128, 1520, 12), (20, 11, 7), (128, 40, 65)])
+@pytest.mark.parametrize("dim,n_dist,len_max", [(128, 200, 50), (64, 40, 9), (128, 1520, 12), (20, 11, 7), (128, 40, 65), (64, 40, 161)])
 def test_one_sequence_path_is_the_reference_step(pa, dim, n_dist, len_max):
     """poi_ctx_set_one_sequence_path: the five-kernel step of one sequence (te_one_*) == the reference step of the oracle, sequentially over
     users whose sequences repeat POIs (hot = 6: the same table row as input, positive and negative target), are as short as one or two
-    positions (decay only / a single step) and as long as len_max (65: the path's limit), with the padding rows' analytic multiplicities;
+    positions (decay only / a single step) and as long as len_max (161: the path's limit - the reference's Foursquare sequences reach 157), with the padding rows' analytic multiplicities;
     and == the batched pipeline on the same launches (same bars).  dim 20: stored zero-padded to 64."""
     T = toy_problem(1700 + dim + len_max, n_user=14, n_item=60, n_dist=n_dist, dim=dim, len_max=len_max, min_len=1, hot=6)
     for u, L in ((3, 1), (5, 2)):            # a sequence of one position (decay only) and one of two (a single step)
