@@ -322,6 +322,7 @@ struct ScoreArgs {
   int n_split;              // item splits for the fused top-K
   float* cand_score; int* cand_idx;   // (n_split, n_pad, k) partial top-K lists
   int dbg;                  // tuning switch (POI_SCORE_DBG), 0 in production
+  int max_stride;           // score_filter_kernel<MAXP>: every max_stride-th item tile
   unsigned* gbound;         // (n_pad) per-user lower bound of the K-th best score shared by all item ranges
   int seeded;               // gbound starts from the caller's seed items' scores (topk_seed_kernel), not from zero
   int* idx_out; float* score_out;
