@@ -196,6 +196,7 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
   constexpr int KB = D / 32, N = 3 * D, NT = N / 32, FR = KB * XS * 64;      // uint4 fragments per column tile
   constexpr int PT = (FR + 255) / 256;
+  static_assert(D <= 128 && D % 32 == 0, "te_gemmx: the int32 merge of the digit-pair classes (x_combine) holds for K <= 128");
   __shared__ uint4 s_b[2][FR];                                 // two column tiles: tile j + 1 lands while tile j is multiplied
   __shared__ double s_rs[4][32];
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
@@ -320,6 +321,7 @@ struct XG12 { double v[12]; };
 template <int D, bool FT, bool PRED = false>      // PRED: poi_gru_predict - all L positions, no per-step stores, the final state -> hts
 __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
   constexpr int KB = D / 64, NW = D / 16, SR = 3, SL = XS - SR, LDP = D + 16, PSZ = 16 * LDP;
+  static_assert(D <= 128 && D % 64 == 0, "te_rec_fwdx: resident digit fragments and x_combine's int32 merge are sized for K <= 128");
   extern __shared__ __align__(16) unsigned char xlds[];
   unsigned char* Hq = xlds;                          // XS planes x 16 rows x LDP bytes
   unsigned char* RHq = Hq + XS * PSZ;
