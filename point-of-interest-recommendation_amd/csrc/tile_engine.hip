@@ -2480,17 +2480,42 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 1 : 2)) void te_head_big3_ker
 // te_wgrad: split-K transposed GEMMs  out[m][n] = sum_r DA[r][m0+m] * Bsrc[r][n0+n]  on TxT output
 // blocks (T = 128 when D % 128 == 0, else 64); K-chunk c covers packed rows [c*chunk, (c+1)*chunk).
 // job -> (A column block, B source).  Waves form a 2x2 grid, each owning (T/2)x(T/2) = Q x Q 32x32
-// accumulators; each 32-row stage is loaded from HBM/L2 into registers BEFORE the MFMA block of the
+// accumulators; each 16-row stage is loaded from HBM/L2 into registers BEFORE the MFMA block of the
 // previous stage and written to the other LDS buffer after it (async-stage split, one barrier/stage).
 // -------------------------------------------------------------------------------------------------
 
+// Split products (round 4): the float32-input MFMA runs at the vector rate on gfx950, 1/16 of the bf16 rate.  Every staged value is cut
+// into three bf16 planes ONCE per workgroup, when it goes to LDS (wg_split2: x = x1 + x2 + x3 exactly; a thread stages rows k and k + 1
+// of four columns, so v_cvt_pk_bf16_f32 / v_perm_b32 pack the pair into the dword the MFMA wants - no transposition), and a product is
+// the six partial products down to 2^-16 on v_mfma_f32_32x32x16_bf16 (exact products, float32 accumulation; dropped terms <= 2^-25 |x y|,
+// random signs - the rule of the recurrent kernels): 12 MFMAs of 8 passes per 32 k-rows and output block against 16 of 16 passes.
+// Measured at the Gowalla launch: 385 us (float32 MFMAs) -> 285 us (planes cut by every wave that reads a value) -> see DESIGN.md.
+// x0, x1 (k and k + 1 of one column) -> one packed dword per plane (low half = k)
+__device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 xv = {x0, x1};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, bf16x2));
+  const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
+  p2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);      // {r1.hi16, r0.hi16}
+  const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
+  p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+#ifndef WG_OCC
+#define WG_OCC 2
+#endif
 template <int D, int T, bool F16 = false>       // F16: the POI table (gather source of the d ui jobs) holds IEEE half
-__global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc) {
-  constexpr int LDT = T + 4, Q = T / 64;         // Q x Q accumulators per wave
+__global__ __launch_bounds__(TE_BLOCK, WG_OCC) void te_wgrad_kernel(TeArgs A, int nkc) {
+  constexpr int LDT = T + 8, Q = T / 64;         // Q x Q accumulators per wave; (4 LDT) % 64 == 32
   const int XW = A.xw;
-  constexpr int F4 = 32 * (T / 4) / TE_BLOCK;                // float4 per thread per operand per stage
-  __shared__ __align__(16) float At[2][32][LDT];
-  __shared__ __align__(16) float Bt[2][32][LDT];
+  constexpr int ITEMS = 8 * (T / 4);             // (row pair, 4 columns) items of a 16-row stage and operand: one per thread (T = 64: threads 0 .. 127)
+  static_assert(ITEMS <= TE_BLOCK && TE_BLOCK % ITEMS == 0, "te_wgrad: one staging item per thread");
+  // a stage = 16 k-rows of both operands as three bf16 planes, rows k and k + 1 of a column packed in one dword: [buffer][plane][row pair][column]
+  // (a thread's four dwords of a plane are one 16-byte write; a lane's MFMA fragment - k = 8 h .. 8 h + 7 of its column - four 4-byte reads,
+  // conflict-free.  Measured against it: the pairs of a row quad side by side, [row quad][column][pair], for two 8-byte reads - with 8-byte
+  // global loads, 4 rows x 2 columns per thread, 256 -> 281 us; with 16-byte loads and four 4-byte writes per plane, 8-way bank conflicts: 348 us)
+  __shared__ __align__(16) unsigned At[2][3][8][LDT];
+  __shared__ __align__(16) unsigned Bt[2][3][8][LDT];
   constexpr int NB_ZR = (2 * D / T) * (D / T), NB_C = (D / T) * (D / T);
   const int XWJ = A.bintab ? D : XW;                         // d ui columns that are GEMM jobs (bintab: POI half only)
   const int NB_UI = (3 * D / T) * (XWJ / T);
@@ -2547,88 +2572,101 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   const int goff = n0 - (gdi ? D : 0);
   const float* gtab = (gdi ? A.di : A.lt) + goff;        // (F16 and !gdi: A.lt is re-read as half below, offsets in elements)
   const int* gidx = bsel == 0 ? (gdi ? A.row_dp : pp ? A.urow_p : A.row_p) : A.row_t;
-  float4 ra0[F4], rb0[F4], ra1[F4], rb1[F4];
-  uint2 rh0[F4], rh1[F4];            // F16: the raw half row of the d ui jobs (unused otherwise)
-  int rt0[F4], rt1[F4];
-  unsigned ni[F4];      // unsigned: a signed index is sign-extended right behind its load, i.e. the wave waits for it there
+  // this thread's staging item: rows 2 rp, 2 rp + 1 of the stage, columns c .. c + 3 (a wave covers two row pairs: 512 contiguous bytes per row)
+  const int item = tid % ITEMS, rp = item / (T / 4), c = (item % (T / 4)) * 4;
+  const int ca = c < acols ? c : 0;
+  float4 ra0[2], rb0[2], ra1[2], rb1[2];
+  uint2 rh0[2], rh1[2];            // F16: the raw half rows of the d ui jobs (unused otherwise)
+  unsigned rt0[2], rt1[2];         // the rows' clamped indices (d wh jobs: position t of the step - its h_{t-1} operand does not exist at t = 0)
+  unsigned ni[2];      // unsigned: a signed index is sign-extended right behind its load, i.e. the wave waits for it there
   // (clamped to the table: a launch WITHOUT steps - every sequence a single position - reads entry 0 of an index array nobody wrote;
   // whatever an earlier launch left there must still be a valid row.  Found by tools/fuzz_engines.py: an aperture violation)
   const unsigned nimax = (unsigned)(gdi ? A.n_dist : A.n_item);
 #pragma unroll
-  for (int s = 0; s < F4; ++s) ni[s] = (unsigned)gidx[min(rb + (tid + s * TE_BLOCK) / (T / 4), rmax)];
-  auto gload = [&](int r0, float4 (&ra)[F4], float4 (&rbv)[F4], int (&rt)[F4], uint2 (&rh)[F4]) {
+  for (int s = 0; s < 2; ++s) ni[s] = (unsigned)gidx[min(rb + 2 * rp + s, rmax)];
+  auto gload = [&](int r0, float4 (&ra)[2], float4 (&rbv)[2], unsigned (&rt)[2], uint2 (&rh)[2]) {
     // The indices of the NEXT stage are requested first, the rows of this stage after them: vmcnt retires in order, so the wait for the
-    // indices at the top of the next call then leaves this call's twelve row loads in flight.  Requested last (as they were), that wait
-    // was s_waitcnt vmcnt(0) - every row load had one MFMA block to land instead of the two the pipeline is built for.
-    // (ni holds the RAW loaded index and is clamped here, where it is consumed: clamped where it is loaded, the min sits right behind
-    // the load and the wave waits a memory latency for it before its MFMA block - 28 % of the kernel, -DTE_HEAD_PROF counters)
-    unsigned nc[F4];
+    // indices at the top of the next call then leaves this call's row loads in flight.  (ni holds the RAW loaded index and is clamped
+    // here, where it is consumed: clamped where it is loaded, the min sits right behind the load and the wave waits a memory latency
+    // for it before its MFMA block)
 #pragma unroll
-    for (int s = 0; s < F4; ++s) nc[s] = min(ni[s], nimax);
+    for (int s = 0; s < 2; ++s) rt[s] = min(ni[s], nimax);
 #pragma unroll
-    for (int s = 0; s < F4; ++s) ni[s] = (unsigned)gidx[min(r0 + 32 + (tid + s * TE_BLOCK) / (T / 4), rmax)];
+    for (int s = 0; s < 2; ++s) ni[s] = (unsigned)gidx[min(r0 + 16 + 2 * rp + s, rmax)];
 #pragma unroll
-    for (int s = 0; s < F4; ++s) {
-      const int e = tid + s * TE_BLOCK;
-      const int r = e / (T / 4), c = (e % (T / 4)) * 4;
-      const int gr = min(r0 + r, rmax);
-      rt[s] = A.row_t[min(gr, Tsteps)];                         // h_{t-1} operand (bsel 1): none at the first step
-      ra[s] = *reinterpret_cast<const float4*>(Ap + (size_t)gr * lda + (c < acols ? c : 0));
+    for (int s = 0; s < 2; ++s) {
+      const int gr = min(r0 + 2 * rp + s, rmax);
+      ra[s] = *reinterpret_cast<const float4*>(Ap + (size_t)gr * lda + ca);
       if constexpr (F16) {
         // branch-free (a branch around a load drains the queue): both typed loads are always issued from valid addresses - the
         // half one from row 0 of the table when this job does not gather it, the float one from H when it does - and selected
         const bool hb = bsel == 0 && !gdi;
-        const float* bptr = (bsel == 0 && gdi) ? gtab + (size_t)nc[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
+        const float* bptr = (bsel == 0 && gdi) ? gtab + (size_t)rt[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
         // (both stay RAW in registers until lstore: converted and selected here, the consumer sits right behind the loads and the wave
         // waits a memory latency in front of its MFMA block - tools/scan_waits.py)
         rbv[s] = *reinterpret_cast<const float4*>(bptr);
-        rh[s] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(A.lt) + (hb ? goff + (size_t)nc[s] * D + c : (size_t)c));
+        rh[s] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(A.lt) + (hb ? goff + (size_t)rt[s] * D + c : (size_t)c));
       } else {
-        const float* bptr = bsel == 0 ? gtab + (size_t)nc[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
+        const float* bptr = bsel == 0 ? gtab + (size_t)rt[s] * D + c : Bp + (size_t)max(gr - bshift, 0) * ldb + c;
         rbv[s] = *reinterpret_cast<const float4*>(bptr);
       }
     }
   };
-  auto lstore = [&](int buf, int r0, const float4 (&ra)[F4], const float4 (&rbv)[F4], const int (&rt)[F4], const uint2 (&rh)[F4]) {
+  // masks, the three-plane split (once per element and workgroup) and the LDS writes
+  auto lstore = [&](int buf, int r0, const float4 (&ra)[2], const float4 (&rbv)[2], const unsigned (&rt)[2], const uint2 (&rh)[2]) {
+    float xa[2][4], xb[2][4];
 #pragma unroll
-    for (int s = 0; s < F4; ++s) {
-      const int e = tid + s * TE_BLOCK;
-      const int r = e / (T / 4), c = (e % (T / 4)) * 4;
-      const bool in = r0 + r < re;
+    for (int s = 0; s < 2; ++s) {
+      const bool in = r0 + 2 * rp + s < re;
       // (component-wise selects: a select between float4 aggregates sends the arrays to scratch)
-      const bool oa = in && c < acols, ob = in && rt[s] >= bshift;
-      *reinterpret_cast<float4*>(&At[buf][r][c]) = make_float4(oa ? ra[s].x : 0.f, oa ? ra[s].y : 0.f, oa ? ra[s].z : 0.f, oa ? ra[s].w : 0.f);
+      const bool oa = in && c < acols, ob = in && (bsel != 1 || rt[s] >= 1u);      // (bsel 1: gidx is row_t)
+      xa[s][0] = oa ? ra[s].x : 0.f; xa[s][1] = oa ? ra[s].y : 0.f; xa[s][2] = oa ? ra[s].z : 0.f; xa[s][3] = oa ? ra[s].w : 0.f;
       float4 bq = rbv[s];
       if constexpr (F16) {
         const bool hb = bsel == 0 && !gdi;
         const float2 fa = __half22float2(*reinterpret_cast<const __half2*>(&rh[s].x)), fb = __half22float2(*reinterpret_cast<const __half2*>(&rh[s].y));
         bq = make_float4(hb ? fa.x : bq.x, hb ? fa.y : bq.y, hb ? fb.x : bq.z, hb ? fb.y : bq.w);
       }
-      *reinterpret_cast<float4*>(&Bt[buf][r][c]) = make_float4(ob ? bq.x : 0.f, ob ? bq.y : 0.f, ob ? bq.z : 0.f, ob ? bq.w : 0.f);
+      xb[s][0] = ob ? bq.x : 0.f; xb[s][1] = ob ? bq.y : 0.f; xb[s][2] = ob ? bq.z : 0.f; xb[s][3] = ob ? bq.w : 0.f;
+    }
+    unsigned pa[3][4], pb[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wg_split2(xa[0][e], xa[1][e], pa[0][e], pa[1][e], pa[2][e]);
+      wg_split2(xb[0][e], xb[1][e], pb[0][e], pb[1][e], pb[2][e]);
+    }
+    if (ITEMS == TE_BLOCK || tid < ITEMS) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        *reinterpret_cast<uint4*>(&At[buf][p][rp][c]) = make_uint4(pa[p][0], pa[p][1], pa[p][2], pa[p][3]);
+        *reinterpret_cast<uint4*>(&Bt[buf][p][rp][c]) = make_uint4(pb[p][0], pb[p][1], pb[p][2], pb[p][3]);
+      }
     }
   };
-  // operands of MFMA step kk+1 are read from LDS before the MFMAs of step kk are issued (the compiler
-  // does not software-pipeline ds_read across the unrolled steps on its own)
+  // one 16-row stage: a lane's fragment of a plane = the four row pairs 4 h .. 4 h + 3 of its column (k = 8 h .. 8 h + 7); six partial
+  // products per output block, small ones first; the Q x Q blocks are independent chains
   auto mma = [&](int buf) {
-    float av[2][Q], bv[2][Q];
+    uint4 pa[Q][3], pb[Q][3];
 #pragma unroll
-    for (int i = 0; i < Q; ++i) av[0][i] = At[buf][h][wm + 32 * i + li];
+    for (int p = 0; p < 3; ++p) {
 #pragma unroll
-    for (int j = 0; j < Q; ++j) bv[0][j] = Bt[buf][h][wn + 32 * j + li];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      if (kk + 1 < 16) {
-#pragma unroll
-        for (int i = 0; i < Q; ++i) av[(kk + 1) & 1][i] = At[buf][2 * (kk + 1) + h][wm + 32 * i + li];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) bv[(kk + 1) & 1][j] = Bt[buf][2 * (kk + 1) + h][wn + 32 * j + li];
+      for (int i = 0; i < Q; ++i) {
+        const unsigned* q = &At[buf][p][4 * h][wm + 32 * i + li];
+        pa[i][p] = make_uint4(q[0], q[LDT], q[2 * LDT], q[3 * LDT]);
       }
-      __builtin_amdgcn_sched_barrier(0);      // keep the reads of step kk+1 above the MFMAs of step kk
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const unsigned* q = &Bt[buf][p][4 * h][wn + 32 * j + li];
+        pb[j][p] = make_uint4(q[0], q[LDT], q[2 * LDT], q[3 * LDT]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int i = 0; i < Q; ++i)
 #pragma unroll
-        for (int j = 0; j < Q; ++j) acc[i][j] = mfma32(av[kk & 1][i], bv[kk & 1][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < Q; ++j) acc[i][j] = mfma32b(pa[i][PA[t]], pb[j][PB[t]], acc[i][j]);
     }
   };
   // Branch-free pipeline (every load is clamped, every LDS write masked by `r < re`): with no control flow
@@ -2636,18 +2674,18 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_wgrad_kernel(TeArgs A, int nkc
   // was fetched just before the MFMA block in flight.  A chunk is a multiple of 64 rows, so the odd stage
   // of the last iteration is the only work that can be empty.
   gload(rb, ra0, rb0, rt0, rh0); lstore(0, rb, ra0, rb0, rt0, rh0);
-  gload(rb + 32, ra0, rb0, rt0, rh0);
+  gload(rb + 16, ra0, rb0, rt0, rh0);
   __syncthreads();
-  for (int r0 = rb; r0 < re; r0 += 64) {
+  for (int r0 = rb; r0 < re; r0 += 32) {
     // even stage: LDS buffer 0; set 0 holds stage +1, set 1 receives stage +2
-    gload(r0 + 64, ra1, rb1, rt1, rh1);
+    gload(r0 + 32, ra1, rb1, rt1, rh1);
     mma(0);
-    lstore(1, r0 + 32, ra0, rb0, rt0, rh0);
+    lstore(1, r0 + 16, ra0, rb0, rt0, rh0);
     __syncthreads();
     // odd stage: LDS buffer 1; set 1 holds stage +1, set 0 receives stage +2
-    gload(r0 + 96, ra0, rb0, rt0, rh0);
+    gload(r0 + 48, ra0, rb0, rt0, rh0);
     mma(1);
-    lstore(0, r0 + 64, ra1, rb1, rt1, rh1);
+    lstore(0, r0 + 32, ra1, rb1, rt1, rh1);
     __syncthreads();
   }
   float* out = A.slab + (size_t)kc * A.dl.total + oo;
