@@ -83,6 +83,27 @@ __device__ __forceinline__ void split3(float v, unsigned& u1, unsigned& u2, unsi
   u3 = __float_as_uint(r1 - __uint_as_float(u2));
 }
 
+// two values -> one packed dword per plane (low half = x0): split3's planes for a pair, v_cvt_pk_bf16_f32 / v_perm_b32 doing the packing
+__device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 xv = {x0, x1};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, bf16x2));
+  const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
+  p2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);      // {r1.hi16, r0.hi16}
+  const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
+  p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+// two planes only, BOTH rounded to nearest (x - x1 - x2 <= 2^-18 |x|): the backward-only products of te_head3
+__device__ __forceinline__ void wg_split2r(float x0, float x1, unsigned& p1, unsigned& p2) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 xv = {x0, x1};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, bf16x2));
+  const f32x2 rv = {x0 - __uint_as_float(p1 << 16), x1 - __uint_as_float(p1 & 0xFFFF0000u)};
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(rv, bf16x2));
+}
+
 // (vb of nvb: the virtual block of the job - te_pack_kernel's own grid, or a slice of te_one_in_kernel's)
 __device__ __forceinline__ void te_pack_block(const PackJob& j, const int vb, const int nvb) {
   if (j.n16 == 3) {      // plain transposed copy for the per-sequence recurrent kernels: dst[n * K + k] = B[k][n]
@@ -396,6 +417,90 @@ __device__ __forceinline__ void mma_lds_packed_s3p(f32x16 (&acc)[1][NTW], const 
 #pragma unroll
       for (int p = 0; p < 3; ++p) ac[p] = an[p];
     }
+  }
+}
+
+// te_head3's two products.  (1) logits: the A tile stays float32 in LDS and a lane cuts its 8 consecutive k into three planes when it reads
+// them; B = planes 1, 2 of the n16 == 4 fragments: five partial products a3 b1 + a2 b2 + a2 b1 + a1 b2 + a1 b1 (dropped: a1 b3, 2^-17).
+template <int NTW, int KG>
+__device__ __forceinline__ void mma_f32a_s2(f32x16 (&acc)[NTW], const float* __restrict__ ldsA, int ldh, const float4* __restrict__ bp, const int (&nt)[NTW]) {
+  const int lane = lane_id(), li = lane & 31, h = lane >> 5;
+  const float* arow = ldsA + li * ldh + 8 * h;
+  const uint4* bj[NTW];
+  uint4 bc[NTW][2], bn[NTW][2];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    bj[j] = reinterpret_cast<const uint4*>(bp) + ((size_t)nt[j] * KG) * 3 * 64 + lane;
+    bc[j][0] = bj[j][0]; bc[j][1] = bj[j][64];
+  }
+  float4 xc0 = *reinterpret_cast<const float4*>(arow), xc1 = *reinterpret_cast<const float4*>(arow + 4);
+#pragma unroll 1
+  for (int m = 0; m < KG; ++m) {
+    const int mn = min(m + 1, KG - 1);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { bn[j][0] = bj[j][(size_t)mn * 3 * 64]; bn[j][1] = bj[j][((size_t)mn * 3 + 1) * 64]; }
+    const float4 xn0 = *reinterpret_cast<const float4*>(arow + 16 * mn), xn1 = *reinterpret_cast<const float4*>(arow + 16 * mn + 4);
+    uint4 a1, a2, a3;
+    wg_split2(xc0.x, xc0.y, a1.x, a2.x, a3.x); wg_split2(xc0.z, xc0.w, a1.y, a2.y, a3.y);
+    wg_split2(xc1.x, xc1.y, a1.z, a2.z, a3.z); wg_split2(xc1.z, xc1.w, a1.w, a2.w, a3.w);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(a3, bc[j][0], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(a2, bc[j][1], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(a2, bc[j][0], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(a1, bc[j][1], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(a1, bc[j][0], acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { bc[j][0] = bn[j][0]; bc[j][1] = bn[j][1]; }
+    xc0 = xn0; xc1 = xn1;
+  }
+}
+// (2) d h: two A planes in LDS (arow: this lane's row of plane 1, + 8 h; ps: elements between the planes), all three B planes: five partial
+// products a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1.  What is lost is the A operand's third plane, 2^-18 (both A planes are rounded to nearest):
+// a backward product - the recurrence does not amplify its error, the bars on the updates are 1e-4.  (Without a1 b3 - B truncated to two
+// planes, 2^-17 - the hot-POI step of test_exact_forward_pass_is_far_inside_the_bar lands at 2.7e-6 instead of under 2e-6: 229 vs 250 us.)
+template <int NTW, int KG>
+__device__ __forceinline__ void mma_p2_s3(f32x16 (&acc)[NTW], const unsigned short* __restrict__ arow, int ps, const float4* __restrict__ bp, const int (&nt)[NTW]) {
+  const int lane = lane_id();
+  const uint4* bj[NTW];
+  uint4 bc[NTW][3], bn[NTW][3];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    bj[j] = reinterpret_cast<const uint4*>(bp) + ((size_t)nt[j] * KG) * 3 * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bc[j][p] = bj[j][p * 64];
+  }
+  uint4 ac0 = *reinterpret_cast<const uint4*>(arow), ac1 = *reinterpret_cast<const uint4*>(arow + ps);
+#pragma unroll 1
+  for (int m = 0; m < KG; ++m) {
+    const int mn = min(m + 1, KG - 1);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bn[j][p] = bj[j][((size_t)mn * 3 + p) * 64];
+    const uint4 an0 = *reinterpret_cast<const uint4*>(arow + 16 * mn), an1 = *reinterpret_cast<const uint4*>(arow + ps + 16 * mn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(ac0, bc[j][2], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(ac1, bc[j][1], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(ac1, bc[j][0], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(ac0, bc[j][1], acc[j]);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[j] = mfma32b(ac0, bc[j][0], acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bc[j][p] = bn[j][p];
+    ac0 = an0; ac1 = an1;
   }
 }
 
@@ -1956,6 +2061,217 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 }
 
 // -------------------------------------------------------------------------------------------------
+// te_head3 (round 4): the training head on split products (poi_ctx_set_split_products; <= 256 bins).  Same tile loop, same LDS budget
+// (three workgroups per CU), the float32-input MFMAs - 3/4 of te_head's time at the vector rate - replaced:
+//   logits   = h . vs^T: the h tile stays float32 in LDS, a lane cuts its fragment into three bf16 planes as it reads it (mma_f32a_s2);
+//   softmax  : a thread keeps its 4 x NBT logits (bins 32 i + 4 sub + e of its row) in REGISTERS through all three passes - one 16-byte LDS
+//              read per four bins instead of three passes of 4-byte reads and writes; the target probabilities by compare + DPP sums;
+//              d logits go to DL as float4 stores from the registers and to LDS as two bf16 planes (both rounded to nearest) that overwrite
+//              the wave's OWN eight float32 rows (8 rows x LDO floats = 2 planes x 8 rows x LDO bf16: no barrier in between);
+//   d h      = d logits . vs from the planes (mma_p2_s3); d bs = column sums of the planes.
+// vs fragments: te_pack n16 == 4 in both orientations (TeArgs.head_split); the logits read planes 1 and 2, d h all three.
+// -------------------------------------------------------------------------------------------------
+template <int D, int NBT>
+__global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int KG = D / 16, LDH = D + 4, NBP = NBT * 32, LDO = NBP + 8, NTW = (NBT + 3) / 4, NTD = D / 32;
+  constexpr int KBG = NBP / 16, DTW = (NTD + 3) / 4, LPR = D / 4;
+  float* Ht = lds;                  // 32 x LDH
+  float* Ot = Ht + 32 * LDH;        // 32 x LDO logits; then per wave region (8 rows): [2 planes][8 rows][LDO] bf16 d logits
+  __shared__ float s_g[32], s_he[32], s_red[8];
+  __shared__ int s_a[32], s_b[32];   // target bins of the tile's rows
+  const int NB = A.n_dist + 1;
+  const int T = A.soff[A.n_seq];
+  const float* __restrict__ Hsrc = A.H;
+  const float* __restrict__ Esrc = A.E;
+  const int w = wave_id(), tid = threadIdx.x;
+  if ((int)blockIdx.x * 32 >= T) return;        // (grid <= number of tiles: not taken; keeps T >= 1 below)
+  float ls0, ls1, wd;
+  {
+    const float a = A.lw[0], b = A.lw[1], m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    ls0 = ea / (ea + eb); ls1 = eb / (ea + eb); wd = A.wd[0];
+  }
+  int nto[NTW];
+  float bsv[NTW];                   // bias of this lane's bins (-inf for the padding bins): loop-invariant
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    nto[j] = min(w + 4 * j, NBT - 1);
+    const int bin = nto[j] * 32 + (tid & 31);
+    bsv[j] = bin < NB ? A.bs[bin] : -INFINITY;
+  }
+  float dbs0 = 0.f, dbs1 = 0.f;     // thread tid < NBP / 2 accumulates d bs[2 tid], d bs[2 tid + 1]
+  float dwd_acc = 0.f;
+  // (global accesses branch-free, next tile fetched in the middle of the current one, staged at its end: see te_head)
+  constexpr int SF4 = 32 * LPR / TE_BLOCK;
+  float4 ph[SF4], pe[SF4];
+  int pab = 0;
+  auto prefetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
+      const size_t gr = (size_t)min(r0 + r, T - 1);
+      ph[q] = *reinterpret_cast<const float4*>(Hsrc + gr * D + c);
+      pe[q] = *reinterpret_cast<const float4*>(Esrc + gr * D + c);
+    }
+    pab = A.row_ab[min(r0 + (tid & 31), T - 1)];
+  };
+  auto stage = [&](int tid) {
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) {
+      const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
+      *reinterpret_cast<float4*>(Ht + r * LDH + c) = make_float4(ph[q].x, ph[q].y, ph[q].z, ph[q].w);
+      float d = (ph[q].x * pe[q].x + ph[q].y * pe[q].y) + (ph[q].z * pe[q].z + ph[q].w * pe[q].w);
+      d += dpp_f<0xB1>(d); d += dpp_f<0x4E>(d); d += dpp_f<0x141>(d); d += dpp_f<0x140>(d);
+#pragma unroll
+      for (int o = 16; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
+      if ((tid % LPR) == 0) s_he[r] = d;
+    }
+    if (tid < 32) { s_a[tid] = pab & 0xffff; s_b[tid] = pab >> 16; }
+  };
+  prefetch(blockIdx.x * 32);
+  stage(tid);
+  for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
+    int tl = tid;                   // (a per-iteration copy the compiler cannot hoist address arithmetic out of: see te_head)
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, li = tl & 31;
+    lds_barrier();        // staged tile visible; every wave is done with the planes (d h MFMAs of the previous tile)
+    {   // logits
+      f32x16 acc[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      mma_f32a_s2<NTW, KG>(acc, Ht, LDH, A.pVsT, nto);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        if (w + 4 * j >= NBT) continue;
+        const int bin = nto[j] * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ot[c_row(r, lane) * LDO + bin] = acc[j][r] + bsv[j];
+      }
+    }
+    lds_barrier();
+    prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
+    {   // row-wise softmax, losses, d logits: 8 lanes per row, the row's logits in registers
+      const int row = tl >> 3, sub = tl & 7, gr = r0 + row;
+      const float* o = Ot + row * LDO + 4 * sub;
+      float v[NBT][4];
+#pragma unroll
+      for (int i = 0; i < NBT; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(o + 32 * i);
+        v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NBT; ++i) mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+      mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx));
+      const int a = s_a[row], b = s_b[row];
+      float sum = 0.f, cum = 0.f, ea = 0.f, eb = 0.f;
+#pragma unroll
+      for (int i = 0; i < NBT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = 32 * i + 4 * sub + e;
+          const float x = __expf(v[i][e] - mx);      // (a padding bin's logit is -inf: 0)
+          v[i][e] = x; sum += x; cum += k <= a ? x : 0.f; ea += k == a ? x : 0.f; eb += k == b ? x : 0.f;
+        }
+      sum += dpp_f<0xB1>(sum); sum += dpp_f<0x4E>(sum); sum += dpp_f<0x141>(sum);
+      cum += dpp_f<0xB1>(cum); cum += dpp_f<0x4E>(cum); cum += dpp_f<0x141>(cum);
+      ea += dpp_f<0xB1>(ea); ea += dpp_f<0x4E>(ea); ea += dpp_f<0x141>(ea);
+      eb += dpp_f<0xB1>(eb); eb += dpp_f<0x4E>(eb); eb += dpp_f<0x141>(eb);
+      const float inv = 1.0f / sum;
+      const float he = s_he[row];
+      const bool live = gr < T;
+      cum *= inv;
+      const float sa = ea * inv, sb = eb * inv;
+      const float u = he + wd * (sa - sb);
+      const float g = live ? -ls1 * sigmoidf_(-u) : 0.f;
+      const float dot = ls0 * cum - ls0 + g * wd * (sa - sb);
+      const size_t rs = (size_t)min(gr, T);      // all 8 lanes of the row store the same values; dead rows -> row T
+      A.rowloss[2 * rs] = cum - __logf(sa);
+      A.rowloss[2 * rs + 1] = fminf(u, 0.f) - __logf(1.0f + __expf(-fabsf(u)));
+      A.gcoef[rs] = g;
+      dwd_acc += sub == 0 ? g * (sa - sb) : 0.f;
+      if (sub == 0) s_g[row] = g;
+      const float gwd = g * wd, ca = gwd - ls0 / sa, invl = live ? inv : 0.f;
+      // the planes overwrite the float32 rows of THIS wave only, which all its lanes have read above
+      unsigned short* pr = reinterpret_cast<unsigned short*>(Ot + (row & ~7) * LDO) + (row & 7) * LDO + 4 * sub;
+      float* dlr = A.DL + rs * NBP + 4 * sub;
+#pragma unroll
+      for (int i = 0; i < NBT; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = 32 * i + 4 * sub + e;
+          float ds = (k <= a ? ls0 : 0.f);
+          ds = k == a ? ds + ca : ds;
+          ds = k == b ? ds - gwd : ds;
+          v[i][e] = (v[i][e] * invl) * (ds - dot);
+        }
+        *reinterpret_cast<float4*>(dlr + 32 * i) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        uint2 p1, p2;
+        wg_split2r(v[i][0], v[i][1], p1.x, p2.x); wg_split2r(v[i][2], v[i][3], p1.y, p2.y);
+        *reinterpret_cast<uint2*>(pr + 32 * i) = p1;
+        *reinterpret_cast<uint2*>(pr + 8 * LDO + 32 * i) = p2;
+      }
+    }
+    lds_barrier();
+    {
+      // g * E of this lane's DH elements: issued now, consumed after the MFMAs
+      int ntd[DTW];
+#pragma unroll
+      for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
+      float ge[DTW][16];
+#pragma unroll
+      for (int j = 0; j < DTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ge[j][r] = Esrc[(size_t)min(r0 + c_row(r, lane), T - 1) * D + ntd[j] * 32 + li];
+      if (tl < NBP / 2) {      // d bs partials: column sums of the two planes (their sum is the float32 value to 2^-18), two bins per thread
+        const unsigned* q = reinterpret_cast<const unsigned*>(Ot) + tl;      // (a plane row is LDO / 2 dwords)
+        float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const unsigned u1 = q[(g * 8 * LDO * 2 + r * LDO) / 2], u2 = q[(g * 8 * LDO * 2 + (8 + r) * LDO) / 2];
+            s0 += __uint_as_float(u1 << 16); s1 += __uint_as_float(u1 & 0xFFFF0000u);
+            t0 += __uint_as_float(u2 << 16); t1 += __uint_as_float(u2 & 0xFFFF0000u);
+          }
+        dbs0 += s0 + t0; dbs1 += s1 + t1;
+      }
+      f32x16 acc[DTW];
+#pragma unroll
+      for (int j = 0; j < DTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      const unsigned short* arow = reinterpret_cast<const unsigned short*>(Ot + (li & ~7) * LDO) + (li & 7) * LDO + 8 * (lane >> 5);
+      mma_p2_s3<DTW, KBG>(acc, arow, 8 * LDO, A.pVs, ntd);
+#pragma unroll
+      for (int j = 0; j < DTW; ++j) {
+        if (w + 4 * j >= NTD) continue;
+        const int col = ntd[j] * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = c_row(r, lane);
+          A.DH[(size_t)min(r0 + i, T) * D + col] = acc[j][r] + s_g[i] * ge[j][r];
+        }
+      }
+    }
+    stage(tl);            // Ht / s_he / s_a / s_b were last read before the previous barrier
+  }
+  {
+    float* hs = A.hslab + (size_t)blockIdx.x * A.hstride;
+    if (tid < NBP / 2) {
+      if (2 * tid < NB) hs[2 * tid] += dbs0;
+      if (2 * tid + 1 < NB) hs[2 * tid + 1] += dbs1;
+    }
+    const float dw = block_sum(dwd_acc, s_red);
+    if (tid == 0) hs[NB] += dw;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // te_head_big: the same head for MORE THAN 256 distance bins (the reference's dd = 25 m configuration has 1520,
 // public/GRU_Spatial.py:247): a 32 x (n_dist + 1) logits tile no longer fits LDS, so the bins go through it in chunks of 256 -
 //   pass A  logits chunk -> LDS -> per-lane running (max, sum of exp, sum of exp over bins <= a) + the two target logits:
@@ -2490,17 +2806,6 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 1 : 2)) void te_head_big3_ker
 // the six partial products down to 2^-16 on v_mfma_f32_32x32x16_bf16 (exact products, float32 accumulation; dropped terms <= 2^-25 |x y|,
 // random signs - the rule of the recurrent kernels): 12 MFMAs of 8 passes per 32 k-rows and output block against 16 of 16 passes.
 // Measured at the Gowalla launch: 385 us (float32 MFMAs) -> 285 us (planes cut by every wave that reads a value) -> see DESIGN.md.
-// x0, x1 (k and k + 1 of one column) -> one packed dword per plane (low half = k)
-__device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 xv = {x0, x1};
-  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, bf16x2));
-  const float r0 = x0 - __uint_as_float(p1 << 16), r1 = x1 - __uint_as_float(p1 & 0xFFFF0000u);
-  p2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);      // {r1.hi16, r0.hi16}
-  const float s0 = r0 - __uint_as_float(p2 << 16), s1 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
-  p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-}
 #ifndef WG_OCC
 #define WG_OCC 2
 #endif
@@ -3033,8 +3338,24 @@ static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_
   return hipGetLastError();
 }
 
+template <int D, int NBT>
+static hipError_t te_launch_head3(const TeArgs& A, int grid, hipStream_t st) {
+  const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (NBT * 32 + 8));
+  hipLaunchKernelGGL((te_head3_kernel<D, NBT>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
+  return hipGetLastError();
+}
+
 template <int D>
 static hipError_t te_head_dispatch(const TeArgs& A, int mode, int grid, hipStream_t st) {
+  if (A.n_dist + 1 <= 256 && A.head_split && mode == 0) {      // training head on split products (te_head3)
+    switch (nbt_for(A.n_dist + 1)) {
+      case 1: return te_launch_head3<D, 1>(A, grid, st);
+      case 2: return te_launch_head3<D, 2>(A, grid, st);
+      case 4: return te_launch_head3<D, 4>(A, grid, st);
+      case 7: return te_launch_head3<D, 7>(A, grid, st);
+      default: return te_launch_head3<D, 8>(A, grid, st);
+    }
+  }
   if (A.n_dist + 1 > 256 && A.head_split) {      // chunked head on split products
     const size_t lds = sizeof(short) * 3 * 32 * (D + 8) + sizeof(short) * 3 * 32 * (256 + 8);
     if (mode) hipLaunchKernelGGL((te_head_big3_kernel<D, 1>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
@@ -3428,6 +3749,8 @@ static hipError_t te_optin_lds() {
   optin(reinterpret_cast<const void*>(&te_head_big3_kernel<128, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<128, 1>));
   optin(reinterpret_cast<const void*>(&te_head_big3_kernel<256, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<256, 1>));
   optin(reinterpret_cast<const void*>(&te_head_big3_kernel<64, 0>)); optin(reinterpret_cast<const void*>(&te_head_big3_kernel<64, 1>));
+  // heads of dim 256 with 8 bin tiles: 67 KB
+  optin(reinterpret_cast<const void*>(&te_head3_kernel<256, 8>)); optin(reinterpret_cast<const void*>(&te_head_kernel<256, 8, 0>)); optin(reinterpret_cast<const void*>(&te_head_kernel<256, 8, 1>));
   // forward table on split products: three 24 KB ring slots
   optin(reinterpret_cast<const void*>(&te_ptab_s3_kernel<128, false>)); optin(reinterpret_cast<const void*>(&te_ptab_s3_kernel<128, true>));
   done = e == hipSuccess;
