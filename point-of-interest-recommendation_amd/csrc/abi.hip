@@ -38,6 +38,7 @@ struct poi_ctx {
   int carnn_fast = 1;       // POI_CARNN_FAST=0: the per-sequence kernel with float atomics on the interval matrices (A/B)
   hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
+  DevBuf xc;                // exact forward over the step-input POIs only: rank tables + per-step table rows (TeArgs.xcomp)
   DevBuf pmark;             // per-POI regrouping: per lt row, S row + 1 of a step-input POI of this launch (te_passign; all-zero between launches)
   int ppoi = 1;             // POI_TE_PPOI=0 disables the regrouping (A/B)
   int early_bins = 1;       // distance-bin chain of the write-back starts next to te_gemm_dx on the side stream; POI_TE_EARLY_BINS=0: at the tail (A/B)
@@ -51,6 +52,7 @@ struct poi_ctx {
   int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
   int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores + float64 gates) for dims 64 / 128; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
+  int xcomp = 1;            // exact forward table over the step-input POIs only; POI_TE_XCOMP=0: every row of the POI table (A/B)
   int head3 = 1;            // training head on split products for <= 256 bins (te_head3); POI_TE_HEAD3
   int xrec1_max = 512;      // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
   DevBuf xw, xg;            // its digit fragments, scales and per-bin table | per-step pre-activations or the forward table (float64)
@@ -150,6 +152,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_XFWD")) c->xfwd = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_XREC1")) c->xrec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_HEAD3")) c->head3 = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_XCOMP")) c->xcomp = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_ONE")) c->one_path = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_BINTAB_MIN")) c->bintab_min = atoi(e);
@@ -181,7 +184,7 @@ static void drop_graphs(poi_ctx* c) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota, &c->xw, &c->xg,
+  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->xc, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota, &c->xw, &c->xg,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
                    &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag, &c->pre_idx, &c->pre_sc, &c->users_pk16, &c->ubound, &c->ugeo};
   (void)hipDeviceSynchronize();
@@ -292,6 +295,14 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.xWhS = xd; A.xUiS = xd + 3 * D; A.ztabx = xd + 6 * D;
     if (A.xft) A.ptabx = (double*)c->xg.p; else A.gx = (double*)c->xg.p;
     A.x_rows_est = (int)(Tcap < (size_t)1 << 30 ? Tcap : (size_t)1 << 30);
+    // the forward table over the launch's step-input POIs only (te_slots marks them for the per-POI regrouping)
+    A.xcomp = (A.xft && A.ppoi && c->xcomp && P->n_item + 1 <= (1 << 22)) ? 1 : 0;
+    if (A.xcomp) {
+      const size_t nr = ((size_t)P->n_item + 2 + 3) & ~(size_t)3;
+      if ((rc = ensure(c, c->xc, sizeof(int) * (2 * nr + 256 + 8 + Tcap), st))) return rc;
+      int* xi = (int*)c->xc.p;
+      A.xidx = xi; A.xlist = xi + nr; A.xblk = xi + 2 * nr; A.xcnt = xi + 2 * nr + 256; A.row_pc = xi + 2 * nr + 256 + 8;
+    }
   }
   float* f = (float*)c->te_ws.p;
   auto take = [&](size_t cnt) { float* r = f; f += (cnt + 3) & ~(size_t)3; return r; };
@@ -495,14 +506,14 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       add(sc, sizeof sc);
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
-      const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
+      const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->xc.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
                             c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, c->xw.p, c->xg.p};
       add(bufs, sizeof bufs);
       // every switch that decides which kernels / which stream topology the launch takes, each in its own word (packed into one
       // word they overlapped and early_min was missing), plus what te_setup derived from them for THIS launch
       const uint64_t sw[] = {(uint64_t)c->fwd_tab, (uint64_t)c->rec_split, (uint64_t)c->one_path, (uint64_t)(unsigned)c->rec1_max, (uint64_t)(unsigned)c->bintab_min,
                              (uint64_t)c->early_bins, (uint64_t)(unsigned)c->early_min, (uint64_t)c->xfwd, (uint64_t)E.early_bins, (uint64_t)E.bintab, (uint64_t)E.rec1,
-                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one};
+                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.xcomp, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one};
       add(sw, sizeof sw);
     }
     poi_ctx::StepGraph* g = nullptr;

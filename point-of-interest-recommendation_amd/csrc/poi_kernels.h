@@ -183,6 +183,7 @@ struct TeArgs {
   unsigned sr_salt;                   // != 0: a half POI table is written back with stochastic rounding (poi_ctx_set_f16_rounding), salt of this launch
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
   // exact forward (te_xfwd.hip): input product + forward recurrence in ~40-bit fixed point on the int8 matrix cores, float64 gate math
+  int xcomp; int *xidx, *xlist, *xblk, *xcnt, *row_pc;      // exact forward table over the launch's step-input POIs only (te_xcount / te_xassign): lt row -> table row, table row -> lt row, per-block counts, row count, per-step table row
   int xrec1;                          // the recurrence of every sequence in its own workgroup on the float64 vector ALUs (te_rec_fwd1x): small launches
   int xfwd, xft;                      // on; pre-activations from the forward table ptabx[p_t] + ztabx[dp_t] (else gx[row])
   double *gx, *ptabx, *ztabx;         // (T + spare) x 3D per step | (n_item + 1 + spare) x 3D | (n_dist + 1) x 3D, gate-major columns (g D + unit)

@@ -479,7 +479,8 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
     // kept: touching the lines of the row of step t + 3 - one dword per 128-byte line, at the top or at the very end of a step - to bring
     // them to L2 two steps early: 412 -> 444 .. 481 us per 12500-user launch; vmcnt retires in order, a far prefetch sits in every wait.)
     int rp = 0, rz = 0;
-    auto ids = [&](int t) { const int rr = t < nsr ? rowb + t : Tsp; rp = A.row_p[rr]; rz = A.spatial ? A.row_dp[rr] : 0; };
+    const int* __restrict__ xrow = A.xcomp ? A.row_pc : A.row_p;      // (compact table: te_gather translated the ids)
+    auto ids = [&](int t) { const int rr = t < nsr ? rowb + t : Tsp; rp = xrow[rr]; rz = A.spatial ? A.row_dp[rr] : 0; };
     auto rows = [&](XG12& pp, XG12& zz) {
       const int p1 = (int)min((unsigned)rp, (unsigned)A.n_item), z1 = A.spatial ? (int)min((unsigned)rz, (unsigned)A.n_dist) : 0;
       load3(pp, A.ptabx + (size_t)p1 * 3 * D);
@@ -663,7 +664,8 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     XGemmArgs P;
     P.tab = A.lt; P.f16 = A.lt_f16; P.idx_max = A.n_item; P.B8 = A.xUi8; P.Bs = A.xUiS; P.z_max = A.spatial ? A.n_dist : 0;
     int rows_est;
-    if (A.xft) { P.idx = nullptr; P.n_ptr = A.iota + A.n_item + 1; P.ztabx = nullptr; P.zidx = nullptr; P.C = A.ptabx; rows_est = A.n_item + 1; }
+    if (A.xft && A.xcomp) { P.idx = A.xlist; P.n_ptr = A.xcnt; P.ztabx = nullptr; P.zidx = nullptr; P.C = A.ptabx; rows_est = min(A.n_item + 1, A.x_rows_est * 2 / 5 + 1); }
+    else if (A.xft) { P.idx = nullptr; P.n_ptr = A.iota + A.n_item + 1; P.ztabx = nullptr; P.zidx = nullptr; P.C = A.ptabx; rows_est = A.n_item + 1; }
     else { P.idx = A.row_p; P.n_ptr = A.soff + n; P.ztabx = A.ztabx; P.zidx = A.spatial ? A.row_dp : nullptr; P.C = A.gx; rows_est = A.x_rows_est; }
     // few row tiles: split the column tiles of a row tile over several workgroups (the slicing of the rows is repeated, it is cheap)
     // (per-step rows: the host only knows the launch's step CAPACITY; sequences average ~40 % of the longest)

@@ -629,6 +629,51 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
   }
 }
 
+// Exact forward table over the launch's step-input POIs only (TeArgs.xcomp): the rows te_slots marked (pmark) are ranked in row order -
+// xidx[lt row] = table row, xlist[table row] = lt row, xcnt = number of rows - by one scan in two small kernels (per-block counts, then
+// block prefix + ballot ranks); te_gather translates the steps' POI ids (row_pc).  45 k of the 100 k Gowalla rows per 12500-user launch:
+// te_gemmx multiplies and writes less than half of the float64 table (110 -> 55 us) and the table fits the 256 MB cache behind L2.
+#define TE_XBLK 256
+__device__ __forceinline__ int te_xper(int N) { return (((N + TE_XBLK - 1) / TE_XBLK) + 255) & ~255; }
+__global__ __launch_bounds__(256) void te_xcount_kernel(TeArgs A) {
+  __shared__ int red[4];
+  const int N = A.n_item + 1, per = te_xper(N), b0 = blockIdx.x * per;
+  int c = 0;
+  for (int i = b0 + threadIdx.x; i < min(N, b0 + per); i += 256) c += A.pmark[i] != 0 ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane_id() == 0) red[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) A.xblk[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void te_xassign_kernel(TeArgs A) {
+  __shared__ int s_w[4];
+  __shared__ int s_base;
+  const int N = A.n_item + 1, per = te_xper(N), tid = threadIdx.x, lane = lane_id(), w = wave_id(), b0 = blockIdx.x * per;
+  {
+    int v = tid < (int)blockIdx.x ? A.xblk[tid] : 0;      // (TE_XBLK == block size: one earlier block per thread)
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_w[w] = v;
+    __syncthreads();
+    if (tid == 0) s_base = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __syncthreads();
+  }
+  int base = s_base;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int i0 = b0; i0 < min(N, b0 + per); i0 += 256) {
+    const int i = i0 + tid;
+    const bool f = i < N && A.pmark[i] != 0;
+    const unsigned long long m = __ballot(f);
+    __syncthreads();
+    if (lane == 0) s_w[w] = __builtin_popcountll(m);
+    __syncthreads();
+    int wb = 0;
+    for (int j = 0; j < w; ++j) wb += s_w[j];
+    if (f) { const int idx = base + wb + __builtin_popcountll(m & below); A.xidx[i] = idx; A.xlist[idx] = i; }
+    base += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) A.xcnt[0] = base;
+}
+
 // E[r] = lt[p_{t+1}] - lt[q_{t+1}] (the BPR difference row of step t).  LPR lanes per row, float4 per lane.
 // The step's input x_t = [lt[p_t] | di[dp_t]] is NOT materialised: te_gemm_nt / te_wgrad gather those table
 // rows straight into their LDS tiles through row_p / row_dp.
@@ -643,6 +688,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A) {
     const float4 a = ld4t(A.lt, (size_t)A.p[s + 1] * D + c, A.lt_f16);
     const float4 b = ld4t(A.lt, (size_t)A.q[s + 1] * D + c, A.lt_f16);
     *reinterpret_cast<float4*>(A.E + (size_t)r * D + c) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    if (A.xcomp && c == 0) A.row_pc[r] = A.xidx[min((unsigned)A.row_p[r], (unsigned)A.n_item)];      // the step's row of the compact forward table
   }
 }
 
@@ -3600,6 +3646,10 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
+  if (A.xcomp) {      // (behind te_rowmap's marks)
+    hipLaunchKernelGGL(te_xcount_kernel, dim3(TE_XBLK), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(te_xassign_kernel, dim3(TE_XBLK), dim3(256), 0, st, A);
+  }
   if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   const int XW = A.xw;
   hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, XW);
@@ -3704,7 +3754,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   if (A.side && A.early_bins && A.bintab) {
     // the distance-bin chain of the write-back needs nothing the main stream still has to produce: it starts here, next to te_gemm_dx
     // (350 tiles on 512 workgroup slots), instead of at the fork in launch_te_scatter, which joins on ev_slots (ev_bwd / ev_slots: both
-    // streams passed them long ago)
+    // streams passed them long ago).  (Round 4, te_wgrad on split products: started right behind te_rec_bwd instead, the chain costs te_wgrad
+    // +105 us and te_psum +16 for -73 us of te_tail: 1870 -> 1855 us per launch, inside the noise between boxes - left here.)
     if (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_bwd, 0) != hipSuccess) return hipGetLastError();
     hipError_t be = launch_te_bins(A, A.bin_alpha, A.bin_lambda, num_cu, A.side, tm);
     if (be != hipSuccess) return be;

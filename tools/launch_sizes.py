@@ -11,6 +11,7 @@ import bench
 
 sizes = [int(x) for x in sys.argv[1:]] or [1, 16, 64, 256, 1024, 1580, 4096, 12500]
 n_item, n_user, max_len, D = pdata.SHAPES["gowalla"]
+n_item = int(os.environ.get("LS_NITEM", n_item))      # (experiments: a smaller POI table under the same steps)
 DD = float(os.environ.get("LS_DD", "200"))        # LS_DD=25 LS_UD=38: the reference's 1520-bin configuration
 ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=0.8, dd=DD, ud_km=float(os.environ.get("LS_UD", "40")))
 tab = ds.shard(0, n_user)
