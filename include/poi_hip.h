@@ -44,7 +44,8 @@ extern "C" {
 /* 3 (round 4): poi_sync_buffer no longer carries the deltas of POI_F16 segments - they travel in poi_sync_buffer16, and poi_sync_apply
  * refuses to combine half segments whose buffer the caller never asked for; new entry points since 2: poi_sync_buffer16,
  * poi_ctx_set_split_products / _small_launch / _one_sequence_path / _regroup_min / _f16_rounding / _topk_filter(_stats), poi_ctx_set_exact_forward. */
-#define POI_ABI_VERSION 3
+/* 4 (round 4): new entry point poi_ctx_set_option. */
+#define POI_ABI_VERSION 4
 
 enum {
   POI_OK = 0,
@@ -146,6 +147,15 @@ int poi_ctx_set_split_products(poi_ctx* ctx, int on);
  * user per step, prog_bpr_gru_spatial.py:249-250 - takes this form), larger ones in 16-sequence tiles on the int8 matrix cores
  * (te_rec_fwdx: 3.6 us per step and tile).  Environment overrides at context creation: POI_TE_XFWD=0|1, POI_TE_XREC1=<per_sequence_max>. */
 int poi_ctx_set_exact_forward(poi_ctx* ctx, int on, int per_sequence_max);
+/* Named tuning switches of the tile engine - every setting computes the same update to the stated tolerances; they exist for A/B
+ * measurements and for the tests that hold the alternative kernels to the oracle.  POI_EINVAL for an unknown name or a value out of range.
+ *   "forward_table_compact" 0|1 (default 1): the exact forward pass forms its float64 input table over the POIs that are step inputs
+ *       of the launch only (ranked on the device) instead of over every row of the POI table - bitwise the same update;
+ *   "forward_table_compact_min" n (default 1536): ... for launches of at least n sequences;
+ *   "head_split" 0|1 (default 1): the training head (public/GRU_Spatial.py:180-200, <= 256 bins) on bf16 split products (te_head3)
+ *       instead of float32-input matrix instructions;
+ *   "early_bins" 0|1 (default 1): the distance-bin rows' write-back chain starts next to the d x product instead of at the tail. */
+int poi_ctx_set_option(poi_ctx* ctx, const char* name, int value);
 /* Small launches: launches of at most max_sequences sequences (default 1024; 0 disables; dim 64 / 128) run the recurrence of every
  * sequence in its own workgroup on the vector ALUs (te_rec_fwd1 / bwd1, weights resident in registers) instead of 16-sequence MFMA
  * tiles - a tile step costs the same whether it holds 16 sequences or one, so the reference schedule (one user per step,

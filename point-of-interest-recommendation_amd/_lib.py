@@ -6,7 +6,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpoi_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 BPR_SNAPSHOT, BPR_HOGWILD = 0, 1
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "poi_ctx_set_f16_rounding": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
     "poi_ctx_set_split_products": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_exact_forward": (c_int, [c_void_p, c_int, c_int]),
+    "poi_ctx_set_option": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
     "poi_ctx_set_small_launch": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_one_sequence_path": (c_int, [c_void_p, c_int]),
     "poi_ctx_set_regroup_min": (c_int, [c_void_p, c_int]),
@@ -210,6 +211,11 @@ class Context:
         """Training launches run the forward pass in fixed point on the int8 matrix cores + float64 gates (poi_ctx_set_exact_forward, default
         on); per_sequence_max: launches of at most this many sequences use the per-sequence float64 kernel (default 512; -1 keeps it)."""
         self.check(self.lib.poi_ctx_set_exact_forward(self.handle, 1 if on else 0, int(per_sequence_max)))
+
+    def set_option(self, name, value):
+        """Named tuning switch of the tile engine (poi_ctx_set_option: "forward_table_compact", "forward_table_compact_min", "head_split",
+        "early_bins")."""
+        self.check(self.lib.poi_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def set_small_launch(self, max_sequences=1024):
         """Launches of at most this many sequences use the per-sequence recurrent kernels (poi_ctx_set_small_launch; 0 disables)."""

@@ -53,6 +53,7 @@ struct poi_ctx {
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
   int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores + float64 gates) for dims 64 / 128; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
   int xcomp = 1;            // exact forward table over the step-input POIs only; POI_TE_XCOMP=0: every row of the POI table (A/B)
+  int xcomp_min = 1536;     // ... for launches of at least this many sequences (below: one row per step - the table form of te_rec_fwdx costs 0.6 us more per step of the latency chain than the ranking saves in te_gemmx; 1300 / 1563 / 2048 / 3125 users: +9 / -6 / -38 / -45 us); POI_TE_XCOMP_MIN
   int head3 = 1;            // training head on split products for <= 256 bins (te_head3); POI_TE_HEAD3
   int xrec1_max = 512;      // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
   DevBuf xw, xg;            // its digit fragments, scales and per-bin table | per-step pre-activations or the forward table (float64)
@@ -153,6 +154,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_XREC1")) c->xrec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_HEAD3")) c->head3 = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_XCOMP")) c->xcomp = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_XCOMP_MIN")) c->xcomp_min = atoi(e);
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_ONE")) c->one_path = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_BINTAB_MIN")) c->bintab_min = atoi(e);
@@ -273,7 +275,9 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const bool want_ft = c->fwd_tab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap;
   A.fwd_tab = (!A.xfwd && want_ft && A.bintab && !A.rec1) ? 1 : 0;      // (the per-sequence kernels read G)
   A.xrec1 = (A.xfwd && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
-  A.xft = (A.xfwd && want_ft && !A.xrec1 && n > 1) ? 1 : 0;      // (n == 1: the one-sequence path writes gx itself, te_one_in)
+  // (the table over the launch's step-input POIs only - te_slots marks them for the per-POI regrouping - never has more rows than the launch has steps)
+  const bool want_xc = c->xcomp && A.ppoi && P->n_item + 1 <= (1 << 22) && n >= c->xcomp_min;
+  A.xft = (A.xfwd && (want_ft || want_xc) && !A.xrec1 && n > 1) ? 1 : 0;      // (n == 1: the one-sequence path writes gx itself, te_one_in)
   if (A.fwd_tab || A.xft) {
     if ((rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
     if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }
@@ -287,7 +291,8 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (A.xfwd) {
     const size_t frag = (size_t)3 * D * D * 5, nz = (size_t)(spatial ? n_dist + 1 : 1) * 3 * D;      // five int8 digit planes per weight
     if ((rc = ensure(c, c->xw, 2 * frag + 64 + sizeof(double) * (6 * (size_t)D + nz + 8), st))) return rc;
-    const size_t xrows = A.xft ? (size_t)P->n_item + 1 + 2 : Tcap;
+    A.xcomp = (A.xft && want_xc) ? 1 : 0;
+    const size_t xrows = A.xcomp ? std::min((size_t)P->n_item + 1, Tcap) + 2 : A.xft ? (size_t)P->n_item + 1 + 2 : Tcap;
     if ((rc = ensure(c, c->xg, sizeof(double) * xrows * 3 * D, st))) return rc;
     char* xp = (char*)c->xw.p;
     A.xWh8 = (uint4*)xp; A.xUi8 = (uint4*)(xp + ((frag + 15) & ~(size_t)15));
@@ -295,8 +300,6 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.xWhS = xd; A.xUiS = xd + 3 * D; A.ztabx = xd + 6 * D;
     if (A.xft) A.ptabx = (double*)c->xg.p; else A.gx = (double*)c->xg.p;
     A.x_rows_est = (int)(Tcap < (size_t)1 << 30 ? Tcap : (size_t)1 << 30);
-    // the forward table over the launch's step-input POIs only (te_slots marks them for the per-POI regrouping)
-    A.xcomp = (A.xft && A.ppoi && c->xcomp && P->n_item + 1 <= (1 << 22)) ? 1 : 0;
     if (A.xcomp) {
       const size_t nr = ((size_t)P->n_item + 2 + 3) & ~(size_t)3;
       if ((rc = ensure(c, c->xc, sizeof(int) * (2 * nr + 256 + 8 + Tcap), st))) return rc;
@@ -513,7 +516,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       // word they overlapped and early_min was missing), plus what te_setup derived from them for THIS launch
       const uint64_t sw[] = {(uint64_t)c->fwd_tab, (uint64_t)c->rec_split, (uint64_t)c->one_path, (uint64_t)(unsigned)c->rec1_max, (uint64_t)(unsigned)c->bintab_min,
                              (uint64_t)c->early_bins, (uint64_t)(unsigned)c->early_min, (uint64_t)c->xfwd, (uint64_t)E.early_bins, (uint64_t)E.bintab, (uint64_t)E.rec1,
-                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.xcomp, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one};
+                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.xcomp, (uint64_t)(unsigned)c->xcomp_min, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one};
       add(sw, sizeof sw);
     }
     poi_ctx::StepGraph* g = nullptr;
@@ -1069,6 +1072,21 @@ int poi_ctx_set_exact_forward(poi_ctx* c, int on, int per_sequence_max) {
   if (per_sequence_max >= 0) c->xrec1_max = per_sequence_max;
   drop_graphs(c);
   return POI_OK;
+}
+
+int poi_ctx_set_option(poi_ctx* c, const char* name, int value) {
+  if (!c || !name) return fail(c, POI_EINVAL, "poi_ctx_set_option: null argument");
+  struct Opt { const char* name; int* p; int lo, hi; };
+  const Opt opts[] = {{"forward_table_compact", &c->xcomp, 0, 1}, {"forward_table_compact_min", &c->xcomp_min, 0, 1 << 30}, {"head_split", &c->head3, 0, 1},
+                      {"early_bins", &c->early_bins, 0, 1}};
+  for (const Opt& o : opts)
+    if (!strcmp(name, o.name)) {
+      if (value < o.lo || value > o.hi) return fail(c, POI_EINVAL, "poi_ctx_set_option: %s must be in [%d, %d] (got %d)", name, o.lo, o.hi, value);
+      *o.p = value;
+      drop_graphs(c);
+      return POI_OK;
+    }
+  return fail(c, POI_EINVAL, "poi_ctx_set_option: unknown option '%s'", name);
 }
 
 int poi_ctx_set_small_launch(poi_ctx* c, int max_sequences) {

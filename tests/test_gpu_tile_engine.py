@@ -675,3 +675,38 @@ def test_exact_forward_pass_is_far_inside_the_bar_and_the_switch_changes_the_ari
             assert not all(np.array_equal(res[(True, mode)][0][k], res[(False, mode)][0][k]) for k in ("wh", "ui", "lt")), "the switch did not change the arithmetic"
     finally:
         ctx.set_exact_forward(True, 512); ctx.set_one_sequence_path(True); ctx.set_engine("auto")
+
+
+def test_forward_table_over_step_input_pois_is_bitwise_invisible_and_head_switch_meets_the_oracle(pa):
+    """poi_ctx_set_option: (1) "forward_table_compact" - the exact forward pass forms its float64 input table over the launch's step-input
+    POIs only (te_xcount / te_xassign rank the rows te_slots marked, te_gather translates the ids): the same arithmetic per row, so the
+    update is BITWISE the one of the table over every row of the POI table, and both meet the oracle; (2) "head_split" - the training head
+    on bf16 split products (te_head3, 201 bins: seven bin tiles) and on float32-input matrix instructions (te_head): both within the bars,
+    different bits; (3) unknown names and values out of range are refused."""
+    T = toy_problem(4100, n_user=1800, n_item=2500, n_dist=200, dim=128, len_max=10, hot=400)
+    P = spatial_params(4101, T)
+    users = np.random.default_rng(9).permutation(1800)[:1700].astype(np.int32)
+    exp, outs = _oracle_batch(P, T, users)
+    ctx = pa._lib.context(0)
+    res = {}
+    try:
+        for name, opts in (("default", {}), ("full-table", {"forward_table_compact": 0}), ("f32-head", {"head_split": 0})):
+            model = _model(pa, T, P)
+            ctx.set_engine("tile")
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            got_out = np.asarray(model.train_batch(users))
+            assert_close(got_out[:, :3], np.array([[float(o[0]), float(o[1]), float(o[2])] for o in outs]), "losses (%s)" % name, rtol=2e-5)
+            res[name] = (_get(model), got_out)
+            assert_step_close(res[name][0], exp, P, SP_NAMES, name)
+            ctx.set_option("forward_table_compact", 1); ctx.set_option("head_split", 1)
+        assert np.array_equal(res["default"][1], res["full-table"][1])
+        for k in SP_NAMES:
+            assert np.array_equal(res["default"][0][k], res["full-table"][0][k]), "the compact forward table changed " + k
+        assert not all(np.array_equal(res["default"][0][k], res["f32-head"][0][k]) for k in ("vs", "wh", "ui")), "the head switch did not change the arithmetic"
+        with pytest.raises(pa.PoiError):
+            ctx.set_option("no_such_option", 1)
+        with pytest.raises(pa.PoiError):
+            ctx.set_option("head_split", 2)
+    finally:
+        ctx.set_option("forward_table_compact", 1); ctx.set_option("head_split", 1); ctx.set_engine("auto")
