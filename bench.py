@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PEAK_I8_TOPS = 5000.0       # MI355X_MICROARCH.md / cdna_hip_programming.md: int8 MFMA = 2 x the 2.5 PF bf16 dense peak (measured 3.9 - 4.4 POP/s)
 PROFILE_TAG = "r04"         # profiles/<tag>_pmc_traffic.json: committed rocprofv3 PMC passes of this command
 
@@ -462,12 +463,22 @@ def main():
     xfwd = D in (64, 128) and os.environ.get("POI_TE_XFWD", "1") != "0"
     if xfwd:
         fwd_tab = (os.environ.get("POI_TE_FWDTAB", "1") != "0" and 2 * (n_item + 1) <= B * max(model.max_len - 1, 1) + 192)
-    ax_rows = (n_item + 1.0) * n_launches_ if fwd_tab else steps_per_epoch
+    # ... over the launch's step-input POIs only (abi.hip: forward_table_compact, launches of >= 1536 sequences on the regrouped path): rho rows per step
+    xcomp = xfwd and bintab and B >= 1536 and os.environ.get("POI_TE_XCOMP", "1") != "0"
+    if xcomp:
+        fwd_tab = True
+    ax_rows = rho * steps_per_epoch if xcomp else (n_item + 1.0) * n_launches_ if fwd_tab else steps_per_epoch
+    # split products (default): te_rec_bwd and te_wgrad form every float32 product from six bf16 partial products, the training head (<= 256
+    # bins: te_head3) from five - priced as EXECUTED bf16 flops against the dense bf16 peak, the float32-equivalent rate beside it
+    split = os.environ.get("POI_TE_SPLIT", "1") != "0"
+    head3 = split and NB <= 256 and os.environ.get("POI_TE_HEAD3", "1") != "0"
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
             "te_gemm_ax": ("i8op", 15 * 6 * D2 * ax_rows) if xfwd else ("flop", xk * D2 * ax_rows),
             "te_rec_fwd": ("i8op", 15 * 6 * D2 * steps_per_epoch) if xfwd else ("flop", 6 * D2 * steps_per_epoch),
-            "te_head": ("flop", 4.0 * NB * D * steps_per_epoch), "te_rec_bwd": ("flop", 6 * D2 * steps_per_epoch),
-            "te_wgrad": ("flop", ((6 + xk * rho) * D2 + 2.0 * NB * D) * steps_per_epoch),     # d ui (over S rows), d wh and d vs (split-K)
+            "te_head": ("bf16x5", 5 * 4.0 * NB * D * steps_per_epoch) if head3 else ("flop", 4.0 * NB * D * steps_per_epoch),
+            "te_rec_bwd": ("bf16x6", 6 * 6 * D2 * steps_per_epoch) if split and B > 1024 else ("flop", 6 * D2 * steps_per_epoch),
+            # d ui (over S rows), d wh and d vs (split-K)
+            "te_wgrad": ("bf16x6", 6 * ((6 + xk * rho) * D2 + 2.0 * NB * D) * steps_per_epoch) if D in (64, 128, 256) else ("flop", ((6 + xk * rho) * D2 + 2.0 * NB * D) * steps_per_epoch),
             "te_gemm_dx": ("flop", xk * rho * D2 * steps_per_epoch),
             # per-POI sums of DA: one read of the 3D-wide DA rows + the S rows written
             "te_psum": ("byte", 3.0 * D * 4 * (1.0 + rho) * steps_per_epoch),
@@ -495,6 +506,10 @@ def main():
             rate = w / (per_step * 1e-3)
             if kind == "flop":
                 ent.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=rate / 1e12 / PEAK_F32_TFLOPS)
+            elif kind.startswith("bf16x"):
+                ent.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s (bf16, executed partial products)", frac=rate / 1e12 / PEAK_BF16_TFLOPS,
+                           float32_equivalent_tflops=rate / float(kind[5:]) / 1e12,
+                           note="every float32 product from %s bf16 partial products of three / two planes per operand (v_mfma_f32_*_bf16, float32 accumulation)" % kind[5:])
             elif kind == "i8op":
                 ent.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_I8_TOPS, unit="TOP/s (int8)", frac=rate / 1e12 / PEAK_I8_TOPS,
                            float64_equivalent_tflops=rate / 15.0 / 1e12,
@@ -532,7 +547,7 @@ def main():
             kernels[k]["traffic_bytes_per_launch"] = traffic[k]
     roofline = dict(kernel=dom, traffic=traffic.get(dom), traffic_source=traffic_src,
                     **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_ms")})
-    roofline["note"] = (kernels[dom].get("note") if kernels[dom].get("unit", "").startswith("TOP") else
+    roofline["note"] = (kernels[dom].get("note") if kernels[dom].get("note") and kernels[dom].get("bound") == "mfma" and kernels[dom].get("peak") != PEAK_F32_TFLOPS else
                         "f32 arithmetic on v_mfma_f32_32x32x2_f32 (f32 vector peak == f32-input MFMA peak on gfx950)")
     roofline_gs_hook = roofline
     # ---- gather / scatter against the HBM roofline: three accountings over the SAME kernel time --------------------
@@ -559,7 +574,8 @@ def main():
     roofline_gs_hook["gather_scatter"] = {"bound": "hbm", "kernels": hbm["kernels"], "ms_per_epoch": gs_ms, "frac_survey_8d": (hbm["survey_8d"] or {}).get("frac"),
                                           "frac_bytes_moved": (hbm["implementation"] or {}).get("frac"), "peak": PEAK_HBM_GBS, "unit": "GB/s"}
     total_flops = step_flops(D, NB) * steps_per_epoch
-    executed_flops = sum((w if kind == "flop" else w / 15.0) for k, (kind, w) in work.items() if kind in ("flop", "i8op") and k in kernels and k != "seq_train") or total_flops
+    executed_flops = sum((w if kind == "flop" else w / 15.0 if kind == "i8op" else w / float(kind[5:])) for k, (kind, w) in work.items()
+                         if (kind in ("flop", "i8op") or kind.startswith("bf16x")) and k in kernels and k != "seq_train") or total_flops
     train_kernel_ms = sum(kernels[k]["ms_per_step"] for k in kernels if k not in (("te_finalize", "te_dsum", "te_bin_gemm", "te_scatter") if forked else ("te_finalize", "te_tail")))
 
     solo = rank == 0 and world == 1 and not a.emulate_world
@@ -817,7 +833,7 @@ def main():
                                          "user order (64 distinct orders drawn before the timed region, cycled): prog_bpr_gru_spatial.py:221-238") if refresh else
                                         "none: one fixed order and negative table (--no-refresh)",
                        "arithmetic": ("forward pass (input product, recurrence, gates): ~40-bit fixed point on the int8 matrix cores + float64 gate math, results "
-                                      "rounded to f32 for the head / BPTT / gradient / write-back kernels, which compute in f32 (te_rec_bwd on bf16 x 3 split products)") if xfwd else
+                                      "rounded to f32 for the head / BPTT / gradient / write-back kernels, which compute in f32 (te_head3, te_rec_bwd, te_wgrad: every product from five / six bf16 partial products, f32 accumulation)") if xfwd else
                                      "f32 results throughout; the recurrent kernels of launches above the small-launch bound and the forward table "
                                      "(te_gemm_ax of large launches: te_ptab_s3) form their f32 products from three bf16 planes per operand (six MFMA "
                                      "partial products, f32 accumulate; <=5.1e-6 of the f64 oracle, same bar as the f32 MFMA path -- "
