@@ -2885,6 +2885,8 @@ __global__ __launch_bounds__(TE_BLOCK, WG_OCC) void te_wgrad_kernel(TeArgs A, in
     const int b = blockIdx.x, nu = NB_UI * n_u;
     if (b < nu) { job = b / n_u; kc = b % n_u; }
     else { job = NB_UI + (b - nu) / n_o; kc = (b - nu) % n_o; }
+    // (round 4, split products: the d wh / d vs jobs of one K-chunk placed on one XCD - block ids 8 apart - so that the four readers of the same
+    // h rows share that XCD's L2: 260 us either way.  The kernel waits on its stage chain, not on HBM bandwidth.)
     if (job >= NB_TOT) return;                       // (the grid is sized for the worst case)
   }
   const bool pp = A.ppoi && job < NB_UI;
