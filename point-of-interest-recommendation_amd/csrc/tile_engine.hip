@@ -557,7 +557,9 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
   }
 }
 
+#ifndef TE_SEQ_PER_WAVE
 #define TE_SEQ_PER_WAVE 4
+#endif
 // Sorted-scatter slots of one sequence (te_scatter.hip): 3 * (ns + 1) slots at 3 * (r0 + k):
 // [0, L) POI ids of p, [L, 2L) negatives q, [2L, 3L) distance bins dp, rest sentinels.  Returns the
 // literal occurrences of the two padding rows (their analytic multiplicity is added by the caller).
