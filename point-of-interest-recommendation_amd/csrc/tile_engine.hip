@@ -309,7 +309,9 @@ __device__ __forceinline__ void mma16s_g2(f32x4& h0, f32x4& l0, f32x4& h1, f32x4
   }
 }
 // one gate: the small products alternate between two accumulators (three chains)
-template <int KG>
+// TR: operands swapped - the weight fragments go in as the A operand (the fragment layouts of the two operands of the 16x16x32 MFMA are the
+// same), so the result is transposed: a lane then holds four consecutive output UNITS of one tile row instead of one unit of four rows
+template <int KG, bool TR = false>
 __device__ __forceinline__ void mma16s_g1(f32x4& h, f32x4& l, f32x4& l2, const unsigned short* __restrict__ ldsA, int ldh, const uint4 (&b)[KG][2],
                                           const uint4* __restrict__ c) {
   const int lane = lane_id(), ps = 16 * ldh;
@@ -319,10 +321,17 @@ __device__ __forceinline__ void mma16s_g1(f32x4& h, f32x4& l, f32x4& l2, const u
     const uint4 a1 = *reinterpret_cast<const uint4*>(arow + 32 * m), a2 = *reinterpret_cast<const uint4*>(arow + ps + 32 * m),
                 a3 = *reinterpret_cast<const uint4*>(arow + 2 * ps + 32 * m);
     const uint4 b3 = c[m * 64];
+    if constexpr (TR) {
+      h = mfma16b(b[m][0], a1, h);
+      l = mfma16b(b[m][1], a1, l); l2 = mfma16b(b[m][0], a2, l2);
+      l = mfma16b(b[m][0], a3, l); l2 = mfma16b(b[m][1], a2, l2);
+      l = mfma16b(b3, a1, l);
+    } else {
     h = mfma16b(a1, b[m][0], h);
     l = mfma16b(a1, b[m][1], l); l2 = mfma16b(a2, b[m][0], l2);
     l = mfma16b(a3, b[m][0], l); l2 = mfma16b(a2, b[m][1], l2);
     l = mfma16b(a1, b3, l);
+    }
   }
 }
 
@@ -1457,6 +1466,130 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
   if (lane < 16) {
     float* bp = A.bi_part + (size_t)tile * 3 * D;
     bp[col] = sbz; bp[D + col] = sbr; bp[2 * D + col] = sbc;
+  }
+}
+
+// te_rec_bwd16 on split products with TRANSPOSED products (round 4, as te_rec_fwdx): the weight fragments are the A operand, so a lane owns
+// FOUR CONSECUTIVE UNITS of ONE sequence instead of one unit of four sequences - every operand of a step is one 16-byte load (5 instead of 20
+// 4-byte ones), d a goes out as three 16-byte stores (12), the bf16 planes of a value quad are one 8-byte LDS write per plane (3 instead of twelve
+// 2-byte ones, which conflict two ways), one activity mask per lane.  Same products in the same order: the same d a, d h bit for bit.
+template <int D>
+__global__ __launch_bounds__(D * 4) void te_rec_bwd16t_kernel(TeArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int KG2 = D / 32, LHA = D + 8, LHB = 2 * D + 8;
+  unsigned short* Acs = reinterpret_cast<unsigned short*>(lds);      // 3 planes x 16 x LHA (bf16): d a_c
+  unsigned short* Azrs = Acs + 3 * 16 * LHA;                          // 3 planes x 16 x LHB: d a_z | d a_r
+  uint4* B3 = reinterpret_cast<uint4*>(Azrs + 3 * 16 * LHB) + (size_t)wave_id() * 3 * KG2 * 64;      // this wave's third weight planes (c | zr)
+  __shared__ int s_r0[16], s_ns[16];
+  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+  const int sq = lane & 15, u0 = 16 * w + 4 * (lane >> 4);            // this lane's sequence of the tile and its first unit
+  const int tile = blockIdx.x;
+  if (tid < 16) {
+    const int k = tile * 16 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  lds_barrier();
+  int ns_max = 0;
+  for (int i = 0; i < 16; ++i) ns_max = max(ns_max, s_ns[i]);
+  const int rowb = s_r0[sq], nsr = s_ns[sq];
+  uint4 bcb[KG2][2], bzrb[2 * KG2][2];
+  const uint4 *cc3 = B3 + lane, *czr3 = B3 + KG2 * 64 + lane;
+  load_bfrag3<KG2>(bcb, B3, A.pWhc16, w);
+  load_bfrag3<2 * KG2>(bzrb, B3 + KG2 * 64, A.pWhzr16, w);
+  float dhn[4], sbz[4], sbr[4], sbc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { dhn[r] = 0.f; sbz[r] = 0.f; sbr[r] = 0.f; sbc[r] = 0.f; }
+  // two steps of operand prefetch in two register sets that alternate by step parity (see te_rec_bwd16)
+  struct Ops { float4 z, r, c, h, d; };
+  float fz[4], fr[4], fc[4], fh[4], fd[4];       // masked operands of the current step
+  const int Tsp = A.soff[A.n_seq];               // unconditional accesses: inactive lanes use the spare packed row
+  auto fetch = [&](int t, Ops& X) {
+    const bool on = t >= 0 && t < nsr;
+    const size_t row = (size_t)(on ? rowb + t : Tsp);
+    const float* g = A.G + row * 3 * D + u0;
+    X.z = *reinterpret_cast<const float4*>(g); X.r = *reinterpret_cast<const float4*>(g + D); X.c = *reinterpret_cast<const float4*>(g + 2 * D);
+    X.h = *reinterpret_cast<const float4*>(A.H + (on && t > 0 ? row - 1 : (size_t)Tsp) * D + u0);
+    X.d = *reinterpret_cast<const float4*>(A.DH + row * D + u0);
+  };
+  auto take = [&](Ops& X, int t) {               // operands of step t <- a landed register set (the spare row holds arbitrary bits: select)
+    asm volatile("" : "+v"(X.z.x), "+v"(X.z.y), "+v"(X.z.z), "+v"(X.z.w), "+v"(X.r.x), "+v"(X.r.y), "+v"(X.r.z), "+v"(X.r.w), "+v"(X.c.x), "+v"(X.c.y), "+v"(X.c.z), "+v"(X.c.w));
+    asm volatile("" : "+v"(X.h.x), "+v"(X.h.y), "+v"(X.h.z), "+v"(X.h.w), "+v"(X.d.x), "+v"(X.d.y), "+v"(X.d.z), "+v"(X.d.w));
+    const bool on = t >= 0 && t < nsr, onh = on && t > 0;
+    fz[0] = on ? X.z.x : 0.f; fz[1] = on ? X.z.y : 0.f; fz[2] = on ? X.z.z : 0.f; fz[3] = on ? X.z.w : 0.f;
+    fr[0] = on ? X.r.x : 0.f; fr[1] = on ? X.r.y : 0.f; fr[2] = on ? X.r.z : 0.f; fr[3] = on ? X.r.w : 0.f;
+    fc[0] = on ? X.c.x : 0.f; fc[1] = on ? X.c.y : 0.f; fc[2] = on ? X.c.z : 0.f; fc[3] = on ? X.c.w : 0.f;
+    fh[0] = onh ? X.h.x : 0.f; fh[1] = onh ? X.h.y : 0.f; fh[2] = onh ? X.h.z : 0.f; fh[3] = onh ? X.h.w : 0.f;
+    fd[0] = on ? X.d.x : 0.f; fd[1] = on ? X.d.y : 0.f; fd[2] = on ? X.d.z : 0.f; fd[3] = on ? X.d.w : 0.f;
+  };
+  // four consecutive values -> their three planes at LDS element `at`: one 8-byte write per plane (wg_split2 == split3 on a pair)
+  auto store4 = [&](unsigned short* at, int ps, const float (&v)[4]) {
+    uint2 p1, p2, p3;
+    wg_split2(v[0], v[1], p1.x, p2.x, p3.x); wg_split2(v[2], v[3], p1.y, p2.y, p3.y);
+    *reinterpret_cast<uint2*>(at) = p1; *reinterpret_cast<uint2*>(at + ps) = p2; *reinterpret_cast<uint2*>(at + 2 * ps) = p3;
+  };
+  auto compute = [&](int t) {
+    const bool on = t < nsr;
+    float dz[4], dhp[4], dacv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dh = on ? dhn[r] + fd[r] : 0.f;
+      dz[r] = dh * (fc[r] - fh[r]);
+      dhp[r] = dh * (1.0f - fz[r]);
+      dacv[r] = dh * fz[r] * (1.0f - fc[r] * fc[r]);
+    }
+    store4(Acs + sq * LHA + u0, 16 * LHA, dacv);
+    lds_barrier();
+    f32x4 m = {0.f, 0.f, 0.f, 0.f}, ml = {0.f, 0.f, 0.f, 0.f}, ml2 = {0.f, 0.f, 0.f, 0.f};
+    mma16s_g1<KG2, true>(m, ml, ml2, Acs, LHA, bcb, cc3);
+    m += ml + ml2;
+    float daz[4], dar[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mv = m[r];
+      const float dr = mv * fh[r];
+      dhp[r] += mv * fr[r];
+      daz[r] = dz[r] * fz[r] * (1.0f - fz[r]);
+      dar[r] = dr * fr[r] * (1.0f - fr[r]);
+      sbz[r] += daz[r]; sbr[r] += dar[r]; sbc[r] += dacv[r];        // zero for inactive steps (dh == 0)
+    }
+    store4(Azrs + sq * LHB + u0, 16 * LHB, daz);
+    store4(Azrs + sq * LHB + D + u0, 16 * LHB, dar);
+    {
+      float* g = A.G + (size_t)(on ? rowb + t : Tsp) * 3 * D + u0;
+      *reinterpret_cast<float4*>(g) = make_float4(daz[0], daz[1], daz[2], daz[3]);
+      *reinterpret_cast<float4*>(g + D) = make_float4(dar[0], dar[1], dar[2], dar[3]);
+      *reinterpret_cast<float4*>(g + 2 * D) = make_float4(dacv[0], dacv[1], dacv[2], dacv[3]);
+    }
+    lds_barrier();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f}, al2 = {0.f, 0.f, 0.f, 0.f};
+    mma16s_g1<2 * KG2, true>(acc, al, al2, Azrs, LHB, bzrb, czr3);
+    acc += al + al2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dhn[r] = on ? dhp[r] + acc[r] : 0.f;
+    // (no barrier here: see te_rec_bwd16)
+  };
+  Ops B0, B1;
+  int t = ns_max - 1;
+  fetch(t, B0); take(B0, t);
+  fetch(t - 1, B1);
+  for (; t >= 1; t -= 2) {
+    fetch(t - 2, B0); compute(t); take(B1, t - 1);
+    fetch(t - 3, B1); compute(t - 1); take(B0, t - 2);
+  }
+  if (t == 0) compute(0);
+  // d bi partial sums of this tile: the sixteen lanes of a group hold the sequences of the same four units; written per tile and summed in
+  // tile order by te_parts_kernel (no float atomics: reproducible)
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { sbz[r] += __shfl_xor(sbz[r], o, 64); sbr[r] += __shfl_xor(sbr[r], o, 64); sbc[r] += __shfl_xor(sbc[r], o, 64); }
+  if (sq == 0) {
+    float* bp = A.bi_part + (size_t)tile * 3 * D + u0;
+    *reinterpret_cast<float4*>(bp) = make_float4(sbz[0], sbz[1], sbz[2], sbz[3]);
+    *reinterpret_cast<float4*>(bp + D) = make_float4(sbr[0], sbr[1], sbr[2], sbr[3]);
+    *reinterpret_cast<float4*>(bp + 2 * D) = make_float4(sbc[0], sbc[1], sbc[2], sbc[3]);
   }
 }
 
@@ -3719,7 +3852,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   if constexpr (D <= 128) {
     if (!A.rec32) {
       if (A.rec1) hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(n), dim3(4 * D), 0, st, A);
-      else if (A.rec_split) hipLaunchKernelGGL((te_rec_bwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
+      else if (A.rec_split && !(A.dbg & 128)) hipLaunchKernelGGL((te_rec_bwd16t_kernel<D>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
+      else if (A.rec_split) hipLaunchKernelGGL((te_rec_bwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);      // (POI_TE_DBG bit 128: one unit of four sequences per lane, for A/B runs)
       else hipLaunchKernelGGL((te_rec_bwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);
     }
   }
@@ -3794,7 +3928,7 @@ static hipError_t te_optin_lds() {
   auto optin = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); };
   optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, false, false, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, true, false, true>));
   optin(reinterpret_cast<const void*>(&te_rec_fwd16_kernel<128, true, true, true>));
-  optin(reinterpret_cast<const void*>(&te_rec_bwd16_kernel<128, true>));
+  optin(reinterpret_cast<const void*>(&te_rec_bwd16_kernel<128, true>)); optin(reinterpret_cast<const void*>(&te_rec_bwd16t_kernel<128>));
   // streaming kernels on split products: three bf16 planes per operand tile (101 KB forward, 147 KB backward at D = 256)
   optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, false, 8, true>)); optin(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true, 8, true>));
   optin(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<256, 8, true>));
