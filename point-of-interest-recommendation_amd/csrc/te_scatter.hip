@@ -283,11 +283,16 @@ __global__ __launch_bounds__(3 * D) void te_pfin_kernel(TeArgs A) {
   }
 }
 
-hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st) {
-  // S-row assignment: on the caller's stream, right before it is needed - next to te_head / te_wgrad (persistent grids sized to the
-  // CU count) a co-resident kernel costs them a workgroup slot (measured: te_head +30 us with these two on the side stream)
+// S-row assignment (needs the sorted slots).  With a side stream it follows the slot sort there, next to te_rec_fwd (one workgroup per CU and no
+// room for a second: two small LDS-free kernels fit beside it; next to te_head's persistent grid they cost it a workgroup slot, +30 us) -
+// 22 us off the main stream; without one, right before te_psum.
+hipError_t launch_te_passign(TeArgs& A, hipStream_t st) {
   hipLaunchKernelGGL(te_pcount_kernel, dim3(TE_PBLK), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_passign_kernel, dim3(TE_PBLK), dim3(256), 0, st, A);
+  return hipGetLastError();
+}
+hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st) {
+  if (!A.side) { hipError_t e = launch_te_passign(A, st); if (e != hipSuccess) return e; }
   if (A.dim == 128) {
     hipLaunchKernelGGL(te_psum_kernel<128>, dim3(num_cu * 8), dim3(384), 0, st, A);
     hipLaunchKernelGGL(te_pfin_kernel<128>, dim3(num_cu * 16), dim3(384), 0, st, A);
