@@ -211,7 +211,8 @@ __host__ __device__ inline int te_nbp_dev(int n_dist) {
 int te_wgrad_jobs(int D, int n_dist, bool spatial, bool bintab);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st);
-hipError_t launch_te_passign(TeArgs& A, hipStream_t st);      // S rows of the per-POI regrouping (behind the slot sort)
+hipError_t launch_te_passign(TeArgs& A, hipStream_t st);
+hipError_t launch_te_dprep(TeArgs& A, hipStream_t st);        // chunk offsets of the distance-bin chain (behind the slot sort; launch_te_bins expects them)      // S rows of the per-POI regrouping (behind the slot sort)
 int te_wgrad_ui_jobs(int D, int n_dist, bool spatial, bool bintab);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);
 hipError_t launch_te_bins(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm);      // te_scatter.hip: per-bin sums of DA -> d di, d ui[:, D:]

@@ -753,12 +753,18 @@ __global__ __launch_bounds__(4 * D) void te_dui_kernel(TeArgs A) {
 
 // The distance-bin chain: per-bin sums of DA -> the two small dense products -> the bin rows' write-back.  It needs DA (te_rec_bwd), the
 // sorted entries and the OLD ui / di, and writes only its own buffers, the di rows and the di half of slab 0's d ui.
+// (early: the chunk offsets of the bins' entry segments - te_dprep, a one-workgroup scan that needs only the sorted segments - were formed
+// behind the slot sort already: launch_te_dprep)
+hipError_t launch_te_dprep(TeArgs& A, hipStream_t st) {
+  hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(TE_DPREP_T), 0, st, A);
+  return hipGetLastError();
+}
 template <int D>
-static hipError_t te_bins_t(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm) {
+static hipError_t te_bins_t(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm, bool early = false) {
   // the per-bin reduction of DA rows is scatter traffic (te_dsum: one pass over DA at HBM speed); the two small
   // dense products that follow (S . ui[:, D:], S^T . di) are timed on their own
   tm->begin("te_dsum", sb);
-  hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(TE_DPREP_T), 0, sb, A);
+  if (!early) hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(TE_DPREP_T), 0, sb, A);
   hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, sb, A);
   tm->end(sb);
   tm->begin("te_bin_gemm", sb);
@@ -769,10 +775,10 @@ static hipError_t te_bins_t(TeArgs& A, float alpha, float lambda, int num_cu, hi
   tm->end(sb);
   return hipGetLastError();
 }
-hipError_t launch_te_bins(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm) {
-  if (A.dim == 64) return te_bins_t<64>(A, alpha, lambda, num_cu, sb, tm);
-  if (A.dim == 128) return te_bins_t<128>(A, alpha, lambda, num_cu, sb, tm);
-  if (A.dim == 256) return te_bins_t<256>(A, alpha, lambda, num_cu, sb, tm);
+hipError_t launch_te_bins(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t sb, Timing* tm) {      // (the early chain: te_dprep ran behind the sort)
+  if (A.dim == 64) return te_bins_t<64>(A, alpha, lambda, num_cu, sb, tm, true);
+  if (A.dim == 128) return te_bins_t<128>(A, alpha, lambda, num_cu, sb, tm, true);
+  if (A.dim == 256) return te_bins_t<256>(A, alpha, lambda, num_cu, sb, tm, true);
   return hipErrorInvalidValue;
 }
 

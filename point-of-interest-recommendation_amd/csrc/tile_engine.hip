@@ -3811,6 +3811,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (hipEventRecord(A.ev_slots, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_slots, 0) != hipSuccess) return hipGetLastError();
     hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
     if (A.ppoi) { se = launch_te_passign(A, A.side); if (se != hipSuccess) return se; }
+    if (A.early_bins && A.bintab) { se = launch_te_dprep(A, A.side); if (se != hipSuccess) return se; }
     if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
   }
   if (A.xfwd) {
