@@ -36,7 +36,7 @@ struct poi_ctx {
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   DevBuf g_wd, mult_wd, nseq_wd, ca_ws, ca_slab, ca_scr, ca2;      // CA-RNN (ca2: workspace of the outer-product path)
   int carnn_fast = 1;       // POI_CARNN_FAST=0: the per-sequence kernel with float atomics on the interval matrices (A/B)
-  hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
+  hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr, ev_start = nullptr, ev_pack = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
   DevBuf xc;                // exact forward over the step-input POIs only: rank tables + per-step table rows (TeArgs.xcomp)
   DevBuf pmark;             // per-POI regrouping: per lt row, S row + 1 of a step-input POI of this launch (te_passign; all-zero between launches)
@@ -170,7 +170,9 @@ int poi_ctx_create(poi_ctx** out, int device) {
         hipEventCreateWithFlags(&c->ev_slots, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_bwd, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       c->side = nullptr;                     // fall back to the inline sort
     }
@@ -194,7 +196,7 @@ int poi_ctx_destroy(poi_ctx* c) {
   c->tm.clear();
   drop_graphs(c);
   if (c->cap) (void)hipStreamDestroy(c->cap);
-  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); }
+  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); (void)hipEventDestroy(c->ev_start); (void)hipEventDestroy(c->ev_pack); }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c;
   return POI_OK;
@@ -474,7 +476,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.out = out; E.bcap = bcap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
     E.kc_dev = (E.bintab && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
-    E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin;
+    E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin; E.ev_start = c->ev_start; E.ev_pack = c->ev_pack;
     E.early_bins = (c->early_bins && E.bintab && c->side && n >= c->early_min) ? 1 : 0; E.bin_alpha = alpha; E.bin_lambda = lambda;
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)

@@ -145,6 +145,7 @@ struct TeArgs {
   int n_slab, n_head, n_kc;
   // the slot sort only feeds te_scatter (the last kernel): it runs on a side stream next to the GEMMs
   hipStream_t side; hipEvent_t ev_slots, ev_sorted;       // side == nullptr: inline on the main stream
+  hipEvent_t ev_start, ev_pack;                           // the weight packs of a launch run on the side stream next to its index preparation
   hipEvent_t ev_bwd, ev_fin;                              // te_finalize / te_parts run on the side stream next to te_wgrad / te_gemm_dx
   float *bi_part, *fin_part;           // per recurrent tile d bi partials (n_tile x 3D); per te_finalize block loss sums
   float* hslab; int hstride;          // te_head's per-workgroup d bs | d wd partials (n_head x hstride)

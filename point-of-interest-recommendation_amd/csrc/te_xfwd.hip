@@ -652,15 +652,17 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 1), dim3(256), 0, st, J);
     return hipGetLastError();
   }
-  if (phase == 0) {
-  if (!A.predict) tm->begin("te_gemm_ax", st);
-  {
+  if (phase == 0 || phase == 3 || phase == 4) {      // 3: the weight digits and the per-bin table only (no timed region: the side stream); 4: the product only
+  if (!A.predict && phase != 3) tm->begin("te_gemm_ax", st);
+  if (phase != 4) {
     XPackJobs J;
     J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
     J.j[1] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 0, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS};
     J.n = 2;
     hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 2), dim3(256), 0, st, J);
     hipLaunchKernelGGL(te_xztab_kernel, dim3(A.spatial ? A.n_dist + 1 : 1), dim3(3 * D), 0, st, A);
+  }
+  if (phase != 3) {
     XGemmArgs P;
     P.tab = A.lt; P.f16 = A.lt_f16; P.idx_max = A.n_item; P.B8 = A.xUi8; P.Bs = A.xUiS; P.z_max = A.spatial ? A.n_dist : 0;
     int rows_est;
@@ -678,7 +680,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     const int grid = min(num_cu * 2, n_tile_est * ncg > 0 ? n_tile_est * ncg : 1);
     hipLaunchKernelGGL(te_gemmx_kernel<D>, dim3(grid), dim3(256), 0, st, P);
   }
-  if (!A.predict) tm->end(st);
+  if (!A.predict && phase != 3) tm->end(st);
   return hipGetLastError();
   }
 #ifdef TE_XPROF

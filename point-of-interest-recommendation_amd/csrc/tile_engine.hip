@@ -3779,6 +3779,18 @@ template <int D>
 static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) {
   const int n = A.n_seq, tiles = (n + 31) / 32;
   PackJobs J; te_pack_jobs(A, J, true);
+  const int XW = A.xw;
+  // The weight packs (MFMA fragment orders, the exact forward's digit planes and per-bin table) depend on nothing the index preparation
+  // produces: with a side stream they run there, next to te_len .. te_gather (four to six small dependent kernels off the main stream's
+  // chain); the side stream waits for the caller's stream first - whatever wrote the parameters is ordered before the launch there.
+  const bool packs_side = A.side && A.ev_pack && !(A.dbg & 256);      // (POI_TE_DBG bit 256: inline, for A/B runs)
+  if (packs_side) {
+    if (hipEventRecord(A.ev_start, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_start, 0) != hipSuccess) return hipGetLastError();
+    if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, A.side, J);
+    hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, A.side, A.ui, A.uiT, 3 * D, XW);
+    if (A.xfwd) { hipError_t xe = launch_te_xfwd(A, num_cu, A.side, tm, 3); if (xe != hipSuccess) return xe; }
+    if (hipEventRecord(A.ev_pack, A.side) != hipSuccess) return hipGetLastError();
+  }
   tm->begin("te_prep", st);
   hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
@@ -3787,16 +3799,18 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     hipLaunchKernelGGL(te_xcount_kernel, dim3(TE_XBLK), dim3(256), 0, st, A);
     hipLaunchKernelGGL(te_xassign_kernel, dim3(TE_XBLK), dim3(256), 0, st, A);
   }
-  if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
-  const int XW = A.xw;
-  hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, XW);
+  if (!packs_side) {
+    if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
+    hipLaunchKernelGGL(te_transpose_kernel, dim3((XW + 31) / 32, (3 * D + 31) / 32), dim3(256), 0, st, A.ui, A.uiT, 3 * D, XW);
+  }
   if (!A.side) { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
   tm->end(st);
+  if (packs_side && hipStreamWaitEvent(st, A.ev_pack, 0) != hipSuccess) return hipGetLastError();
   if (A.xfwd) {      // exact forward (te_xfwd.hip): the input product in fixed point on the int8 matrix cores, float64 tables
-    hipError_t xe = launch_te_xfwd(A, num_cu, st, tm, 0);
+    hipError_t xe = launch_te_xfwd(A, num_cu, st, tm, packs_side ? 4 : 0);
     if (xe != hipSuccess) return xe;
   } else {
   tm->begin("te_gemm_ax", st);
