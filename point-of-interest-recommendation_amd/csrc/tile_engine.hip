@@ -873,9 +873,13 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_nt_kernel(NtArgs P) {
 //  * the epilogue is branch-free: columns beyond N (N % 128 != 0) go to the spare row T.
 //  * ZADD: the epilogue adds row zidx[r] of a small table instead of a bias (te_gemm_ax: the distance-bin half
 //    of the step input only takes n_dist + 1 values, so its product with ui is a table, see te_ztab_kernel).
-template <bool BIAS, bool GATHER, int K, int DG, int N, int LDB = K, int LDC = N, bool ZADD = false, bool F16 = false>
+// SP3 (round 4): split products - every staged float4 (four consecutive k of a row) is cut into three bf16 planes on its way to LDS (8 bytes per
+// plane), a lane's fragment - eight consecutive k of its row - is one 16-byte read per plane, six partial products on v_mfma_f32_32x32x16_bf16;
+// 16-k stages in the same 72 KB of LDS ([buffer][plane][row][16 + 8 pad] bf16).
+template <bool BIAS, bool GATHER, int K, int DG, int N, int LDB = K, int LDC = N, bool ZADD = false, bool F16 = false, bool SP3 = false>
 __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
-  constexpr int NCH = K / 32, ldb = LDB, ldc = LDC;       // B is N x K (row pitch LDB), C is T x N (row pitch LDC)
+  constexpr int KC = SP3 ? 16 : 32, NCH = K / KC, ldb = LDB, ldc = LDC;       // B is N x K (row pitch LDB), C is T x N (row pitch LDC)
+  constexpr int F4S = 128 * (KC / 4) / TE_BLOCK, LPK = KC / 4, LDP = KC + 8;     // float4 per thread, operand and stage; float4 per row and stage; plane row pitch (bf16)
   static_assert(K % 64 == 0 && NCH >= 4, "te_gemm_ntk: K must be a multiple of 64, >= 128");
   __shared__ __align__(16) float As[2][128][NT_LDK];
   __shared__ __align__(16) float Bs[2][128][NT_LDK];
@@ -902,33 +906,66 @@ __global__ __launch_bounds__(TE_BLOCK, 2) void te_gemm_ntk_kernel(NtArgs P) {
   int r0 = ((L / ntl) * 8 + xcd) * 128, n0 = (L % ntl) * 128, par = 0;
   const int irow = tid & 127;                                   // (both halves of the workgroup: duplicates are harmless)
   const int* __restrict__ idx0 = P.idx0; const int* __restrict__ idx1 = ONE_TAB ? P.idx0 : P.idx1;
-  float4 ra[2][4], rb[2][4];
+  float4 ra[2][F4S], rb[2][F4S];
+  unsigned short* Ap = reinterpret_cast<unsigned short*>(&As[0][0][0]);      // SP3: [buffer][plane][128][LDP]
+  unsigned short* Bp = reinterpret_cast<unsigned short*>(&Bs[0][0][0]);
+  static_assert(!SP3 || 2 * 3 * 128 * (16 + 8) * 2 <= (int)sizeof(float) * 2 * 128 * NT_LDK, "te_gemm_ntk: the planes fit the float32 tiles' LDS");
   // chunk kc of the tile at (tr0, tn0), whose gather indices are in s_idx[tp], -> register set `set`
   auto gload = [&](int set, int tr0, int tn0, int tp, int kc) {
-    const int half = (GATHER && kc * 32 >= DG) ? 1 : 0;
+    const int half = (GATHER && kc * KC >= DG) ? 1 : 0;
     const float* tab = half ? P.tab1 : P.tab0;
-    const int coff = kc * 32 - half * DG;
+    const int coff = kc * KC - half * DG;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
+    for (int s = 0; s < F4S; ++s) {
+      const int e = tid + s * TE_BLOCK, row = e / LPK, c = (e % LPK) * 4;
       if (GATHER) {
         if (F16 && !half) ra[set][s] = ld4(reinterpret_cast<const __half*>(P.tab0) + (size_t)s_idx[ONE_TAB ? tp : 0][row] * DG + coff + c);
         else ra[set][s] = *reinterpret_cast<const float4*>(tab + (size_t)s_idx[ONE_TAB ? tp : half][row] * DG + coff + c);
       }
-      else ra[set][s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(tr0 + row, T - 1) * lda + kc * 32 + c);
-      rb[set][s] = *reinterpret_cast<const float4*>(Bg + (size_t)min(tn0 + row, N - 1) * ldb + kc * 32 + c);
+      else ra[set][s] = *reinterpret_cast<const float4*>(Ag + (size_t)min(tr0 + row, T - 1) * lda + kc * KC + c);
+      rb[set][s] = *reinterpret_cast<const float4*>(Bg + (size_t)min(tn0 + row, N - 1) * ldb + kc * KC + c);
     }
   };
   auto lstore = [&](int buf, int set) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int e = tid + s * TE_BLOCK, row = e >> 3, c = (e & 7) * 4;
+    for (int s = 0; s < F4S; ++s) {
+      const int e = tid + s * TE_BLOCK, row = e / LPK, c = (e % LPK) * 4;
+      if constexpr (SP3) {
+        uint2 pa[3], pb[3];
+        wg_split2(ra[set][s].x, ra[set][s].y, pa[0].x, pa[1].x, pa[2].x); wg_split2(ra[set][s].z, ra[set][s].w, pa[0].y, pa[1].y, pa[2].y);
+        wg_split2(rb[set][s].x, rb[set][s].y, pb[0].x, pb[1].x, pb[2].x); wg_split2(rb[set][s].z, rb[set][s].w, pb[0].y, pb[1].y, pb[2].y);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          *reinterpret_cast<uint2*>(Ap + ((buf * 3 + p) * 128 + row) * LDP + c) = pa[p];
+          *reinterpret_cast<uint2*>(Bp + ((buf * 3 + p) * 128 + row) * LDP + c) = pb[p];
+        }
+      } else {
       *reinterpret_cast<float4*>(&As[buf][row][c]) = make_float4(ra[set][s].x, ra[set][s].y, ra[set][s].z, ra[set][s].w);
       *reinterpret_cast<float4*>(&Bs[buf][row][c]) = make_float4(rb[set][s].x, rb[set][s].y, rb[set][s].z, rb[set][s].w);
+      }
     }
   };
   f32x16 acc[2][2];
   auto mma = [&](int buf) {
+    if constexpr (SP3) {
+      uint4 pa[2][3], pb[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          pa[i][p] = *reinterpret_cast<const uint4*>(Ap + ((buf * 3 + p) * 128 + wm + 32 * i + li) * LDP + 8 * h);
+          pb[i][p] = *reinterpret_cast<const uint4*>(Bp + ((buf * 3 + p) * 128 + wn + 32 * i + li) * LDP + 8 * h);
+        }
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32b(pa[i][PA[t]], pb[j][PB[t]], acc[i][j]);
+      }
+      return;
+    }
     float4 a[2][2], b[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[0][i] = *reinterpret_cast<const float4*>(&As[buf][wm + 32 * i + li][4 * h]);
@@ -3708,7 +3745,9 @@ static void te_launch_ax_t(const TeArgs& A, int num_cu, hipStream_t st) {
         hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, D, 3 * D, false, F16>), grid, block, 0, st, P);
       } else {
         NtArgs P{nullptr, 0, A.lt, nullptr, A.row_p, nullptr, D, A.ui, 2 * D, A.G, 3 * D, nullptr, A.soff + n, 3 * D, D, A.ztab, A.row_dp};
-        hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true, F16>), grid, block, 0, st, P);
+        // split products for TRAINING launches (predict keeps the float32-input MFMAs: its sts are held to 1e-5 at dim 256 too - 1.07e-5 on split products)
+        if (A.rec_split && !A.predict && !(A.dbg & 512)) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true, F16, true>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((te_gemm_ntk_kernel<false, true, D, D, 3 * D, 2 * D, 3 * D, true, F16>), grid, block, 0, st, P);      // (POI_TE_DBG bit 512: float32-input MFMAs, for A/B runs)
       }
     }
   } else if (A.spatial) {
@@ -3922,8 +3961,13 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     // (ppoi: one row per distinct step-input POI - S . ui[:, :D] - instead of one per step)
     NtArgs P{A.ppoi ? A.S : A.G, 3 * D, nullptr, nullptr, nullptr, nullptr, 0, A.uiT, 3 * D, A.X, XW, nullptr, A.ppoi ? A.cnt + 4 : A.soff + n, A.bintab ? D : XW, 3 * D, nullptr, nullptr};
     const dim3 grid(((num_cu * 2 + 7) / 8) * 8), block(TE_BLOCK);
-    if (A.bintab) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D, 3 * D, 2 * D>), grid, block, 0, st, P);
+    // split products (POI_TE_DBG bit 512: float32-input MFMAs, for A/B runs); dims <= 128: at K = 768 the unrolled 48-stage tile spills (404 -> 823 us at dim 256)
+    const bool sp3 = A.rec_split && D <= 128 && !(A.dbg & 512);
+    if (A.bintab && sp3) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D, 3 * D, 2 * D, false, false, true>), grid, block, 0, st, P);
+    else if (A.bintab) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D, 3 * D, 2 * D>), grid, block, 0, st, P);
+    else if (A.spatial && sp3) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D, 3 * D, 2 * D, false, false, true>), grid, block, 0, st, P);
     else if (A.spatial) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, 2 * D>), grid, block, 0, st, P);
+    else if (sp3) hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D, 3 * D, D, false, false, true>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((te_gemm_ntk_kernel<false, false, 3 * D, 0, D>), grid, block, 0, st, P);
   }
   tm->end(st);
