@@ -473,13 +473,13 @@ def main():
     split = os.environ.get("POI_TE_SPLIT", "1") != "0"
     head3 = split and NB <= 256 and os.environ.get("POI_TE_HEAD3", "1") != "0"
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
-            "te_gemm_ax": ("i8op", 15 * 6 * D2 * ax_rows) if xfwd else ("flop", xk * D2 * ax_rows),
+            "te_gemm_ax": ("i8op", 15 * 6 * D2 * ax_rows) if xfwd else ("bf16x6", 6 * xk * D2 * ax_rows) if split and bintab and D >= 256 else ("flop", xk * D2 * ax_rows),
             "te_rec_fwd": ("i8op", 15 * 6 * D2 * steps_per_epoch) if xfwd else ("flop", 6 * D2 * steps_per_epoch),
             "te_head": ("bf16x5", 5 * 4.0 * NB * D * steps_per_epoch) if head3 else ("flop", 4.0 * NB * D * steps_per_epoch),
             "te_rec_bwd": ("bf16x6", 6 * 6 * D2 * steps_per_epoch) if split and B > 1024 else ("flop", 6 * D2 * steps_per_epoch),
             # d ui (over S rows), d wh and d vs (split-K)
             "te_wgrad": ("bf16x6", 6 * ((6 + xk * rho) * D2 + 2.0 * NB * D) * steps_per_epoch) if D in (64, 128, 256) else ("flop", ((6 + xk * rho) * D2 + 2.0 * NB * D) * steps_per_epoch),
-            "te_gemm_dx": ("flop", xk * rho * D2 * steps_per_epoch),
+            "te_gemm_dx": ("bf16x6", 6 * xk * rho * D2 * steps_per_epoch) if split and D <= 128 else ("flop", xk * rho * D2 * steps_per_epoch),
             # per-POI sums of DA: one read of the 3D-wide DA rows + the S rows written
             "te_psum": ("byte", 3.0 * D * 4 * (1.0 + rho) * steps_per_epoch),
             # implementation bytes of the HBM-bound kernels (what each kernel has to move given the decomposition):
