@@ -292,7 +292,7 @@ hipError_t launch_te_passign(TeArgs& A, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st) {
-  if (!A.side) { hipError_t e = launch_te_passign(A, st); if (e != hipSuccess) return e; }
+  if (!A.side || (A.dbg & 1024)) { hipError_t e = launch_te_passign(A, st); if (e != hipSuccess) return e; }      // (POI_TE_DBG bit 1024: on the main stream, for A/B runs)
   if (A.dim == 128) {
     hipLaunchKernelGGL(te_psum_kernel<128>, dim3(num_cu * 8), dim3(384), 0, st, A);
     hipLaunchKernelGGL(te_pfin_kernel<128>, dim3(num_cu * 16), dim3(384), 0, st, A);

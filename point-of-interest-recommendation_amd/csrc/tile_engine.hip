@@ -3844,6 +3844,20 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   if (!A.side) { hipError_t se = launch_te_sort(A, st); if (se != hipSuccess) return se; }
   tm->end(st);
+  // The slot sort (+ the S-row assignment and the bin chain's chunk offsets behind it) is needed from te_psum on: it runs on the side stream,
+  // next to te_rec_fwd - a latency chain that leaves most of the chip idle.  NOT next to the float32 te_gemm_ax of rounds 1 - 3: its grid is
+  // exactly two persistent workgroups per CU, and a co-resident sort kernel whose LDS displaces one of them pushes that workgroup's whole
+  // tile list into a second round (measured: ax 1.6 -> 2.3 ms when its LDS grew by 1 KB).  Exact forward (round 4): forked right behind the
+  // index preparation, next to te_gather / te_gemmx as well - the chain then ends inside te_rec_fwdx instead of beside te_head.
+  auto fork_sort = [&]() -> hipError_t {
+    if (hipEventRecord(A.ev_slots, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_slots, 0) != hipSuccess) return hipGetLastError();
+    hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
+    if (A.ppoi && !(A.dbg & 1024)) { se = launch_te_passign(A, A.side); if (se != hipSuccess) return se; }
+    if (A.early_bins && A.bintab) { se = launch_te_dprep(A, A.side); if (se != hipSuccess) return se; }
+    return hipEventRecord(A.ev_sorted, A.side);
+  };
+  const bool sort_early = A.side && A.xfwd && !(A.dbg & 2048);      // (POI_TE_DBG bit 2048: behind te_gemm_ax, for A/B runs)
+  if (sort_early) { hipError_t se = fork_sort(); if (se != hipSuccess) return se; }
   tm->begin("te_gather", st);
   hipLaunchKernelGGL(te_gather_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
   tm->end(st);
@@ -3856,17 +3870,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   te_launch_ax<D>(A, num_cu, st);
   tm->end(st);
   }
-  if (A.side) {
-    // The slot sort is needed only by te_scatter, so it runs on the side stream - next to te_rec_fwd, a
-    // latency chain that leaves most of the chip idle.  NOT next to the GEMMs: their grids are exactly two
-    // persistent workgroups per CU, and a co-resident sort kernel whose LDS displaces one of them pushes that
-    // workgroup's whole tile list into a second round (measured: ax 1.6 -> 2.3 ms when its LDS grew by 1 KB).
-    if (hipEventRecord(A.ev_slots, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_slots, 0) != hipSuccess) return hipGetLastError();
-    hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
-    if (A.ppoi) { se = launch_te_passign(A, A.side); if (se != hipSuccess) return se; }
-    if (A.early_bins && A.bintab) { se = launch_te_dprep(A, A.side); if (se != hipSuccess) return se; }
-    if (hipEventRecord(A.ev_sorted, A.side) != hipSuccess) return hipGetLastError();
-  }
+  if (A.side && !sort_early) { hipError_t se = fork_sort(); if (se != hipSuccess) return se; }
   if (A.xfwd) {
     hipError_t xe = launch_te_xfwd(A, num_cu, st, tm, 1);
     if (xe != hipSuccess) return xe;
