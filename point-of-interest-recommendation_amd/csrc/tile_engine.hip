@@ -1509,7 +1509,8 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16_kernel(TeArgs A) {
 // te_rec_bwd16 on split products with TRANSPOSED products (round 4, as te_rec_fwdx): the weight fragments are the A operand, so a lane owns
 // FOUR CONSECUTIVE UNITS of ONE sequence instead of one unit of four sequences - every operand of a step is one 16-byte load (5 instead of 20
 // 4-byte ones), d a goes out as three 16-byte stores (12), the bf16 planes of a value quad are one 8-byte LDS write per plane (3 instead of twelve
-// 2-byte ones, which conflict two ways), one activity mask per lane.  Same products in the same order: the same d a, d h bit for bit.
+// 2-byte ones, which conflict two ways), one activity mask per lane.  Same formulas on the same MFMA products: d a, d h agree with te_rec_bwd16<SP>
+// to float32 rounding (tests: 1e-6; the compiler contracts the gate-derivative expressions differently).
 template <int D>
 __global__ __launch_bounds__(D * 4) void te_rec_bwd16t_kernel(TeArgs A) {
   extern __shared__ __align__(16) float lds[];

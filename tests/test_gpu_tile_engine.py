@@ -710,3 +710,41 @@ def test_forward_table_over_step_input_pois_is_bitwise_invisible_and_head_switch
             ctx.set_option("head_split", 2)
     finally:
         ctx.set_option("forward_table_compact", 1); ctx.set_option("head_split", 1); ctx.set_engine("auto")
+
+
+def test_stream_placements_and_transposed_bptt_are_bitwise_invisible(pa):
+    """Round 4 moved work without changing arithmetic: the BPTT tile kernel with transposed products (te_rec_bwd16t: a lane owns four
+    consecutive units of one sequence) evaluates the same formulas on the same MFMA products as te_rec_bwd16<SP>, and the side-stream placements
+    (weight packs next to the index preparation, slot sort forked behind it, S-row assignment behind the sort) only reorder independent
+    kernels.  The tuning bits of POI_TE_DBG (read at every launch) switch each of them back: the placements must not change the update by one
+    bit; the two BPTT kernels agree to float32 rounding (1e-6 of the max-norm: the compiler contracts the gate-derivative expressions
+    differently, and d bi is summed over the sequences in another order)."""
+    import os
+    T = toy_problem(5200, n_user=1800, n_item=2500, n_dist=200, dim=128, len_max=10, hot=400)
+    P = spatial_params(5201, T)
+    users = np.random.default_rng(11).permutation(1800)[:1700].astype(np.int32)
+    ctx = pa._lib.context(0)
+    res = {}
+    old = os.environ.get("POI_TE_DBG")
+    try:
+        for name, bits in (("default", 0), ("bptt one unit of four sequences per lane", 128), ("packs inline", 256), ("S rows on the main stream", 1024),
+                           ("sort behind te_gemm_ax", 2048)):
+            os.environ["POI_TE_DBG"] = str(bits)
+            model = _model(pa, T, P)
+            ctx.set_engine("tile")
+            out = np.asarray(model.train_batch(users))
+            res[name] = (_get(model), out)
+        ref, ref_out = res["default"]
+        for name, (got, out) in res.items():
+            assert np.array_equal(out, ref_out), name
+            for k in SP_NAMES:
+                if "bptt" in name:      # same formulas, another instruction selection (fma contraction) and d bi summation order: float32 rounding apart
+                    assert_close(got[k], np.asarray(ref[k], np.float64) if k != "wd" else float(ref[k]), k + ", " + name, rtol=1e-6)
+                else:
+                    assert np.array_equal(got[k], ref[k]), "%s changed %s" % (name, k)
+    finally:
+        if old is None:
+            os.environ.pop("POI_TE_DBG", None)
+        else:
+            os.environ["POI_TE_DBG"] = old
+        ctx.set_engine("auto")
