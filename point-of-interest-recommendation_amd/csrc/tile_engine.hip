@@ -2361,7 +2361,14 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-      mma_f32a_s2<NTW, KG>(acc, Ht, LDH, A.pVsT, nto);
+      // (a wave whose last bin tile does not exist - 7 tiles on 4 waves - multiplies one tile less instead of a duplicate: 1/8 of the vs^T stream)
+      if (NTW > 1 && w + 4 * (NTW - 1) >= NBT) {
+        f32x16 (&acc1)[NTW - 1 > 0 ? NTW - 1 : 1] = reinterpret_cast<f32x16 (&)[NTW - 1 > 0 ? NTW - 1 : 1]>(acc);
+        int nto1[NTW - 1 > 0 ? NTW - 1 : 1];
+#pragma unroll
+        for (int j = 0; j < (NTW - 1 > 0 ? NTW - 1 : 1); ++j) nto1[j] = nto[j];
+        mma_f32a_s2<(NTW - 1 > 0 ? NTW - 1 : 1), KG>(acc1, Ht, LDH, A.pVsT, nto1);
+      } else mma_f32a_s2<NTW, KG>(acc, Ht, LDH, A.pVsT, nto);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         if (w + 4 * j >= NBT) continue;
