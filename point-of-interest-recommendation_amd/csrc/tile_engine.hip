@@ -474,7 +474,8 @@ __device__ __forceinline__ void mma_f32a_s2(f32x16 (&acc)[NTW], const float* __r
 // a backward product - the recurrence does not amplify its error, the bars on the updates are 1e-4.  (Without a1 b3 - B truncated to two
 // planes, 2^-17 - the hot-POI step of test_exact_forward_pass_is_far_inside_the_bar lands at 2.7e-6 instead of under 2e-6: 229 vs 250 us.)
 template <int NTW, int KG>
-__device__ __forceinline__ void mma_p2_s3(f32x16 (&acc)[NTW], const unsigned short* __restrict__ arow, int ps, const float4* __restrict__ bp, const int (&nt)[NTW]) {
+__device__ __forceinline__ void mma_p2_s3(f32x16 (&acc)[NTW], const unsigned short* __restrict__ arow, int ps, const float4* __restrict__ bp, const int (&nt)[NTW], const int kg_run = KG) {
+  // (kg_run <= KG: k groups that hold real bins - the padding bins' d logits are zero, their groups need not be multiplied)
   const int lane = lane_id();
   const uint4* bj[NTW];
   uint4 bc[NTW][3], bn[NTW][3];
@@ -486,8 +487,8 @@ __device__ __forceinline__ void mma_p2_s3(f32x16 (&acc)[NTW], const unsigned sho
   }
   uint4 ac0 = *reinterpret_cast<const uint4*>(arow), ac1 = *reinterpret_cast<const uint4*>(arow + ps);
 #pragma unroll 1
-  for (int m = 0; m < KG; ++m) {
-    const int mn = min(m + 1, KG - 1);
+  for (int m = 0; m < kg_run; ++m) {
+    const int mn = min(m + 1, kg_run - 1);
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -2472,7 +2473,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const unsigned short* arow = reinterpret_cast<const unsigned short*>(Ot + (li & ~7) * LDO) + (li & 7) * LDO + 8 * (lane >> 5);
-      mma_p2_s3<DTW, KBG>(acc, arow, 8 * LDO, A.pVs, ntd);
+      mma_p2_s3<DTW, KBG>(acc, arow, 8 * LDO, A.pVs, ntd, (NB + 15) / 16);
 #pragma unroll
       for (int j = 0; j < DTW; ++j) {
         if (w + 4 * j >= NTD) continue;
