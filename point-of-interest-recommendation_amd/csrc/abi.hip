@@ -51,7 +51,7 @@ struct poi_ctx {
   int one_path = 1;         // launches of ONE sequence (Distance2Pre, plain GRU) take the five-kernel path (te_one_*); POI_TE_ONE=0 -> the batched pipeline
   int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
-  int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores + float64 gates) for dims 64 / 128; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
+  int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores / float64 MFMA + float64 gates) for dims 64 / 128 / 256; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
   int xcomp = 1;            // exact forward table over the step-input POIs only; POI_TE_XCOMP=0: every row of the POI table (A/B)
   int xcomp_min = 1536;     // ... for launches of at least this many sequences (below: one row per step - the table form of te_rec_fwdx costs 0.6 us more per step of the latency chain than the ranking saves in te_gemmx; 1300 / 1563 / 2048 / 3125 users: +9 / -6 / -38 / -45 us); POI_TE_XCOMP_MIN
   int head3 = 1;            // training head on split products for <= 256 bins (te_head3); POI_TE_HEAD3
@@ -274,10 +274,11 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   // forward table: worth it when the table has clearly fewer rows than the launch has steps (Tcap is the upper bound: sequences
   // average ~40 % of the longest) - te_gemm_ax then multiplies n_item + 1 rows instead of one row per step
   // exact forward (dims 64 / 128): input product and forward recurrence in fixed point / float64 (te_xfwd.hip)
-  A.xfwd = (c->xfwd && !A.rec32 && poi::te_xfwd_supported(D)) ? 1 : 0;      // (training launches and predict alike)
+  // dim 256 (config X): the streaming backward kernels keep their 32-sequence tiles, the forward pass runs te_gemmx<256> + te_rec_fwdd (float64 MFMA)
+  A.xfwd = (c->xfwd && (!A.rec32 || D == 256) && poi::te_xfwd_supported(D)) ? 1 : 0;      // (training launches and predict alike)
   const bool want_ft = c->fwd_tab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap;
   A.fwd_tab = (!A.xfwd && want_ft && A.bintab && !A.rec1) ? 1 : 0;      // (the per-sequence kernels read G)
-  A.xrec1 = (A.xfwd && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
+  A.xrec1 = (A.xfwd && D <= 128 && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
   // (the table over the launch's step-input POIs only - te_slots marks them for the per-POI regrouping - never has more rows than the launch has steps)
   const bool want_xc = c->xcomp && A.ppoi && P->n_item + 1 <= (1 << 22) && n >= c->xcomp_min;
   A.xft = (A.xfwd && (want_ft || want_xc) && !A.xrec1 && n > 1) ? 1 : 0;      // (n == 1: the one-sequence path writes gx itself, te_one_in)

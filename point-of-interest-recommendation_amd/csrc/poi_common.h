@@ -2,6 +2,7 @@
 // reductions through LDS, and the two GEMV shapes the per-sequence engine uses.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
@@ -231,4 +232,22 @@ __device__ __forceinline__ void rule_scales(float alpha, float lambda, int nseq,
   else { sc = alpha * fminf((float)nseq, cap) / (float)max(nseq, 1); lm = lambda * (float)mult; }
 }
 
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is an attribute of the function ON ONE DEVICE: a process with contexts on several devices
+// must opt in on each of them, and two host threads may race to it.  One flag per device, under a mutex.
+struct DeviceOnce {
+  std::mutex mu;
+  bool done[64] = {};
+  template <class F> hipError_t run(F&& f) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev]) return hipSuccess;
+    e = f();
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+  }
+};
 }  // namespace poi

@@ -723,8 +723,9 @@ static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStrea
   const size_t lds = score_filter_lds(D, A.n_dist, bins != 0, bins == 3);
   const int ut = score_filter_ut(D, A.n_dist, bins != 0, bins == 3);
   const dim3 grid((n_utile + ut - 1) / ut, n_split_f / POI_NWAVE);
-  static bool optin = false;
-  if (!optin) {
+  static DeviceOnce once;      // (per device: poi_common.h)
+  {
+    const hipError_t oe = once.run([&]() -> hipError_t {
     hipError_t e = hipSuccess;
     auto big = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
     big(reinterpret_cast<const void*>(&score_filter_kernel<D, 3, 1>));
@@ -734,8 +735,9 @@ static hipError_t launch_two_stage_t(const ScoreArgs& A, int n_split_f, hipStrea
       big(reinterpret_cast<const void*>(&score_filter_kernel<D, 0, 2>));
     }
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_rescore_kernel<D / 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e != hipSuccess) return e;
-    optin = true;
+    return e;
+    });
+    if (oe != hipSuccess) return oe;
   }
   tm->begin("score_filter", st);
   if (bins == 3 && A.users_packed16) {        // item-stationary (huge item table, few users): see score_filter_items_kernel
@@ -788,15 +790,17 @@ static hipError_t launch_maxpass_t(const ScoreArgs& A, int n_split_f, hipStream_
   const size_t lds = score_filter_lds(D, A.n_dist, bins != 0, false);
   const int ut = score_filter_ut(D, A.n_dist, bins != 0, false);
   const dim3 grid((n_utile + ut - 1) / ut, nsm / POI_NWAVE);
-  static bool optin = false;
-  if (!optin) {
+  static DeviceOnce once;
+  {
+    const hipError_t oe = once.run([&]() -> hipError_t {
     hipError_t e = hipSuccess;
     auto big = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
     big(reinterpret_cast<const void*>(&score_filter_kernel<D, 2, 1, true>)); big(reinterpret_cast<const void*>(&score_filter_kernel<D, 1, 1, true>));
     big(reinterpret_cast<const void*>(&score_filter_kernel<D, 2, 2, true>)); big(reinterpret_cast<const void*>(&score_filter_kernel<D, 1, 2, true>));
     big(reinterpret_cast<const void*>(&score_filter_kernel<D, 0, 2, true>));
-    if (e != hipSuccess) return e;
-    optin = true;
+    return e;
+    });
+    if (oe != hipSuccess) return oe;
   }
   tm->begin("score_maxpass", st);
   if (bins == 1 && ut == 2) hipLaunchKernelGGL((score_filter_kernel<D, 1, 2, true>), grid, dim3(256), lds, st, F);

@@ -815,12 +815,9 @@ static hipError_t launch_score_t(const ScoreArgs& A, hipStream_t st, Timing* tm)
   tm->begin(A.k > 0 ? "score_topk" : "score_all", st);
   if (A.geo) {
     // static candidate lists (62 KB) + the dynamic threshold / user-coordinate block exceed the default 64 KB of LDS per workgroup
-    static bool optin = false;
-    if (!optin) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<D8, DB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      if (e != hipSuccess) return e;
-      optin = true;
-    }
+    static DeviceOnce once;      // (per device: poi_common.h)
+    const hipError_t oe = once.run([]() { return hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<D8, DB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
+    if (oe != hipSuccess) return oe;
     hipLaunchKernelGGL((score_kernel<D8, DB, true>), grid, dim3(POI_BLOCK), sizeof(double) * (A.n_dist + 96), st, A);
   }
   else hipLaunchKernelGGL((score_kernel<D8, DB, false>), grid, dim3(POI_BLOCK), 0, st, A);
@@ -860,12 +857,9 @@ template <int D8>
 static hipError_t launch_score_geo_stream_t(const ScoreArgs& A, hipStream_t st, Timing* tm) {
   const size_t total = (size_t)((A.n_item + 31) / 32) * D8 * 64;
   const size_t lds = score_geo_stream_lds(A.dim, A.n_dist);
-  static bool optin = false;
-  if (!optin) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel_geo_stream<D8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    optin = true;
-  }
+  static DeviceOnce once;
+  const hipError_t oe = once.run([]() { return hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel_geo_stream<D8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  if (oe != hipSuccess) return oe;
   tm->begin("pack_items", st);
   hipLaunchKernelGGL(pack_items_kernel, dim3(2048), dim3(POI_BLOCK), 0, st, A.items, A.items_f16, A.n_item, A.dim, D8, A.items_packed, total);
   tm->end(st);

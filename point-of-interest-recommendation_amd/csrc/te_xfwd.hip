@@ -61,10 +61,18 @@ __device__ __forceinline__ unsigned x_digit(unsigned lo, unsigned hi, int s) { r
 
 // 256 sum_w acc_w 256^-w in float64: the digit-pair classes 0|1 and 2|3 are merged in int32 first ((a0 << 8) + a1 and (a2 << 8) + a3 stay
 // below 2^31 for K <= 128: |a0| <= 65^2 K, |a2| <= 2^15 K + 2^14 K), then three conversions and two FMAs (every step exact: < 53 bits).
-__device__ __forceinline__ double x_combine(const i32x4 (&acc)[XS], int r) {
-  const int m01 = (acc[0][r] << 8) + acc[1][r], m23 = (acc[2][r] << 8) + acc[3][r];
-  return __builtin_fma(__builtin_fma((double)acc[4][r], 0x1p-8, (double)m23), 0x1p-16, (double)m01);
+template <int K>
+__device__ __forceinline__ double x_merge(int a0, int a1, int a2, int a3, int a4) {
+  const int m01 = (a0 << 8) + a1;
+  if constexpr (K <= 128) {
+    const int m23 = (a2 << 8) + a3;
+    return __builtin_fma(__builtin_fma((double)a4, 0x1p-8, (double)m23), 0x1p-16, (double)m01);
+  } else {      // K = 256: |a2| <= 2^23.1, (a2 << 8) + a3 no longer fits - classes 2, 3, 4 one by one (the last FMA rounds at 2^-53 of the sum)
+    const double t = __builtin_fma(__builtin_fma((double)a4, 0x1p-8, (double)a3), 0x1p-8, (double)a2);
+    return __builtin_fma(t, 0x1p-8, (double)m01);
+  }
 }
+__device__ __forceinline__ double x_combine(const i32x4 (&acc)[XS], int r) { return x_merge<128>(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r]); }
 
 // float64 exp / sigmoid / tanh, branch-free (the gate math sits on the per-step chain): e^x = 2^m T[j] p(r) with n = rint(64 x / ln 2) =
 // 64 m + j, T[j] = 2^(j / 64) (64 doubles in LDS), r = x - n ln2 / 64 (Cody-Waite, |r| <= 0.0055) and the degree-4 Taylor polynomial
@@ -85,11 +93,14 @@ __device__ __forceinline__ double x_rcp(double d) {       // v_rcp_f64 is good t
   const double y = __builtin_amdgcn_rcp(d);
   return __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
 }
+// (the clamps: the reduction of x_exp needs |x| < 2^31 ln2 / 64.  v_max_f64 / v_min_f64 return the non-NaN operand: a NaN pre-activation -
+// diverged or NaN weights - would come out as a finite gate where the float64 reference propagates it.  x * 0 is 0 for every finite x and
+// NaN for a non-finite one: one FMA on the result hands NaN (and, stricter than the reference, +-inf) through.)
 __device__ __forceinline__ double x_sigmoid(double x, const double* __restrict__ T) {
-  return x_rcp(1.0 + x_exp(-__builtin_fmin(__builtin_fmax(x, -700.0), 700.0), T));      // (clamped: the reduction of x_exp needs |x| < 2^31 ln2 / 64)
+  return __builtin_fma(x, 0.0, x_rcp(1.0 + x_exp(-__builtin_fmin(__builtin_fmax(x, -700.0), 700.0), T)));
 }
 __device__ __forceinline__ double x_tanh(double x, const double* __restrict__ T) {
-  return __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * __builtin_fmin(__builtin_fmax(x, -350.0), 350.0), T)), 1.0);
+  return __builtin_fma(x, 0.0, __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * __builtin_fmin(__builtin_fmax(x, -350.0), 350.0), T)), 1.0));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -192,12 +203,15 @@ __device__ __forceinline__ void x_glds16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// D = 256 (config X): a wave's resident row digits are 160 registers and the two column-tile slots 80 KB - one workgroup per CU, dynamic LDS;
+// the int32 merge of the digit-pair classes 2|3 would overflow at K = 256 (x_combine_wide).
 template <int D>
-__global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void te_gemmx_kernel(XGemmArgs P) {
   constexpr int KB = D / 32, N = 3 * D, NT = N / 32, FR = KB * XS * 64;      // uint4 fragments per column tile
   constexpr int PT = (FR + 255) / 256;
-  static_assert(D <= 128 && D % 32 == 0, "te_gemmx: the int32 merge of the digit-pair classes (x_combine) holds for K <= 128");
-  __shared__ uint4 s_b[2][FR];                                 // two column tiles: tile j + 1 lands while tile j is multiplied
+  static_assert(D <= 256 && D % 32 == 0, "te_gemmx: int32 accumulators hold five digit pairs of K <= 256 terms");
+  extern __shared__ __align__(16) uint4 xg_lds[];
+  uint4 (*s_b)[FR] = reinterpret_cast<uint4 (*)[FR]>(xg_lds);   // two column tiles: tile j + 1 lands while tile j is multiplied
   __shared__ double s_rs[4][32];
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id(), li = lane & 31, h = lane >> 5;
   const int n_rows = *P.n_ptr;
@@ -281,8 +295,7 @@ __global__ __launch_bounds__(256, 2) void te_gemmx_kernel(XGemmArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = x_crow(r, lane), grow = t * 128 + w * 32 + rr;
-        const int m01 = (acc[0][r] << 8) + acc[1][r], m23 = (acc[2][r] << 8) + acc[3][r];
-        const double v = __builtin_fma(__builtin_fma((double)acc[4][r], 0x1p-8, (double)m23), 0x1p-16, (double)m01);
+        const double v = x_merge<D>(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r]);
         P.C[(size_t)min(grow, n_rows) * N + col] = __builtin_fma(v, s_rs[w][rr] * (cs * 0x1p-8), zadd[r]);      // (exactly 16 stores, last in the tile)
       }
     }
@@ -621,9 +634,187 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// te_rec_fwdd: the exact forward recurrence for D = 256 (config X) - the recurrent products in FLOAT64 on the matrix cores
+// (v_mfma_f64_16x16x4_f64), weights streamed from L2.
+//
+// Why not the digit scheme of te_rec_fwdx: at dim 256 the digit planes of wh are 983 KB - not resident in one CU - and the reference's
+// uniform(-0.5, 0.5) init makes the chain expand perturbations ~10^6-fold over 50 positions (tools/precision_split.py with PS_D=256: a
+// float32 forward pass leaves the update O(1) off; a chain held to 2^-38 ~1e-6; float64 forward + float32 everything else 0.5 - 4e-6).
+// The f64 MFMA runs at the float64 vector rate (a 16x16x4 block is 16 passes), i.e. 2.3x the matrix time of fifteen streamed int8 digit
+// products - but it needs no digit cutting, no scales and a quarter of the weight bytes (float32 fragments converted on the fly, 786 KB
+// per step of a tile against 983 KB of digit planes), its 64-cycle issue shadow hides the float64 gate math of the other waves, and its
+// result is the float64 product itself: no conditioning of the chain can push it outside the bar.
+//
+// Tiling: 16 sequences per workgroup of D / 32 waves; wave w owns hidden units [32 w, 32 w + 32) of z, r and c (two 16-unit MFMA tiles
+// per gate).  Products TRANSPOSED as in te_rec_fwdx: weights = A operand (16 units x 4 k), state = B operand (4 k x 16 sequences);
+// the weight rows are packed in the order unit(rho) = 4 (rho & 3) + (rho >> 2) so that the f64 C layout (row = (lane >> 4) + 4 reg) gives
+// a lane FOUR CONSECUTIVE units of ONE sequence - the gate / store code of te_rec_fwdx.  State h_{t-1}, r * h_{t-1}: float64 in LDS,
+// k-major (hT[k][16 sequences]: the four lane groups of a B fragment read four consecutive 128-byte rows, no bank conflicts).
+// MFMA j of k-block kq contracts k = 16 kq + 4 j + (lane >> 4): the A fragments of four MFMAs are ONE 16-byte load per lane (te_xwpackd).
+// Pre-activations (te_gemmx: int8 digits, float64 tables), gates, outputs: as te_rec_fwdx.
+// -------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// wh (3, D, D) float32 -> dst[((gate NT + ut) KQ + kq) 64 + lane] = float4 { wh[gate][16 ut + 4 (i & 3) + (i >> 2)][16 kq + 4 j + g] : j = 0..3 }, i = lane & 15, g = lane >> 4
+__global__ __launch_bounds__(256) void te_xwpackd_kernel(const float* __restrict__ wh, float4* __restrict__ dst, int D) {
+  const int NT = D / 16, KQ = D / 16, total = 3 * NT * KQ * 64;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int lane = e & 63, kq = (e >> 6) % KQ, tu = (e >> 6) / KQ;      // tu = gate NT + ut
+    const int i = lane & 15, g = lane >> 4;
+    const int gate = tu / NT, ut = tu % NT;
+    const float* src = wh + ((size_t)gate * D + 16 * ut + 4 * (i & 3) + (i >> 2)) * D + 16 * kq + g;
+    dst[e] = make_float4(src[0], src[4], src[8], src[12]);
+  }
+}
+
+template <int D, bool FT, bool PRED = false>
+__global__ __launch_bounds__(D * 2) void te_rec_fwdd_kernel(TeArgs A) {
+  constexpr int NW = D / 32, NT = D / 16, KQ = D / 16;
+  static_assert(D % 32 == 0 && D >= 64, "te_rec_fwdd: a wave owns 32 units of every gate");
+  extern __shared__ __align__(16) unsigned char xlds[];
+  double* hT = reinterpret_cast<double*>(xlds);      // [D][16]
+  double* rhT = hT + D * 16;
+  __shared__ int s_r0[16], s_ns[16];
+  __shared__ double s_t64[64];
+  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x;
+  if (tid < 16) {
+    const int k = tile * 16 + tid;
+    int r0 = 0, ns = 0;
+    if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
+    s_r0[tid] = r0; s_ns[tid] = ns;
+  }
+  if (tid >= 64 && tid < 128) s_t64[tid - 64] = exp2((double)(tid - 64) * (1.0 / 64.0));
+  for (int e = tid; e < 2 * D * 16; e += blockDim.x) hT[e] = 0.0;      // h_0 = 0
+  __syncthreads();
+  int ns_max = 0;
+  for (int q = 0; q < 16; ++q) ns_max = max(ns_max, s_ns[q]);
+  const int rowb = s_r0[i], nsr = s_ns[i];
+  const int Tsp = A.soff[A.n_seq];                   // spare packed row: finished sequences read / write it unconditionally
+  const float4* __restrict__ Wp = reinterpret_cast<const float4*>(A.xWh8);
+  // this lane: units ub[u] .. ub[u] + 3 (u = 0, 1: the wave's two unit tiles) of sequence i
+  int ub[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) ub[u] = 32 * w + 16 * u + 4 * g;
+  double hcur[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  struct XG4 { double v[4]; };
+  // products of NG gates (gt0 ..) x this wave's two unit tiles with the state in sT: acc[gate][tile] (C layout: reg r = unit ub + r)
+  auto mma = [&](auto& acc, const double* __restrict__ sT, const int gt0, auto ng) {
+    constexpr int NG = decltype(ng)::value;
+    float4 ac[NG][2], an[NG][2];
+    auto fetch = [&](float4 (&o)[NG][2], int kq) {
+#pragma unroll
+      for (int q = 0; q < NG; ++q)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) o[q][u] = Wp[(((size_t)(gt0 + q) * NT + 2 * w + u) * KQ + kq) * 64 + lane];
+    };
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[q][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+    fetch(ac, 0);
+#pragma unroll 2
+    for (int kq = 0; kq < KQ; ++kq) {
+      fetch(an, min(kq + 1, KQ - 1));
+      const double* bp = sT + (size_t)(16 * kq + g) * 16 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double b = bp[64 * j];
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float a = j == 0 ? ac[q][u].x : j == 1 ? ac[q][u].y : j == 2 ? ac[q][u].z : ac[q][u].w;
+            acc[q][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a, b, acc[q][u], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < NG; ++q)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ac[q][u] = an[q][u];
+    }
+  };
+  // pre-activations of gate gt, both unit tiles, of packed row `row` (FT: table rows p1 / z1)
+  auto pre = [&](XG4 (&o)[2], int gt, size_t row, int p1, int z1) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if constexpr (FT) {
+        const XG4 a = *reinterpret_cast<const XG4*>(A.ptabx + (size_t)p1 * 3 * D + gt * D + ub[u]);
+        const XG4 b = *reinterpret_cast<const XG4*>(A.ztabx + (size_t)z1 * 3 * D + gt * D + ub[u]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[u].v[r] = a.v[r] + b.v[r];
+      } else {
+        o[u] = *reinterpret_cast<const XG4*>(A.gx + row * 3 * D + gt * D + ub[u]);
+      }
+    }
+  };
+  const int* __restrict__ xrow = A.xcomp ? A.row_pc : A.row_p;
+  for (int t = 0; t < ns_max; ++t) {
+    const bool on = t < nsr;
+    const size_t row = (size_t)(on ? rowb + t : Tsp);
+    int p1 = 0, z1 = 0;
+    if constexpr (FT) {
+      p1 = (int)min((unsigned)xrow[row], (unsigned)A.n_item);
+      z1 = A.spatial ? (int)min((unsigned)A.row_dp[row], (unsigned)A.n_dist) : 0;
+    }
+    XG4 gz[2], gr[2], gcc[2];
+    pre(gz, 0, row, p1, z1); pre(gr, 1, row, p1, z1);
+    f64x4 azr[2][2], ac1[1][2];
+    mma(azr, hT, 0, std::integral_constant<int, 2>());
+    double zv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      double rh[4];
+      float rv4[4], rh4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        zv[u][r] = x_sigmoid(azr[0][u][r] + gz[u].v[r], s_t64);
+        const double rv = x_sigmoid(azr[1][u][r] + gr[u].v[r], s_t64);
+        rh[r] = rv * hcur[u][r];
+        rv4[r] = (float)rv; rh4[r] = (float)rh[r];
+        rhT[(size_t)(ub[u] + r) * 16 + i] = rh[r];
+      }
+      if constexpr (!PRED) {
+        *reinterpret_cast<float4*>(A.G + row * 3 * D + D + ub[u]) = make_float4(rv4[0], rv4[1], rv4[2], rv4[3]);
+        *reinterpret_cast<float4*>(A.RH + row * D + ub[u]) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
+      }
+    }
+    pre(gcc, 2, row, p1, z1);
+    x_lds_barrier();
+    mma(ac1, rhT, 2, std::integral_constant<int, 1>());
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float z4[4], c4[4], h4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double c = x_tanh(ac1[0][u][r] + gcc[u].v[r], s_t64);
+        const double hn = on ? __builtin_fma(zv[u][r], c - hcur[u][r], hcur[u][r]) : hcur[u][r];
+        hcur[u][r] = hn;
+        z4[r] = (float)zv[u][r]; c4[r] = (float)c; h4[r] = (float)hn;
+        hT[(size_t)(ub[u] + r) * 16 + i] = hn;
+      }
+      if constexpr (!PRED) {
+        *reinterpret_cast<float4*>(A.G + row * 3 * D + ub[u]) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+        *reinterpret_cast<float4*>(A.G + row * 3 * D + 2 * D + ub[u]) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+        *reinterpret_cast<float4*>(A.H + row * D + ub[u]) = make_float4(h4[0], h4[1], h4[2], h4[3]);
+      }
+    }
+    x_lds_barrier();
+  }
+  if constexpr (PRED) {
+    const int k = tile * 16 + i;
+    if (k < A.n_seq)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        *reinterpret_cast<float4*>(A.hts + (size_t)(A.out_row ? A.out_row[k] : k) * D + ub[u]) =
+            make_float4((float)hcur[u][0], (float)hcur[u][1], (float)hcur[u][2], (float)hcur[u][3]);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-bool te_xfwd_supported(int D) { return D == 64 || D == 128; }
+bool te_xfwd_supported(int D) { return D == 64 || D == 128 || D == 256; }
 
 size_t te_xfwd_lds(int D) {
   const int KB = D / 64, NW = D / 16, SL = XS - 3;
@@ -633,33 +824,62 @@ size_t te_xfwd_lds(int D) {
 // bytes of the digit fragments / doubles of the scales for a (rows x K) operand
 size_t te_xfrag_bytes(int rows, int K) { return (size_t)rows * K * XS; }
 
+// D <= 128: te_rec_fwdx (int8 digit products, resident fragments); D = 256: te_rec_fwdd (float64 MFMA, streamed float32 fragments)
+template <int D> struct XRec {
+  static constexpr bool F64 = D > 128;
+  static size_t lds() { return F64 ? sizeof(double) * 2 * D * 16 : te_xfwd_lds(D <= 128 ? D : 128); }
+  static dim3 block() { return dim3(F64 ? D * 2 : D * 4); }
+  template <bool FT, bool PRED> static const void* fn() {
+    if constexpr (F64) return reinterpret_cast<const void*>(&te_rec_fwdd_kernel<D, FT, PRED>);
+    else return reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, FT, PRED>);
+  }
+  template <bool FT, bool PRED> static void launch(const TeArgs& A, hipStream_t st) {
+    const dim3 grid((A.n_seq + 15) / 16);
+    if constexpr (F64) hipLaunchKernelGGL((te_rec_fwdd_kernel<D, FT, PRED>), grid, block(), lds(), st, A);
+    else hipLaunchKernelGGL((te_rec_fwdx_kernel<D, FT, PRED>), grid, block(), lds(), st, A);
+  }
+};
+
 template <int D>
 static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing* tm, int phase) {
-  static bool optin = false;
-  if (!optin) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwdx_kernel<D, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    if (e != hipSuccess) return e;
-    optin = true;
+  // the LDS opt-in is a per-device attribute of the function (DeviceOnce, poi_common.h)
+  static DeviceOnce once;
+  {
+    const hipError_t oe = once.run([&]() -> hipError_t {
+      const void* fns[5] = {XRec<D>::template fn<false, false>(), XRec<D>::template fn<true, false>(), XRec<D>::template fn<false, true>(), XRec<D>::template fn<true, true>(),
+                            reinterpret_cast<const void*>(&te_gemmx_kernel<D>)};
+      for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    });
+    if (oe != hipSuccess) return oe;
   }
+  // the recurrent weights for the recurrence kernel: int8 digit fragments (te_rec_fwdx) or float32 fragments in f64-MFMA order (te_rec_fwdd)
+  auto pack_wh = [&](hipStream_t s) {
+    if constexpr (XRec<D>::F64) hipLaunchKernelGGL(te_xwpackd_kernel, dim3(3 * D * D / 4 / 256), dim3(256), 0, s, A.wh, reinterpret_cast<float4*>(A.xWh8), D);
+  };
   const int n = A.n_seq;
-  if (phase == 2) {      // digit fragments of the recurrent weights only (one-sequence path with the tile recurrence: te_one_in forms gx itself)
-    XPackJobs J;
-    J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
-    J.n = 1;
-    hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 1), dim3(256), 0, st, J);
+  if (phase == 2) {      // fragments of the recurrent weights only (one-sequence path with the tile recurrence: te_one_in forms gx itself)
+    if constexpr (XRec<D>::F64) pack_wh(st);
+    else {
+      XPackJobs J;
+      J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
+      J.n = 1;
+      hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 1), dim3(256), 0, st, J);
+    }
     return hipGetLastError();
   }
   if (phase == 0 || phase == 3 || phase == 4) {      // 3: the weight digits and the per-bin table only (no timed region: the side stream); 4: the product only
   if (!A.predict && phase != 3) tm->begin("te_gemm_ax", st);
   if (phase != 4) {
     XPackJobs J;
-    J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
-    J.j[1] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 0, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS};
-    J.n = 2;
-    hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 2), dim3(256), 0, st, J);
+    J.j[0] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 0, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS};
+    J.j[1] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
+    J.n = XRec<D>::F64 ? 1 : 2;
+    hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, J.n), dim3(256), 0, st, J);
+    pack_wh(st);
     hipLaunchKernelGGL(te_xztab_kernel, dim3(A.spatial ? A.n_dist + 1 : 1), dim3(3 * D), 0, st, A);
   }
   if (phase != 3) {
@@ -678,7 +898,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     if (ncg * 2 <= NT && NT % (ncg * 3) == 0 && n_tile_est * ncg < num_cu) ncg *= 3;
     P.ncg = ncg;
     const int grid = min(num_cu * 2, n_tile_est * ncg > 0 ? n_tile_est * ncg : 1);
-    hipLaunchKernelGGL(te_gemmx_kernel<D>, dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(te_gemmx_kernel<D>, dim3(D <= 128 ? grid : min(grid, num_cu)), dim3(256), sizeof(uint4) * 2 * (D / 32) * XS * 64, st, P);
   }
   if (!A.predict && phase != 3) tm->end(st);
   return hipGetLastError();
@@ -701,15 +921,18 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   } } dump_at_exit;
 #endif
   if (A.predict) {      // (inside the caller's te_predict region)
-    if (A.xrec1) hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, true>), dim3(n), dim3(4 * D), 0, st, A);
-    else if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
-    else hipLaunchKernelGGL((te_rec_fwdx_kernel<D, false, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
+    if constexpr (!XRec<D>::F64) { if (A.xrec1) { hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, true>), dim3(n), dim3(4 * D), 0, st, A); return hipGetLastError(); } }
+    if (A.xft) XRec<D>::template launch<true, true>(A, st);
+    else XRec<D>::template launch<false, true>(A, st);
     return hipGetLastError();
   }
   tm->begin("te_rec_fwd", st);
-  if (A.xrec1) hipLaunchKernelGGL(te_rec_fwd1x_kernel<D>, dim3(n), dim3(4 * D), 0, st, A);
-  else if (A.xft) hipLaunchKernelGGL((te_rec_fwdx_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
-  else hipLaunchKernelGGL((te_rec_fwdx_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), te_xfwd_lds(D), st, A);
+  bool done = false;
+  if constexpr (!XRec<D>::F64) { if (A.xrec1) { hipLaunchKernelGGL(te_rec_fwd1x_kernel<D>, dim3(n), dim3(4 * D), 0, st, A); done = true; } }
+  if (!done) {
+    if (A.xft) XRec<D>::template launch<true, false>(A, st);
+    else XRec<D>::template launch<false, false>(A, st);
+  }
   tm->end(st);
   return hipGetLastError();
 }
@@ -718,6 +941,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
 hipError_t launch_te_xfwd(const TeArgs& A, int num_cu, hipStream_t st, Timing* tm, int phase) {
   if (A.dim == 64) return te_xfwd_t<64>(A, num_cu, st, tm, phase);
   if (A.dim == 128) return te_xfwd_t<128>(A, num_cu, st, tm, phase);
+  if (A.dim == 256) return te_xfwd_t<256>(A, num_cu, st, tm, phase);
   return hipErrorInvalidValue;
 }
 

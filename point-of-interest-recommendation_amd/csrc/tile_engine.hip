@@ -702,6 +702,9 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A) {
     *reinterpret_cast<float4*>(A.E + (size_t)r * D + c) = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
     if (A.xcomp && c == 0) A.row_pc[r] = A.xidx[min((unsigned)A.row_p[r], (unsigned)A.n_item)];      // the step's row of the compact forward table
   }
+  // the spare packed row T: finished sequences of a tile read its table row unconditionally (te_rec_fwdx / te_rec_fwdd) - row 0 of the compact
+  // table always exists, whatever an earlier launch with another n_item left in this buffer
+  if (A.xcomp && blockIdx.x == 0 && threadIdx.x == 0) A.row_pc[T] = 0;
 }
 
 // Plain GRU + BPR head (public/GRU.py:349-357): u = h_t . (x_p' - x_q'), loss -= log sigmoid(u),
@@ -3991,8 +3994,8 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
 
 static hipError_t te_optin_lds() {
   // the streaming recurrent kernels need more than the default 64 KB of dynamic LDS at D = 256 (99 KB backward)
-  static bool done = false;
-  if (done) return hipSuccess;
+  static DeviceOnce once;      // (per device, thread-safe: poi_common.h)
+  return once.run([]() -> hipError_t {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_bwd32_kernel<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&te_rec_fwd32_kernel<256, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -4015,8 +4018,8 @@ static hipError_t te_optin_lds() {
   optin(reinterpret_cast<const void*>(&te_head3_kernel<256, 8>)); optin(reinterpret_cast<const void*>(&te_head_kernel<256, 8, 0>)); optin(reinterpret_cast<const void*>(&te_head_kernel<256, 8, 1>));
   // forward table on split products: three 24 KB ring slots
   optin(reinterpret_cast<const void*>(&te_ptab_s3_kernel<128, false>)); optin(reinterpret_cast<const void*>(&te_ptab_s3_kernel<128, true>));
-  done = e == hipSuccess;
   return e;
+  });
 }
 
 #ifdef TE_HEAD_PROF

@@ -1,5 +1,6 @@
 """-m gpu: BASELINE.json configs[4] at its TIMED launch size (bench.py --shape x1: 15625 users per launch, L <= 50, D = 256, 10 M-row half POI
-table, batch cap 64, length-sorted - the streaming recurrent kernels on split products) against the oracle:
+table, batch cap 64, length-sorted - float64-MFMA forward recurrence, streaming backward kernels on split products), with the
+REFERENCE'S OWN INIT, against the oracle:
   * the launch: per-sequence losses, `di` and the seven dense tensors against oracle/c_oracle.spatial_batch_mean (the float64 capped-sum
     rule) re-stated on the COMPACT table of the launch's POIs - the sequences are drawn over 300 k POI ids that are then spread over the
     10 M rows of the real table (the oracle cannot hold 10 M x 256 doubles), so the compact problem IS the drawn one; touched rows ==
@@ -38,14 +39,11 @@ def launch():
     coords = np.stack([40.0 + rng.random(N_ITEM) * 0.36, -74.0 + rng.random(N_ITEM) * 0.47], 1)
     model = poi_amd.models.OboSpatialGru(train=Tb["train"], test=Tb["test"], dist=T["dist"], alpha_lambda=[0.01, 0.001], n_user=N_USER,
                                          n_item=N_ITEM, n_dists=[N_DIST, 0.2], n_in=DIM, n_hidden=DIM, seed=6, table_dtype="f16", coords=coords)
-    # CONDITIONING.  With the reference's uniform(-0.5, 0.5) init at dim 256 the recurrence is violently expansive: over 50 positions a
-    # float32 forward pass is 5e-3 off in the losses (3.7e-7 for L < 10, 3e-5 for L < 30, 3e-4 for L < 40: a factor 10 per 10 positions),
-    # the gradients explode and the dense updates are O(1) - there is no 6e-5 parity to check against ANY arithmetic short of float64
-    # end to end (the exact forward pass of dims 64 / 128 would land at ~1e-4 here), and no training either.  What this test is for is the
-    # MACHINERY at launch size - 489 streaming tiles of 32 sequences, the half table's write-back under cap 64, 300 k touched rows
-    # among 10 M - so the recurrent and input weights are scaled to a contractive regime (x 0.2: |W h| ~ 1 instead of ~ 5).
-    for name in ("ui", "wh"):
-        getattr(model, name).set_value(np.asarray(getattr(model, name).get_value(), np.float32) * np.float32(0.2))
+    # CONDITIONING.  The parameters keep the reference's own init (uniform(-0.5, 0.5): public/GRU_Spatial.py:50-71, public/GRU.py:60-62).  At dim 256
+    # that recurrence is violently expansive - a float32 forward pass is 2e-3 off in the losses of the 40 .. 50-position sequences and O(1) off
+    # in the updates (tools/x256_check.py), the gradients explode (updates of 10^2 .. 10^3 on weights of 0.5) - which is why the forward pass
+    # of this configuration runs in float64 on the matrix cores (te_rec_fwdd, te_xfwd.hip) behind an int8-digit input product: every tensor
+    # lands inside the standard bars below.  (Rounds 3 - 4 scaled ui / wh by 0.2 here to make the problem contractive: gone.)
     return poi_amd, T, big_of, coords, model
 
 
@@ -86,7 +84,7 @@ def test_configx_timed_launch_against_the_oracle(launch):
     assert not bool((changed & ~is_t).any()), "a row no sequence of the launch touches changed"
     assert int(changed.sum()) > 0.9 * int(tch["lt"].sum())
     del lt0
-    # (well conditioned, see the fixture: the standard bars - 1e-5 on the weights, 1e-4 per row on the updates)
+    # the standard bars - 1e-5 on the weights, 1e-4 per row on the updates
     import os
     got = _dense_state(m)
     if os.environ.get("X_DIAG"):
