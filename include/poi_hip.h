@@ -45,7 +45,7 @@ extern "C" {
  * refuses to combine half segments whose buffer the caller never asked for; new entry points since 2: poi_sync_buffer16,
  * poi_ctx_set_split_products / _small_launch / _one_sequence_path / _regroup_min / _f16_rounding / _topk_filter(_stats), poi_ctx_set_exact_forward. */
 /* 4 (round 4): new entry point poi_ctx_set_option. */
-#define POI_ABI_VERSION 4
+#define POI_ABI_VERSION 5
 
 enum {
   POI_OK = 0,
@@ -372,6 +372,7 @@ int poi_delta_apply(poi_ctx* ctx, float* cur, const float* base, const float* de
  * one torch.distributed broadcast); every rank then calls poi_comm_init_rank (collective). */
 #define POI_UNIQUE_ID_BYTES 128
 typedef struct poi_comm poi_comm;
+int poi_comm_available(void);          /* ABI 5: POI_OK when librccl can be bound in this process; makes no RCCL call (the probe of ranks != 0) */
 int poi_comm_unique_id(char* id_host);
 int poi_comm_init_rank(const char* id_host, int world, int rank, int device, poi_comm** out);
 int poi_comm_destroy(poi_comm* comm);

@@ -6,7 +6,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpoi_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 BPR_SNAPSHOT, BPR_HOGWILD = 0, 1
 
@@ -94,6 +94,7 @@ SIGNATURES = {
                                   c_void_p, c_void_p]),
     "poi_delta_make": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "poi_delta_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "poi_comm_available": (c_int, []),
     "poi_comm_unique_id": (c_int, [c_void_p]),
     "poi_comm_init_rank": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     "poi_comm_destroy": (c_int, [c_void_p]),

@@ -13,15 +13,19 @@ __global__ __launch_bounds__(POI_BLOCK) void auc_kernel(const float* __restrict_
   if (e >= n * len) return;
   const int u = e / len;
   const float* ur = users + (size_t)u * D;
-  float acc = 0.f;
+  // float64: the differences and products of float32 values are EXACT in float64 (25 + 24 bits), only the D-term sum rounds (1e-16 of its
+  // mass) - the flag is the sign of the reference's own float64 margin (public/GRU.py:98-110) whatever its size; a float32 sum flipped the
+  // flags of margins below ~1e-4 (rounds 1 - 4 skipped those in the parity test).  n x len dot products: the cost is nothing.
+  double acc = 0.0;
   for (int j = lane_id() * 4; j < D; j += 256) {
     const float4 a = *reinterpret_cast<const float4*>(ur + j);
     const float4 b = ld4t(items, (size_t)tp[e] * D + j, items_f16);
     const float4 c = ld4t(items, (size_t)tq[e] * D + j, items_f16);
-    acc += a.x * (b.x - c.x) + a.y * (b.y - c.y) + a.z * (b.z - c.z) + a.w * (b.w - c.w);
+    acc = __builtin_fma((double)a.x, (double)b.x - (double)c.x, acc); acc = __builtin_fma((double)a.y, (double)b.y - (double)c.y, acc);
+    acc = __builtin_fma((double)a.z, (double)b.z - (double)c.z, acc); acc = __builtin_fma((double)a.w, (double)b.w - (double)c.w, acc);
   }
-  acc = wave_sum(acc);
-  if (lane_id() == 0) out[e] = (acc * (float)tm[e] > 0.f) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane_id() == 0) out[e] = (acc * (double)tm[e] > 0.0) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(POI_BLOCK) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* out) {

@@ -160,6 +160,14 @@ extern "C" {
 
 const char* poi_sync_last_error(void) { return g_sync_err.c_str(); }
 
+// Can this process bind librccl (dlopen + the nccl* entry points)?  No RCCL call is made: ncclGetUniqueId on a rank that is not the root
+// would leave a bootstrap listener (socket + thread) behind that nothing uses or releases.
+int poi_comm_available(void) {
+  poi::Rccl* R = poi::rccl();
+  if (!R->h) return sfail(nullptr, POI_ENOTSUP, R->err);
+  return POI_OK;
+}
+
 int poi_comm_unique_id(char* id_host) {
   if (!id_host) return sfail(nullptr, POI_EINVAL, "poi_comm_unique_id: NULL");
   poi::Rccl* R = poi::rccl();

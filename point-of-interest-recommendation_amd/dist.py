@@ -83,15 +83,18 @@ class HipSyncBackend:
     def init_comm(self, group=None):
         """The library's own RCCL communicator: rank 0 draws the id, one broadcast hands it to the others.  Returns True when every rank
         holds a communicator, False when the ranks AGREED not to build one.  The collective sequence is the same on every rank whatever
-        fails locally: (1) every rank probes that the library can bind librccl (poi_comm_unique_id into a scratch buffer - rank 0's
-        draw is the id), (2) ONE broadcast of the id (zeros if rank 0 could not draw it), (3) ONE all-reduce (MIN) of the probe results,
-        and only if all ranks passed (4) the collective poi_comm_init_rank, followed by (5) a second MIN all-reduce of its outcome."""
+        fails locally: (1) every rank probes that the library can bind librccl - rank 0 by drawing the id (poi_comm_unique_id), the others
+        with poi_comm_available, which makes no RCCL call (ncclGetUniqueId on a non-root rank would leave an unused bootstrap listener
+        behind), (2) ONE broadcast of the id (zeros if rank 0 could not draw it), (3) ONE all-reduce (MIN) of the probe results, and only
+        if all ranks passed (4) the collective poi_comm_init_rank, followed by (5) a second MIN all-reduce of its outcome.
+        Caveat: (4) is RCCL's own rendezvous - a rank whose ncclCommInitRank fails FAST leaves the others inside theirs until RCCL's
+        bootstrap timeout; the agreement of (5) is only reached after that."""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         on_dev = dist.get_backend(group) == "nccl"
         buf = (ctypes.c_char * 128)()
         ok = 1
         try:
-            self._check(self.lib.poi_comm_unique_id(buf))
+            self._check(self.lib.poi_comm_unique_id(buf) if rank == 0 else self.lib.poi_comm_available())
         except Exception:      # noqa: BLE001 - agreed on across ranks below
             ok = 0
             buf = (ctypes.c_char * 128)()

@@ -95,6 +95,70 @@ def test_full_size_topk_matches_explicit_scores(setup):
     check(idx2, full2)
 
 
+def test_full_size_rank_agreement_with_the_float64_oracle(setup):
+    """SURVEY section 7 "bit-exact ranks vs precision", public/Valuate.py:132-146 at the Gowalla shape: the device's top-20 lists of 2048 users over all
+    100 k POIs (fused float16 filter + exact float32 rescoring) against the FLOAT64 oracle's (oracle.score_all + oracle.topk_desc from the same
+    float32 user vectors / snapshot table), after one epoch of training, without and with the distance term.  Reported: the fraction of
+    identical lists and of identical recall@{5, 10, 15, 20} flags; asserted: >= 99.5 % identical lists, EVERY differing position is a swap of
+    two POIs whose float64 scores differ by less than 1e-6 of the row's largest score (below float32 resolution), recall flags identical on
+    >= 99.9 % of the users."""
+    import torch
+    from oracle import poi_oracle as O
+    from poi_amd import data as pdata
+    pa, ds, tab, make = setup
+    m = make()
+    m.ctx.set_batch_cap(64.0)
+    try:
+        order = np.random.default_rng(1).permutation(ds.n_user).astype(np.int32)
+        for b0 in range(0, ds.n_user, 12500):
+            m.train_batch(order[b0:b0 + 12500], sync=False)
+    finally:
+        m.ctx.set_batch_cap(1.0)
+    m.update_trained_items(); m.update_trained_dists()
+    hts, sts = m.predict_device(np.arange(ds.n_user, dtype=np.int32))
+    m.update_trained_users(hts)
+    n, K = 2048, 20
+    ids = np.arange(n, dtype=np.int32)
+    users64 = hts[:n].double().cpu().numpy()
+    items64 = m.trained_items.t.double().cpu().numpy()          # (n_item + 1, D): score_all drops the padding row
+    sts64 = sts[:n].double().cpu().numpy()
+    wd = float(m.wd.get_value())
+    tes = np.asarray(tab.tes_p).reshape(-1)[:n]
+    lens = np.diff(tab.off.astype(np.int64))[:n]
+    last = np.asarray(tab.p)[tab.off[:n].astype(np.int64) + lens - 1]      # last train POI of every user
+
+    def compare(idx, with_dist):
+        """-> (identical lists, identical recall flags) per user; every differing position must be a near-tie in the oracle's float64 scores"""
+        same = np.zeros(n, bool); rec_same = np.ones(n, bool)
+        for c0 in range(0, n, 256):
+            sl = slice(c0, c0 + 256)
+            prob = None
+            if with_dist:
+                prob = np.empty((256, ds.n_item))
+                for r, u in enumerate(range(c0, c0 + 256)):
+                    b = pdata.cal_dis_vec(ds.coords[last[u], 0], ds.coords[last[u], 1], ds.coords[:, 0], ds.coords[:, 1], ds.dd, ds.dist_num)
+                    prob[r] = np.where(b < ds.dist_num, sts64[u][np.minimum(b, ds.dist_num)], 0.0)
+            sc = O.score_all(users64[sl], items64, wd, prob)
+            cand = np.argpartition(-sc, K + 8, axis=1)[:, :K + 8]            # the oracle's top-K rule on the K + 8 best columns (they contain the top K)
+            exp = np.take_along_axis(cand, O.topk_desc(np.take_along_axis(sc, cand, axis=1), K), axis=1)
+            same[sl] = (idx[sl] == exp).all(axis=1)
+            for k in (5, 10, 15, 20):
+                rec_same[sl] &= (idx[sl][:, :k] == tes[sl, None]).any(axis=1) == (exp[:, :k] == tes[sl, None]).any(axis=1)
+            for r in np.nonzero(~same[sl])[0]:
+                pos = np.nonzero(idx[c0 + r] != exp[r])[0]
+                d = np.abs(sc[r][idx[c0 + r][pos]] - sc[r][exp[r][pos]]).max()
+                assert d < 1e-6 * np.abs(sc[r][exp[r]]).max(), "user %d: lists differ where the float64 scores are %.2e apart" % (c0 + r, d)
+        return same, rec_same
+
+    for with_dist in (False, True):
+        if with_dist:
+            m.update_trained_sus(sts)
+        idx = m.compute_sub_topk(ids, K).cpu().numpy().astype(np.int64)
+        same, rec_same = compare(idx, with_dist)
+        print("rank agreement vs float64 (distance term %s): identical top-20 lists %.4f, identical recall@{5,10,15,20} %.4f" % (with_dist, same.mean(), rec_same.mean()))
+        assert same.mean() >= 0.995 and rec_same.mean() >= 0.999
+
+
 SP_NAMES = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
 
 

@@ -207,12 +207,46 @@ def test_predict_and_scores_parity(pa):
     users64 = allh.astype(np.float64)
     exp = O.score_all(users64[ids], P["lt"], P["wd"], prob.astype(np.float32).astype(np.float64)[ids])
     assert_close(sc, exp, "scores")
-    # AUC preference flags: bit-exact away from zero margins
+    # AUC preference flags: bit-exact on EVERY margin (the device sums the exact float64 products: misc.hip auc_kernel) - the small ones are
+    # counted, not skipped
     flags = model.compute_sub_auc_preference(ids)
     eflags = O.auc_preference(users64[ids], P["lt"], T["test"][0][ids], T["test"][2][ids], T["test"][1][ids])
-    margins = np.einsum("nd,nld->nl", users64[ids], P["lt"][T["test"][0][ids]] - P["lt"][T["test"][2][ids]])
-    safe = np.abs(margins) > 1e-4
-    assert np.array_equal(flags[safe], eflags[safe])
+    assert np.array_equal(flags, eflags)
+
+
+def test_auc_flags_bit_exact_on_tiny_margins(pa):
+    """compute_sub_auc_preference (public/GRU.py:98-110) where a float32 margin has no reliable sign: every user's negative test POI is its
+    positive one with ONE coordinate moved by one float32 ulp - margins of ~1e-8 x |u_j|, some exactly zero.  The device sums the exact
+    float64 products (misc.hip auc_kernel): flags == the float64 oracle's on EVERY margin; the tiny ones are counted, not skipped."""
+    T = toy_problem(77, n_user=400, n_item=900, n_dist=23, dim=64, len_max=8)
+    P = spatial_params(77, T)
+    rng = np.random.default_rng(5)
+    T["test"][0][:, 0] = rng.permutation(900)[:400]                      # distinct positives, negatives = their perturbed copies in fresh rows
+    T["test"][2][:, 0] = (T["test"][0][:, 0] + 1 + rng.integers(0, 3, 400)) % 900
+    used = set(T["test"][0][:, 0].tolist())
+    lt = np.asarray(P["lt"], np.float32)
+    for u in range(400):
+        p_, q_ = int(T["test"][0][u, 0]), int(T["test"][2][u, 0])
+        if q_ in used:
+            continue                                                        # (a row that is someone's positive keeps its values: ordinary margin)
+        lt[q_] = lt[p_]
+        j = int(rng.integers(0, 64))
+        if u % 7:                                                           # every seventh pair stays identical: margin exactly 0 -> flag 0
+            lt[q_, j] = np.nextafter(lt[q_, j], np.float32(np.inf if u % 2 else -np.inf))
+    P["lt"] = lt.astype(np.float64)
+    model = _spatial_model(pa, T, P)
+    model.update_trained_items(); model.update_trained_dists()
+    ids = np.arange(400, dtype=np.int32)
+    allh, _ = model.predict(ids)
+    model.update_trained_users(allh)
+    flags = model.compute_sub_auc_preference(ids)
+    users64 = allh.astype(np.float64)
+    eflags = O.auc_preference(users64, P["lt"], T["test"][0], T["test"][2], T["test"][1])
+    margins = np.einsum("nd,nld->nl", users64, P["lt"][T["test"][0]] - P["lt"][T["test"][2]])
+    tiny = np.abs(margins) <= 1e-4
+    assert tiny.sum() > 200 and (margins == 0).sum() > 10, (int(tiny.sum()), int((margins == 0).sum()))
+    assert np.array_equal(flags, eflags), "%d of %d flags differ (%d tiny margins)" % ((flags != eflags).sum(), flags.size, tiny.sum())
+    assert 0 < flags[tiny].sum() < tiny.sum()                              # both signs occur among the tiny margins
 
 
 def test_gru_predict_parity(pa):

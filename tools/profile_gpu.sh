@@ -13,5 +13,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/fetch -o f -- $CMD > $O
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
   -f csv -d $OUT/sq -o s -- $CMD > $OUT/sq.log 2>&1
+# calibration: pure-MFMA loops under the same SQ counter set (what MFMA_BUSY/BUSY reads at 100 % matrix-pipe issue)
+[ -x tools/micro/mfma_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_calib.hip -o tools/micro/mfma_calib > $OUT/calib_build.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
+  -f csv -d $OUT/calib -o c -- tools/micro/mfma_calib > $OUT/calib.log 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls -R $OUT | head -30
