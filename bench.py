@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--quality-seconds", type=float, default=3.0, help="training wall time of the batched modes in the quality block")
     ap.add_argument("--reference-seconds", type=float, default=15.0, help="training wall time of the reference schedule (one user per step)")
+    ap.add_argument("--no-bpr", action="store_true", help="skip the secondary_bpr block (BPR-MF step at the gowalla shape)")
     ap.add_argument("--no-projection", action="store_true", help="skip the multi_gpu.projection block (N = 2 / 4 / 8 shards emulated on this GPU)")
     ap.add_argument("--emulate-world", type=int, default=0, help="tuning aid: train only rank 0's shard of an N-way split on one GPU")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -794,6 +795,42 @@ def main():
                         "and epoch as the one-GPU run (learns like it, DESIGN.md section 7), throughput = launches of ~--batch-users users")
         multi["projection"] = proj
 
+    # ---- secondary_bpr: the BPR-MF step (flag 0: OboBpr.bpr_train, public/BPR.py:201-241) - the one piece of the path that IS a pure gather / scatter:
+    # every (user, positive, negative) triple of an epoch (prog_bpr_gru_spatial.py:240-244), snapshot mode (sorted, no float atomics: bitwise reproducible)
+    secondary_bpr = None
+    if solo and not a.no_bpr and a.shape == "gowalla":
+        mb = poi_amd.models.OboBpr(train=tab, test=None, alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=D, n_hidden=D, device=dev, seed=7)
+        ctx.set_batch_cap(a.batch_cap)
+        bu, bp, bq = mb.epoch_triples()
+        nt = int(bu.numel())
+        bytes_triple = 6.0 * D * 4 + 12.0      # three rows read, three rows written, three int32
+        secondary_bpr = {"workload": "BPR-MF step over the %d (user, positive, negative) triples of one epoch of the gowalla shape, dim %d, float32 tables" % (nt, D),
+                         "bytes_per_triple_survey_8d": bytes_triple, "launches": {}}
+        for Bt, mode in ((nt, "snapshot"), (262144, "snapshot"), (nt, "hogwild")):
+            def bpr_epoch():
+                for b0 in range(0, nt, Bt):
+                    mb.train_batch(bu[b0:b0 + Bt], bp[b0:b0 + Bt], bq[b0:b0 + Bt], mode=mode, sync=False)
+            for _ in range(3):
+                bpr_epoch()
+            torch.cuda.synchronize(dev); t0 = time.perf_counter()
+            for _ in range(20):
+                bpr_epoch()
+            torch.cuda.synchronize(dev); tb = (time.perf_counter() - t0) / 20
+            ctx.timing(True)
+            for _ in range(4):
+                bpr_epoch()
+            ktb = {k: ctx.timing_get(k) for k in ("bpr_sort", "bpr_users", "bpr_items", "bpr_hogwild")}
+            ctx.timing(False)
+            secondary_bpr["launches"]["%s, %d triples per launch" % (mode, Bt)] = {
+                "ms_per_epoch": 1e3 * tb, "triples_per_s": nt / tb,
+                "roofline": {"bound": "hbm", "achieved": nt * bytes_triple / tb / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nt * bytes_triple / tb / 1e9 / PEAK_HBM_GBS},
+                "regions_us_per_launch": {k: 1e3 * v[0] / max(v[1], 1) for k, v in ktb.items() if v[1]}}
+        secondary_bpr["note"] = ("snapshot = every triple at the launch-entry values, rows combined by the capped-sum rule, 3 n table touches sorted by row and summed in a fixed "
+                                 "order (csrc/bpr.hip: no float atomics, bitwise reproducible - tests/test_gpu_bpr.py); hogwild = the racy in-place kernel, for scale.  The "
+                                 "tables (77 MB) sit in the 256 MB cache behind L2: a fraction above 1 is possible and says so")
+        secondary_bpr["finite"] = bool(torch.isfinite(mb.lt.t).all() and torch.isfinite(mb.ux.t).all())
+        del mb
+
     # ---- secondary_dd25: the reference's other spatial configuration (dd = 25 m: 1520 bins, public/GRU_Spatial.py:247), training only --------
     secondary_dd25 = None
     if solo and not a.no_secondary and a.shape == "gowalla" and a.dd == 200.0:
@@ -897,7 +934,7 @@ def main():
                                      "matrix peak; te_wgrad / te_head / te_gemm_dx use the f32 MFMA",
                        "s_rows_per_step": rho},
             "timed_window_s": dt,
-            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_dd25": secondary_dd25, "launch_sweep": launch_sweep, "secondary_x1": secondary_x1,
+            "kernels": kernels, "quality": quality, "multi_gpu": multi, "secondary": secondary, "secondary_dd25": secondary_dd25, "launch_sweep": launch_sweep, "secondary_x1": secondary_x1, "secondary_bpr": secondary_bpr,
             "train_step_tflops": executed_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "train_step_tflops_reference_formulation": total_flops / (train_kernel_ms * 1e-3) / 1e12 if train_kernel_ms > 0 else None,
             "reference_schedule": reference_schedule, "eval": eval_detail, "roofline_gather_scatter": hbm,
@@ -919,6 +956,8 @@ def main():
             "time_to_reference_recall_s": quality and {k: (v.get("seconds") if isinstance(v, dict) else v) for k, v in quality["time_to_recall"].items() if k.startswith("B=")},
             "x1_train_seq_per_s": secondary_x1 and secondary_x1.get("train_seq_per_s"), "x1_eval_users_per_s": secondary_x1 and secondary_x1.get("eval_users_per_s"),
             "dd25_1520_bins_train_seq_per_s": secondary_dd25 and secondary_dd25["train_seq_per_s"],
+            "bpr_triples_per_s": secondary_bpr and max(v["triples_per_s"] for k, v in secondary_bpr["launches"].items() if k.startswith("snapshot")),
+            "bpr_snapshot_hbm_frac": secondary_bpr and max(v["roofline"]["frac"] for k, v in secondary_bpr["launches"].items() if k.startswith("snapshot")),
             "cpu_1core_seq_per_s": cpu and cpu["value"], "cpu_allcores_seq_per_s": cpu and cpu["all_cores"] and cpu["all_cores"]["value"],
         }
         print(json.dumps(out))

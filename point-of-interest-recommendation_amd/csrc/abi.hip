@@ -731,9 +731,11 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
                  const int32_t* uidx, const int32_t* p, const int32_t* q, int32_t n,
                  float alpha, float lambda, float* loss_out, int mode, void* stream) {
   if (!c || !ux || !lt || !uidx || !p || !q || !loss_out) return fail(c, POI_EINVAL, "poi_bpr_step: NULL argument");
-  if (is_f16(c, lt) || is_f16(c, ux)) return fail(c, POI_ENOTSUP, "BPR-MF supports float32 tables only");
-  if (dim <= 0 || dim % 4 != 0) return fail(c, POI_ENOTSUP, "dim must be a positive multiple of 4 (got %d)", dim);
+  if (is_f16(c, ux)) return fail(c, POI_ENOTSUP, "BPR-MF keeps the user table in float32 (a half POI table is supported in snapshot mode)");
+  if (is_f16(c, lt) && mode != POI_BPR_SNAPSHOT) return fail(c, POI_ENOTSUP, "a half POI table needs POI_BPR_SNAPSHOT");
+  if (dim <= 0 || dim % 4 != 0 || dim > 1024) return fail(c, POI_ENOTSUP, "dim must be a multiple of 4 in [4, 1024] (got %d)", dim);
   if (n < 0 || n_user <= 0 || n_item <= 0) return fail(c, POI_EINVAL, "bad sizes");
+  if ((int64_t)n * 3 >= (int64_t)1 << 31) return fail(c, POI_ENOTSUP, "at most 2^31 / 3 triples per launch");
   if (mode != POI_BPR_SNAPSHOT && mode != POI_BPR_HOGWILD) return fail(c, POI_EINVAL, "unknown mode %d", mode);
   if (c->batch_cap == 0.0f) return fail(c, POI_ENOTSUP, "the mini-batch rule (batch cap 0) applies to poi_gru_step / poi_spatial_step only");
   if (n == 0) return POI_OK;
@@ -742,16 +744,29 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
   poi::BprArgs A;
   memset(&A, 0, sizeof A);
   A.ux = ux; A.lt = lt; A.n_user = n_user; A.n_item = n_item; A.dim = dim;
+  A.lt_f16 = is_f16(c, lt);
+  A.sr_salt = (c->f16_rounding && A.lt_f16) ? (++c->sr_counter) * 0x9E3779B1u | 1u : 0u;
   A.uidx = uidx; A.p = p; A.q = q; A.n = n; A.alpha = alpha; A.lambda = lambda; A.loss = loss_out; A.bcap = c->batch_cap;
   if (mode == POI_BPR_SNAPSHOT) {
+    // workspace: the 3 n touches' sort buffers, per-triple coefficients, per-window partial sums; the shadow user table (grow-only, ctx-owned)
     int rc;
+    size_t ni = 0, nf = 0;
+    poi::bpr_ws_sizes(n, dim, &ni, &nf);
     if ((rc = ensure(c, c->g_ux, sizeof(float) * (size_t)n_user * dim, st))) return rc;
-    if ((rc = ensure(c, c->cnt_ux, sizeof(int) * (size_t)n_user, st))) return rc;
-    if ((rc = ensure(c, c->g_blt, sizeof(float) * (size_t)(n_item + 1) * dim, st))) return rc;
-    if ((rc = ensure(c, c->cnt_blt, sizeof(int) * (size_t)(n_item + 1), st))) return rc;
-    A.g_ux = (float*)c->g_ux.p; A.cnt_ux = (int*)c->cnt_ux.p; A.g_lt = (float*)c->g_blt.p; A.cnt_lt = (int*)c->cnt_blt.p;
+    if ((rc = ensure(c, c->g_blt, sizeof(int) * ni + sizeof(float) * nf + 256, st))) return rc;
+    A.shadow = (float*)c->g_ux.p;
+    const size_t chunks = (size_t)(n + 63) / 64 + (size_t)(2 * (size_t)n + 63) / 64 + 2, per = 3 * (size_t)n + 64;
+    int* ip = (int*)c->g_blt.p;
+    A.keys0 = ip; A.keys1 = ip + per; A.vals0 = ip + 2 * per; A.vals1 = ip + 3 * per; ip += 4 * per;
+    A.hist = ip; ip += RS_HIST_INTS + RS_MAXBIN;
+    A.cnt = ip; ip += 64;
+    A.meta = (int4*)ip; ip += 4 * chunks;
+    float* fp = (float*)ip;
+    A.g = fp; fp += ((size_t)n + 64 + 3) & ~(size_t)3;      // (lead / trail rows are read as float4)
+    A.lead = fp; fp += chunks * (size_t)dim;
+    A.trail = fp;
   }
-  HIPCHK(c, poi::launch_bpr(A, mode, st, &c->tm));
+  HIPCHK(c, poi::launch_bpr(A, mode, c->num_cu, st, &c->tm));
   return POI_OK;
 }
 

@@ -298,17 +298,24 @@ hipError_t launch_carnn_score(const float* users, const float* items, const floa
 
 // BPR-MF
 struct BprArgs {
-  float *ux, *lt;
+  float* ux; void* lt;    // lt: float32, or IEEE half when lt_f16 (float32 arithmetic; config X's table storage)
+  int lt_f16; unsigned sr_salt;      // != 0: stochastic rounding of the half write-back (poi_ctx_set_f16_rounding)
   int n_user, n_item, dim;
   const int *uidx, *p, *q;
   int n;
   float alpha, lambda;
   float* loss;
-  float *g_ux, *g_lt;
-  int *cnt_ux, *cnt_lt;   // touches per row in this launch (== multiplicity == distinct triples)
   float bcap;             // batch rule cap (see SeqArgs)
+  // snapshot mode (bpr.hip): 3 n table touches sorted by row
+  int *keys0, *keys1, *vals0, *vals1, *hist, *cnt;
+  const int *ks, *vs;     // sorted keys / touch ids (set by launch_bpr)
+  int4* meta;             // per 64-touch window: {touches of its opening run, that run goes on, touches of its closing run, its row}
+  float *g;               // per triple: d loss / d u
+  float *shadow;          // (n_user, D): new user rows until the POI pass has read the entry values
+  float *lead, *trail;    // per window: partial sum of its opening / closing run
 };
-hipError_t launch_bpr(const BprArgs& A, int mode, hipStream_t st, Timing* tm);
+hipError_t launch_bpr(BprArgs& A, int mode, int num_cu, hipStream_t st, Timing* tm);
+void bpr_ws_sizes(int n, int dim, size_t* n_int, size_t* n_float);
 
 // scoring / top-K
 struct ScoreArgs {

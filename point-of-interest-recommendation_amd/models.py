@@ -836,19 +836,33 @@ class OboCARNN(GruBasic):
 class MfBasic(_Base):
     """public/BPR.py:28-134."""
 
-    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None):
+    def __init__(self, train, test, alpha_lambda, n_user, n_item, n_in, n_hidden, device="cuda:0", init=None, seed=None, table_dtype="f32"):
+        """table_dtype="f16": the POI table `lt` and its evaluation snapshot are STORED as IEEE half (float32 arithmetic, snapshot-mode steps only)."""
         self._setup(device, alpha_lambda)
         self.n_user, self.n_item, self.dim = int(n_user), int(n_item), int(n_in)
         self.kdim = self.dim
+        if table_dtype not in ("f32", "f16"):
+            raise ValueError("table_dtype must be 'f32' or 'f16'")
+        self.table_dtype = table_dtype
         self._load_tables(train, test)
         rng = np.random.default_rng(seed) if seed is not None else np.random
         u = lambda *s: rng.uniform(-0.5, 0.5, s)
         init = init or {}
         g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
+        tab = (lambda a: self._dev(a).to(torch.float16)) if table_dtype == "f16" else self._dev
         self.ux = Shared(self._dev(g("ux", lambda: u(n_user, self.dim))))                  # BPR.py:51
-        self.lt = Shared(self._dev(g("lt", lambda: u(n_item + 1, self.dim))))              # :52
-        self.trained_items = Shared(self._dev(u(n_item + 1, self.dim)))
+        self.lt = Shared(tab(g("lt", lambda: u(n_item + 1, self.dim))))                    # :52
+        self.trained_items = Shared(tab(u(n_item + 1, self.dim)))
         self.trained_users = Shared(self._dev(u(n_user, self.dim)))
+        if table_dtype == "f16":
+            self.ctx.register_f16(self.lt.t); self.ctx.register_f16(self.trained_items.t)
+
+    def __del__(self):
+        try:
+            if getattr(self, "table_dtype", "f32") == "f16":
+                self.ctx.unregister_f16(self.lt.t); self.ctx.unregister_f16(self.trained_items.t)
+        except Exception:
+            pass
 
     def update_trained_users(self):
         """public/BPR.py:71-74 (no argument: copies ux)."""

@@ -1,0 +1,111 @@
+"""-m gpu: the BPR-MF step (OboBpr.bpr_train, public/BPR.py:201-241) in SNAPSHOT mode on launches whose triples SHARE rows - the sorted,
+atomic-free path of csrc/bpr.hip (round 5) - against the float64 oracle's per-triple step (oracle.bpr_step) combined by the batch rule of
+include/poi_hip.h: a row touched by k triples moves by min(k, cap) / k of the sum of their reference updates.  Hot users and hot POIs give runs
+longer than one 64-touch window (the opening / closing partial sums and their fixed-order combination), dims 32 .. 320 cover every lane
+layout; identical launches must give bitwise identical tables; a half POI table == half(oracle from the half-rounded table) to one ulp."""
+import numpy as np
+import pytest
+
+from oracle import poi_oracle as O
+from tests.gpu_util import assert_close, assert_step_close, round_f32, toy_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import torch
+    assert torch.cuda.is_available()
+    import poi_amd
+    return poi_amd
+
+
+def _triples(seed, n, n_user, n_item, hot_users, hot_items):
+    rng = np.random.default_rng(seed)
+    u = np.where(rng.random(n) < 0.5, rng.integers(0, hot_users, n), rng.integers(0, n_user, n))
+    p = np.where(rng.random(n) < 0.5, rng.integers(0, hot_items, n), rng.integers(0, n_item, n))
+    q = rng.integers(0, n_item, n)
+    q = np.where(q == p, (q + 1) % n_item, q)
+    return u.astype(np.int32), p.astype(np.int32), q.astype(np.int32)
+
+
+def _expected(P, u, p, q, alpha, lam, cap):
+    """batch rule on top of the oracle's single-triple step, every triple at the entry values"""
+    acc = {k: np.zeros_like(P[k]) for k in ("ux", "lt")}
+    cnt = {k: np.zeros(P[k].shape[0]) for k in ("ux", "lt")}
+    losses = []
+    for ui, pi, qi in zip(u, p, q):
+        Pn, l = O.bpr_step(P, int(ui), int(pi), int(qi), alpha, lam)
+        losses.append(l)
+        for name, rows in (("ux", [ui]), ("lt", [pi, qi])):
+            for r in rows:
+                acc[name][r] += Pn[name][r] - P[name][r]; cnt[name][r] += 1
+    out = {}
+    for name in ("ux", "lt"):
+        k = np.maximum(cnt[name], 1)
+        out[name] = P[name] + acc[name] * (np.minimum(k, cap) / k)[:, None]
+    return out, np.asarray(losses)
+
+
+@pytest.mark.parametrize("dim,cap", [(32, 1.0), (64, 8.0), (128, 64.0), (256, 8.0), (320, 1e9), (20, 4.0)])
+def test_bpr_snapshot_with_shared_rows_matches_the_batch_rule(pa, dim, cap):
+    n_user, n_item, n = 120, 300, 3000
+    T = toy_problem(50, n_user=n_user, n_item=n_item, dim=dim)
+    P = round_f32(O.init_bpr_params(np.random.default_rng(7), n_user, n_item, dim))
+    u, p, q = _triples(dim, n, n_user, n_item, hot_users=3, hot_items=4)      # ~500 touches on a hot user, ~400 on a hot POI: runs over many windows
+    exp, el = _expected(P, u, p, q, 0.01, 0.001, cap)
+    m = pa.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P)
+    m.ctx.set_batch_cap(cap)
+    try:
+        got_l = m.train_batch(u, p, q)
+    finally:
+        m.ctx.set_batch_cap(1.0)
+    assert_close(got_l, el, "losses")
+    assert_step_close({k: getattr(m, k).get_value() for k in ("ux", "lt")}, exp, P, ("ux", "lt"), "dim %d cap %g" % (dim, cap))
+    # rows no triple touches are bit-identical
+    lt = m.lt.get_value()
+    untouched = np.setdiff1d(np.arange(n_item + 1), np.concatenate((p, q)))
+    assert np.array_equal(lt[untouched], np.asarray(P["lt"], np.float32)[untouched])
+
+
+def test_bpr_snapshot_is_bitwise_reproducible_and_order_defined(pa):
+    import torch
+    dim, n_user, n_item, n = 128, 500, 2000, 40000
+    T = toy_problem(51, n_user=n_user, n_item=n_item, dim=dim)
+    P = round_f32(O.init_bpr_params(np.random.default_rng(8), n_user, n_item, dim))
+    u, p, q = _triples(3, n, n_user, n_item, hot_users=5, hot_items=6)
+    runs = []
+    for _ in range(3):
+        m = pa.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P)
+        m.ctx.set_batch_cap(64.0)
+        try:
+            l = m.train_batch(u, p, q, sync=False)
+            m.train_batch(u, p, q, sync=False)      # (a second launch on the moved tables: the workspace is reused)
+        finally:
+            m.ctx.set_batch_cap(1.0)
+        runs.append((m.ux.t.clone(), m.lt.t.clone(), l.clone()))
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2])
+    assert torch.isfinite(runs[0][0]).all() and torch.isfinite(runs[0][1]).all()
+
+
+def test_bpr_snapshot_half_poi_table(pa):
+    dim, n_user, n_item, n = 64, 60, 200, 1500
+    T = toy_problem(52, n_user=n_user, n_item=n_item, dim=dim)
+    P = round_f32(O.init_bpr_params(np.random.default_rng(9), n_user, n_item, dim))
+    P["lt"] = np.asarray(P["lt"], np.float16).astype(np.float64)      # the stored values ARE halves
+    u, p, q = _triples(4, n, n_user, n_item, hot_users=2, hot_items=3)
+    exp, el = _expected(P, u, p, q, 0.01, 0.001, 8.0)
+    m = pa.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P,
+                         table_dtype="f16")
+    m.ctx.set_batch_cap(8.0)
+    try:
+        got_l = m.train_batch(u, p, q)
+    finally:
+        m.ctx.set_batch_cap(1.0)
+    assert_close(got_l, el, "losses")
+    assert_close(m.ux.get_value(), exp["ux"], "ux")
+    lt = m.lt.get_value().astype(np.float64)
+    want = np.asarray(exp["lt"], np.float16).astype(np.float64)
+    ulp = np.spacing(np.abs(want).astype(np.float16)).astype(np.float64)
+    assert (np.abs(lt - want) <= ulp).all() and (lt == want).mean() > 0.97

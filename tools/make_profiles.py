@@ -84,7 +84,10 @@ REGION = {"te_gather": ["te_gather_kernel"], "te_gemm_ax": ["te_gemm_nt_kernel<t
           "dense_apply": ["dense_apply_kernel"], "te_finalize": ["te_finalize_kernel", "te_parts_kernel"],
           "te_prep": ["te_len_kernel", "te_scan_kernel", "te_rowmap_kernel", "te_pack_kernel", "te_transpose_kernel", "rs_hist_kernel",
                       "rs_digit_scan_kernel", "rs_scatter_kernel", "te_segment_kernel"],
-          "score_topk": ["score_kernel_packed", "score_filter_kernel", "score_rescore_kernel", "sf_select_kernel", "score_merge_kernel"], "te_predict": []}
+          "score_topk": ["score_kernel_packed", "score_filter_kernel", "score_rescore_kernel", "sf_select_kernel", "score_merge_kernel"], "te_predict": [],
+          # secondary_bpr block of bench.py (BPR-MF step, csrc/bpr.hip; its radix-sort passes are the rs_* kernels listed under te_prep)
+          "bpr_users": ["bpr_keys_kernel", "bpr_chunk_kernel<0", "bpr_span_kernel<0"], "bpr_items": ["bpr_chunk_kernel<1", "bpr_span_kernel<1", "bpr_commit_kernel"],
+          "bpr_hogwild": ["bpr_hogwild_kernel"]}
 out = {"config": "bench.py default (gowalla shape, batch_users 12500)",
        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                "(gfx950 reports half of wide coalesced reads); WRITE_SIZE calibrated with tools/micro/write_calib.hip (exact for the 64-byte-segment pattern of the recurrent kernels); counter unit KB (x 1024); per launch of the TIMED REGION (sum over its kernels), each pass normalised by its own launch count",
