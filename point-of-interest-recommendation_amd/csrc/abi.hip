@@ -51,11 +51,13 @@ struct poi_ctx {
   int one_path = 1;         // launches of ONE sequence (Distance2Pre, plain GRU) take the five-kernel path (te_one_*); POI_TE_ONE=0 -> the batched pipeline
   int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
+  int xlaunch = 0;          // launch id of the exact forward's non-finite-input flag (TeArgs.xflag)
   int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores / float64 MFMA + float64 gates) for dims 64 / 128 / 256; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
   int xcomp = 1;            // exact forward table over the step-input POIs only; POI_TE_XCOMP=0: every row of the POI table (A/B)
   int xcomp_min = 1536;     // ... for launches of at least this many sequences (below: one row per step - the table form of te_rec_fwdx costs 0.6 us more per step of the latency chain than the ranking saves in te_gemmx; 1300 / 1563 / 2048 / 3125 users: +9 / -6 / -38 / -45 us); POI_TE_XCOMP_MIN
   int head3 = 1;            // training head on split products for <= 256 bins (te_head3); POI_TE_HEAD3
   int xrec1_max = 512;      // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
+  DevBuf xflag;             // launch id of the last launch whose operands held a NaN / inf (TeArgs.xflag)
   DevBuf xw, xg;            // its digit fragments, scales and per-bin table | per-step pre-activations or the forward table (float64)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
   // A launch is captured the second time its key (every pointer / size / scalar the kernels receive) is seen; the caller's uidx /
@@ -189,7 +191,7 @@ static void drop_graphs(poi_ctx* c) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->xc, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota, &c->xw, &c->xg,
+  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->xc, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota, &c->xw, &c->xg, &c->xflag,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
                    &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag, &c->pre_idx, &c->pre_sc, &c->users_pk16, &c->ubound, &c->ugeo};
   (void)hipDeviceSynchronize();
@@ -294,7 +296,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   }
   if (A.xfwd) {
     const size_t frag = (size_t)3 * D * D * 5, nz = (size_t)(spatial ? n_dist + 1 : 1) * 3 * D;      // five int8 digit planes per weight
-    if ((rc = ensure(c, c->xw, 2 * frag + 64 + sizeof(double) * (6 * (size_t)D + nz + 8), st))) return rc;
+    if ((rc = ensure(c, c->xw, 2 * frag + 64 + sizeof(double) * (6 * (size_t)D + nz + 8) + 64, st))) return rc;
     A.xcomp = (A.xft && want_xc) ? 1 : 0;
     const size_t xrows = A.xcomp ? std::min((size_t)P->n_item + 1, Tcap) + 2 : A.xft ? (size_t)P->n_item + 1 + 2 : Tcap;
     if ((rc = ensure(c, c->xg, sizeof(double) * xrows * 3 * D, st))) return rc;
@@ -302,6 +304,10 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.xWh8 = (uint4*)xp; A.xUi8 = (uint4*)(xp + ((frag + 15) & ~(size_t)15));
     double* xd = (double*)(xp + 2 * ((frag + 15) & ~(size_t)15));
     A.xWhS = xd; A.xUiS = xd + 3 * D; A.ztabx = xd + 6 * D;
+    // (its own allocation: the address must not move with the dim / bin count of the launch - whatever an earlier launch left at a recycled
+    // offset would be read as a launch id; zero-filled at allocation, ids start at 1)
+    if ((rc = ensure(c, c->xflag, 64, st))) return rc;
+    A.xflag = (int*)c->xflag.p; A.xlaunch = ++c->xlaunch;
     if (A.xft) A.ptabx = (double*)c->xg.p; else A.gx = (double*)c->xg.p;
     A.x_rows_est = (int)(Tcap < (size_t)1 << 30 ? Tcap : (size_t)1 << 30);
     if (A.xcomp) {

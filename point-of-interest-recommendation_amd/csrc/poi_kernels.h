@@ -190,6 +190,7 @@ struct TeArgs {
   double *gx, *ptabx, *ztabx;         // (T + spare) x 3D per step | (n_item + 1 + spare) x 3D | (n_dist + 1) x 3D, gate-major columns (g D + unit)
   uint4 *xWh8, *xUi8; double *xWhS, *xUiS;      // digit fragments + row scales of wh (16x16x64 order) and of ui's POI half (32x32x32 order)
   int x_rows_est;                     // host-side bound of the packed row count (grid sizing of te_gemmx)
+  int* xflag; int xlaunch;            // != launch id: no non-finite weight / input row seen while this launch's operands were prepared (te_xfwd.hip x_flag_bad)
 };
 // entry code: packed-row index of the position (28 bits) + what the position contributes
 #define TE_ENT_ROW 0x0FFFFFFF

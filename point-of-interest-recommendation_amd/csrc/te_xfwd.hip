@@ -72,6 +72,15 @@ __device__ __forceinline__ double x_merge(int a0, int a1, int a2, int a3, int a4
     return __builtin_fma(t, 0x1p-8, (double)m01);
   }
 }
+// K = 256, digit-pair classes 0 .. 6 (te_gemmx<256>): 256 sum_w a_w 256^-w by Horner from the smallest class (exact up to 53 bits, then rounded at
+// 2^-53 of the running sum)
+__device__ __forceinline__ double x_merge7(int a0, int a1, int a2, int a3, int a4, int a5, int a6) {
+  double t = __builtin_fma((double)a6, 0x1p-8, (double)a5);
+  t = __builtin_fma(t, 0x1p-8, (double)a4);
+  t = __builtin_fma(t, 0x1p-8, (double)a3);
+  t = __builtin_fma(t, 0x1p-8, (double)a2);
+  return __builtin_fma(t, 0x1p-8, (double)((a0 << 8) + a1));
+}
 __device__ __forceinline__ double x_combine(const i32x4 (&acc)[XS], int r) { return x_merge<128>(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r]); }
 
 // float64 exp / sigmoid / tanh, branch-free (the gate math sits on the per-step chain): e^x = 2^m T[j] p(r) with n = rint(64 x / ln 2) =
@@ -94,14 +103,24 @@ __device__ __forceinline__ double x_rcp(double d) {       // v_rcp_f64 is good t
   return __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
 }
 // (the clamps: the reduction of x_exp needs |x| < 2^31 ln2 / 64.  v_max_f64 / v_min_f64 return the non-NaN operand: a NaN pre-activation -
-// diverged or NaN weights - would come out as a finite gate where the float64 reference propagates it.  x * 0 is 0 for every finite x and
-// NaN for a non-finite one: one FMA on the result hands NaN (and, stricter than the reference, +-inf) through.)
+// diverged or NaN weights - would come out as a finite gate where the float64 reference propagates it.  NANP: x * 0 is 0 for every finite x
+// and NaN for a non-finite one - one FMA on the result hands NaN (and, stricter than the reference, +-inf) through.  te_rec_fwdx sits at its
+// register limit and cannot keep x alive that long: there the launch is poisoned as a whole through TeArgs.xflag, see x_flag_bad.)
+template <bool NANP = false>
 __device__ __forceinline__ double x_sigmoid(double x, const double* __restrict__ T) {
-  return __builtin_fma(x, 0.0, x_rcp(1.0 + x_exp(-__builtin_fmin(__builtin_fmax(x, -700.0), 700.0), T)));
+  const double v = x_rcp(1.0 + x_exp(-__builtin_fmin(__builtin_fmax(x, -700.0), 700.0), T));
+  return NANP ? __builtin_fma(x, 0.0, v) : v;
 }
+template <bool NANP = false>
 __device__ __forceinline__ double x_tanh(double x, const double* __restrict__ T) {
-  return __builtin_fma(x, 0.0, __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * __builtin_fmin(__builtin_fmax(x, -350.0), 350.0), T)), 1.0));
+  const double v = __builtin_fma(-2.0, x_rcp(1.0 + x_exp(2.0 * __builtin_fmin(__builtin_fmax(x, -350.0), 350.0), T)), 1.0);
+  return NANP ? __builtin_fma(x, 0.0, v) : v;
 }
+// A non-finite weight or table row seen while the operands of a launch are prepared (te_xpack, te_xztab, te_gemmx: they scan every value
+// anyway): the launch id goes into TeArgs.xflag, and te_rec_fwdx starts every sequence of a flagged launch from h_0 = NaN - every hidden
+// state, loss and gradient of the launch is NaN, as in the float64 reference one dense SGD step later at the latest.  (No reset needed:
+// the id only grows.)
+__device__ __forceinline__ void x_flag_bad(const TeArgs& A) { if (A.xflag) atomicMax(A.xflag, A.xlaunch); }
 
 // -------------------------------------------------------------------------------------------------
 // te_xpack: rows of a float32 weight matrix -> digit planes in MFMA B-fragment order + the row scales 2^(e - 12)
@@ -112,7 +131,7 @@ __device__ __forceinline__ double x_tanh(double x, const double* __restrict__ T)
 // A and B fragments use the SAME (lane group, byte) -> k assignment, which is all the contraction needs.
 // inter: destination row n = 3 c + g is source row g (rows / 3) + c (the gate-interleaved columns of the forward table).
 // -------------------------------------------------------------------------------------------------
-struct XPackJob { const float* src; int ld, koff, rows, K, inter, frag32; unsigned char* dst; double* scale; };
+struct XPackJob { const float* src; int ld, koff, rows, K, inter, frag32; unsigned char* dst; double* scale; int* flag; int launch; };
 struct XPackJobs { XPackJob j[2]; int n; };
 
 __global__ __launch_bounds__(256) void te_xpack_kernel(XPackJobs J) {
@@ -122,12 +141,14 @@ __global__ __launch_bounds__(256) void te_xpack_kernel(XPackJobs J) {
     const int sr = j.inter ? (n % 3) * (j.rows / 3) + n / 3 : n;
     const float* src = j.src + (size_t)sr * j.ld + j.koff;
     float v[4], m = 0.f;
+    bool bad = false;      // a NaN / inf weight has no digits: the row's SCALE carries it into every product of the row (the float64 reference propagates it)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int k = lane + 64 * i; v[i] = k < j.K ? src[k] : 0.f; m = fmaxf(m, fabsf(v[i])); }
+    for (int i = 0; i < 4; ++i) { const int k = lane + 64 * i; v[i] = k < j.K ? src[k] : 0.f; m = fmaxf(m, fabsf(v[i])); bad |= !(fabsf(v[i]) <= 3.0e38f); }
     m = wave_max(m);
-    const int e = x_exponent(m);
+    bad = __any(bad);
+    const int e = bad ? 0 : x_exponent(m);
     const double sc = x_pow2(XQB - e);
-    if (lane == 0) j.scale[n] = x_pow2(e - 12);
+    if (lane == 0) { j.scale[n] = bad ? __longlong_as_double(0x7FF8000000000000ll) : x_pow2(e - 12); if (bad && j.flag) atomicMax(j.flag, j.launch); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = lane + 64 * i;
@@ -165,7 +186,9 @@ __global__ __launch_bounds__(768) void te_xztab_kernel(TeArgs A) {
       a0 = __builtin_fma((double)drow[k + 2], (double)uv.z, a0); a1 = __builtin_fma((double)drow[k + 3], (double)uv.w, a1);
     }
   }
-  A.ztabx[(size_t)b * 3 * D + n] = a0 + a1;
+  const double zv = a0 + a1;
+  A.ztabx[(size_t)b * 3 * D + n] = zv;
+  if (!(__builtin_fabs(zv) <= 1.0e300)) x_flag_bad(A);      // (bi / di / the distance half of ui hold a NaN or inf)
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -191,6 +214,7 @@ struct XGemmArgs {
   const uint4* B8; const double* Bs;        // digit fragments + scales of uiP (te_xpack, frag32)
   const double* ztabx; const int* zidx; int z_max;      // epilogue: + ztabx[min(zidx[r], z_max)] (null: nothing)
   double* C;
+  int* flag; int launch;                    // x_flag_bad: a non-finite input row poisons the launch
   int ncg;                                  // column groups per row tile (work items = row tiles x ncg)
 };
 
@@ -209,6 +233,10 @@ template <int D>
 __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void te_gemmx_kernel(XGemmArgs P) {
   constexpr int KB = D / 32, N = 3 * D, NT = N / 32, FR = KB * XS * 64;      // uint4 fragments per column tile
   constexpr int PT = (FR + 255) / 256;
+  // digit pairs (i, j) with i + j <= XW.  Dims <= 128: XW = 4, the products carry ~2^-39 of the row scales.  Dim 256 (config X): the reference's init
+  // makes the chain amplify a perturbation of the pre-activations ~10^6-fold over 50 positions (tests/test_gpu_dim256.py) - the classes 5 and 6 are
+  // kept as well (22 MFMAs per 32 k instead of 15): ~2^-55, the float64 rounding of the sum itself.
+  constexpr int XW = D <= 128 ? XS - 1 : XS + 1, NC = XW + 1;
   static_assert(D <= 256 && D % 32 == 0, "te_gemmx: int32 accumulators hold five digit pairs of K <= 256 terms");
   extern __shared__ __align__(16) uint4 xg_lds[];
   uint4 (*s_b)[FR] = reinterpret_cast<uint4 (*)[FR]>(xg_lds);   // two column tiles: tile j + 1 lands while tile j is multiplied
@@ -233,18 +261,21 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void te_gemmx_kernel(XGemm
       const int row = min(t * 128 + w * 32 + li, n_rows - 1);
       const size_t src = (size_t)(P.idx ? min((unsigned)P.idx[row], (unsigned)P.idx_max) : row) * D;
       float4 x[KB][4];
-      float m = 0.f;
+      unsigned mb = 0u;      // largest |x| as a BIT PATTERN (integer max: a NaN element - pattern above inf's - survives it, v_max_f32 would drop it)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           x[kb][q] = ld4t(P.tab, src + 32 * kb + 16 * h + 4 * q, P.f16);
-          m = fmaxf(fmaxf(m, fmaxf(fabsf(x[kb][q].x), fabsf(x[kb][q].y))), fmaxf(fabsf(x[kb][q].z), fabsf(x[kb][q].w)));
+          mb = max(max(mb, max(__float_as_uint(x[kb][q].x) & 0x7FFFFFFFu, __float_as_uint(x[kb][q].y) & 0x7FFFFFFFu)),
+                   max(__float_as_uint(x[kb][q].z) & 0x7FFFFFFFu, __float_as_uint(x[kb][q].w) & 0x7FFFFFFFu));
         }
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      const int e = x_exponent(m);
+      mb = max(mb, (unsigned)__shfl_xor((int)mb, 32, 64));
+      const bool bad = mb >= 0x7F800000u;      // a NaN / inf element: the row scale carries it into every product of the row
+      const int e = bad ? 0 : x_exponent(__uint_as_float(mb));
       const double sc = x_pow2(XQB - e);
-      if (h == 0) s_rs[w][li] = x_pow2(e);
+      if (h == 0) s_rs[w][li] = bad ? __longlong_as_double(0x7FF8000000000000ll) : x_pow2(e);
+      if (bad && P.flag) atomicMax(P.flag, P.launch);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         unsigned lo[16], hi[16];
@@ -269,9 +300,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void te_gemmx_kernel(XGemm
       x_lds_barrier();                                         // every wave's pieces are in; the other slot (tile j - 1) has been read; s_rs is visible
       if (j + 1 < j0 + tpg) request(j + 1, slot ^ 1);
       const uint4* cur = s_b[slot];
-      i32x16 acc[XS];
+      i32x16 acc[NC];
 #pragma unroll
-      for (int s = 0; s < XS; ++s)
+      for (int s = 0; s < NC; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[s][r] = 0;
 #pragma unroll
@@ -282,7 +313,8 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void te_gemmx_kernel(XGemm
 #pragma unroll
         for (int sa = 0; sa < XS; ++sa)
 #pragma unroll
-          for (int sb = 0; sb < XS - sa; ++sb) acc[sa + sb] = x_mfma32(a[kb][sa], b[sb], acc[sa + sb]);
+          for (int sb = 0; sb < XS; ++sb)
+            if (sa + sb <= XW) acc[sa + sb] = x_mfma32(a[kb][sa], b[sb], acc[sa + sb]);
       }
       const int col = j * 32 + li;
       const double cs = P.Bs[col];
@@ -295,7 +327,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void te_gemmx_kernel(XGemm
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = x_crow(r, lane), grow = t * 128 + w * 32 + rr;
-        const double v = x_merge<D>(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r]);
+        double v;
+        if constexpr (NC == 7) v = x_merge7(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r], acc[5][r], acc[6][r]);
+        else v = x_merge<D>(acc[0][r], acc[1][r], acc[2][r], acc[3][r], acc[4][r]);
         P.C[(size_t)min(grow, n_rows) * N + col] = __builtin_fma(v, s_rs[w][rr] * (cs * 0x1p-8), zadd[r]);      // (exactly 16 stores, last in the tile)
       }
     }
@@ -372,7 +406,9 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
   for (int q = 0; q < 16; ++q) ns_max = max(ns_max, s_ns[q]);
   const int rowb = s_r0[i], nsr = s_ns[i];
   const int Tsp = A.soff[A.n_seq];                   // spare packed row: finished sequences read / write it unconditionally
-  double hcur[4] = {0.0, 0.0, 0.0, 0.0};
+  // (a launch whose weights / input rows hold a NaN or inf - x_flag_bad - starts from h_0 = NaN: the digits of a state cannot carry it)
+  const double h_init = (A.xflag && *A.xflag == A.xlaunch) ? __longlong_as_double(0x7FF8000000000000ll) : 0.0;
+  double hcur[4] = {h_init, h_init, h_init, h_init};
   XG12 gc;                                           // pre-activations of the current step
   struct XG4 { double v[4]; };
   auto load3 = [&](XG12& o, const double* __restrict__ rowp) {
@@ -596,7 +632,7 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) a[o] = x_group_sum<8>(a[o]);
     {
-      const double v = x_sigmoid(x_pick4(a, sz & 3) + gzr, s_t64);
+      const double v = x_sigmoid<true>(x_pick4(a, sz & 3) + gzr, s_t64);
       const double rh = v * hs[jr];
       if (ownz) { if (isr) rhs[jr] = rh; else zs[jr] = v; }
       const bool st = ownz && isr;
@@ -616,7 +652,7 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) b[o] = x_group_sum<16>(b[o]);
     {
-      const double c = x_tanh(x_pick4(b, sc & 3) + gcc, s_t64);
+      const double c = x_tanh<true>(x_pick4(b, sc & 3) + gcc, s_t64);
       const double z = zs[jc], hp = hs[jc];
       const double hn = __builtin_fma(z, c - hp, hp);
       if (ownc) hs[jc] = hn;               // (the c phase reads rhs only; the lanes that share jc are in one wave)
@@ -768,8 +804,8 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwdd_kernel(TeArgs A) {
       float rv4[4], rh4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        zv[u][r] = x_sigmoid(azr[0][u][r] + gz[u].v[r], s_t64);
-        const double rv = x_sigmoid(azr[1][u][r] + gr[u].v[r], s_t64);
+        zv[u][r] = x_sigmoid<true>(azr[0][u][r] + gz[u].v[r], s_t64);
+        const double rv = x_sigmoid<true>(azr[1][u][r] + gr[u].v[r], s_t64);
         rh[r] = rv * hcur[u][r];
         rv4[r] = (float)rv; rh4[r] = (float)rh[r];
         rhT[(size_t)(ub[u] + r) * 16 + i] = rh[r];
@@ -787,7 +823,7 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwdd_kernel(TeArgs A) {
       float z4[4], c4[4], h4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double c = x_tanh(ac1[0][u][r] + gcc[u].v[r], s_t64);
+        const double c = x_tanh<true>(ac1[0][u][r] + gcc[u].v[r], s_t64);
         const double hn = on ? __builtin_fma(zv[u][r], c - hcur[u][r], hcur[u][r]) : hcur[u][r];
         hcur[u][r] = hn;
         z4[r] = (float)zv[u][r]; c4[r] = (float)c; h4[r] = (float)hn;
@@ -865,7 +901,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
     if constexpr (XRec<D>::F64) pack_wh(st);
     else {
       XPackJobs J;
-      J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
+      J.j[0] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS, A.xflag, A.xlaunch};
       J.n = 1;
       hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, 1), dim3(256), 0, st, J);
     }
@@ -875,8 +911,8 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   if (!A.predict && phase != 3) tm->begin("te_gemm_ax", st);
   if (phase != 4) {
     XPackJobs J;
-    J.j[0] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 0, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS};
-    J.j[1] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS};
+    J.j[0] = XPackJob{A.ui, A.xw, 0, 3 * D, D, 0, 1, reinterpret_cast<unsigned char*>(A.xUi8), A.xUiS, A.xflag, A.xlaunch};
+    J.j[1] = XPackJob{A.wh, D, 0, 3 * D, D, 0, 0, reinterpret_cast<unsigned char*>(A.xWh8), A.xWhS, A.xflag, A.xlaunch};
     J.n = XRec<D>::F64 ? 1 : 2;
     hipLaunchKernelGGL(te_xpack_kernel, dim3(3 * D / 4, J.n), dim3(256), 0, st, J);
     pack_wh(st);
@@ -884,6 +920,7 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   }
   if (phase != 3) {
     XGemmArgs P;
+    P.flag = A.xflag; P.launch = A.xlaunch;
     P.tab = A.lt; P.f16 = A.lt_f16; P.idx_max = A.n_item; P.B8 = A.xUi8; P.Bs = A.xUiS; P.z_max = A.spatial ? A.n_dist : 0;
     int rows_est;
     if (A.xft && A.xcomp) { P.idx = A.xlist; P.n_ptr = A.xcnt; P.ztabx = nullptr; P.zidx = nullptr; P.C = A.ptabx; rows_est = min(A.n_item + 1, A.x_rows_est * 2 / 5 + 1); }

@@ -15,7 +15,8 @@ len_max = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 cap = float(sys.argv[3]) if len(sys.argv) > 3 else 64.0
 dim = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 n_dist, n_item = 200, 4000
-T = toy_problem(4242, n_user=n_user, n_item=n_item, n_dist=n_dist, dim=dim, len_max=len_max, min_len=4)
+hot = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+T = toy_problem(4242, n_user=n_user, n_item=n_item, n_dist=n_dist, dim=dim, len_max=len_max, min_len=4, hot=hot)
 P0 = spatial_params(4243, T)
 lens = np.asarray(T["lens"])
 users = np.argsort(-lens, kind="stable").astype(np.int32)
