@@ -41,6 +41,7 @@ struct poi_ctx {
   DevBuf xc;                // exact forward over the step-input POIs only: rank tables + per-step table rows (TeArgs.xcomp)
   DevBuf pmark;             // per-POI regrouping: per lt row, S row + 1 of a step-input POI of this launch (te_passign; all-zero between launches)
   int ppoi = 1;             // POI_TE_PPOI=0 disables the regrouping (A/B)
+  int hot_bins = 1;         // te_psum also sums the DA rows of the most frequent distance bins (TeArgs.dhot); POI_TE_HOTBINS=0 / option "hot_bins"
   int early_bins = 1;       // distance-bin chain of the write-back starts next to te_gemm_dx on the side stream; POI_TE_EARLY_BINS=0: at the tail (A/B)
   int early_min = 1024;     // ... for launches of at least this many sequences (POI_TE_EARLY_MIN; 1300 .. 2000 users: -5 % per launch against the inline chain)
   DevBuf kc_dev;            // te_wgrad's K-chunk split, chosen on the device per launch
@@ -149,6 +150,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_SCORE_VARIANT")) { int v = atoi(e); if (v >= 0 && v <= 1) c->score_variant = v; }
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_EARLY_BINS")) c->early_bins = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_HOTBINS")) c->hot_bins = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_EARLY_MIN")) c->early_min = atoi(e);
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
@@ -261,13 +263,14 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const bool listed = sorted && (size_t)Rrows > 4 * Ncap;      // table much larger than the launch's footprint: touched-row list
   const size_t sin = sorted ? 7 * Ncap + (listed ? Ncap : 0) + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
   // per-bin tables (bintab): ztab + per-bin sums + d di sums, and (training) the sliced partial sums of DA
-  const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2;      // 64-entry chunks of the bins' entry segments
+  const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2 + (size_t)TE_HB * (size_t)(c->num_cu * 4);      // (+ the hot bins' per-workgroup partials: TeArgs.dhot)
+  A.npw = c->num_cu * 4;      // workgroups of te_psum: 96 registers x 384 threads - three or four of them fit a CU at a time      // 64-entry chunks of the bins' entry segments
   const size_t n_dsuper = n_dchunk / 32 + NBt + 2;
   const size_t bfl = A.bintab ? NBt * (size_t)(3 * D) * 2 + NBt * D + (sorted ? (n_dchunk + n_dsuper) * (size_t)(3 * D) : 0) + 64 : 0;
   const size_t n_prange = Tcap / 64 + 4;
   const size_t pfl = A.ppoi ? Tcap * (size_t)(3 * D) + 2 * n_prange * (size_t)(3 * D) + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl + pfl;
-  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 4 * NBt + 64 : 0) + NBt + 16 + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
+  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 4 * NBt + 64 : 0) + 3 * NBt + 48 + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
@@ -348,7 +351,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
     A.urow = listed ? itake(Ncap) : nullptr;
     A.hot_rows = (int4*)itake(4 * n_hot); A.hot_chunks = (int2*)itake(2 * n_chunk); A.hot_nf = itake(n_chunk);
     A.seg_start = (int*)c->seg_s.p; A.seg_end = (int*)c->seg_e.p;
-    A.dch0 = itake(NBt + 8);
+    A.dch0 = itake(NBt + 8); A.dhot = itake(NBt + 16); A.dcc0 = itake(NBt + 8);
     if (A.ppoi) {
       A.urow_p = itake(Tcap); A.pblk = itake(2 * 1024); A.dxe = itake(Tcap); A.dxs = itake(Tcap); A.dstart = itake(Tcap + 4);
       A.pmark = (int*)c->pmark.p;
@@ -485,6 +488,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin; E.ev_start = c->ev_start; E.ev_pack = c->ev_pack;
     E.early_bins = (c->early_bins && E.bintab && c->side && n >= c->early_min) ? 1 : 0; E.bin_alpha = alpha; E.bin_lambda = lambda;
+    E.dhot_on = (E.early_bins && E.ppoi && c->hot_bins) ? 1 : 0;      // (te_dprep - the selection - must have run before te_psum: the early chain)
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)
     // one sequence (the reference schedule): the whole step in five kernels (tile_engine.hip, te_one_*)
@@ -1103,7 +1107,7 @@ int poi_ctx_set_option(poi_ctx* c, const char* name, int value) {
   if (!c || !name) return fail(c, POI_EINVAL, "poi_ctx_set_option: null argument");
   struct Opt { const char* name; int* p; int lo, hi; };
   const Opt opts[] = {{"forward_table_compact", &c->xcomp, 0, 1}, {"forward_table_compact_min", &c->xcomp_min, 0, 1 << 30}, {"head_split", &c->head3, 0, 1},
-                      {"early_bins", &c->early_bins, 0, 1}};
+                      {"early_bins", &c->early_bins, 0, 1}, {"hot_bins", &c->hot_bins, 0, 1}};
   for (const Opt& o : opts)
     if (!strcmp(name, o.name)) {
       if (value < o.lo || value > o.hi) return fail(c, POI_EINVAL, "poi_ctx_set_option: %s must be in [%d, %d] (got %d)", name, o.lo, o.hi, value);

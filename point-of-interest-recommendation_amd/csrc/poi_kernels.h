@@ -126,6 +126,12 @@ struct TeArgs {
   int bintab;                         // spatial && D >= 128: distance-bin half through per-bin tables (te_ztab / te_dsum)
   float *ztab, *dpart, *dsum, *dgd;   // (n_dist+1) x 3D table; per-chunk partial sums of DA; per-bin sums; per-bin d di sums
   int *dch0, *dch1;                   // first 64-entry chunk / first super-chunk of each bin (+ total)
+  // hot bins (round 5): on check-in data a few distance bins hold most steps (short hops) - te_psum, which streams every DA row once for the per-POI
+  // sums anyway, also adds the rows of the (<= TE_HB) most frequent bins into per-workgroup partials that take the place of those bins' 64-entry chunk
+  // partials (dpart); te_dsum then reads only the rows of the remaining bins.  dhot[0] = number of hot bins, dhot[1 .. TE_HB] = their ids,
+  // dhot[8 + b] = hot index of bin b or -1 (te_dprep); npw = workgroups of te_psum (= chunk partials of a hot bin); dhot_on: host switch
+  int* dhot; int npw, dhot_on;
+  int* dcc0;                          // exclusive scan of the COLD bins' chunk counts (+ total): te_dsum's work list
   float* dpart2; int *dnf, *dnf2, *dbn;   // super-chunk partial sums; distinct-sequence counts per chunk / super-chunk / bin
   int dbg;                            // tuning switch (POI_TE_DBG), 0 in production
   int early_bins; float bin_alpha, bin_lambda;      // the distance-bin chain of the write-back starts on the side stream behind te_wgrad (launch_te_train)
@@ -198,6 +204,8 @@ struct TeArgs {
 #define TE_ENT_GH 0x20000000      // + g[row-1] * h[row-1]
 #define TE_ENT_NEG 0x40000000     // the g*h term enters with a minus sign (negative sample)
 #define TE_ENT_FIRST 0x80000000u  // first entry of its sequence within the row segment
+#define TE_HB 4                   // hot distance bins summed by te_psum (TeArgs.dhot)
+#define TE_HOT_BIN_MIN 4096       // ... when they hold at least this many steps of the launch
 #define TE_COLD_MAX 64            // rows with more entries are reduced in 256-entry chunks by whole workgroups
 #define TE_HOT_CHUNK 256
 #define RS_MAXBIN 512

@@ -234,11 +234,18 @@ template <int D>
 __global__ __launch_bounds__(3 * D) void te_psum_kernel(TeArgs A) {
   const int Ndx = A.cnt[5], col = threadIdx.x, lane = lane_id();
   const int nr = (Ndx + 63) / 64;
+  // hot bins (TeArgs.dhot): this workgroup's sums of the DA rows whose step-input bin is one of them - the rows are in registers here anyway
+  const bool hot_on = A.dhot_on != 0;
+  int hb[TE_HB];
+  float hacc[TE_HB];
+#pragma unroll
+  for (int k = 0; k < TE_HB; ++k) { hb[k] = hot_on ? A.dhot[1 + k] : -1; hacc[k] = 0.f; }
   for (int r = blockIdx.x; r < nr; r += gridDim.x) {
     const int j0 = 64 * r, j1 = min(Ndx, j0 + 64);
     // the range's entries, one per lane (every wave holds the same lists), handed out through v_readlane: scalar row
     // addresses, scalar run detection, and all 64 row loads in flight behind one dependent index load
     const int me = A.dxe[min(j0 + lane, j1 - 1)], ms = A.dxs[min(j0 + lane, j1 - 1)];
+    const int mb = hot_on ? A.row_dp[me] : -2;
     float v[64];
 #pragma unroll
     for (int u = 0; u < 64; ++u) v[u] = A.G[(size_t)__builtin_amdgcn_readlane(me, u) * 3 * D + col];
@@ -252,9 +259,20 @@ __global__ __launch_bounds__(3 * D) void te_psum_kernel(TeArgs A) {
         if (first) A.pfirst[(size_t)r * 3 * D + col] = acc; else A.S[(size_t)cur * 3 * D + col] = acc;
         first = false; cur = sr; acc = 0.f;
       }
-      acc += j0 + u < j1 ? v[u] : 0.f;
+      const float vu = j0 + u < j1 ? v[u] : 0.f;
+      acc += vu;
+      if (hot_on) {                                         // (scalar compares: the bin of entry u is the same for every thread)
+        const int bu = __builtin_amdgcn_readlane(mb, u);
+#pragma unroll
+        for (int k = 0; k < TE_HB; ++k) if (bu == hb[k]) hacc[k] += vu;
+      }
     }
     if (first) A.pfirst[(size_t)r * 3 * D + col] = acc; else A.plast[(size_t)r * 3 * D + col] = acc;
+  }
+  if (hot_on) {
+#pragma unroll
+    for (int k = 0; k < TE_HB; ++k)
+      if (hb[k] >= 0) A.dpart[(size_t)(A.dch0[hb[k]] + (int)blockIdx.x) * 3 * D + col] = hacc[k];
   }
 }
 
@@ -294,10 +312,10 @@ hipError_t launch_te_passign(TeArgs& A, hipStream_t st) {
 hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st) {
   if (!A.side || (A.dbg & 1024)) { hipError_t e = launch_te_passign(A, st); if (e != hipSuccess) return e; }      // (POI_TE_DBG bit 1024: on the main stream, for A/B runs)
   if (A.dim == 128) {
-    hipLaunchKernelGGL(te_psum_kernel<128>, dim3(num_cu * 8), dim3(384), 0, st, A);
+    hipLaunchKernelGGL(te_psum_kernel<128>, dim3(A.npw), dim3(384), 0, st, A);
     hipLaunchKernelGGL(te_pfin_kernel<128>, dim3(num_cu * 16), dim3(384), 0, st, A);
   } else if (A.dim == 256) {
-    hipLaunchKernelGGL(te_psum_kernel<256>, dim3(num_cu * 8), dim3(768), 0, st, A);
+    hipLaunchKernelGGL(te_psum_kernel<256>, dim3(A.npw), dim3(768), 0, st, A);
     hipLaunchKernelGGL(te_pfin_kernel<256>, dim3(num_cu * 16), dim3(768), 0, st, A);
   } else return hipErrorInvalidValue;
   return hipGetLastError();
@@ -594,30 +612,70 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
 #define TE_DSUPER 32
 #define TE_DPREP_T 1024           // two bins per thread: up to 2048 bins (te_supported's limit)
 __global__ __launch_bounds__(TE_DPREP_T) void te_dprep_kernel(TeArgs A) {
-  __shared__ int s[2 * TE_DPREP_T], s2[2 * TE_DPREP_T];
+  __shared__ int s[2 * TE_DPREP_T], s2[2 * TE_DPREP_T], s3[2 * TE_DPREP_T];      // chunks, super-chunks, chunks of the cold bins (te_dsum's work list)
   const int NB = A.n_dist + 1, t = threadIdx.x;
   int n[2], n2[2];
+  int ent[2], hot[2] = {-1, -1};
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int b = t + u * TE_DPREP_T;
-    n[u] = 0;
-    if (b < NB) { const int row = A.n_item + 1 + b, end = A.seg_end[row]; n[u] = end ? (end - A.seg_start[row] + 63) / 64 : 0; }
+    n[u] = 0; ent[u] = 0;
+    if (b < NB) { const int row = A.n_item + 1 + b, end = A.seg_end[row]; ent[u] = end ? end - A.seg_start[row] : 0; n[u] = (ent[u] + 63) / 64; }
+  }
+  // hot bins (TeArgs.dhot): the TE_HB bins with the most entries (ties: lower bin first), at least TE_HOT_BIN_MIN each - te_psum sums their DA rows,
+  // one partial per te_psum workgroup in the place of the bin's chunk partials.  A function of the launch's own counts: reproducible.
+  {
+    __shared__ long long s_w[TE_DPREP_T / 64];
+    __shared__ long long s_pick;
+    int n_hot = 0;
+    for (int k = 0; k < TE_HB; ++k) {
+      long long key = -1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int b = t + u * TE_DPREP_T;
+        if (A.dhot_on && b < NB && hot[u] < 0 && ent[u] >= TE_HOT_BIN_MIN) key = max(key, ((long long)ent[u] << 12) | (long long)(4095 - b));
+      }
+      for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
+      if (lane_id() == 0) s_w[wave_id()] = key;
+      __syncthreads();
+      if (t == 0) { long long m = -1; for (int q = 0; q < TE_DPREP_T / 64; ++q) m = max(m, s_w[q]); s_pick = m; }
+      __syncthreads();
+      const long long pick = s_pick;
+      __syncthreads();
+      if (pick < 0) break;                      // (block-uniform)
+      const int pb = 4095 - (int)(pick & 4095);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) if (t + u * TE_DPREP_T == pb) { hot[u] = k; n[u] = A.npw; }
+      if (t == 0) A.dhot[1 + k] = pb;
+      ++n_hot;
+    }
+    if (t == 0) { A.dhot[0] = n_hot; for (int k = n_hot; k < TE_HB; ++k) A.dhot[1 + k] = -1; }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int b = t + u * TE_DPREP_T;
+    if (b < NB) A.dhot[8 + b] = hot[u];
     n2[u] = (n[u] + TE_DSUPER - 1) / TE_DSUPER;
-    s[b] = n[u]; s2[b] = n2[u];
+    s[b] = n[u]; s2[b] = n2[u]; s3[b] = hot[u] >= 0 ? 0 : n[u];
   }
   __syncthreads();
   for (int o = 1; o < 2 * TE_DPREP_T; o <<= 1) {          // inclusive Hillis-Steele scan over the 2048 slots
-    int v[2], v2[2];
+    int v[2], v2[2], v3[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; v[u] = b >= o ? s[b - o] : 0; v2[u] = b >= o ? s2[b - o] : 0; }
+    for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; v[u] = b >= o ? s[b - o] : 0; v2[u] = b >= o ? s2[b - o] : 0; v3[u] = b >= o ? s3[b - o] : 0; }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; s[b] += v[u]; s2[b] += v2[u]; }
+    for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; s[b] += v[u]; s2[b] += v2[u]; s3[b] += v3[u]; }
     __syncthreads();
   }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) { const int b = t + u * TE_DPREP_T; if (b < NB) { A.dch0[b] = s[b] - n[u]; A.dch1[b] = s2[b] - n2[u]; } }
-  if (t == TE_DPREP_T - 1) { A.dch0[NB] = s[2 * TE_DPREP_T - 1]; A.dch1[NB] = s2[2 * TE_DPREP_T - 1]; }
+  for (int u = 0; u < 2; ++u) {
+    const int b = t + u * TE_DPREP_T;
+    if (b < NB) { A.dch0[b] = s[b] - n[u]; A.dch1[b] = s2[b] - n2[u]; A.dcc0[b] = s3[b] - (hot[u] >= 0 ? 0 : n[u]); }
+  }
+  if (t == TE_DPREP_T - 1) { A.dch0[NB] = s[2 * TE_DPREP_T - 1]; A.dch1[NB] = s2[2 * TE_DPREP_T - 1]; A.dcc0[NB] = s3[2 * TE_DPREP_T - 1]; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) if (hot[u] >= 0) A.dnf[s[t + u * TE_DPREP_T] - n[u]] = 0;      // te_dhot adds the slices' counts here
 }
 
 // one 64-entry chunk of one bin per workgroup iteration, thread = column of DA; thread 0 also counts the chunk's
@@ -625,12 +683,13 @@ __global__ __launch_bounds__(TE_DPREP_T) void te_dprep_kernel(TeArgs A) {
 template <int D>
 __global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
   const int NB = A.n_dist + 1, col = threadIdx.x, lane = lane_id();
-  const int total = A.dch0[NB];
-  for (int ci = blockIdx.x; ci < total; ci += gridDim.x) {
-    int lo = 0, hi = NB - 1;                    // last bin with dch0[b] <= ci
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.dch0[mid] <= ci) lo = mid; else hi = mid - 1; }
+  const int total = A.dcc0[NB];                 // the chunks of the COLD bins (a hot bin's chunk partials are te_psum's per-workgroup sums)
+  for (int cc = blockIdx.x; cc < total; cc += gridDim.x) {
+    int lo = 0, hi = NB - 1;                    // last bin with dcc0[b] <= cc: the bin whose range holds cc (empty ranges - hot or unused bins - start
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (A.dcc0[mid] <= cc) lo = mid; else hi = mid - 1; }      // where the next non-empty one does and lose)
     const int row = A.n_item + 1 + lo;
-    const int c0 = A.seg_start[row] + 64 * (ci - A.dch0[lo]), ce = min(A.seg_end[row], c0 + 64);
+    const int ci = A.dch0[lo] + (cc - A.dcc0[lo]);
+    const int c0 = A.seg_start[row] + 64 * (cc - A.dcc0[lo]), ce = min(A.seg_end[row], c0 + 64);
     // the chunk's entries: one per lane (every wave holds the same list), handed out through v_readlane - the row
     // addresses are scalar, and all 64 row loads are in flight behind ONE dependent index load (16 rows behind
     // each of four index batches left the memory pipe idle half of the time: 3.6 TB/s)
@@ -652,6 +711,28 @@ __global__ __launch_bounds__(3 * D) void te_dsum_kernel(TeArgs A) {
     A.dpart[(size_t)ci * 3 * D + col] = (s0 + s1) + (s2 + s3);
     if (col == 0) A.dnf[ci] = nf;
   }
+}
+
+// hot bins: the distinct-sequence count of the batch rule (TE_ENT_FIRST flags of the bin's entries) - the DA rows themselves went through te_psum.
+// Workgroup (k, y) = slice y of hot bin k's entries; the slices' counts meet in the bin's first chunk slot (integer atomics: order-free; te_dprep
+// zeroed it), the other npw - 1 slots count nothing.
+#define TE_DHOT_Y 32
+__global__ __launch_bounds__(256) void te_dhot_kernel(TeArgs A) {
+  __shared__ int s_w[4];
+  const int k = blockIdx.x, t = threadIdx.x;
+  if (k >= A.dhot[0]) return;
+  const int b = A.dhot[1 + k], row = A.n_item + 1 + b;
+  const int s0 = A.seg_start[row], s1 = A.seg_end[row];
+  const int per = (((s1 - s0 + TE_DHOT_Y - 1) / TE_DHOT_Y) + 255) & ~255;
+  const int lo = s0 + (int)blockIdx.y * per, hi = min(s1, lo + per);
+  int c = 0;
+  for (int i = lo + t; i < hi; i += 256) c += A.ent[i] < 0 ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((t & 63) == 0) s_w[t >> 6] = c;
+  __syncthreads();
+  const int base = A.dch0[b];
+  if (t == 0) { const int tot = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]); if (tot) atomicAdd(&A.dnf[base], tot); }
+  for (int w = 1 + (int)blockIdx.y * 256 + t; w < A.npw; w += TE_DHOT_Y * 256) A.dnf[base + w] = 0;
 }
 
 // one super-chunk (<= TE_DSUPER consecutive chunk partials of one bin) per workgroup iteration
@@ -766,6 +847,7 @@ static hipError_t te_bins_t(TeArgs& A, float alpha, float lambda, int num_cu, hi
   tm->begin("te_dsum", sb);
   if (!early) hipLaunchKernelGGL(te_dprep_kernel, dim3(1), dim3(TE_DPREP_T), 0, sb, A);
   hipLaunchKernelGGL(te_dsum_kernel<D>, dim3(num_cu * 8), dim3(3 * D), 0, sb, A);
+  if (A.dhot_on) hipLaunchKernelGGL(te_dhot_kernel, dim3(TE_HB, TE_DHOT_Y), dim3(256), 0, sb, A);
   tm->end(sb);
   tm->begin("te_bin_gemm", sb);
   hipLaunchKernelGGL(te_dred_kernel<D>, dim3(num_cu * 2), dim3(3 * D), 0, sb, A);
