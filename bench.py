@@ -474,7 +474,7 @@ def main():
     # split products (default): te_rec_bwd and te_wgrad form every float32 product from six bf16 partial products, the training head (<= 256
     # bins: te_head3) from five - priced as EXECUTED bf16 flops against the dense bf16 peak, the float32-equivalent rate beside it
     split = os.environ.get("POI_TE_SPLIT", "1") != "0"
-    rec1_max = int(os.environ.get("POI_TE_REC1", "1024"))        # launches of at most this many sequences: per-sequence recurrent kernels (float32 FMAs)
+    rec1_max = int(os.environ.get("POI_TE_REC1", "1800"))        # launches of at most this many sequences: per-sequence recurrent kernels (float32 FMAs)
     head3 = split and NB <= 256 and os.environ.get("POI_TE_HEAD3", "1") != "0"
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
             "te_gemm_ax": ("i8op", 15 * 6 * D2 * ax_rows) if xfwd else ("bf16x6", 6 * xk * D2 * ax_rows) if split and bintab and D >= 256 else ("flop", xk * D2 * ax_rows),

@@ -218,7 +218,7 @@ class Context:
         "early_bins")."""
         self.check(self.lib.poi_ctx_set_option(self.handle, name.encode(), int(value)))
 
-    def set_small_launch(self, max_sequences=1024):
+    def set_small_launch(self, max_sequences=1800):
         """Launches of at most this many sequences use the per-sequence recurrent kernels (poi_ctx_set_small_launch; 0 disables)."""
         self.check(self.lib.poi_ctx_set_small_launch(self.handle, int(max_sequences)))
 

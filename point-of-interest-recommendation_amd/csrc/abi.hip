@@ -50,14 +50,14 @@ struct poi_ctx {
   int fwd_tab = 1;          // POI_TE_FWDTAB=0 disables (A/B)
   int bintab_min = 1280;    // launches below this many sequences take the two-table path (no per-bin tables / per-POI regrouping); POI_TE_BINTAB_MIN
   int one_path = 1;         // launches of ONE sequence (Distance2Pre, plain GRU) take the five-kernel path (te_one_*); POI_TE_ONE=0 -> the batched pipeline
-  int rec1_max = 1024;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1); POI_TE_REC1
+  int rec1_max = 1800;      // launches of at most this many sequences run the per-sequence recurrent kernels (te_rec_fwd1 / bwd1: persistent since round 5 - crossover with the 16-sequence tiles measured at ~1800 for the backward, ~1100 for the float64 forward pass); POI_TE_REC1
   int rec_split = 1;        // recurrent kernels on bf16 x 3 split operands; POI_TE_SPLIT=0 -> float32-input MFMA (A/B)
   int xlaunch = 0;          // launch id of the exact forward's non-finite-input flag (TeArgs.xflag)
   int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores / float64 MFMA + float64 gates) for dims 64 / 128 / 256; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
   int xcomp = 1;            // exact forward table over the step-input POIs only; POI_TE_XCOMP=0: every row of the POI table (A/B)
   int xcomp_min = 1536;     // ... for launches of at least this many sequences (below: one row per step - the table form of te_rec_fwdx costs 0.6 us more per step of the latency chain than the ranking saves in te_gemmx; 1300 / 1563 / 2048 / 3125 users: +9 / -6 / -38 / -45 us); POI_TE_XCOMP_MIN
   int head3 = 1;            // training head on split products for <= 256 bins (te_head3); POI_TE_HEAD3
-  int xrec1_max = 512;      // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
+  int xrec1_max = 1100;     // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
   DevBuf xflag;             // launch id of the last launch whose operands held a NaN / inf (TeArgs.xflag)
   DevBuf xw, xg;            // its digit fragments, scales and per-bin table | per-step pre-activations or the forward table (float64)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
@@ -286,7 +286,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.xrec1 = (A.xfwd && D <= 128 && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
   // (the table over the launch's step-input POIs only - te_slots marks them for the per-POI regrouping - never has more rows than the launch has steps)
   const bool want_xc = c->xcomp && A.ppoi && P->n_item + 1 <= (1 << 22) && n >= c->xcomp_min;
-  A.xft = (A.xfwd && (want_ft || want_xc) && !A.xrec1 && n > 1) ? 1 : 0;      // (n == 1: the one-sequence path writes gx itself, te_one_in)
+  A.xft = (A.xfwd && (want_ft || want_xc) && n > 1) ? 1 : 0;      // (n == 1: the one-sequence path writes gx itself, te_one_in; the per-sequence kernel has a table variant too)
   if (A.fwd_tab || A.xft) {
     if ((rc = ensure(c, c->iota, sizeof(int) * (size_t)(P->n_item + 8), st))) return rc;
     if (c->iota_n != P->n_item + 1) { poi::launch_te_iota((int*)c->iota.p, P->n_item + 1, st); c->iota_n = P->n_item + 1; }

@@ -582,17 +582,20 @@ template <int N> __device__ __forceinline__ double x_group_sum(double v) {      
 }
 __device__ __forceinline__ double x_pick4(const double (&a)[4], int o) { return o == 0 ? a[0] : o == 1 ? a[1] : o == 2 ? a[2] : a[3]; }
 
-template <int D, bool PRED = false>
+// Round 5: PERSISTENT - the grid is one workgroup per CU and a workgroup walks the launch's sequences k = b, 2 G - 1 - b, 2 G + b, ... (snake
+// order over the length-sorted launch: every workgroup gets one sequence of each length class) with its weights loaded ONCE: a launch of
+// 1563 sequences was six rounds of workgroups, each paying the longest sequence of its round and a 196 KB weight fetch (te_rec_fwd 217 us;
+// the 16-row tiles: 221 us), now ~113 steps per CU.  FT: pre-activations from the forward table (ptabx[p_t] + ztabx[dp_t]) instead of gx.
+template <int D, bool PRED = false, bool FT = false>
 __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
   constexpr int LZ = D / 8, LC = D / 16;
   __shared__ __align__(16) double hs[D], rhs[D], zs[D];
   __shared__ double s_t64[64];
-  const int tid = threadIdx.x, k = blockIdx.x;
+  const int tid = threadIdx.x;
   const int gz = tid >> 3, sz = tid & 7, gc = tid >> 4, sc = tid & 15;
   const int jz = 4 * gz + (sz & 3), jc = 4 * gc + (sc & 3);        // the output this lane finishes (lanes sz / sc < 4)
   const bool isr = jz >= D;
   const int jr = isr ? jz - D : jz;
-  const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
   double wzr[4][LZ], wc[4][LC];
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
@@ -607,66 +610,83 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
       wc[o][i] = (double)v.x; wc[o][i + 1] = (double)v.y; wc[o][i + 2] = (double)v.z; wc[o][i + 3] = (double)v.w;
     }
   }
-  if (tid < D) hs[tid] = 0.0;
   if (tid >= 64 && tid < 128) s_t64[tid - 64] = exp2((double)(tid - 64) * (1.0 / 64.0));
-  __syncthreads();
-  double gzr = 0.0, gcc = 0.0;
-  if (ns > 0) { gzr = A.gx[(size_t)r0 * 3 * D + jz]; gcc = A.gx[(size_t)r0 * 3 * D + 2 * D + jc]; }
   // every lane issues every global store of a step (non-owners write their duplicate into the spare packed row): straight-line code,
   // exact vmcnt waits (te_rec_fwd1)
-  const size_t Tsp = (size_t)A.soff[A.n_seq];
+  // (one of the 128 spare rows behind the packed rows per workgroup: 256 CUs storing their duplicates into ONE row serialised on its lines)
+  const size_t Tsp = (size_t)A.soff[A.n_seq] + 1 + (blockIdx.x & 127);
   const bool ownz = sz < 4, ownc = sc < 4;
   float* const dG = A.G + Tsp * 3 * D + (tid % (3 * D));
   float* const dH = A.H + Tsp * D + (tid % D);
   float* const dR = A.RH + Tsp * D + (tid % D);
-  for (int t = 0; t < ns; ++t) {
-    const size_t row = (size_t)(r0 + t), rn = (size_t)(r0 + min(t + 1, ns - 1));
-    double nzr = A.gx[rn * 3 * D + jz], nc = A.gx[rn * 3 * D + 2 * D + jc];
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
+  const int* __restrict__ xrow = A.xcomp ? A.row_pc : A.row_p;
+  // pre-activations of packed row rr, columns jz (z | r) and 2 D + jc (c)
+  auto pre = [&](size_t rr, double& ozr, double& oc) {
+    if constexpr (FT) {
+      const size_t p1 = (size_t)min((unsigned)xrow[rr], (unsigned)A.n_item) * 3 * D, z1 = (size_t)(A.spatial ? min((unsigned)A.row_dp[rr], (unsigned)A.n_dist) : 0u) * 3 * D;
+      ozr = A.ptabx[p1 + jz] + A.ztabx[z1 + jz]; oc = A.ptabx[p1 + 2 * D + jc] + A.ztabx[z1 + 2 * D + jc];
+    } else { ozr = A.gx[rr * 3 * D + jz]; oc = A.gx[rr * 3 * D + 2 * D + jc]; }
+  };
+  const int G = gridDim.x, bq = blockIdx.x;
+  for (int j = 0;; ++j) {
+    const int k = j * G + ((j & 1) ? G - 1 - bq : bq);
+    if (k >= A.n_seq) break;                 // (workgroup-uniform; the snake's odd legs run downwards: a later even leg may still exist)
+    if (tid < D) hs[tid] = 0.0;
+    const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
+    __syncthreads();
+    double gzr = 0.0, gcc = 0.0;
+    if (ns > 0) pre((size_t)r0, gzr, gcc);
+    for (int t = 0; t < ns; ++t) {
+      const size_t row = (size_t)(r0 + t), rn = (size_t)(r0 + min(t + 1, ns - 1));
+      double nzr, nc;
+      pre(rn, nzr, nc);
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < LZ; i += 2) {
-      const double2 x = *reinterpret_cast<const double2*>(hs + sz * LZ + i);
+      for (int i = 0; i < LZ; i += 2) {
+        const double2 x = *reinterpret_cast<const double2*>(hs + sz * LZ + i);
 #pragma unroll
-      for (int o = 0; o < 4; ++o) a[o] = __builtin_fma(wzr[o][i + 1], x.y, __builtin_fma(wzr[o][i], x.x, a[o]));
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) a[o] = x_group_sum<8>(a[o]);
-    {
-      const double v = x_sigmoid<true>(x_pick4(a, sz & 3) + gzr, s_t64);
-      const double rh = v * hs[jr];
-      if (ownz) { if (isr) rhs[jr] = rh; else zs[jr] = v; }
-      const bool st = ownz && isr;
-      if constexpr (!PRED) {
-        *(st ? A.G + row * 3 * D + D + jr : dG) = (float)v;
-        *(st ? A.RH + row * D + jr : dR) = (float)rh;
+        for (int o = 0; o < 4; ++o) a[o] = __builtin_fma(wzr[o][i + 1], x.y, __builtin_fma(wzr[o][i], x.x, a[o]));
       }
-    }
-    x_lds_barrier();
-    double b[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < LC; i += 2) {
-      const double2 x = *reinterpret_cast<const double2*>(rhs + sc * LC + i);
-#pragma unroll
-      for (int o = 0; o < 4; ++o) b[o] = __builtin_fma(wc[o][i + 1], x.y, __builtin_fma(wc[o][i], x.x, b[o]));
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) b[o] = x_group_sum<16>(b[o]);
-    {
-      const double c = x_tanh<true>(x_pick4(b, sc & 3) + gcc, s_t64);
-      const double z = zs[jc], hp = hs[jc];
-      const double hn = __builtin_fma(z, c - hp, hp);
-      if (ownc) hs[jc] = hn;               // (the c phase reads rhs only; the lanes that share jc are in one wave)
-      if constexpr (!PRED) {
-        *(ownc ? A.G + row * 3 * D + jc : dG) = (float)z;
-        *(ownc ? A.G + row * 3 * D + 2 * D + jc : dG) = (float)c;
-        *(ownc ? A.H + row * D + jc : dH) = (float)hn;
+      for (int o = 0; o < 4; ++o) a[o] = x_group_sum<8>(a[o]);
+      {
+        const double v = x_sigmoid<true>(x_pick4(a, sz & 3) + gzr, s_t64);
+        const double rh = v * hs[jr];
+        if (ownz) { if (isr) rhs[jr] = rh; else zs[jr] = v; }
+        const bool st = ownz && isr;
+        if constexpr (!PRED) {
+          *(st ? A.G + row * 3 * D + D + jr : dG) = (float)v;
+          *(st ? A.RH + row * D + jr : dR) = (float)rh;
+        }
       }
+      x_lds_barrier();
+      double b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < LC; i += 2) {
+        const double2 x = *reinterpret_cast<const double2*>(rhs + sc * LC + i);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) b[o] = __builtin_fma(wc[o][i + 1], x.y, __builtin_fma(wc[o][i], x.x, b[o]));
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) b[o] = x_group_sum<16>(b[o]);
+      {
+        const double c = x_tanh<true>(x_pick4(b, sc & 3) + gcc, s_t64);
+        const double z = zs[jc], hp = hs[jc];
+        const double hn = __builtin_fma(z, c - hp, hp);
+        if (ownc) hs[jc] = hn;               // (the c phase reads rhs only; the lanes that share jc are in one wave)
+        if constexpr (!PRED) {
+          *(ownc ? A.G + row * 3 * D + jc : dG) = (float)z;
+          *(ownc ? A.G + row * 3 * D + 2 * D + jc : dG) = (float)c;
+          *(ownc ? A.H + row * D + jc : dH) = (float)hn;
+        }
+      }
+      x_lds_barrier();
+      asm volatile("" : "+v"(nzr), "+v"(nc));      // the wait for the prefetch is counted HERE, behind this step's stores
+      gzr = nzr; gcc = nc;
     }
-    x_lds_barrier();
-    asm volatile("" : "+v"(nzr), "+v"(nc));      // the wait for the prefetch is counted HERE, behind this step's stores
-    gzr = nzr; gcc = nc;
+    if (PRED && tid < D) A.hts[(size_t)(A.out_row ? A.out_row[k] : k) * D + tid] = (float)hs[tid];
+    __syncthreads();                         // hs is reset for the next sequence: every lane has read its last values
   }
-  if (PRED && tid < D) A.hts[(size_t)(A.out_row ? A.out_row[k] : k) * D + tid] = (float)hs[tid];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -958,14 +978,26 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   } } dump_at_exit;
 #endif
   if (A.predict) {      // (inside the caller's te_predict region)
-    if constexpr (!XRec<D>::F64) { if (A.xrec1) { hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, true>), dim3(n), dim3(4 * D), 0, st, A); return hipGetLastError(); } }
+    if constexpr (!XRec<D>::F64) {
+      if (A.xrec1) {
+        if (A.xft) hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, true, true>), dim3(min(n, num_cu * (D <= 64 ? 3 : 1))), dim3(4 * D), 0, st, A);
+        else hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, true, false>), dim3(min(n, num_cu * (D <= 64 ? 3 : 1))), dim3(4 * D), 0, st, A);
+        return hipGetLastError();
+      }
+    }
     if (A.xft) XRec<D>::template launch<true, true>(A, st);
     else XRec<D>::template launch<false, true>(A, st);
     return hipGetLastError();
   }
   tm->begin("te_rec_fwd", st);
   bool done = false;
-  if constexpr (!XRec<D>::F64) { if (A.xrec1) { hipLaunchKernelGGL(te_rec_fwd1x_kernel<D>, dim3(n), dim3(4 * D), 0, st, A); done = true; } }
+  if constexpr (!XRec<D>::F64) {
+    if (A.xrec1) {      // persistent: one workgroup per CU walks the launch's sequences
+      if (A.xft) hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, false, true>), dim3(min(n, num_cu * (D <= 64 ? 3 : 1))), dim3(4 * D), 0, st, A);
+      else hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, false, false>), dim3(min(n, num_cu * (D <= 64 ? 3 : 1))), dim3(4 * D), 0, st, A);
+      done = true;
+    }
+  }
   if (!done) {
     if (A.xft) XRec<D>::template launch<true, false>(A, st);
     else XRec<D>::template launch<false, false>(A, st);

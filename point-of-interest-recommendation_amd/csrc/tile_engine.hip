@@ -1757,66 +1757,74 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1_kernel(TeArgs A) {
 }
 
 // thread (g, s): hidden columns 4g .. 4g+3, j-slice s of 16 - of D / 16 (m = da_c . Wc) and of D / 8 ([da_z | da_r] . Wzr)
+// (round 5: persistent, as te_rec_fwd1x - one workgroup per CU slot walks the launch's sequences in snake order, the transposed weights loaded once)
 template <int D>
 __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
   constexpr int LC = D / 16, LZ = D / 8;
   __shared__ __align__(16) float dac[D], dazr[2 * D];
-  const int tid = threadIdx.x, k = blockIdx.x;
+  const int tid = threadIdx.x;
   const int g = tid >> 4, s = tid & 15;
   const int kk = 4 * g + (s & 3);          // the column this lane finishes (lanes s < 4)
-  const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
   f32x2 wc[2][LC], wzr[2][LZ];
   load_rows4<LC>(wc, reinterpret_cast<const float*>(A.pWhc16) + (size_t)4 * g * D + s * LC, D);              // Wc^T:  [k][j]
   load_rows4<LZ>(wzr, reinterpret_cast<const float*>(A.pWhzr16) + (size_t)4 * g * 2 * D + s * LZ, 2 * D);     // Wzr^T: [k][j], j < 2D
-  float dhn = 0.f, sbz = 0.f, sbr = 0.f, sbc = 0.f;
-  // operands of step t - 1 are requested while step t computes
-  float z = 0.f, r = 0.f, c = 0.f, hp = 0.f, dd = 0.f;
-  auto fetch = [&](int t, float& fz, float& fr, float& fc, float& fh, float& fd) {
-    const size_t row = (size_t)(r0 + max(t, 0));
-    const float* gp = A.G + row * 3 * D;
-    fz = gp[kk]; fr = gp[D + kk]; fc = gp[2 * D + kk];
-    fh = A.H[(row - (t > 0 ? 1 : 0)) * D + kk];
-    fd = A.DH[row * D + kk];
-  };
-  if (ns > 0) fetch(ns - 1, z, r, c, hp, dd);
   const bool own = s < 4;
-  float* const dG = A.G + (size_t)A.soff[A.n_seq] * 3 * D + (tid % (3 * D));      // spare packed row: see te_rec_fwd1
-  for (int t = ns - 1; t >= 0; --t) {
-    float nz, nr, nc, nh, nd;
-    fetch(t - 1, nz, nr, nc, nh, nd);
-    const float h = t > 0 ? hp : 0.f;
-    const float dh = dhn + dd;
-    const float dz = dh * (c - h);
-    float dhp = dh * (1.0f - z);
-    const float dacv = dh * z * (1.0f - c * c);
-    if (own) dac[kk] = dacv;
-    lds_barrier();
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    dot4_reg_lds<LC>(wc, dac + s * LC, a);
+  float* const dG = A.G + ((size_t)A.soff[A.n_seq] + 1 + (blockIdx.x & 127)) * 3 * D + (tid % (3 * D));      // a spare packed row of its own: see te_rec_fwd1x
+  const int NG = gridDim.x, bq = blockIdx.x;
+  for (int j = 0;; ++j) {
+    const int k = j * NG + ((j & 1) ? NG - 1 - bq : bq);
+    if (k >= A.n_seq) break;
+    const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
+    float dhn = 0.f, sbz = 0.f, sbr = 0.f, sbc = 0.f;
+    // operands of step t - 1 are requested while step t computes
+    float z = 0.f, r = 0.f, c = 0.f, hp = 0.f, dd = 0.f;
+    auto fetch = [&](int t, float& fz, float& fr, float& fc, float& fh, float& fd) {
+      const size_t row = (size_t)(r0 + max(t, 0));
+      const float* gp = A.G + row * 3 * D;
+      fz = gp[kk]; fr = gp[D + kk]; fc = gp[2 * D + kk];
+      fh = A.H[(row - (t > 0 ? 1 : 0)) * D + kk];
+      fd = A.DH[row * D + kk];
+    };
+    if (ns > 0) fetch(ns - 1, z, r, c, hp, dd);
+    for (int t = ns - 1; t >= 0; --t) {
+      float nz, nr, nc, nh, nd;
+      fetch(t - 1, nz, nr, nc, nh, nd);
+      const float h = t > 0 ? hp : 0.f;
+      const float dh = dhn + dd;
+      const float dz = dh * (c - h);
+      float dhp = dh * (1.0f - z);
+      const float dacv = dh * z * (1.0f - c * c);
+      if (own) dac[kk] = dacv;
+      lds_barrier();
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      dot4_reg_lds<LC>(wc, dac + s * LC, a);
 #pragma unroll
-    for (int o = 0; o < 4; ++o) a[o] = group_sum<16>(a[o]);
-    const float m = pick4(a, s & 3);
-    const float dr = m * h;
-    dhp += m * r;
-    const float daz = dz * z * (1.0f - z), dar = dr * r * (1.0f - r);
-    if (own) { dazr[kk] = daz; dazr[D + kk] = dar; }
-    {
-      float* gp = A.G + (size_t)(r0 + t) * 3 * D;
-      *(own ? gp + kk : dG) = daz; *(own ? gp + D + kk : dG) = dar; *(own ? gp + 2 * D + kk : dG) = dacv;
-      sbz += daz; sbr += dar; sbc += dacv;      // (every lane of a column holds the same values; lanes s < 4 write them)
+      for (int o = 0; o < 4; ++o) a[o] = group_sum<16>(a[o]);
+      const float m = pick4(a, s & 3);
+      const float dr = m * h;
+      dhp += m * r;
+      const float daz = dz * z * (1.0f - z), dar = dr * r * (1.0f - r);
+      if (own) { dazr[kk] = daz; dazr[D + kk] = dar; }
+      {
+        float* gp = A.G + (size_t)(r0 + t) * 3 * D;
+        *(own ? gp + kk : dG) = daz; *(own ? gp + D + kk : dG) = dar; *(own ? gp + 2 * D + kk : dG) = dacv;
+        sbz += daz; sbr += dar; sbc += dacv;      // (every lane of a column holds the same values; lanes s < 4 write them)
+      }
+      lds_barrier();
+      float b[4] = {0.f, 0.f, 0.f, 0.f};
+      dot4_reg_lds<LZ>(wzr, dazr + s * LZ, b);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) b[o] = group_sum<16>(b[o]);
+      dhn = dhp + pick4(b, s & 3);
+      asm volatile("" : "+v"(nz), "+v"(nr), "+v"(nc), "+v"(nh), "+v"(nd));      // (wait for the prefetch behind this step's stores)
+      z = nz; r = nr; c = nc; hp = nh; dd = nd;
     }
-    lds_barrier();
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    dot4_reg_lds<LZ>(wzr, dazr + s * LZ, b);
-#pragma unroll
-    for (int o = 0; o < 4; ++o) b[o] = group_sum<16>(b[o]);
-    dhn = dhp + pick4(b, s & 3);
-    asm volatile("" : "+v"(nz), "+v"(nr), "+v"(nc), "+v"(nh), "+v"(nd));      // (wait for the prefetch behind this step's stores)
-    z = nz; r = nr; c = nc; hp = nh; dd = nd;
-  }
-  if (s < 4) {
-    float* bp = A.bi_part + (size_t)k * 3 * D;
-    bp[kk] = sbz; bp[D + kk] = sbr; bp[2 * D + kk] = sbc;
+    if (s < 4) {
+      float* bp = A.bi_part + (size_t)k * 3 * D;
+      bp[kk] = sbz; bp[D + kk] = sbr; bp[2 * D + kk] = sbc;
+    }
+    // (no barrier between sequences: the next one's first LDS write - dac - follows this one's last barrier, and its dazr write sits behind its own
+    // first barrier, which no wave passes before every wave has finished the dazr reads above)
   }
 }
 
@@ -3922,7 +3930,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
-      if (A.rec1) hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(n), dim3(4 * D), 0, st, A);
+      if (A.rec1) hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(min(n, num_cu * (D <= 64 ? 4 : 1))), dim3(4 * D), 0, st, A);      // persistent: the workgroups one CU holds at a time
       else if (A.rec_split && !(A.dbg & 128)) hipLaunchKernelGGL((te_rec_bwd16t_kernel<D>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
       else if (A.rec_split) hipLaunchKernelGGL((te_rec_bwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);      // (POI_TE_DBG bit 128: one unit of four sequences per lane, for A/B runs)
       else hipLaunchKernelGGL((te_rec_bwd16_kernel<D, false>), dim3((n + 15) / 16), dim3(D * 4), sizeof(float) * (16 * (D + 4) + 16 * (2 * D + 4)), st, A);

@@ -485,7 +485,7 @@ def test_forward_table_any_table_size(pa, n_item):
             eh, es = O.spatial_predict(Pn, Pn["lt"], Pn["di"], T["train"][0][ids], T["dist"][0][ids], T["train"][1][ids])
             assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
     finally:
-        pa._lib.context(0).set_engine("auto"); pa._lib.context(0).set_small_launch(1024); pa._lib.context(0).set_split_products(True)
+        pa._lib.context(0).set_engine("auto"); pa._lib.context(0).set_small_launch(1800); pa._lib.context(0).set_split_products(True)
 
 
 @pytest.mark.parametrize("dim,n_dist,spatial", [(64, 11, True), (128, 255, True), (128, 300, True), (256, 40, True), (64, 0, False), (128, 0, False)])
@@ -557,7 +557,7 @@ def test_forked_write_back_is_bitwise_the_serial_one(pa, monkeypatch):
 def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user, n_dist):
     """The three arithmetic forms of the recurrence - 16-sequence MFMA tiles on bf16 x 3 split products (poi_ctx_set_split_products, default
     for launches above the small-launch threshold), on float32-input MFMAs, and one sequence per workgroup on the vector ALUs
-    (poi_ctx_set_small_launch, default for launches of <= 1024 sequences) - with the forward table (n_item small against the launch) and
+    (poi_ctx_set_small_launch, default for launches of <= 1800 sequences) - with the forward table (n_item small against the launch) and
     without (n_item 5000): training launch against the oracle's mean rule at the usual bars, predict against the oracle, and the
     variants against each other (same bars: float32-accurate evaluations of the same step).  1520 bins: the chunked head on split products
     (te_head_big3) against the float32-input one (te_head_big); dim 256: the streaming recurrent kernels in both forms (no per-sequence form)."""
@@ -569,7 +569,7 @@ def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user, 
     try:
         for split in (True, False, "per-sequence"):
             model = _model(pa, T, P)
-            model.ctx.set_engine("tile"); model.ctx.set_split_products(split is True); model.ctx.set_small_launch(1024 if split == "per-sequence" else 0)
+            model.ctx.set_engine("tile"); model.ctx.set_split_products(split is True); model.ctx.set_small_launch(1800 if split == "per-sequence" else 0)
             got_out = model.train_batch(users)
             for k, out in enumerate(outs):
                 assert_close(got_out[k][:3], out[:3], "losses[%d]" % k, rtol=2e-5)
@@ -587,7 +587,7 @@ def test_recurrent_kernel_variants_all_meet_the_oracle(pa, dim, n_item, n_user, 
             assert_step_close(res[True][0], {k: np.asarray(v, np.float64) if k != "wd" else float(v) for k, v in res[other][0].items()}, P, SP_NAMES, "split vs %s" % other)
             assert not all(np.array_equal(res[True][0][k], res[other][0][k]) for k in ("wh", "ui")), "the switch did not change the arithmetic"
     finally:
-        pa._lib.context(0).set_split_products(True); pa._lib.context(0).set_small_launch(1024); pa._lib.context(0).set_engine("auto")
+        pa._lib.context(0).set_split_products(True); pa._lib.context(0).set_small_launch(1800); pa._lib.context(0).set_engine("auto")
 
 
 @pytest.mark.parametrize("dim,n_dist,len_max", [(128, 200, 50), (64, 40, 9), (128, 1520, 12), (20, 11, 7), (128, 40, 65), (64, 40, 161)])

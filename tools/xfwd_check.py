@@ -45,4 +45,4 @@ for xf in (True, False):
         else:
             u = 0
             r = m.train(np.int32(u)); report("xfwd=%d %s" % (xf, mode), get(m), news[0])
-ctx.set_exact_forward(True); ctx.set_one_sequence_path(True); ctx.set_small_launch(1024); ctx.set_engine("auto"); ctx.set_regroup_min(1280)
+ctx.set_exact_forward(True); ctx.set_one_sequence_path(True); ctx.set_small_launch(1800); ctx.set_engine("auto"); ctx.set_regroup_min(1280)
