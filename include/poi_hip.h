@@ -45,6 +45,8 @@ extern "C" {
  * refuses to combine half segments whose buffer the caller never asked for; new entry points since 2: poi_sync_buffer16,
  * poi_ctx_set_split_products / _small_launch / _one_sequence_path / _regroup_min / _f16_rounding / _topk_filter(_stats), poi_ctx_set_exact_forward. */
 /* 4 (round 4): new entry point poi_ctx_set_option. */
+/* 5 (round 5): new entry point poi_comm_available; poi_bpr_step's snapshot mode is sorted and atomic-free and accepts a half POI table; the exact
+ * forward pass covers dim 256 (config X); option "hot_bins". */
 #define POI_ABI_VERSION 5
 
 enum {
@@ -134,7 +136,7 @@ int poi_ctx_set_f16_rounding(poi_ctx* ctx, int mode, uint32_t seed);
  * public/GRU_Spatial.py:247): logits and d h of the chunked head on the same split products (te_head_big3) instead of float32-input MFMAs.
  * on = 0: float32-input v_mfma_f32_16x16x4_f32 (rounds 1 - 2).  Environment override at context creation: POI_TE_SPLIT=0|1. */
 int poi_ctx_set_split_products(poi_ctx* ctx, int on);
-/* Exact forward pass of the tile engine's training launches AND of poi_gru_predict (dims 64 / 128; default on).  The reference computes in float64 (Theano
+/* Exact forward pass of the tile engine's training launches AND of poi_gru_predict (dims 64 / 128 / 256; default on).  The reference computes in float64 (Theano
  * floatX: public/GRU.py:57, public/GRU_Spatial.py:52) and with its uniform(-0.5, 0.5) init the forward recurrence h_{t-1} -> h_t
  * (public/GRU_Spatial.py:170-178) EXPANDS perturbations: a float32 forward pass, whatever its summation order, leaves a 50-position
  * sequence 1e-5 off the float64 result, and the whole update with it; the backward pass is linear in its carry and is not affected.
@@ -142,10 +144,15 @@ int poi_ctx_set_split_products(poi_ctx* ctx, int on);
  * (five signed base-256 digit planes per operand, exact int32 accumulation, digit pairs combined in float64: te_xfwd.hip), the gates
  * and the state in float64; everything behind the forward pass (head, BPTT, gradients, write-back) stays float32 and reads the
  * float32 roundings of z, r, c, h.  on = 0: the float32 forward kernels of rounds 1 - 3 (split products / per-sequence / forward table).
- * per_sequence_max (>= 0; < 0 keeps the current value, default 512): launches of at most this many sequences run the recurrence of every
- * sequence in its own workgroup in float64 on the vector ALUs (te_rec_fwd1x: ~1 us per step and sequence; the reference's schedule - one
- * user per step, prog_bpr_gru_spatial.py:249-250 - takes this form), larger ones in 16-sequence tiles on the int8 matrix cores
- * (te_rec_fwdx: 3.6 us per step and tile).  Environment overrides at context creation: POI_TE_XFWD=0|1, POI_TE_XREC1=<per_sequence_max>. */
+ * Dim 256 (config X of BASELINE.json; round 5): the input product keeps the digit-pair classes 0 .. 6 (22 int8 MFMAs per 32 k: ~2^-55) and the
+ * recurrence runs in float64 on the matrix cores (v_mfma_f64_16x16x4_f64, float32 weight fragments streamed from L2: te_rec_fwdd) - with the
+ * reference's init at that dim the chain amplifies a perturbation ~10^6-fold over 50 positions and nothing less holds 1e-5.
+ * A NaN / inf weight or input row makes every hidden state, loss and updated tensor of the launch NaN (the float64 reference propagates it
+ * to everything that depends on it; the int8 digits of a state cannot carry it, so the launch is flagged while its operands are prepared).
+ * per_sequence_max (>= 0; < 0 keeps the current value, default 1100; dims 64 / 128): launches of at most this many sequences run the recurrence
+ * per sequence in float64 on the vector ALUs (te_rec_fwd1x: persistent workgroups, one per CU, walk the launch's sequences with the weights in
+ * registers; the reference's schedule - one user per step, prog_bpr_gru_spatial.py:249-250 - takes this form), larger ones in 16-sequence tiles
+ * on the int8 matrix cores (te_rec_fwdx: 3.6 us per step and tile).  Environment overrides at context creation: POI_TE_XFWD=0|1, POI_TE_XREC1=<per_sequence_max>. */
 int poi_ctx_set_exact_forward(poi_ctx* ctx, int on, int per_sequence_max);
 /* Named tuning switches of the tile engine - every setting computes the same update to the stated tolerances; they exist for A/B
  * measurements and for the tests that hold the alternative kernels to the oracle.  POI_EINVAL for an unknown name or a value out of range.
@@ -154,10 +161,14 @@ int poi_ctx_set_exact_forward(poi_ctx* ctx, int on, int per_sequence_max);
  *   "forward_table_compact_min" n (default 1536): ... for launches of at least n sequences;
  *   "head_split" 0|1 (default 1): the training head (public/GRU_Spatial.py:180-200, <= 256 bins) on bf16 split products (te_head3)
  *       instead of float32-input matrix instructions;
- *   "early_bins" 0|1 (default 1): the distance-bin rows' write-back chain starts next to the d x product instead of at the tail. */
+ *   "early_bins" 0|1 (default 1): the distance-bin rows' write-back chain starts next to the d x product instead of at the tail;
+ *   "hot_bins" 0|1 (default 1; ABI 5): the per-POI pass over DA also sums the rows of the (<= 4) most frequent step-input distance bins of the
+ *       launch - on check-in data a few bins hold most steps - so the per-bin pass reads only the rows of the others; reproducible,
+ *       another fixed summation order than 0. */
 int poi_ctx_set_option(poi_ctx* ctx, const char* name, int value);
-/* Small launches: launches of at most max_sequences sequences (default 1024; 0 disables; dim 64 / 128) run the recurrence of every
- * sequence in its own workgroup on the vector ALUs (te_rec_fwd1 / bwd1, weights resident in registers) instead of 16-sequence MFMA
+/* Small launches: launches of at most max_sequences sequences (default 1800; 0 disables; dim 64 / 128) run the recurrence of every
+ * sequence per workgroup on the vector ALUs (te_rec_fwd1 / bwd1, weights resident in registers; persistent since round 5: one workgroup per
+ * CU slot walks the launch's sequences) instead of 16-sequence MFMA
  * tiles - a tile step costs the same whether it holds 16 sequences or one, so the reference schedule (one user per step,
  * prog_bpr_gru_spatial.py:249-250) and launches that do not fill the chip are bound by it.  Same formulas, float32 FMA chains; the
  * summation order differs from the tile kernels.  Environment override at context creation: POI_TE_REC1=<max_sequences>. */
@@ -209,9 +220,12 @@ int poi_ctx_set_batch_cap(poi_ctx* ctx, float cap);
 
 /* ---- a5: BPR-MF step - OboBpr.bpr_train(uidx, [p, q]), public/BPR.py:201-241 ----------------
  * n independent (user, positive, negative) triples.  ux (n_user, D), lt (n_item+1, D).
- * loss_out[n] = -log sigmoid(u).  mode: POI_BPR_SNAPSHOT = batch semantics above;
+ * loss_out[n] = -log sigmoid(u).  mode: POI_BPR_SNAPSHOT = batch semantics above - every triple at the launch-entry
+ * values; the 3 n table touches are sorted by row and summed in a fixed order (no float atomics: identical launches give
+ * bitwise identical tables; ABI 5); lt may be a registered IEEE-half table (float32 arithmetic, poi_ctx_set_f16_rounding
+ * applies), ux stays float32; dim a multiple of 4 up to 1024.
  * POI_BPR_HOGWILD = in-place racy update (one pass over the three rows; identical to the
- * reference whenever no row is shared inside the launch, e.g. n == 1). */
+ * reference whenever no row is shared inside the launch, e.g. n == 1; float32 tables only). */
 enum { POI_BPR_SNAPSHOT = 0, POI_BPR_HOGWILD = 1 };
 int poi_bpr_step(poi_ctx* ctx, float* ux, float* lt, int32_t n_user, int32_t n_item, int32_t dim,
                  const int32_t* uidx, const int32_t* p, const int32_t* q, int32_t n,

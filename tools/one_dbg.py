@@ -28,4 +28,4 @@ for mode in ("one", "batched", "batched-mfma", "seq"):
     for k in SP_NAMES:
         a, b, o = np.asarray(g[k], np.float64), np.asarray(Pn[k], np.float64), np.asarray(P0[k], np.float64)
         print("   %-12s w %.2e   delta %.2e  (|delta| max %.2e)" % (k, np.abs(a - b).max() / max(np.abs(b).max(), 1e-30), np.abs((a - o) - (b - o)).max() / max(np.abs(b - o).max(), 1e-30), np.abs(b - o).max()))
-m.ctx.set_one_sequence_path(True); m.ctx.set_small_launch(1024); m.ctx.set_engine("auto")
+m.ctx.set_one_sequence_path(True); m.ctx.set_small_launch(1800); m.ctx.set_engine("auto")
