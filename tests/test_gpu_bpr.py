@@ -109,3 +109,54 @@ def test_bpr_snapshot_half_poi_table(pa):
     want = np.asarray(exp["lt"], np.float16).astype(np.float64)
     ulp = np.spacing(np.abs(want).astype(np.float16)).astype(np.float64)
     assert (np.abs(lt - want) <= ulp).all() and (lt == want).mean() > 0.97
+
+
+def _expected_vec(P, u, p, q, alpha, lam, cap):
+    """_expected, vectorised (np.add.at over the triples) - checked against the oracle loop below before it is used at sizes the loop cannot reach"""
+    ux, lt = np.asarray(P["ux"], np.float64), np.asarray(P["lt"], np.float64)
+    d = lt[p] - lt[q]
+    m = np.einsum("nd,nd->n", ux[u], d)
+    g = -1.0 / (1.0 + np.exp(m))
+    loss = np.logaddexp(0.0, -m)
+    G = {"ux": np.zeros_like(ux), "lt": np.zeros_like(lt)}
+    C = {"ux": np.zeros(ux.shape[0]), "lt": np.zeros(lt.shape[0])}
+    np.add.at(G["ux"], u, g[:, None] * d); np.add.at(C["ux"], u, 1)
+    np.add.at(G["lt"], p, g[:, None] * ux[u]); np.add.at(C["lt"], p, 1)
+    np.add.at(G["lt"], q, -g[:, None] * ux[u]); np.add.at(C["lt"], q, 1)
+    out = {}
+    for name, T in (("ux", ux), ("lt", lt)):
+        k = C[name]
+        sc = np.where(k > 0, alpha * np.minimum(k, cap), 0.0)
+        out[name] = T - sc[:, None] * (G[name] / np.maximum(k, 1)[:, None] + lam * T)
+    return out, loss
+
+
+def test_bpr_snapshot_fuzz_sizes_and_dims(pa):
+    """random launch sizes 1 .. 60000, dims 4 .. 1024 (every lane layout and column-pass count), user / POI tables small against the launch (long runs
+    over many windows) and large (mostly single touches), caps 1 .. inf - against the vectorised batch rule (== the oracle loop, checked first)"""
+    rng = np.random.default_rng(2026)
+    T0 = toy_problem(60, n_user=9, n_item=40, dim=8)
+    P0 = round_f32(O.init_bpr_params(np.random.default_rng(1), 9, 40, 8))
+    u0, p0, q0 = _triples(1, 200, 9, 40, 3, 4)
+    a, la = _expected(P0, u0, p0, q0, 0.01, 0.001, 4.0); b, lb = _expected_vec(P0, u0, p0, q0, 0.01, 0.001, 4.0)
+    assert np.allclose(a["ux"], b["ux"], rtol=1e-12, atol=1e-14) and np.allclose(a["lt"], b["lt"], rtol=1e-12, atol=1e-14) and np.allclose(la, lb, rtol=1e-12)
+    for it in range(24):
+        dim = int(rng.choice([4, 20, 32, 64, 100, 128, 192, 256, 320, 512, 1024]))
+        n = int(rng.choice([1, 2, 63, 64, 65, 1000, 4097, 20000, 60000]))
+        if dim >= 512:
+            n = min(n, 4097)
+        n_user = int(rng.choice([3, 50, 3000])); n_item = int(rng.choice([5, 80, 5000]))
+        cap = float(rng.choice([1.0, 3.0, 64.0, 1e9]))
+        T = toy_problem(61 + it, n_user=n_user, n_item=n_item, dim=dim, hot=min(8, n_item))      # (only the model's bookkeeping tables: the triples come from below)
+        P = round_f32(O.init_bpr_params(np.random.default_rng(100 + it), n_user, n_item, dim))
+        u, p, q = _triples(200 + it, n, n_user, n_item, hot_users=max(1, n_user // 10), hot_items=max(2, n_item // 10))
+        exp, el = _expected_vec(P, u, p, q, 0.01, 0.001, cap)
+        m = pa.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=dim, n_hidden=dim, init=P)
+        m.ctx.set_batch_cap(cap)
+        try:
+            got_l = m.train_batch(u, p, q)
+        finally:
+            m.ctx.set_batch_cap(1.0)
+        what = "fuzz %d: dim %d n %d users %d items %d cap %g" % (it, dim, n, n_user, n_item, cap)
+        assert_close(got_l, el, "losses " + what)
+        assert_step_close({k: getattr(m, k).get_value() for k in ("ux", "lt")}, exp, P, ("ux", "lt"), what)
