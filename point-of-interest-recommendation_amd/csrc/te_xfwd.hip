@@ -757,7 +757,9 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwdd_kernel(TeArgs A) {
   // products of NG gates (gt0 ..) x this wave's two unit tiles with the state in sT: acc[gate][tile] (C layout: reg r = unit ub + r)
   auto mma = [&](auto& acc, const double* __restrict__ sT, const int gt0, auto ng) {
     constexpr int NG = decltype(ng)::value;
-    float4 ac[NG][2], an[NG][2];
+    // the weight fragments of k-block kq + 2 are requested while kq is multiplied (an L2 round trip under a full chip is longer than one
+    // block's sixteen MFMAs); the four state values of a block are read from LDS in front of its MFMAs
+    float4 ac[NG][2], an[NG][2], af[NG][2];
     auto fetch = [&](float4 (&o)[NG][2], int kq) {
 #pragma unroll
       for (int q = 0; q < NG; ++q)
@@ -768,26 +770,28 @@ __global__ __launch_bounds__(D * 2) void te_rec_fwdd_kernel(TeArgs A) {
     for (int q = 0; q < NG; ++q)
 #pragma unroll
       for (int u = 0; u < 2; ++u) acc[q][u] = f64x4{0.0, 0.0, 0.0, 0.0};
-    fetch(ac, 0);
+    fetch(ac, 0); fetch(an, 1);
 #pragma unroll 2
     for (int kq = 0; kq < KQ; ++kq) {
-      fetch(an, min(kq + 1, KQ - 1));
+      fetch(af, min(kq + 2, KQ - 1));
       const double* bp = sT + (size_t)(16 * kq + g) * 16 + i;
+      double b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = bp[64 * j];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const double b = bp[64 * j];
 #pragma unroll
         for (int q = 0; q < NG; ++q)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const float a = j == 0 ? ac[q][u].x : j == 1 ? ac[q][u].y : j == 2 ? ac[q][u].z : ac[q][u].w;
-            acc[q][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a, b, acc[q][u], 0, 0, 0);
+            acc[q][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a, b[j], acc[q][u], 0, 0, 0);
           }
       }
 #pragma unroll
       for (int q = 0; q < NG; ++q)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) ac[q][u] = an[q][u];
+        for (int u = 0; u < 2; ++u) { ac[q][u] = an[q][u]; an[q][u] = af[q][u]; }
     }
   };
   // pre-activations of gate gt, both unit tiles, of packed row `row` (FT: table rows p1 / z1)
