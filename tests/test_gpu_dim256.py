@@ -53,13 +53,14 @@ def test_dim256_launch_with_the_reference_init(pa, n_user, n_item):
     assert_step_close(got, exp, Pin, SP, "dim 256, reference init, %d users" % n_user)
 
 
-def test_dim256_predict_with_the_reference_init(pa):
+@pytest.mark.parametrize("n_user,n_item", [(40, 900), (1700, 500)])      # (3 tiles; 107 tiles, every POI row read by many sequences)
+def test_dim256_predict_with_the_reference_init(pa, n_user, n_item):
     dim = 256
-    T = toy_problem(77, n_user=40, n_item=900, n_dist=200, dim=dim, len_max=50, min_len=4)
+    T = toy_problem(77, n_user=n_user, n_item=n_item, n_dist=200, dim=dim, len_max=30 if n_user > 100 else 50, min_len=4)
     P = spatial_params(78, T)
     m = _model(pa, T, P, dim)
     m.update_trained_items(); m.update_trained_dists()
-    ids = np.arange(40, dtype=np.int32)
+    ids = np.arange(n_user, dtype=np.int32)
     hts, sts = m.predict(ids)
     eh, es = O.spatial_predict(P, P["lt"], P["di"], np.asarray(T["train"][0])[ids], np.asarray(T["dist"][0])[ids], np.asarray(T["train"][1])[ids])
     assert_close(hts, eh, "hts"); assert_close(sts, es, "sts")
