@@ -311,6 +311,67 @@ def make_synthetic(n_user, n_item, max_len, seed, dd=200, ud_km=40, min_len=4, b
     return ds
 
 
+def load_sequence_file(path, split=-1, dd=200, dist_num=200, seed=0, return_aliases=False):
+    """The reference's `load_data` (public/Load_Data_by_length.py:45-112) on its own sequence file - the space-separated table the ETL writes
+    (poidata/extract_whole_user_buys.py:81-90: columns check_times pois_different u_id u_pois u_times u_coordinates; `u_pois` = ids joined by
+    '/', `u_coordinates` = 'lat,lon' pairs joined by '/') - straight into the CSR PoiDataset the generator returns.  Same rules:
+      * train = upois[:split], held-out = upois[split] (split -1: test mode, -2: valid mode; :64-65);
+      * distance bin of check-in i = cal_dis(check-in i, check-in i-1) from the PER-CHECK-IN coordinates, dist_num at i = 0 (:68-74);
+      * a POI's coordinate in `coords` is the one of its LAST occurrence in file order (dict(zip(...)), :56);
+      * n_item = number of distinct ids in the WHOLE file, held-out check-ins included (:57,98).
+    Aliases: the reference numbers the POIs in the iteration order of a Python `set` of strings (:98-99) - arbitrary, and different from run to
+    run under hash randomisation.  Here: order of first appearance in the file - a relabelling of the same data (tests/test_host_cpu.py checks
+    equality with the reference's output modulo that relabelling).  Negatives are drawn as the driver does right after loading
+    (prog_bpr_gru_spatial.py:88-91) from `seed`."""
+    import pandas as pd
+    tab = pd.read_csv(path, sep=" ")                                                      # :52
+    seqs = [str(s).split("/") for s in tab["u_pois"]]
+    cods = [[tuple(float(v) for v in c.split(",")) for c in str(s).split("/")] for s in tab["u_coordinates"]]
+    alias, coord_of = {}, {}
+    for upois, ucods in zip(seqs, cods):
+        if len(upois) != len(ucods):
+            raise ValueError("%s: a user with %d POIs and %d coordinates" % (path, len(upois), len(ucods)))
+        if len(upois) < -split:
+            raise IndexError("%s: a sequence of %d check-ins cannot be split at %d" % (path, len(upois), split))      # (the reference: IndexError at :65)
+        for s_, c_ in zip(upois, ucods):
+            if s_ not in alias:
+                alias[s_] = len(alias)
+            coord_of[s_] = c_
+    n_user, n_item = len(seqs), len(alias)
+    coords = np.empty((n_item, 2), np.float64)
+    for s_, a_ in alias.items():
+        coords[a_] = coord_of[s_]
+    ids = [np.fromiter((alias[s_] for s_ in upois), np.int32, count=len(upois)) for upois in seqs]
+    dist = []
+    for ucods in cods:                                                                    # :68-74
+        c = np.asarray(ucods, np.float64)
+        d = np.full(len(c), dist_num, np.int64)
+        if len(c) > 1:
+            d[1:] = cal_dis_vec(c[1:, 0], c[1:, 1], c[:-1, 0], c[:-1, 1], dd, dist_num)
+        dist.append(d.astype(np.int32))
+    lens = np.array([len(x[:split]) for x in ids], np.int64)
+    off = np.zeros(n_user + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    ds = PoiDataset(n_user=n_user, n_item=n_item, dist_num=int(dist_num), dd=float(dd), coords=coords, off=off.astype(np.int32),
+                    tra_p=np.concatenate([x[:split] for x in ids]).astype(np.int32), tra_dp=np.concatenate([d[:split] for d in dist]).astype(np.int32),
+                    tes_p=np.array([x[split] for x in ids], np.int32), tes_dp=np.array([d[split] for d in dist], np.int32))
+    ds.resample_negatives(np.random.default_rng(seed))
+    return (ds, alias) if return_aliases else ds
+
+
+def write_sequence_file(path, seqs, coords, user_ids=None):
+    """Write check-in sequences in the ETL's format (poidata/extract_whole_user_buys.py:81-90) - the inverse of load_sequence_file, for tests and
+    for handing synthetic data to the reference driver.  seqs: list of POI-id lists; coords: (n_item, 2) or a list of per-check-in lists."""
+    import pandas as pd
+    rows = []
+    for k, s in enumerate(seqs):
+        cc = coords[k] if isinstance(coords, list) else [coords[i] for i in s]
+        rows.append((len(s), "%0.2f" % (1.0 * len(set(s)) / len(s)), user_ids[k] if user_ids is not None else k, "/".join(str(i) for i in s),
+                     "/".join(str(t) for t in range(len(s))), "/".join("%r,%r" % (float(c[0]), float(c[1])) for c in cc)))
+    cols = ["check_times", "pois_different", "u_id", "u_pois", "u_times", "u_coordinates"]
+    pd.DataFrame(rows, columns=cols).to_csv(path, sep=" ", index=False, columns=cols)
+
+
 def shard_users(n_user, world_size, rank, lens=None):
     """Contiguous user shard [lo, hi) of rank `rank`; with `lens`, boundaries balance the number of
     check-ins (GRU steps) rather than the number of users."""

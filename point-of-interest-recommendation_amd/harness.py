@@ -27,6 +27,23 @@ def default_params():
                 dataset="synthetic", UD=40, dd=200, load_epoch=0, save_per_epoch=0)       # :54-78 (checkpoint naming / cadence)
 
 
+def load_dataset(p, root="."):
+    """Params.__init__ of the driver (prog_bpr_gru_spatial.py:81-91): p['dataset'] names a sequence file in the ETL's format
+    ('Foursquare.txt' / 'Gowalla.txt' under `root`, or any path) -> data.load_sequence_file with p['split'] (-1 test / -2 valid), p['dd'] and
+    dist_num = int(UD * 1000 / dd) (:81).  'synthetic' / 'synthetic:<shape>' -> the generator (data.SHAPES)."""
+    from . import data as pdata
+    name = str(p.get("dataset", "synthetic"))
+    dist_num = int(p["UD"] * 1000 / p["dd"])
+    if name.startswith("synthetic"):
+        shape = name.split(":", 1)[1] if ":" in name else "tiny"
+        n_item, n_user, max_len, _ = pdata.SHAPES[shape]
+        return pdata.make_synthetic(n_user, n_item, max_len, seed=p.get("seed", 0), dd=p["dd"], ud_km=p["UD"], local=p.get("local", 0.8))
+    path = name if os.path.exists(name) else os.path.join(root, name)
+    if not os.path.exists(path):
+        raise FileNotFoundError("dataset %r: no such sequence file (looked at %s)" % (name, path))
+    return pdata.load_sequence_file(path, split=p.get("split", -1), dd=p["dd"], dist_num=dist_num, seed=p.get("seed", 0))
+
+
 def build_model(ds, p, device="cuda:0", seed=None):
     tab = ds.shard()
     size = p["latent_size"]
@@ -50,7 +67,7 @@ CKPT_ORDER = ("loss_weight", "wd", "lt", "di", "ui", "wh", "bi", "vs", "bs")    
 
 def checkpoint_path(p, model_name, epoch, root="./model"):
     """File name of prog_bpr_gru_spatial.py:207-209,321-322."""
-    return os.path.join(root, str(p["dataset"]), "%s_size%s_UD%s_dd%s_epoch%s" % (model_name, p["latent_size"], p["UD"], p["dd"], epoch))
+    return os.path.join(root, os.path.basename(str(p["dataset"])), "%s_size%s_UD%s_dd%s_epoch%s" % (model_name, p["latent_size"], p["UD"], p["dd"], epoch))
 
 
 def _py2_compatible(stream):
@@ -103,6 +120,10 @@ def load_checkpoint(model, path):
 
 
 def train_valid_or_test(ds, p, device="cuda:0", log=print):
+    if ds is None or isinstance(ds, str):                          # a sequence file: BASELINE.json configs[0] through the product
+        if isinstance(ds, str):
+            p = dict(p, dataset=ds)
+        ds = load_dataset(p)
     model = build_model(ds, p, device, seed=p.get("seed"))
     ini_epoch = 0
     if p["gru"] == 2 and p.get("load_epoch", 0):                  # prog_bpr_gru_spatial.py:204-214

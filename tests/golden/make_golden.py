@@ -87,6 +87,29 @@ def main():
              ragged_pois=ragged, ragged_dist=ragged_d, pois_m=np.array(pois_m), dist_m=np.array(dist_m),
              msks=np.array(msks), negs=np.array(negs), dist_neg=np.array(dist_neg), ulptai=np.array(ulptai))
 
+    # ---- load_data on a small sequence file in the ETL's format (poidata/extract_whole_user_buys.py:81-90) ----------------
+    # The file is written here (synthetic data; committed as a data fixture), the reference's own load_data reads it.  POI ids are
+    # non-contiguous strings, one POI changes its coordinate between check-ins (bins come from the per-check-in coordinates, the table
+    # keeps the last one), sequences are ragged; aliases are whatever this process's set order gives - the test compares modulo that.
+    import io, contextlib
+    from poi_amd import data as pdata
+    Nf, Uf = 45, 14
+    rng_f = np.random.default_rng(20260929)          # (its own stream: the vectors of Part 2 keep theirs)
+    cf = np.stack([40.0 + rng_f.uniform(0, 0.3, Nf), -74.0 + rng_f.uniform(0, 0.4, Nf)], 1)
+    names = rng_f.permutation(5000)[:Nf] + 17
+    seqs_i = [list(map(int, rng_f.integers(0, Nf, L))) for L in rng_f.integers(5, 19, Uf)]
+    per_checkin = [[tuple(cf[i]) for i in s] for s in seqs_i]
+    moved = seqs_i[3][1]
+    per_checkin[3][1] = (cf[moved][0] + 0.01, cf[moved][1] - 0.02)           # an earlier check-in at another coordinate: the last one wins (:56)
+    fpath = os.path.join(HERE, "sequences_small.txt")
+    pdata.write_sequence_file(fpath, [[int(names[i]) for i in s] for s in seqs_i], per_checkin, user_ids=list(range(100, 100 + Uf)))
+    for split in (-1, -2):
+        with contextlib.redirect_stdout(io.StringIO()):
+            [(un, inum), pcs, (trp, tep), (trd, ted)] = LD.load_data(fpath, "test" if split == -1 else "valid", split, 200, 200)
+        np.savez(os.path.join(HERE, "load_data_split%d.npz" % -split), user_num=un, item_num=inum, pois_cordis=np.array(pcs),
+                 lens=np.array([len(x) for x in trp]), tra_pois=np.concatenate(trp), tes_pois=np.array(tep).reshape(-1),
+                 tra_dist=np.concatenate(trd), tes_dist=np.array(ted).reshape(-1))
+
     # ---- Part 2: oracle-generated step vectors (drift guard; NOT reference outputs) -------------
     N, B, D, LM, L = 37, 11, 8, 10, 7
     P = O.init_spatial_params(rng, N, B, D)

@@ -122,3 +122,27 @@ def test_cal_s_mode_saves_the_bin_probabilities_of_a_checkpoint(pa, tmp_path):
     model.update_trained_items(); model.update_trained_dists()
     _, exp = model.predict(np.arange(60, dtype=np.int32))
     assert np.allclose(saved, exp, rtol=1e-6, atol=1e-7)
+
+
+def test_reference_sequence_file_through_the_driver_loop_dim32(pa, golden_dir):
+    """BASELINE.json configs[0] in miniature: a sequence file in the ETL's format -> data.load_sequence_file (== the reference's load_data,
+    tests/test_host_cpu.py) -> the driver loop, Distance2Pre at dim 32, one user per step - against the plain-C float64 oracle's
+    sequential epoch on the same shuffled order."""
+    from poi_amd import harness
+    path = os.path.join(golden_dir, "sequences_small.txt")
+    p = harness.default_params()
+    p.update(latent_size=32, epochs=1, gru=2, batch_users=1, seed=5, dataset=path, split=-1, UD=40, dd=200)
+    ds = harness.load_dataset(p)
+    assert (ds.n_user, ds.n_item, ds.dist_num) == (14, 45, 200)
+    probe = harness.build_model(ds, p, seed=5)
+    names = ("lt", "di", "ui", "wh", "bi", "vs", "bs", "wd", "loss_weight")
+    P = {k: np.asarray(getattr(probe, k).get_value(), np.float64) for k in names}
+    P["wd"] = float(P["wd"]); P["h0"] = np.zeros(32)
+    order = np.random.default_rng(123).permutation(ds.n_user).astype(np.int32)
+    exp_out = C.spatial_epoch(P, ds.off, ds.tra_p, ds.tra_q, ds.tra_dp, ds.tra_dq, order, ds.len_max, 0.01, 0.001)
+    model, best, hist = harness.train_valid_or_test(None, p, log=lambda *a: None)
+    for k in names:
+        assert_close(np.asarray(getattr(model, k).get_value(), np.float64), np.asarray(P[k]), k)
+    assert np.isclose(hist[0]["loss"], exp_out[:, 0].sum(), rtol=1e-4)
+    ids = np.arange(ds.n_user, dtype=np.int32)
+    assert np.array_equal(model.compute_sub_topk(ids, 20).cpu().numpy(), O.topk_desc(model.compute_sub_all_scores(ids), 20))

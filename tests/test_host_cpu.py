@@ -183,3 +183,47 @@ def test_coalesce_ranges_merges_contiguous_batches_only():
     odd = [np.array([5, 6, 7]), np.array([9, 10]), np.array([11, 12]), np.array([3, 1])]
     out = ev.coalesce_ranges(odd, target=100)
     assert [list(o) for o in out] == [[5, 6, 7], [9, 10, 11, 12], [3, 1]]
+
+
+@pytest.mark.parametrize("split", [-1, -2])
+def test_load_sequence_file_matches_the_reference_load_data(golden_dir, split):
+    """data.load_sequence_file == public/Load_Data_by_length.py:45-112 on the same file (golden = the reference's own output, made by
+    tests/golden/make_golden.py), modulo the POI relabelling: the reference numbers POIs in the iteration order of a set of strings."""
+    g = np.load(os.path.join(golden_dir, "load_data_split%d.npz" % -split))
+    ds = D.load_sequence_file(os.path.join(golden_dir, "sequences_small.txt"), split=split, dd=200, dist_num=200, seed=3)
+    assert (ds.n_user, ds.n_item) == (int(g["user_num"]), int(g["item_num"]))
+    # reference alias -> alias here through the coordinate rows (distinct per POI in this file)
+    ref_c = g["pois_cordis"]
+    key = {tuple(c): i for i, c in enumerate(ds.coords.tolist())}
+    assert len(key) == ds.n_item
+    to_here = np.array([key[tuple(c)] for c in ref_c.tolist()])                 # every reference coordinate is here, bit for bit
+    assert sorted(to_here.tolist()) == list(range(ds.n_item))
+    assert np.array_equal(np.diff(ds.off.astype(np.int64)), g["lens"])
+    assert np.array_equal(ds.tra_p, to_here[g["tra_pois"]])
+    assert np.array_equal(ds.tes_p, to_here[g["tes_pois"]])
+    assert np.array_equal(ds.tra_dp, g["tra_dist"])
+    assert np.array_equal(ds.tes_dp, g["tes_dist"])
+    # the driver's tables right after loading (prog_bpr_gru_spatial.py:86-91): padded form, negatives outside the user's own POIs
+    pad = ds.to_padded()
+    assert pad["train"][0].shape == (ds.n_user, int(g["lens"].max())) and pad["train"][0].max() == ds.n_item
+    off = ds.off.astype(np.int64)
+    for u in range(ds.n_user):
+        assert not set(ds.tra_q[off[u]:off[u + 1]].tolist()) & set(ds.tra_p[off[u]:off[u + 1]].tolist())
+        assert ds.tra_dp[off[u]] == 200 and ds.tra_dq[off[u]] == 200
+
+
+def test_sequence_file_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    coords = np.stack([40.0 + rng.uniform(0, 0.3, 30), -74.0 + rng.uniform(0, 0.4, 30)], 1)
+    seqs = [list(map(int, rng.integers(0, 30, L))) for L in (5, 9, 6, 12)]
+    path = str(tmp_path / "seq.txt")
+    D.write_sequence_file(path, seqs, coords)
+    ds, alias = D.load_sequence_file(path, split=-1, return_aliases=True)
+    assert ds.n_user == 4 and ds.n_item == len({i for s in seqs for i in s})
+    back = {v: int(k) for k, v in alias.items()}
+    off = ds.off.astype(np.int64)
+    for u, s in enumerate(seqs):
+        assert [back[int(i)] for i in ds.tra_p[off[u]:off[u + 1]]] == s[:-1] and back[int(ds.tes_p[u])] == s[-1]
+    assert np.array_equal(ds.coords, coords[[back[a] for a in range(ds.n_item)]])
+    with pytest.raises(IndexError):
+        D.load_sequence_file(path, split=-13)
