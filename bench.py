@@ -121,9 +121,9 @@ def emit(a, out):
     compact["headline"] = out["headline"]
     if out.get("multi_gpu"):
         m = out["multi_gpu"]
-        compact["multi_gpu"] = {k: m[k] for k in ("world_size", "rccl_world_size", "collective", "replica_checksums_equal", "epochs_synced", "allreduce_ms_last", "allreduce_bytes") if k in m}
+        compact["multi_gpu"] = {k: v for k, v in m.items() if not isinstance(v, (dict, list))}
         if "throughput_schedule" in m:
-            compact["multi_gpu"]["throughput_schedule_seq_per_s"] = m["throughput_schedule"]["seq_per_s"]
+            compact["multi_gpu"]["throughput_schedule"] = {k: v for k, v in m["throughput_schedule"].items() if k != "note"}
         if "projection" in m:
             compact["multi_gpu"]["projected_speedup"] = {Nw: {s_: round(e[s_]["projected_speedup"], 3) for s_ in ("quality", "throughput") if s_ in e}
                                                          for Nw, e in m["projection"]["worlds"].items()}

@@ -268,7 +268,7 @@ def test_emulated_replicas_converge_like_one_gpu(pa):
     assert four["recall"] >= 0.85 * one["recall"], (one, four)
 
 
-def test_bench_two_ranks_end_to_end_on_one_gpu():
+def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks on THIS GPU and gloo as the
     host-side collective (RCCL refuses two ranks on one device): user sharding, the quality schedule, the library's delta / combine
     kernels around a real cross-process all-reduce every epoch, the evaluation on each shard, and the self-check that makes a SCALE run
@@ -281,10 +281,14 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--same-device", "--shape", "foursquare", "--steps", "5", "--warmup", "1",
-           "--eval-steps", "1", "--no-quality", "--no-secondary", "--no-cpu-baseline", "--no-exact", "--no-x1"]
+           "--eval-steps", "1", "--no-quality", "--no-secondary", "--no-cpu-baseline", "--no-exact", "--no-x1", "--full-out", str(tmp_path / "full.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 6000                                   # the compact record: a driver that keeps a few KB of the tail still parses it
+    d = json.loads(last)
+    assert {"metric", "value", "unit", "roofline", "roofline_gather_scatter", "cpu_baseline", "headline", "config"} <= set(d)
+    assert json.load(open(tmp_path / "full.json"))["kernels"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     mg = d["multi_gpu"]
     assert mg["world_size"] == 2 and mg["world_size_seen_by_all_gather"] == 2 and mg["replica_checksums_equal"] and mg["epochs_synced"] >= 5
