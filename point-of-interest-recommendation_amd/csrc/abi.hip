@@ -56,6 +56,7 @@ struct poi_ctx {
   int xfwd = 1;             // exact forward (te_xfwd.hip: fixed point on the int8 matrix cores / float64 MFMA + float64 gates) for dims 64 / 128 / 256; POI_TE_XFWD=0 / poi_ctx_set_exact_forward
   int xcomp = 1;            // exact forward table over the step-input POIs only; POI_TE_XCOMP=0: every row of the POI table (A/B)
   int xcomp_min = 1536;     // ... for launches of at least this many sequences (below: one row per step - the table form of te_rec_fwdx costs 0.6 us more per step of the latency chain than the ranking saves in te_gemmx; 1300 / 1563 / 2048 / 3125 users: +9 / -6 / -38 / -45 us); POI_TE_XCOMP_MIN
+  int efuse = 1;            // E = lt[p'] - lt[q'] gathered inside te_head3 (dim 128) instead of written by te_gather and read back twice; POI_TE_EFUSE
   int head3 = 1;            // training head on split products for <= 256 bins (te_head3); POI_TE_HEAD3
   int xrec1_max = 1100;     // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
   DevBuf xflag;             // launch id of the last launch whose operands held a NaN / inf (TeArgs.xflag)
@@ -157,6 +158,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_XFWD")) c->xfwd = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_XREC1")) c->xrec1_max = atoi(e);
   if (const char* e = getenv("POI_TE_HEAD3")) c->head3 = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_EFUSE")) c->efuse = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_XCOMP")) c->xcomp = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_XCOMP_MIN")) c->xcomp_min = atoi(e);
   if (const char* e = getenv("POI_TE_REC1")) c->rec1_max = atoi(e);
@@ -245,6 +247,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.rec32 = (D >= 256 || (D == 128 && c->engine == 3)) ? 1 : 0;
   A.rec_split = c->rec_split ? 1 : 0;          // (16-sequence tiles and the streaming kernels of dim 256 alike)
   A.head_split = (c->rec_split && A.spatial && (P->n_dist + 1 > 256 || (c->head3 && !predict))) ? 1 : 0;      // (<= 256 bins: te_head3, training launches only)
+  A.efuse = (c->efuse && A.head_split && !predict && P->n_dist + 1 <= 256 && D == 128) ? 1 : 0;      // (the one-sequence path clears it: te_one_in writes E)
   A.rec1 = (!A.rec32 && n <= c->rec1_max) ? 1 : 0;
   A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
@@ -263,14 +266,14 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const bool listed = sorted && (size_t)Rrows > 4 * Ncap;      // table much larger than the launch's footprint: touched-row list
   const size_t sin = sorted ? 7 * Ncap + (listed ? Ncap : 0) + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
   // per-bin tables (bintab): ztab + per-bin sums + d di sums, and (training) the sliced partial sums of DA
-  const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2 + (size_t)TE_HB * (size_t)(c->num_cu * 4);      // (+ the hot bins' per-workgroup partials: TeArgs.dhot)
-  A.npw = c->num_cu * 4;      // workgroups of te_psum: 96 registers x 384 threads - three or four of them fit a CU at a time      // 64-entry chunks of the bins' entry segments
+  const size_t NBt = (size_t)(n_dist + 1), n_dchunk = (Tcap + (size_t)n) / 64 + NBt + 2 + (size_t)TE_HB * (size_t)TE_PSUM_WG;      // (+ the hot bins' per-workgroup partials: TeArgs.dhot)
+  A.npw = TE_PSUM_WG;         // workgroups of te_psum: a CONSTANT (the hot bins' partial sums are formed per workgroup: their summation order must not depend on the device's CU count); 96 registers x 384 threads - three or four of them fit a CU at a time      // 64-entry chunks of the bins' entry segments
   const size_t n_dsuper = n_dchunk / 32 + NBt + 2;
   const size_t bfl = A.bintab ? NBt * (size_t)(3 * D) * 2 + NBt * D + (sorted ? (n_dchunk + n_dsuper) * (size_t)(3 * D) : 0) + 64 : 0;
   const size_t n_prange = Tcap / 64 + 4;
   const size_t pfl = A.ppoi ? Tcap * (size_t)(3 * D) + 2 * n_prange * (size_t)(3 * D) + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl + pfl;
-  const size_t nin = Tcap * 5 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 4 * NBt + 64 : 0) + 3 * NBt + 48 + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
+  const size_t nin = Tcap * 7 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 4 * NBt + 64 : 0) + 3 * NBt + 48 + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
@@ -340,7 +343,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   }
   int* ip = (int*)f;
   auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
-  A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_p = itake(Tcap); A.row_dp = itake(Tcap); A.row_ab = itake(Tcap);
+  A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_p = itake(Tcap); A.row_dp = itake(Tcap); A.row_ab = itake(Tcap); A.row_pq = (int2*)itake(2 * Tcap);
   if (sorted) {
     int bits = 1; while ((1 << bits) <= R) ++bits;      // keys 0..R (R = sentinel)
     A.key_bits = bits;
@@ -494,7 +497,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     // one sequence (the reference schedule): the whole step in five kernels (tile_engine.hip, te_one_*)
     const bool one = n == 1 && c->one_path && E.rec1 && !E.lt_f16 && poi::te_one_supported(D, spatial, T->max_len);
     auto run = [&](hipStream_t s) -> hipError_t {
-      if (one) return poi::launch_te_one(E, alpha, lambda, T->max_len, s, &c->tm);
+      if (one) { E.efuse = 0; return poi::launch_te_one(E, alpha, lambda, T->max_len, s, &c->tm); }
       hipError_t e = poi::launch_te_train(E, c->num_cu, s, &c->tm);
       // early distance-bin chain (launch_te_train started it on the side stream behind te_wgrad): the dense write-back needs te_wgrad's slabs,
       // te_finalize's parts and te_dui's - all of them older on the side stream - and nothing the POI rows' reduction on `s` reads: it

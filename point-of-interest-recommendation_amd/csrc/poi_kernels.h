@@ -191,6 +191,8 @@ struct TeArgs {
   const float* zrow;                  // resident all-zero row (>= 2 * dim floats), never written: target of branch-free "no contribution" loads
   // exact forward (te_xfwd.hip): input product + forward recurrence in ~40-bit fixed point on the int8 matrix cores, float64 gate math
   int xcomp; int *xidx, *xlist, *xblk, *xcnt, *row_pc;      // exact forward table over the launch's step-input POIs only (te_xcount / te_xassign): lt row -> table row, table row -> lt row, per-block counts, row count, per-step table row
+  int efuse;                          // (round 6) te_head3 gathers E = lt[p'] - lt[q'] itself (row_pq: the step's positive / negative POI): no E rows in HBM, te_gather only translates ids; dim 128, training, <= 256 bins; POI_TE_EFUSE
+  int2* row_pq;
   int xrec1;                          // the recurrence of every sequence in its own workgroup on the float64 vector ALUs (te_rec_fwd1x): small launches
   int xfwd, xft;                      // on; pre-activations from the forward table ptabx[p_t] + ztabx[dp_t] (else gx[row])
   double *gx, *ptabx, *ztabx;         // (T + spare) x 3D per step | (n_item + 1 + spare) x 3D | (n_dist + 1) x 3D, gate-major columns (g D + unit)
@@ -204,6 +206,7 @@ struct TeArgs {
 #define TE_ENT_GH 0x20000000      // + g[row-1] * h[row-1]
 #define TE_ENT_NEG 0x40000000     // the g*h term enters with a minus sign (negative sample)
 #define TE_ENT_FIRST 0x80000000u  // first entry of its sequence within the row segment
+#define TE_PSUM_WG 1024          // workgroups of te_psum = chunk partials of a hot bin: device-independent (was num_cu * 4)
 #define TE_HB 4                   // hot distance bins summed by te_psum (TeArgs.dhot)
 #define TE_HOT_BIN_MIN 4096       // ... when they hold at least this many steps of the launch
 #define TE_COLD_MAX 64            // rows with more entries are reduced in 256-entry chunks by whole workgroups

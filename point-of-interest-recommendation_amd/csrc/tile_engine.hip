@@ -622,6 +622,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_rowmap_kernel(TeArgs A) {
       if (A.spatial) A.row_dp[r0 + t] = A.dp[base + t];      // straight into their LDS tiles (no packed copy of X)
       // target bins of the step (positive | negative << 16) for te_head: one load instead of a dependent chain
       if (A.spatial && !A.predict) A.row_ab[r0 + t] = A.dp[base + t + 1] | (A.dq[base + t + 1] << 16);
+      if (A.efuse) A.row_pq[r0 + t] = make_int2(A.p[base + t + 1], A.q[base + t + 1]);      // the rows of E = lt[p'] - lt[q']: te_head3 gathers them itself
     }
     if (A.predict) continue;
     int plt, pdi;
@@ -695,6 +696,9 @@ __global__ __launch_bounds__(TE_BLOCK) void te_gather_kernel(TeArgs A) {
   constexpr int RPB = TE_BLOCK / LPR;           // rows per block pass
   const int T = A.soff[A.n_seq];
   const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
+  if (A.efuse) {      // (round 6) no E rows: the training head gathers lt[p'] / lt[q'] itself (row_pq, te_rowmap) - only the compact table's ids are left here
+    for (int r = blockIdx.x * TE_BLOCK + threadIdx.x; A.xcomp && r < T; r += gridDim.x * TE_BLOCK) A.row_pc[r] = A.xidx[min((unsigned)A.row_p[r], (unsigned)A.n_item)];
+  } else
   for (int r = blockIdx.x * RPB + sub; r < T; r += gridDim.x * RPB) {
     const int s = A.row_src[r];
     const float4 a = ld4t(A.lt, (size_t)A.p[s + 1] * D + c, A.lt_f16);
@@ -2302,14 +2306,21 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head_kernel(T
 //   d h      = d logits . vs from the planes (mma_p2_s3); d bs = column sums of the planes.
 // vs fragments: te_pack n16 == 4 in both orientations (TeArgs.head_split); the logits read planes 1 and 2, d h all three.
 // -------------------------------------------------------------------------------------------------
-template <int D, int NBT>
+// EF (round 6, TeArgs.efuse, dim 128): E = lt[p'] - lt[q'] is gathered HERE instead of written by te_gather (118 MB per 12500-user launch) and read
+// back twice.  The staging map changes with it: a wave owns 32 COLUMNS of the tile (eight lanes x float4 per row, eight rows per pass) - the h tile
+// goes to Ht, the E values stay in registers through the logits and are then parked in the wave's OWN columns of Ht (dead once the logits exist),
+// where the DH epilogue - wave w writes column tile w - reads them back in the MFMA's C layout: no second pass over E in global memory, no
+// cross-wave hazard on Ht, no extra barrier.  h . E is four per-wave partial dots (s_he4) summed in a fixed order.
+template <int D, int NBT, bool EF = false>
 __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(TeArgs A) {
+  static_assert(!EF || D == 128, "te_head3<EF>: a wave owns D / 4 = 32 columns = its DH column tile");
   extern __shared__ __align__(16) float lds[];
   constexpr int KG = D / 16, LDH = D + 4, NBP = NBT * 32, LDO = NBP + 8, NTW = (NBT + 3) / 4, NTD = D / 32;
   constexpr int KBG = NBP / 16, DTW = (NTD + 3) / 4, LPR = D / 4;
   float* Ht = lds;                  // 32 x LDH
   float* Ot = Ht + 32 * LDH;        // 32 x LDO logits; then per wave region (8 rows): [2 planes][8 rows][LDO] bf16 d logits
   __shared__ float s_g[32], s_he[32], s_red[8];
+  __shared__ float s_he4[EF ? 4 : 1][32];
   __shared__ int s_a[32], s_b[32];   // target bins of the tile's rows
   const int NB = A.n_dist + 1;
   const int T = A.soff[A.n_seq];
@@ -2335,9 +2346,25 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
   float dwd_acc = 0.f;
   // (global accesses branch-free, next tile fetched in the middle of the current one, staged at its end: see te_head)
   constexpr int SF4 = 32 * LPR / TE_BLOCK;
-  float4 ph[SF4], pe[SF4];
+  constexpr int EW = 8, ERP = 64 / EW;         // EF: lanes per row inside a wave's 32 columns, rows per pass (SF4 = 32 / ERP passes)
+  float4 ph[SF4], pe[SF4], pb[EF ? SF4 : 1];
+  int2 pid[EF ? SF4 : 1];
   int pab = 0;
+  auto ids = [&](int r0, int tl) {             // EF: the tile's (p', q') pairs, one tile ahead of its rows
+#pragma unroll
+    for (int q = 0; q < SF4; ++q) pid[q] = A.row_pq[min(r0 + q * ERP + ((tl & 63) / EW), T - 1)];
+  };
   auto prefetch = [&](int r0) {
+    if constexpr (EF) {
+#pragma unroll
+      for (int q = 0; q < SF4; ++q) {
+        const int r = q * ERP + ((tid & 63) / EW), c = 32 * w + 4 * (tid & (EW - 1));
+        const size_t gr = (size_t)min(r0 + r, T - 1);
+        ph[q] = *reinterpret_cast<const float4*>(Hsrc + gr * D + c);
+        pe[q] = ld4t(A.lt, (size_t)pid[q].x * D + c, A.lt_f16);
+        pb[q] = ld4t(A.lt, (size_t)pid[q].y * D + c, A.lt_f16);
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
       const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
@@ -2345,9 +2372,21 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
       ph[q] = *reinterpret_cast<const float4*>(Hsrc + gr * D + c);
       pe[q] = *reinterpret_cast<const float4*>(Esrc + gr * D + c);
     }
+    }
     pab = A.row_ab[min(r0 + (tid & 31), T - 1)];
   };
   auto stage = [&](int tid) {
+    if constexpr (EF) {
+#pragma unroll
+      for (int q = 0; q < SF4; ++q) {
+        const int r = q * ERP + ((tid & 63) / EW), c = 32 * (tid >> 6) + 4 * (tid & (EW - 1));
+        *reinterpret_cast<float4*>(Ht + r * LDH + c) = make_float4(ph[q].x, ph[q].y, ph[q].z, ph[q].w);
+        pe[q] = make_float4(pe[q].x - pb[q].x, pe[q].y - pb[q].y, pe[q].z - pb[q].z, pe[q].w - pb[q].w);
+        float d = (ph[q].x * pe[q].x + ph[q].y * pe[q].y) + (ph[q].z * pe[q].z + ph[q].w * pe[q].w);
+        d += dpp_f<0xB1>(d); d += dpp_f<0x4E>(d); d += dpp_f<0x141>(d);      // the eight lanes of the row
+        if ((tid & (EW - 1)) == 0) s_he4[tid >> 6][r] = d;
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < SF4; ++q) {
       const int e = tid + q * TE_BLOCK, r = e / LPR, c = (e % LPR) * 4;
@@ -2358,8 +2397,10 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
       for (int o = 16; o < LPR; o <<= 1) d += __shfl_xor(d, o, 64);
       if ((tid % LPR) == 0) s_he[r] = d;
     }
+    }
     if (tid < 32) { s_a[tid] = pab & 0xffff; s_b[tid] = pab >> 16; }
   };
+  if constexpr (EF) ids(blockIdx.x * 32, tid);
   prefetch(blockIdx.x * 32);
   stage(tid);
   for (int r0 = blockIdx.x * 32; r0 < T; r0 += gridDim.x * 32) {
@@ -2367,6 +2408,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
     asm volatile("" : "+v"(tl));
     const int lane = tl & 63, li = tl & 31;
     lds_barrier();        // staged tile visible; every wave is done with the planes (d h MFMAs of the previous tile)
+    if constexpr (EF) ids(min(r0 + (int)gridDim.x * 32, T - 1), tl);      // the next tile's (p', q'): its rows are requested behind the logits
     {   // logits
       f32x16 acc[NTW];
 #pragma unroll
@@ -2390,6 +2432,11 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
       }
     }
     lds_barrier();
+    if constexpr (EF) {     // the logits are out: Ht is dead until the next stage - this wave's 32 columns of it take the tile's E values
+#pragma unroll
+      for (int q = 0; q < SF4; ++q)
+        *reinterpret_cast<float4*>(Ht + (q * ERP + ((tl & 63) / EW)) * LDH + 32 * w + 4 * (tl & (EW - 1))) = pe[q];
+    }
     prefetch(min(r0 + (int)gridDim.x * 32, T - 1));
     {   // row-wise softmax, losses, d logits: 8 lanes per row, the row's logits in registers
       const int row = tl >> 3, sub = tl & 7, gr = r0 + row;
@@ -2419,7 +2466,7 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
       ea += dpp_f<0xB1>(ea); ea += dpp_f<0x4E>(ea); ea += dpp_f<0x141>(ea);
       eb += dpp_f<0xB1>(eb); eb += dpp_f<0x4E>(eb); eb += dpp_f<0x141>(eb);
       const float inv = 1.0f / sum;
-      const float he = s_he[row];
+      const float he = EF ? (s_he4[0][row] + s_he4[EF ? 1 : 0][row]) + (s_he4[EF ? 2 : 0][row] + s_he4[EF ? 3 : 0][row]) : s_he[row];
       const bool live = gr < T;
       cum *= inv;
       const float sa = ea * inv, sb = eb * inv;
@@ -2460,11 +2507,13 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
 #pragma unroll
       for (int j = 0; j < DTW; ++j) ntd[j] = min(w + 4 * j, NTD - 1);
       float ge[DTW][16];
+      if constexpr (!EF) {
 #pragma unroll
       for (int j = 0; j < DTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           ge[j][r] = Esrc[(size_t)min(r0 + c_row(r, lane), T - 1) * D + ntd[j] * 32 + li];
+      }
       if (tl < NBP / 2) {      // d bs partials: column sums of the two planes (their sum is the float32 value to 2^-18), two bins per thread
         const unsigned* q = reinterpret_cast<const unsigned*>(Ot) + tl;      // (a plane row is LDO / 2 dwords)
         float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
@@ -2485,6 +2534,10 @@ __global__ __launch_bounds__(TE_BLOCK, (D >= 256 ? 2 : 3)) void te_head3_kernel(
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const unsigned short* arow = reinterpret_cast<const unsigned short*>(Ot + (li & ~7) * LDO) + (li & 7) * LDO + 8 * (lane >> 5);
       mma_p2_s3<DTW, KBG>(acc, arow, 8 * LDO, A.pVs, ntd, (NB + 15) / 16);
+      if constexpr (EF) {     // the tile's E values, parked in this wave's columns of Ht (DTW == 1, ntd[0] == w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ge[0][r] = Ht[c_row(r, lane) * LDH + 32 * w + li];
+      }
 #pragma unroll
       for (int j = 0; j < DTW; ++j) {
         if (w + 4 * j >= NTD) continue;
@@ -3581,6 +3634,10 @@ static hipError_t te_launch_head(const TeArgs& A, int mode, int grid, hipStream_
 template <int D, int NBT>
 static hipError_t te_launch_head3(const TeArgs& A, int grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (32 * (D + 4) + 32 * (NBT * 32 + 8));
+  if constexpr (D == 128) {
+    if (A.efuse) { hipLaunchKernelGGL((te_head3_kernel<D, NBT, true>), dim3(grid), dim3(TE_BLOCK), lds, st, A); return hipGetLastError(); }
+  }
+  if (A.efuse) return hipErrorInvalidValue;
   hipLaunchKernelGGL((te_head3_kernel<D, NBT>), dim3(grid), dim3(TE_BLOCK), lds, st, A);
   return hipGetLastError();
 }
@@ -3959,6 +4016,17 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     if (pe != hipSuccess) return pe;
     tm->end(st);
   }
+  // the distance-bin chain of the write-back needs nothing the main stream still has to produce once te_psum has formed the hot bins' partials
+  auto bins_fork = [&]() -> hipError_t {
+    if (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_bwd, 0) != hipSuccess) return hipGetLastError();
+    return launch_te_bins(A, A.bin_alpha, A.bin_lambda, num_cu, A.side, tm);
+    // (the caller puts the dense write-back behind the chain on the side stream and records ev_slots: abi.hip)
+  };
+  const bool bins_side = A.side && A.early_bins && A.bintab;
+  // (round 6) beside te_wgrad: with the hot bins summed by te_psum the chain reads a fifth of DA (57 us instead of 177) and now costs te_wgrad +14 us for
+  // -22 us of te_tail (12500 users: -9 us per launch, 4096 users: -15).  POI_TE_DBG bit 4096: beside te_gemm_dx as in round 5, for A/B runs
+  const bool bins_first = bins_side && !(A.dbg & 4096);
+  if (bins_first) { hipError_t be = bins_fork(); if (be != hipSuccess) return be; }
   tm->begin("te_wgrad", st);
   {
     constexpr int T = (D % 128 == 0) ? 128 : 64;
@@ -3968,16 +4036,10 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
-  if (A.side && A.early_bins && A.bintab) {
-    // the distance-bin chain of the write-back needs nothing the main stream still has to produce: it starts here, next to te_gemm_dx
-    // (350 tiles on 512 workgroup slots), instead of at the fork in launch_te_scatter, which joins on ev_slots (ev_bwd / ev_slots: both
-    // streams passed them long ago).  (Round 4, te_wgrad on split products: started right behind te_rec_bwd instead, the chain costs te_wgrad
-    // +105 us and te_psum +16 for -73 us of te_tail: 1870 -> 1855 us per launch, inside the noise between boxes - left here.)
-    if (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_bwd, 0) != hipSuccess) return hipGetLastError();
-    hipError_t be = launch_te_bins(A, A.bin_alpha, A.bin_lambda, num_cu, A.side, tm);
-    if (be != hipSuccess) return be;
-    // (the caller puts the dense write-back behind the chain on the side stream and records ev_slots: abi.hip)
-  }
+  // it starts here, next to te_gemm_dx (350 tiles on 512 workgroup slots), instead of at the fork in launch_te_scatter, which joins on ev_slots
+  // (ev_bwd / ev_slots: both streams passed them long ago).  (Round 4, te_wgrad on split products: started right behind te_rec_bwd instead, the chain
+  // costs te_wgrad +105 us and te_psum +16 for -73 us of te_tail: 1870 -> 1855 us per launch, inside the noise between boxes - left here.)
+  if (bins_side && !bins_first) { hipError_t be = bins_fork(); if (be != hipSuccess) return be; }
   tm->begin("te_gemm_dx", st);
   {
     // dx = DA . ui: K = 3D is always wide enough for the compile-time-K kernel.  With the per-bin table only the
