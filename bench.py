@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s ach
 PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PEAK_F64_TFLOPS = 78.6      # float64 vector rate = float64 MFMA rate on gfx950 (half the float32 vector peak of MI355X_MICROARCH.md)
 PEAK_I8_TOPS = 5000.0       # MI355X_MICROARCH.md / cdna_hip_programming.md: int8 MFMA = 2 x the 2.5 PF bf16 dense peak (measured 3.9 - 4.4 POP/s)
-PROFILE_TAG = "r05"         # profiles/<tag>_pmc_traffic.json: committed rocprofv3 PMC passes of this command
+PROFILE_TAG = "r06"         # profiles/<tag>_pmc_traffic.json: committed rocprofv3 PMC passes of this command
 
 
 def parse():
@@ -112,7 +112,8 @@ def emit(a, out):
         "bound": "hbm", "kernels": g["kernels"], "ms_per_epoch": g["ms_per_epoch"], "achieved": g["achieved"], "peak": g["peak"], "unit": g["unit"], "frac": g["frac"],
         "frac_survey_8d": (g.get("survey_8d") or {}).get("frac"), "frac_bytes_moved": (g.get("implementation") or {}).get("frac"),
         "frac_embedding_rows_only": (g.get("embedding_rows_only") or {}).get("frac"), "bytes_per_epoch_survey_8d": (g.get("survey_8d") or {}).get("bytes_per_epoch"),
-        "traffic": g.get("traffic"), "sort_ms_hidden": g.get("sort_ms_hidden"), "x1": g.get("x1")}
+        "traffic": g.get("traffic"), "sort_ms_hidden": g.get("sort_ms_hidden"),
+        "frac_survey_8d_with_fused_gather_charged": (g.get("fused_gather") or {}).get("frac_survey_8d_with_it"), "x1": g.get("x1")}
     if c:
         compact["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "sample": c["sample"][:160],
                                    "all_cores": sub(c.get("all_cores"), ("value", "cores"))}
@@ -297,7 +298,7 @@ def main():
     barrier()
     dt = rank_max(time.perf_counter() - t0)
     KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_psum", "te_wgrad", "te_gemm_dx",
-          "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "te_tail", "rows_apply", "dense_apply"]
+          "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "te_tail", "rows_apply", "dense_apply", "te_sort"]
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
     seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
@@ -489,7 +490,7 @@ def main():
         s_rows += len(np.unique(np.concatenate([tab.p[off64[u]:off64[u + 1] - 1] for u in ids])))
         uniq += len(np.unique(np.concatenate((tab.p[sel], tab.q[sel])))) + 1 + len(np.unique(np.append(tab.dp[sel], ds.dist_num)))
         pos += len(sel)
-    if n_local <= 60000:
+    if n_local <= 200000:
         # per-sequence unique counts, vectorised: sort (user, id) pairs
         user_of = np.repeat(np.arange(n_local), lens_local)
         for arrs in ((tab.p, tab.q), (tab.dp,)):
@@ -526,6 +527,7 @@ def main():
     split = os.environ.get("POI_TE_SPLIT", "1") != "0"
     rec1_max = int(os.environ.get("POI_TE_REC1", "1800"))        # launches of at most this many sequences: per-sequence recurrent kernels (float32 FMAs)
     head3 = split and NB <= 256 and os.environ.get("POI_TE_HEAD3", "1") != "0"
+    efuse = head3 and D == 128 and os.environ.get("POI_TE_EFUSE", "1") != "0"      # (abi.hip te_setup: E gathered inside te_head3)
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
             "te_gemm_ax": ("i8op", 15 * 6 * D2 * ax_rows) if xfwd else ("bf16x6", 6 * xk * D2 * ax_rows) if split and bintab and D >= 256 else ("flop", xk * D2 * ax_rows),
             # (dim 256: te_rec_fwdd - the recurrent products in float64 on the matrix cores, v_mfma_f64_16x16x4_f64)
@@ -538,8 +540,9 @@ def main():
             # per-POI sums of DA: one read of the 3D-wide DA rows + the S rows written
             "te_psum": ("byte", 3.0 * D * 4 * (1.0 + rho) * steps_per_epoch),
             # implementation bytes of the HBM-bound kernels (what each kernel has to move given the decomposition):
-            # te_gather builds E = lt[p'] - lt[q'] (two table rows + two indices in, one packed row out per step)
-            "te_gather": ("byte", (3.0 * D * 4 + 8) * steps_per_epoch),
+            # te_gather builds E = lt[p'] - lt[q'] (two table rows + two indices in, one packed row out per step); round 6, dim 128: te_head3 gathers
+            # the two rows itself (TeArgs.efuse) - te_gather only translates the steps' ids for the compact forward table (three ints per step)
+            "te_gather": ("byte", 12.0 * steps_per_epoch) if efuse else ("byte", (3.0 * D * 4 + 8) * steps_per_epoch),
             "rows_apply": ("byte", 2.0 * uniq * D * 4.0),      # read + write of every touched row
             # sorted scatter: h twice per step (the g*h term of the positive and of the negative row) + the dx sums (per-POI regrouping:
             # one D-row per S row; otherwise D floats per step, two-table path 2D) in, every touched row read + written
@@ -582,6 +585,9 @@ def main():
             ent["note"] = ("the distance-bin chain (te_dsum, te_bin_gemm) runs on the side stream from the end of te_wgrad on, next to te_gemm_dx and "
                            "te_scatter (POI rows): the spans overlap and stretch each other (stand-alone: 0.37 / 0.14 / 0.44 ms per epoch, POI_TE_DBG=1) - "
                            "te_tail, te_scatter's start to the join, is the span that counts")
+        if k == "te_sort":
+            ent["note"] = ("side stream, beside te_rec_fwd: stable radix sort of the table-touch slots + segment bounds + S-row assignment + the bin chain's chunk offsets - part "
+                           "of the scatter, hidden from the main stream's chain (roofline_gather_scatter.sort_ms_hidden); the span stretches with what runs beside it")
         if k == "te_tail":
             ent["note"] = ("te_scatter's start to the join with the side stream's distance-bin chain (te_dsum + te_bin_gemm, started behind te_wgrad) "
                            "and the dense write-back that follows it there (dense_apply: its time is inside this span on launches of >= 1024 users); "
@@ -614,7 +620,7 @@ def main():
     forked = "te_tail" in kernels          # te_dsum (+ te_bin_gemm) and te_scatter overlap: their time is the fork-to-join span
     gs_ms = sum(kernels[k]["ms_per_step"] for k in GS if k in kernels and not (forked and k in ("te_dsum", "te_scatter"))) + (kernels["te_tail"]["ms_per_step"] if forked else 0.0)
     gs_impl = sum(work[k][1] for k in GS if k in kernels)
-    e = 4.0
+    e = 2.0 if a.table_dtype == "f16" else 4.0      # (config X counts 2-byte elements)
     survey_bytes = 3.0 * pos * D * e + 16.0 * pos + uniq_seq * D * e if uniq_seq else None      # SURVEY.md 8(d) bytes_seq, summed
     rows_only = 2.0 * steps_per_epoch * D * e + 2.0 * uniq * D * e          # E's two table rows per step + touched rows r/w
     acc = lambda b: {"bytes_per_epoch": b, "achieved_GBps": b / (gs_ms * 1e-3) / 1e9, "frac": b / (gs_ms * 1e-3) / 1e9 / PEAK_HBM_GBS} if b and gs_ms > 0 else None
@@ -628,6 +634,14 @@ def main():
                "implementation": "bytes the HBM-bound kernels have to move in this decomposition, intermediates included (E rows out, h rows and the per-POI "
                                  "dx sums in, DA rows read once for the per-bin and once for the per-POI sums, S rows out, touched rows read + written)",
                "embedding_rows_only": "table rows only: the two rows of E per step + every touched row read and written once per launch"}}
+    hbm["sort_ms_hidden"] = kernels["te_sort"]["ms_per_step"] if "te_sort" in kernels else None
+    if efuse:
+        # the two table rows of E are gathered inside te_head3 (an MFMA-bound kernel): A/B on one box (profiles/r06, POI_TE_EFUSE=0 / 1, 12500-user launches):
+        # te_gather 71.0 -> 6.7 us, te_head 217.6 -> 228.4 us per launch - the 10.8 us are charged here
+        fused_ms = 10.8e-3 * n_launches
+        hbm["fused_gather"] = {"what": "E = lt[p'] - lt[q'] is gathered inside te_head3 (no E rows in HBM): te_gather 71.0 -> 6.7 us, te_head +10.8 us per 12500-user launch (same-box A/B)",
+                               "ms_per_epoch_charged": fused_ms,
+                               "frac_survey_8d_with_it": (survey_bytes / ((gs_ms + fused_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS) if survey_bytes else None}
     hbm["achieved"] = (hbm["survey_8d"] or hbm["implementation"])["achieved_GBps"]
     hbm["frac"] = (hbm["survey_8d"] or hbm["implementation"])["frac"]
     roofline_gs_hook["gather_scatter"] = {"bound": "hbm", "kernels": hbm["kernels"], "ms_per_epoch": gs_ms, "frac_survey_8d": (hbm["survey_8d"] or {}).get("frac"),
@@ -911,6 +925,8 @@ def main():
             secondary_x1 = {"workload": j["config"]["workload"], "table_storage": j["table_storage"], "f16_rounding": j["config"].get("f16_rounding"),
                             "train_seq_per_s": j["value"], "ms_per_epoch": j["ms_per_step"], "batch_users_per_launch": j["config"]["batch_users_per_launch"],
                             "dominant_kernel": j["roofline"]["kernel"], "dominant_frac": j["roofline"]["frac"], "wall_s_incl_data_generation": time.perf_counter() - t0,
+                            "gather_scatter": {k: (j.get("roofline_gather_scatter") or {}).get(k) for k in ("kernels", "ms_per_epoch", "frac", "traffic")},
+                            "gather_scatter_frac_bytes_moved": ((j.get("roofline_gather_scatter") or {}).get("implementation") or {}).get("frac"),
                             "eval_users_per_s": j.get("eval_users_per_s"), "eval_ms_per_8192_users_x_10M_pois": (j.get("eval") or {}).get("ms_per_eval"),
                             "eval_filter_ms": ((j.get("eval") or {}).get("two_stage") or {}).get("ms_filter_per_eval"),
                             "tests": "tests/test_gpu_configx.py: the 10 M x 256 half table at full size (touched rows vs the float64 oracle, > 2^31-element indexing, stochastic rounding, GEO top-K over 10 M POIs)"}
@@ -958,6 +974,10 @@ def main():
                          "plain-C float64 port of public/GRU_Spatial.py:127-229 (Theano cannot be built or shipped)" % S,
                "eval_users_per_s": ne / te, "host_cores_available": os.cpu_count()}
 
+    if secondary_x1 and secondary_x1.get("gather_scatter"):
+        # config X's slice: the one shape whose POI table (5.1 GB of half rows) streams from HBM instead of sitting in the 256 MB cache
+        hbm["x1"] = {"frac_survey_8d": secondary_x1["gather_scatter"].get("frac"), "frac_bytes_moved": secondary_x1.get("gather_scatter_frac_bytes_moved"),
+                     "ms_per_epoch": secondary_x1["gather_scatter"].get("ms_per_epoch")}
     if rank == 0:
         out = {
             "metric": "check-in sequences/sec training (Distance2Pre) + all-POI top-K eval users/sec",

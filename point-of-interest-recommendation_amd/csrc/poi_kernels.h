@@ -210,7 +210,7 @@ struct TeArgs {
 #define TE_HB 4                   // hot distance bins summed by te_psum (TeArgs.dhot)
 #define TE_HOT_BIN_MIN 4096       // ... when they hold at least this many steps of the launch
 #define TE_COLD_MAX 64            // rows with more entries are reduced in 256-entry chunks by whole workgroups
-#define TE_HOT_CHUNK 256
+#define TE_HOT_CHUNK 64
 #define RS_MAXBIN 512
 #define RS_GRID 256
 #define RS_HIST_INTS (RS_MAXBIN * RS_GRID)   // radix histogram: bins x blocks

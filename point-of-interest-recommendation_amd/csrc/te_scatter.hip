@@ -375,7 +375,7 @@ __device__ __forceinline__ float4 ent_contrib(const TeArgs& A, int e, int doff, 
 }
 
 // One wavefront sums entries ent[s, s + cnt), cnt <= 64, in a fixed order: D/4 lanes per entry
-// (float4 each), 64/(D/4) entries per pass, four passes in flight.  The sum ends up in every lane
+// (float4 each), 64/(D/4) entries per pass, eight passes in flight.  The sum ends up in every lane
 // group (all groups hold the same total); *nfirst = number of TE_ENT_FIRST entries.
 template <int D>
 __device__ __forceinline__ float4 seg_sum(const TeArgs& A, int s, int cnt, int doff, int* nfirst) {
@@ -384,18 +384,18 @@ __device__ __forceinline__ float4 seg_sum(const TeArgs& A, int s, int cnt, int d
   const int mine = lane < cnt ? A.ent[s + lane] : 0;
   *nfirst = __builtin_popcountll(__ballot(mine < 0));
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i0 = 0; i0 < cnt; i0 += 4 * EPW) {
-    int e[4];
+  for (int i0 = 0; i0 < cnt; i0 += 8 * EPW) {
+    int e[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int idx = i0 + u * EPW + grp;
       const int got = __shfl(mine, idx & 63, 64);
       e[u] = idx < cnt ? got : 0;
     }
-    float4 v[4];
+    float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = ent_contrib<D>(A, e[u], doff, c);
-    acc = f4_add(acc, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+    for (int u = 0; u < 8; ++u) v[u] = ent_contrib<D>(A, e[u], doff, c);
+    acc = f4_add(acc, f4_add(f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])), f4_add(f4_add(v[4], v[5]), f4_add(v[6], v[7]))));
   }
 #pragma unroll
   for (int o = LPR; o < 64; o <<= 1) {
@@ -460,8 +460,10 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
   // another indirection and keep the plain order): te_scatter 131 -> 124 us per 12500-user launch.  (Also the first eight entry codes of the
   // next pair, bounds two pairs ahead: 140 us - 26 registers more and loads for rows without entries.)
   const int first0 = (blockIdx.x * 4 + wave_id()) * RPW;
-  int p_end = 0, p_start = 0;
-  if (!A.urow && first0 + sub < R) { p_end = A.seg_end[first0 + sub]; p_start = A.seg_start[first0 + sub]; }
+  // (round 6) ... and so is the row's S-row mark, and the loads that depend on the row alone - its table values, its dx-sum row of X - are issued at
+  // the top, next to the entry codes: a row pair's update was FIVE dependent round trips (codes -> h rows -> mark -> X row -> table row), now two
+  int p_end = 0, p_start = 0, p_pmk = 0;
+  if (!A.urow && first0 + sub < R) { p_end = A.seg_end[first0 + sub]; p_start = A.seg_start[first0 + sub]; if (PPOI && first0 + sub <= A.n_item) p_pmk = A.pmark[first0 + sub]; }
   for (int row0 = first0; row0 < R; row0 += nw * RPW) {
     const int idx = min(row0 + sub, R - 1);
     bool in = row0 + sub < R;
@@ -472,13 +474,17 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
     }
     const int end = A.urow ? (in ? A.seg_end[row] : 0) : (in ? p_end : 0);
     const int start_pre = p_start;
+    // per-POI regrouping: the summed dx of the row's step inputs = S[row] . ui, row pmark[row] - 1 of X (te_gemm_dx over S)
+    const int pmk = !PPOI ? 0 : A.urow ? ((in && row <= A.n_item) ? A.pmark[row] : 0) : (in ? p_pmk : 0);          // S row + 1 (te_passign), 0: not a step input
     if (!A.urow) {
       const int nx = row0 + nw * RPW + sub;
       const int nxc = min(nx, R - 1);
-      p_end = A.seg_end[nxc]; p_start = A.seg_start[nxc];
-      if (nx >= R) p_end = 0;
+      p_end = A.seg_end[nxc]; p_start = A.seg_start[nxc]; p_pmk = (PPOI && nxc <= A.n_item) ? A.pmark[nxc] : 0;
+      if (nx >= R) { p_end = 0; p_pmk = 0; }
     }
     const RowInfo ri = row_info(A, row);
+    float4 tv = ld4t(ri.trow, (size_t)c, ri.f16);
+    const float4 xs = *reinterpret_cast<const float4*>(pmk ? A.X + (size_t)(pmk - 1) * A.xw + c : zrow + c);
     // padding rows: analytic multiplicity / sequence count from te_rowmap
     const int am = (in && ri.pm) ? *ri.pm : 0, an = (in && ri.pn) ? *ri.pn : 0;
     const int start = end ? (A.urow ? A.seg_start[row] : start_pre) : 0, cnt = end - start;
@@ -522,17 +528,13 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
       }
       acc = f4_add(acc, f4_add(f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])), f4_add(f4_add(v[4], v[5]), f4_add(v[6], v[7]))));
     }
-    // per-POI regrouping: the summed dx of the row's step inputs = S[row] . ui, row pmark[row] - 1 of X (te_gemm_dx over S)
-    const int pmk = (PPOI && in && row <= A.n_item) ? A.pmark[row] : 0;          // S row + 1 (te_passign), 0: not a step input
     if (pmk && !hot) {
-      const float4 xs = *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + c);
       acc = f4_add(acc, xs);
       if (lane == lead) A.pmark[row] = 0;
     }
     if (in && !hot && (end != 0 || an != 0)) {
       const int nseq = ri.pn ? an : nf, mult = cnt + am;
       float sc, lm; rule_scales(alpha, lambda, nseq, mult, A.bcap, sc, lm);
-      float4 tv = ld4t(ri.trow, (size_t)c, ri.f16);
       tv.x -= sc * (acc.x + lm * tv.x); tv.y -= sc * (acc.y + lm * tv.y);
       tv.z -= sc * (acc.z + lm * tv.z); tv.w -= sc * (acc.w + lm * tv.w);
       st4t_sr(ri.trow, (size_t)c, ri.f16, tv, A.sr_salt, (size_t)row * D + c);
@@ -541,53 +543,49 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
   }
 }
 
+// (round 6) one WAVE per 64-entry chunk (a workgroup took 256 entries, its four waves 64 each, and combined them through LDS): four times the
+// jobs for the same rows - the kernel is a handful of hot rows deep and was ~500 workgroups on 256 CUs.
 template <int D>
 __global__ __launch_bounds__(256) void te_hot_reduce_kernel(TeArgs A) {
-  __shared__ __align__(16) float part[4][D];
-  __shared__ int s_nf[4];
+  static_assert(TE_HOT_CHUNK == 64, "te_hot_reduce: a chunk is what seg_sum takes in one call");
   constexpr int LPR = D / 4;
   const int nchunk = A.cnt[2];
-  const int lane = lane_id(), w = wave_id();
-  for (int ci = blockIdx.x; ci < nchunk; ci += gridDim.x) {
+  const int lane = lane_id();
+  for (int ci = blockIdx.x * 4 + wave_id(); ci < nchunk; ci += gridDim.x * 4) {
     const int2 item = A.hot_chunks[ci];
     const int4 hr = A.hot_rows[item.x];
     const int doff = hr.x <= A.n_item ? 0 : D;
-    const int s = hr.y + item.y * TE_HOT_CHUNK + 64 * w;
-    int wc = hr.z - item.y * TE_HOT_CHUNK - 64 * w;
-    wc = wc < 0 ? 0 : (wc > 64 ? 64 : wc);
+    const int s = hr.y + item.y * TE_HOT_CHUNK;
+    const int wc = min(TE_HOT_CHUNK, hr.z - item.y * TE_HOT_CHUNK);
     int nf = 0;
     const float4 g = seg_sum<D>(A, s, wc, doff, &nf);
-    if (lane < LPR) *reinterpret_cast<float4*>(&part[w][lane * 4]) = g;
-    if (lane == 0) s_nf[w] = nf;
-    __syncthreads();
-    if (threadIdx.x < D) {
-      const int j = threadIdx.x;
-      A.hot_part[(size_t)ci * D + j] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
-    }
-    if (threadIdx.x == 0) A.hot_nf[ci] = s_nf[0] + s_nf[1] + s_nf[2] + s_nf[3];
-    __syncthreads();
+    if (lane < LPR) *reinterpret_cast<float4*>(A.hot_part + (size_t)ci * D + lane * 4) = g;
+    if (lane == 0) A.hot_nf[ci] = nf;
   }
 }
 
+// (round 6) one WORKGROUP per hot row: its four waves sum a quarter of the row's chunk partials each (a fixed split, 16 partial rows in flight
+// per wave), LDS combine in wave order - one wave walked all of them, and the hottest POI of a 12500-user launch has hundreds of chunks.
 template <int D>
 __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha, float lambda) {
   constexpr int LPR = D / 4, EPW = 64 / LPR;
+  __shared__ __align__(16) float part[4][D];
+  __shared__ int s_nf[4];
   const int nhot = A.cnt[1];
-  const int lane = lane_id(), grp = lane / LPR, c = (lane % LPR) * 4;
-  for (int h = blockIdx.x * 4 + wave_id(); h < nhot; h += gridDim.x * 4) {
+  const int lane = lane_id(), grp = lane / LPR, c = (lane % LPR) * 4, w = wave_id();
+  for (int h = blockIdx.x; h < nhot; h += gridDim.x) {
     const int4 hr = A.hot_rows[h];
     const int row = hr.x, cnt = hr.z, c0 = hr.w, nch = (cnt + TE_HOT_CHUNK - 1) / TE_HOT_CHUNK;
-    const RowInfo ri = row_info(A, row);
-    const int am = ri.pm ? *ri.pm : 0, an = ri.pn ? *ri.pn : 0;
+    const int per = (nch + 3) / 4, k0 = w * per, k1 = min(nch, k0 + per);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i0 = 0; i0 < nch; i0 += 4 * EPW) {
-      float4 v[4];
+    for (int i0 = k0; i0 < k1; i0 += 8 * EPW) {
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int idx = i0 + u * EPW + grp;
-        v[u] = idx < nch ? *reinterpret_cast<const float4*>(A.hot_part + (size_t)(c0 + idx) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = idx < k1 ? *reinterpret_cast<const float4*>(A.hot_part + (size_t)(c0 + idx) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      acc = f4_add(acc, f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])));
+      acc = f4_add(acc, f4_add(f4_add(f4_add(v[0], v[1]), f4_add(v[2], v[3])), f4_add(f4_add(v[4], v[5]), f4_add(v[6], v[7]))));
     }
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) {
@@ -595,16 +593,31 @@ __global__ __launch_bounds__(256) void te_hot_apply_kernel(TeArgs A, float alpha
       acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
     }
     int nf = 0;
-    for (int i = lane; i < nch; i += 64) nf += A.hot_nf[c0 + i];
+    for (int i = k0 + lane; i < k1; i += 64) nf += A.hot_nf[c0 + i];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) nf += __shfl_xor(nf, o, 64);
-    const int pmk = (A.ppoi && row <= A.n_item) ? A.pmark[row] : 0;
-    if (pmk) {
-      acc = f4_add(acc, *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + c));
-      if (lane == 0) A.pmark[row] = 0;
+    __syncthreads();                                        // (the previous row's partials have been read)
+    if (lane < LPR) *reinterpret_cast<float4*>(&part[w][lane * 4]) = acc;
+    if (lane == 0) s_nf[w] = nf;
+    __syncthreads();
+    if (w == 0) {
+      const RowInfo ri = row_info(A, row);
+      const int am = ri.pm ? *ri.pm : 0, an = ri.pn ? *ri.pn : 0;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < LPR) {
+        const float4 p0 = *reinterpret_cast<const float4*>(&part[0][lane * 4]), p1 = *reinterpret_cast<const float4*>(&part[1][lane * 4]);
+        const float4 p2 = *reinterpret_cast<const float4*>(&part[2][lane * 4]), p3 = *reinterpret_cast<const float4*>(&part[3][lane * 4]);
+        g = f4_add(f4_add(p0, p1), f4_add(p2, p3));
+      }
+      const int nft = (s_nf[0] + s_nf[1]) + (s_nf[2] + s_nf[3]);
+      const int pmk = (A.ppoi && row <= A.n_item) ? A.pmark[row] : 0;
+      if (pmk) {
+        if (lane < LPR) g = f4_add(g, *reinterpret_cast<const float4*>(A.X + (size_t)(pmk - 1) * A.xw + lane * 4));
+        if (lane == 0) A.pmark[row] = 0;
+      }
+      apply_sum<D>(ri.trow, ri.f16, g, cnt + am, ri.pn ? an : nft, alpha, lambda, A.bcap, A.sr_salt, (size_t)row * D);
+      if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
     }
-    apply_sum<D>(ri.trow, ri.f16, acc, cnt + am, ri.pn ? an : nf, alpha, lambda, A.bcap, A.sr_salt, (size_t)row * D);
-    if (lane == 0) { A.seg_end[row] = 0; if (ri.pm) { *ri.pm = 0; *ri.pn = 0; } }
   }
 }
 
@@ -904,7 +917,7 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   if (A.ppoi) hipLaunchKernelGGL((te_reduce_kernel<D, true>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   else hipLaunchKernelGGL((te_reduce_kernel<D, false>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu), dim3(256), 0, st, A, alpha, lambda);
+  hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A, alpha, lambda);
   tm->end(st);
   if (fork && hipStreamWaitEvent(st, A.ev_fin, 0) != hipSuccess) return hipGetLastError();       // join: dense_apply reads te_dui's slab
   if (early && hipStreamWaitEvent(st, A.ev_slots, 0) != hipSuccess) return hipGetLastError();     // (recorded behind the chain by launch_te_train)

@@ -3928,9 +3928,11 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   // index preparation, next to te_gather / te_gemmx as well - the chain then ends inside te_rec_fwdx instead of beside te_head.
   auto fork_sort = [&]() -> hipError_t {
     if (hipEventRecord(A.ev_slots, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_slots, 0) != hipSuccess) return hipGetLastError();
+    const long sp = tm->span_begin("te_sort", A.side);      // (a span: it overlaps the main stream's regions - the slot sort is part of the scatter, hidden beside te_rec_fwd)
     hipError_t se = launch_te_sort(A, A.side); if (se != hipSuccess) return se;
     if (A.ppoi && !(A.dbg & 1024)) { se = launch_te_passign(A, A.side); if (se != hipSuccess) return se; }
     if (A.early_bins && A.bintab) { se = launch_te_dprep(A, A.side); if (se != hipSuccess) return se; }
+    tm->span_end(sp, A.side);
     return hipEventRecord(A.ev_sorted, A.side);
   };
   const bool sort_early = A.side && A.xfwd && !(A.dbg & 2048);      // (POI_TE_DBG bit 2048: behind te_gemm_ax, for A/B runs)
@@ -4036,6 +4038,9 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     else hipLaunchKernelGGL((te_wgrad_kernel<D, T, false>), grid, dim3(TE_BLOCK), 0, st, A, A.n_kc);
   }
   tm->end(st);
+  // (the dense write-back the caller queues behind the chain on the side stream reads te_wgrad's slabs: the side stream waits for te_wgrad HERE, behind the
+  // chain's kernels - they run beside it, the write-back after it)
+  if (bins_first && (hipEventRecord(A.ev_bwd, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_bwd, 0) != hipSuccess)) return hipGetLastError();
   // it starts here, next to te_gemm_dx (350 tiles on 512 workgroup slots), instead of at the fork in launch_te_scatter, which joins on ev_slots
   // (ev_bwd / ev_slots: both streams passed them long ago).  (Round 4, te_wgrad on split products: started right behind te_rec_bwd instead, the chain
   // costs te_wgrad +105 us and te_psum +16 for -73 us of te_tail: 1870 -> 1855 us per launch, inside the noise between boxes - left here.)

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void gather_k(const float4* __restrict__ buf, 
   constexpr int GPW = 64 / LPR > 0 ? 64 / LPR : 1;      // row groups per wave
   const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
   const int grp = lane / LPR, c = lane % LPR;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i0 = wave * GPW * U; i0 < n; i0 += nw * GPW * U) {
     int id[U];
 #pragma unroll
@@ -23,11 +24,10 @@ __global__ __launch_bounds__(256) void gather_k(const float4* __restrict__ buf, 
     float4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = buf[(size_t)id[u] * LPR + c];
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < U; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-    if ((i0 / (GPW * U)) % 8 == 0) out[(size_t)(i0 / (GPW * U * 8)) * 64 + lane] = a;
   }
+  out[(size_t)wave * 64 + lane] = a;      // (every load feeds the result: one row per wave written)
 }
 // 1536-byte rows: 96 lanes per row = thread = one float4 column group, 384-thread... here: 3 x 32-lane thirds, a wave takes two rows' halves -
 // simpler and equivalent for the memory system: treat the row as three 512-byte pieces handled by three lane groups of one wave pair
@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; ++i) idx[i] = std::min(n - 1, blk[i / 64] * 64 + i % 64);
   }
   float4* buf; int* didx; float4* out; float4* fl;
-  hipMalloc(&buf, rows * rowb + 4096); hipMalloc(&didx, n * 4ull); hipMalloc(&out, rows * rowb / 8 + (1 << 20)); hipMalloc(&fl, 512ull << 20);
+  hipMalloc(&buf, rows * rowb + 4096); hipMalloc(&didx, n * 4ull); hipMalloc(&out, rows * rowb / 8 + (64 << 20)); hipMalloc(&fl, 512ull << 20);
   hipMemset(buf, 0, rows * rowb);
   hipMemcpy(didx, idx.data(), n * 4ull, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
