@@ -531,7 +531,8 @@ def main():
     work = {"seq_train": ("flop", step_flops(D, NB) * steps_per_epoch),
             "te_gemm_ax": ("i8op", 15 * 6 * D2 * ax_rows) if xfwd else ("bf16x6", 6 * xk * D2 * ax_rows) if split and bintab and D >= 256 else ("flop", xk * D2 * ax_rows),
             # (dim 256: te_rec_fwdd - the recurrent products in float64 on the matrix cores, v_mfma_f64_16x16x4_f64)
-            "te_rec_fwd": ("f64flop", 6 * D2 * steps_per_epoch) if xfwd and D >= 256 else ("i8op", 15 * 6 * D2 * steps_per_epoch) if xfwd else ("flop", 6 * D2 * steps_per_epoch),
+            # (launches of at most xrec1_max sequences: te_rec_fwd1x - float64 FMAs on the vector ALUs, priced against the float64 vector rate)
+            "te_rec_fwd": ("f64flop", 6 * D2 * steps_per_epoch) if xfwd and (D >= 256 or B <= int(os.environ.get("POI_TE_XREC1", "1100"))) else ("i8op", 15 * 6 * D2 * steps_per_epoch) if xfwd else ("flop", 6 * D2 * steps_per_epoch),
             "te_head": ("bf16x5", 5 * 4.0 * NB * D * steps_per_epoch) if head3 else ("flop", 4.0 * NB * D * steps_per_epoch),
             "te_rec_bwd": ("bf16x6", 6 * 6 * D2 * steps_per_epoch) if split and (B > rec1_max or D >= 256) else ("flop", 6 * D2 * steps_per_epoch),
             # d ui (over S rows), d wh and d vs (split-K)
@@ -570,8 +571,9 @@ def main():
                            note="every float32 product from %s bf16 partial products of three / two planes per operand (v_mfma_f32_*_bf16, float32 accumulation)" % kind[5:])
             elif kind == "f64flop":
                 ent.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_F64_TFLOPS, unit="TFLOP/s (float64 MFMA)", frac=rate / 1e12 / PEAK_F64_TFLOPS,
-                           note="exact forward pass at dim 256: the recurrent products on v_mfma_f64_16x16x4_f64 (16 passes: the float64 vector rate), float32 weight "
-                                "fragments streamed from L2, float64 gates in the MFMA's issue shadow")
+                           note=("exact forward pass at dim 256: the recurrent products on v_mfma_f64_16x16x4_f64 (16 passes: the float64 vector rate), float32 weight "
+                                 "fragments streamed from L2, float64 gates in the MFMA's issue shadow") if D >= 256 else
+                                "exact forward pass of a small launch: te_rec_fwd1x, one sequence per workgroup, float64 FMAs with register-resident weights")
             elif kind == "i8op":
                 ent.update(bound="mfma", achieved=rate / 1e12, peak=PEAK_I8_TOPS, unit="TOP/s (int8)", frac=rate / 1e12 / PEAK_I8_TOPS,
                            float64_equivalent_tflops=rate / 15.0 / 1e12,
@@ -810,8 +812,10 @@ def main():
                 torch.cuda.synchronize(dev); win.append((time.perf_counter() - t0) / reps)
             ts = sorted(win)[1]
             launch_sweep["B=%d" % Bs] = {"us_per_launch": 1e6 * ts, "seq_per_s": Bs / ts, "us_min": 1e6 * min(win), "us_max": 1e6 * max(win)}
-        launch_sweep["note"] = ("median of three windows; one fixed launch repeated (host loop through models.train_batch): B = 1 takes the one-sequence path, B <= 1024 the per-sequence "
-                                "recurrent kernels, above that 16-sequence tiles on split products")
+        xrec1_max = int(os.environ.get("POI_TE_XREC1", "1100"))
+        launch_sweep["note"] = ("median of three windows; one fixed launch repeated (host loop through models.train_batch): B = 1 takes the one-sequence path; the forward recurrence runs per "
+                                "sequence in float64 (te_rec_fwd1x) up to %d sequences and the backward one per sequence (te_rec_bwd1) up to %d, above that 16-sequence tiles "
+                                "(int8 digits forward, bf16 split products backward)" % (xrec1_max, rec1_max))
         del msw
 
     # ---- multi_gpu.projection: rank 0's shard of an N-way user split trained on THIS GPU under both replica schedules (what --emulate-world N times),
@@ -862,37 +866,59 @@ def main():
     # ---- secondary_bpr: the BPR-MF step (flag 0: OboBpr.bpr_train, public/BPR.py:201-241) - the one piece of the path that IS a pure gather / scatter:
     # every (user, positive, negative) triple of an epoch (prog_bpr_gru_spatial.py:240-244), snapshot mode (sorted, no float atomics: bitwise reproducible)
     secondary_bpr = None
-    if solo and not a.no_bpr and a.shape == "gowalla":
-        mb = poi_amd.models.OboBpr(train=tab, test=None, alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=D, n_hidden=D, device=dev, seed=7)
+    if solo and not a.no_bpr and a.shape in ("gowalla", "x1"):
+        mb = poi_amd.models.OboBpr(train=tab, test=None, alpha_lambda=[0.01, 0.001], n_user=n_local, n_item=n_item, n_in=D, n_hidden=D, device=dev, seed=7,
+                                   table_dtype=a.table_dtype)
         ctx.set_batch_cap(a.batch_cap)
         bu, bp, bq = mb.epoch_triples()
         nt = int(bu.numel())
-        bytes_triple = 6.0 * D * 4 + 12.0      # three rows read, three rows written, three int32
-        secondary_bpr = {"workload": "BPR-MF step over the %d (user, positive, negative) triples of one epoch of the gowalla shape, dim %d, float32 tables" % (nt, D),
-                         "bytes_per_triple_survey_8d": bytes_triple, "launches": {}}
-        for Bt, mode in ((nt, "snapshot"), (262144, "snapshot"), (nt, "hogwild")):
+        e_lt = 2.0 if a.table_dtype == "f16" else 4.0
+        bytes_triple = 2.0 * D * 4 + 4.0 * D * e_lt + 12.0      # three rows read, three rows written (user row float32, POI rows in the table's type), three int32
+        table_mb = ((n_item + 1) * D * e_lt + n_local * D * 4.0) / 1e6
+        resident = table_mb < 256.0
+        secondary_bpr = {"workload": "BPR-MF step over the %d (user, positive, negative) triples of one epoch of the %s shape, dim %d, %s POI table (%.0f MB of tables: %s)"
+                                     % (nt, a.shape, D, a.table_dtype, table_mb, "inside the 256 MB cache behind L2 - the rates below are NOT HBM traffic" if resident else "streamed from HBM"),
+                         "bytes_per_triple_survey_8d": bytes_triple, "tables_MB": table_mb, "tables_cache_resident": resident, "launches": {}}
+        hu, hp, hq = bu.cpu().numpy(), bp.cpu().numpy(), bq.cpu().numpy()
+        for Bt, mode in ((nt, "snapshot"), (262144, "snapshot")) + (((nt, "hogwild"),) if a.table_dtype == "f32" else ()):
             def bpr_epoch():
                 for b0 in range(0, nt, Bt):
                     mb.train_batch(bu[b0:b0 + Bt], bp[b0:b0 + Bt], bq[b0:b0 + Bt], mode=mode, sync=False)
             for _ in range(3):
                 bpr_epoch()
+            n_rep = 20 if a.shape == "gowalla" else 5
             torch.cuda.synchronize(dev); t0 = time.perf_counter()
-            for _ in range(20):
+            for _ in range(n_rep):
                 bpr_epoch()
-            torch.cuda.synchronize(dev); tb = (time.perf_counter() - t0) / 20
+            torch.cuda.synchronize(dev); tb = (time.perf_counter() - t0) / n_rep
             ctx.timing(True)
-            for _ in range(4):
+            for _ in range(2):
                 bpr_epoch()
             ktb = {k: ctx.timing_get(k) for k in ("bpr_sort", "bpr_users", "bpr_items", "bpr_hogwild")}
             ctx.timing(False)
-            secondary_bpr["launches"]["%s, %d triples per launch" % (mode, Bt)] = {
-                "ms_per_epoch": 1e3 * tb, "triples_per_s": nt / tb,
-                "roofline": {"bound": "hbm", "achieved": nt * bytes_triple / tb / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nt * bytes_triple / tb / 1e9 / PEAK_HBM_GBS},
-                "regions_us_per_launch": {k: 1e3 * v[0] / max(v[1], 1) for k, v in ktb.items() if v[1]}}
+            ent = {"ms_per_epoch": 1e3 * tb, "triples_per_s": nt / tb,
+                   # the contract count (what the per-triple reference formulation moves) over the measured time: an EQUIVALENT rate - the snapshot kernels
+                   # move fewer rows than that (sorted touches: a run's row is read once), and tables below 256 MB never leave the cache
+                   "reference_formulation_equivalent_GBs": nt * bytes_triple / tb / 1e9,
+                   "reference_formulation_equivalent_frac_of_hbm_peak": nt * bytes_triple / tb / 1e9 / PEAK_HBM_GBS,
+                   "regions_us_per_launch": {k: 1e3 * v[0] / max(v[1], 1) for k, v in ktb.items() if v[1]}}
+            if mode == "snapshot":
+                # bytes the sorted kernels move (csrc/bpr.hip), from the launch compositions themselves: per launch, users pass = one ux row per distinct user +
+                # two POI rows per triple in, one shadow row per distinct user out; items pass = one ux row per POI touch in, every distinct POI row read + written;
+                # commit = shadow -> ux per distinct user; sort = three 9-bit passes over 3 n (key, value) pairs, read + written
+                moved = 0.0
+                for b0 in range(0, nt, Bt):
+                    n_b = min(Bt, nt - b0)
+                    du = len(np.unique(hu[b0:b0 + n_b])); di_ = len(np.unique(np.concatenate((hp[b0:b0 + n_b], hq[b0:b0 + n_b]))))
+                    moved += (du * D * 4.0 + 2.0 * n_b * D * e_lt + du * D * 4.0) + (2.0 * n_b * D * 4.0 + 2.0 * di_ * D * e_lt) + 2.0 * du * D * 4.0 + 3.0 * 3 * n_b * 8.0 * 2
+                ent["moved_bytes_model_per_epoch"] = moved
+                ent["roofline"] = {"bound": "hbm", "achieved": moved / tb / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": moved / tb / 1e9 / PEAK_HBM_GBS,
+                                   "note": "bytes the sorted kernels move (model from the launch's distinct rows) over the measured time" +
+                                           ("; the tables sit in the 256 MB cache: an L2 / cache rate, not HBM" if resident else "; the POI table streams from HBM")}
+            secondary_bpr["launches"]["%s, %d triples per launch" % (mode, Bt)] = ent
         secondary_bpr["note"] = ("snapshot = every triple at the launch-entry values, rows combined by the capped-sum rule, 3 n table touches sorted by row and summed in a fixed "
-                                 "order (csrc/bpr.hip: no float atomics, bitwise reproducible - tests/test_gpu_bpr.py); hogwild = the racy in-place kernel, for scale.  The "
-                                 "tables (77 MB) sit in the 256 MB cache behind L2: a fraction above 1 is possible and says so")
-        secondary_bpr["finite"] = bool(torch.isfinite(mb.lt.t).all() and torch.isfinite(mb.ux.t).all())
+                                 "order (csrc/bpr.hip: no float atomics, bitwise reproducible - tests/test_gpu_bpr.py); hogwild = the racy in-place kernel, for scale")
+        secondary_bpr["finite"] = bool(torch.isfinite(mb.lt.t[:1 << 20].float()).all() and torch.isfinite(mb.ux.t).all())
         del mb
 
     # ---- secondary_dd25: the reference's other spatial configuration (dd = 25 m: 1520 bins, public/GRU_Spatial.py:247), training only --------
@@ -926,6 +952,10 @@ def main():
                             "train_seq_per_s": j["value"], "ms_per_epoch": j["ms_per_step"], "batch_users_per_launch": j["config"]["batch_users_per_launch"],
                             "dominant_kernel": j["roofline"]["kernel"], "dominant_frac": j["roofline"]["frac"], "wall_s_incl_data_generation": time.perf_counter() - t0,
                             "gather_scatter": {k: (j.get("roofline_gather_scatter") or {}).get(k) for k in ("kernels", "ms_per_epoch", "frac", "traffic")},
+                            "bpr": (lambda L: L and {"workload": j["secondary_bpr"]["workload"], "triples_per_s": L["triples_per_s"], "ms_per_epoch": L["ms_per_epoch"],
+                                                     "frac_survey_8d": L["reference_formulation_equivalent_frac_of_hbm_peak"], "frac_bytes_moved": (L.get("roofline") or {}).get("frac"),
+                                                     "regions_us_per_launch": L["regions_us_per_launch"]})(
+                                next((v for k, v in ((j.get("secondary_bpr") or {}).get("launches") or {}).items() if k.startswith("snapshot")), None)),
                             "gather_scatter_frac_bytes_moved": ((j.get("roofline_gather_scatter") or {}).get("implementation") or {}).get("frac"),
                             "eval_users_per_s": j.get("eval_users_per_s"), "eval_ms_per_8192_users_x_10M_pois": (j.get("eval") or {}).get("ms_per_eval"),
                             "eval_filter_ms": ((j.get("eval") or {}).get("two_stage") or {}).get("ms_filter_per_eval"),
@@ -1028,7 +1058,10 @@ def main():
             "x1_train_seq_per_s": secondary_x1 and secondary_x1.get("train_seq_per_s"), "x1_eval_users_per_s": secondary_x1 and secondary_x1.get("eval_users_per_s"),
             "dd25_1520_bins_train_seq_per_s": secondary_dd25 and secondary_dd25["train_seq_per_s"],
             "bpr_triples_per_s": secondary_bpr and max(v["triples_per_s"] for k, v in secondary_bpr["launches"].items() if k.startswith("snapshot")),
-            "bpr_snapshot_hbm_frac": secondary_bpr and max(v["roofline"]["frac"] for k, v in secondary_bpr["launches"].items() if k.startswith("snapshot")),
+            "bpr_reference_formulation_equivalent_frac": secondary_bpr and max(v["reference_formulation_equivalent_frac_of_hbm_peak"] for k, v in secondary_bpr["launches"].items() if k.startswith("snapshot")),
+            "bpr_x1_triples_per_s": secondary_x1 and (secondary_x1.get("bpr") or {}).get("triples_per_s"),
+            "bpr_x1_frac_of_hbm_on_bytes_moved": secondary_x1 and (secondary_x1.get("bpr") or {}).get("frac_bytes_moved"),
+            "bpr_x1_frac_of_hbm_survey_8d": secondary_x1 and (secondary_x1.get("bpr") or {}).get("frac_survey_8d"),
             "cpu_1core_seq_per_s": cpu and cpu["value"], "cpu_allcores_seq_per_s": cpu and cpu["all_cores"] and cpu["all_cores"]["value"],
         }
         emit(a, out)

@@ -47,7 +47,7 @@ extern "C" {
 /* 4 (round 4): new entry point poi_ctx_set_option. */
 /* 5 (round 5): new entry point poi_comm_available; poi_bpr_step's snapshot mode is sorted and atomic-free and accepts a half POI table; the exact
  * forward pass covers dim 256 (config X); option "hot_bins". */
-#define POI_ABI_VERSION 5
+#define POI_ABI_VERSION 6
 
 enum {
   POI_OK = 0,
@@ -112,6 +112,11 @@ int poi_ctx_set_engine(poi_ctx* ctx, int engine);
  * poi_ctx_graph_replays: number of launches served by a replay so far. */
 int poi_ctx_set_graph(poi_ctx* ctx, int on, int min_n, int max_n);
 int64_t poi_ctx_graph_replays(const poi_ctx* ctx);
+/* ABI 6.  Out-of-range ids in poi_bpr_step (the reference - a Theano gather, public/BPR.py:214-218 - raises IndexError): the kernels never touch
+ * memory outside the tables; a triple with a user id outside [0, n_user) or a POI id outside [0, n_item] contributes NO gradient, its loss is NaN,
+ * and it is counted on the device.  poi_ctx_take_bad_ids synchronises `stream`, returns the count since the last call and clears it - the Python
+ * mirror raises IndexError from OboBpr.train / train_batch(sync=True), as the reference does. */
+int64_t poi_ctx_take_bad_ids(poi_ctx* ctx, void* stream);
 /* fp16 POI tables: declare that the device buffer [ptr, ptr + bytes) holds IEEE half elements.  From then on every entry point that is
  * handed a pointer INSIDE a registered buffer as its POI table (`lt` of poi_gru_params for poi_spatial_step / poi_gru_step /
  * poi_gru_predict; `items` of poi_score_all / poi_score_topk* / poi_auc_preference; `x` of poi_sumsq) reads / writes it as half.

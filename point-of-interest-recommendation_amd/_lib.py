@@ -6,7 +6,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpoi_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 BPR_SNAPSHOT, BPR_HOGWILD = 0, 1
 
@@ -50,6 +50,7 @@ SIGNATURES = {
     "poi_ctx_set_topk_filter": (c_int, [c_void_p, c_int]),
     "poi_ctx_topk_filter_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "poi_ctx_graph_replays": (c_int64, [c_void_p]),
+    "poi_ctx_take_bad_ids": (c_int64, [c_void_p, c_void_p]),
     "poi_ctx_register_f16": (c_int, [c_void_p, c_void_p, c_int64]),
     "poi_ctx_unregister_f16": (c_int, [c_void_p, c_void_p]),
     "poi_ctx_set_f16_rounding": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
@@ -187,6 +188,13 @@ class Context:
         v = [c_int64(0) for _ in range(4)]
         self.check(self.lib.poi_ctx_topk_filter_stats(self.handle, *[ctypes.byref(x) for x in v]))
         return dict(zip(("users", "survivors", "tiles", "tiles_flagged"), (x.value for x in v)))
+
+    def take_bad_ids(self, stream=None):
+        """Out-of-range ids seen by poi_bpr_step since the last call (synchronises the stream, clears the counter)."""
+        v = int(self.lib.poi_ctx_take_bad_ids(self.handle, ctypes.c_void_p(stream or 0)))
+        if v < 0:
+            self.check(v)
+        return v
 
     def graph_replays(self):
         return int(self.lib.poi_ctx_graph_replays(self.handle))

@@ -59,6 +59,7 @@ struct poi_ctx {
   int efuse = 1;            // E = lt[p'] - lt[q'] gathered inside te_head3 (dim 128) instead of written by te_gather and read back twice; POI_TE_EFUSE
   int head3 = 1;            // training head on split products for <= 256 bins (te_head3); POI_TE_HEAD3
   int xrec1_max = 1100;     // ... launches of at most this many sequences run its recurrence per sequence in float64 on the vector ALUs (te_rec_fwd1x); POI_TE_XREC1
+  DevBuf bad_ids;           // out-of-range ids seen by poi_bpr_step (poi_ctx_take_bad_ids)
   DevBuf xflag;             // launch id of the last launch whose operands held a NaN / inf (TeArgs.xflag)
   DevBuf xw, xg;            // its digit fragments, scales and per-bin table | per-step pre-activations or the forward table (float64)
   // hipGraph replay of the tile engine's training launch (poi_ctx_set_graph): ~40 kernels on two streams become one graph launch.
@@ -195,7 +196,7 @@ static void drop_graphs(poi_ctx* c) {
 
 int poi_ctx_destroy(poi_ctx* c) {
   if (!c) return POI_OK;
-  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->xc, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota, &c->xw, &c->xg, &c->xflag,
+  DevBuf* all[] = {&c->ex_ws, &c->ex_slab, &c->ex_glt, &c->ex_gdi, &c->ws, &c->slab, &c->te_ws, &c->hslab, &c->zrow, &c->g_lt, &c->mult_lt, &c->nseq_lt, &c->g_di, &c->mult_di, &c->nseq_di, &c->seg_s, &c->seg_e, &c->pmark, &c->xc, &c->kc_dev, &c->uidx_stage, &c->out_stage, &c->ptab, &c->iota, &c->xw, &c->xg, &c->xflag, &c->bad_ids,
                    &c->g_wd, &c->mult_wd, &c->nseq_wd, &c->ca_ws, &c->ca_slab, &c->ca_scr, &c->ca2, &c->g_ux, &c->cnt_ux, &c->g_blt, &c->cnt_blt, &c->cand_s, &c->cand_i, &c->items_pk, &c->gbound, &c->st,
                    &c->items_pk16, &c->inorm, &c->surv_cnt, &c->surv_idx, &c->surv_sc, &c->tflag, &c->pre_idx, &c->pre_sc, &c->users_pk16, &c->ubound, &c->ugeo};
   (void)hipDeviceSynchronize();
@@ -496,7 +497,12 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)
     // one sequence (the reference schedule): the whole step in five kernels (tile_engine.hip, te_one_*)
     const bool one = n == 1 && c->one_path && E.rec1 && !E.lt_f16 && poi::te_one_supported(D, spatial, T->max_len);
+    // captured: a replay re-issues the launch id this launch got when it was captured - atomicMax against whatever a LATER launch left in xflag
+    // would keep the newer id and lose this replay's NaN flag.  The captured sequence therefore starts by clearing the flag: only
+    // its own pack kernels can raise it to its own id (they run behind ev_start, i.e. behind this node).
+    bool captured = false;
     auto run = [&](hipStream_t s) -> hipError_t {
+      if (captured && E.xflag) { hipError_t me = hipMemsetAsync(E.xflag, 0, sizeof(int), s); if (me != hipSuccess) return me; }
       if (one) { E.efuse = 0; return poi::launch_te_one(E, alpha, lambda, T->max_len, s, &c->tm); }
       hipError_t e = poi::launch_te_train(E, c->num_cu, s, &c->tm);
       // early distance-bin chain (launch_te_train started it on the side stream behind te_wgrad): the dense write-back needs te_wgrad's slabs,
@@ -527,7 +533,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       const float fs[] = {alpha, lambda, c->batch_cap, 0.f};
       add(fs, sizeof fs);
       const void* bufs[] = {c->te_ws.p, c->slab.p, c->hslab.p, c->zrow.p, c->seg_s.p, c->seg_e.p, c->pmark.p, c->xc.p, c->kc_dev.p, c->mult_lt.p, c->nseq_lt.p,
-                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, c->xw.p, c->xg.p};
+                            c->mult_di.p, c->nseq_di.p, c->uidx_stage.p, c->out_stage.p, c->ptab.p, c->iota.p, c->xw.p, c->xg.p, c->xflag.p};
       add(bufs, sizeof bufs);
       // every switch that decides which kernels / which stream topology the launch takes, each in its own word (packed into one
       // word they overlapped and early_min was missing), plus what te_setup derived from them for THIS launch
@@ -550,7 +556,9 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
       hipError_t e = hipStreamBeginCapture(c->cap, hipStreamCaptureModeRelaxed);
       if (e == hipSuccess) {
+        captured = true;
         e = run(c->cap);
+        captured = false;
         const hipError_t e2 = hipStreamEndCapture(c->cap, &graph);
         if (e == hipSuccess) e = e2;
       }
@@ -760,6 +768,8 @@ int poi_bpr_step(poi_ctx* c, float* ux, float* lt, int32_t n_user, int32_t n_ite
   A.lt_f16 = is_f16(c, lt);
   A.sr_salt = (c->f16_rounding && A.lt_f16) ? (++c->sr_counter) * 0x9E3779B1u | 1u : 0u;
   A.uidx = uidx; A.p = p; A.q = q; A.n = n; A.alpha = alpha; A.lambda = lambda; A.loss = loss_out; A.bcap = c->batch_cap;
+  { int rc0 = ensure(c, c->bad_ids, 64, st); if (rc0) return rc0; }      // (zero-filled at allocation)
+  A.bad = (int*)c->bad_ids.p;
   if (mode == POI_BPR_SNAPSHOT) {
     // workspace: the 3 n touches' sort buffers, per-triple coefficients, per-window partial sums; the shadow user table (grow-only, ctx-owned)
     int rc;
@@ -1177,6 +1187,16 @@ int poi_ctx_set_graph(poi_ctx* c, int on, int min_n, int max_n) {
 }
 
 int64_t poi_ctx_graph_replays(const poi_ctx* c) { return c ? (int64_t)c->graph_replays : POI_EINVAL; }
+int64_t poi_ctx_take_bad_ids(poi_ctx* c, void* stream) {
+  if (!c) return POI_EINVAL;
+  if (!c->bad_ids.p) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int v = 0;
+  if (hipSetDevice(c->device) != hipSuccess || hipMemcpyAsync(&v, c->bad_ids.p, sizeof v, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) return fail(c, POI_EHIP, "poi_ctx_take_bad_ids: %s", hipGetErrorString(hipGetLastError()));
+  if (v && (hipMemsetAsync(c->bad_ids.p, 0, sizeof v, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) return fail(c, POI_EHIP, "poi_ctx_take_bad_ids: reset failed");
+  return v;
+}
 
 int poi_ctx_register_f16(poi_ctx* c, const void* ptr, int64_t bytes) {
   if (!c || !ptr || bytes <= 0) return fail(c, POI_EINVAL, "poi_ctx_register_f16: bad argument");

@@ -36,6 +36,11 @@ __global__ __launch_bounds__(POI_BLOCK) void bpr_hogwild_kernel(BprArgs A) {
   const int gl = threadIdx.x % LPT;
   const int gpb = POI_BLOCK / LPT;
   for (int i = blockIdx.x * gpb + threadIdx.x / LPT; i < A.n; i += gridDim.x * gpb) {
+    // (an id outside its table: the reference raises IndexError - here the triple is skipped, counted, its loss NaN: include/poi_hip.h, ABI 6)
+    if ((unsigned)A.uidx[i] >= (unsigned)A.n_user || (unsigned)A.p[i] > (unsigned)A.n_item || (unsigned)A.q[i] > (unsigned)A.n_item) {
+      if (gl == 0) { atomicAdd(A.bad, 1); A.loss[i] = __int_as_float(0x7fc00000); }
+      continue;
+    }
     float* ur = A.ux + (size_t)A.uidx[i] * D;
     float* pr = reinterpret_cast<float*>(A.lt) + (size_t)A.p[i] * D;      // (float32 tables only: launch_bpr)
     float* qr = reinterpret_cast<float*>(A.lt) + (size_t)A.q[i] * D;
@@ -77,7 +82,10 @@ __global__ __launch_bounds__(256) void bpr_keys_kernel(BprArgs A) {
   if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt[0] = 3 * n;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < 3 * n; e += gridDim.x * 256) {
     const int kind = e >= 2 * n ? 2 : e >= n ? 1 : 0, i = e - kind * n;
-    // (ids clamped into their tables: the reference raises IndexError on a bad id, a device kernel must not write outside)
+    // (ids clamped into their tables: the reference raises IndexError on a bad id, a device kernel must not write outside; the triple of a bad id
+    // gets g = 0 and a NaN loss in bpr_chunk<users> and is counted here: poi_ctx_take_bad_ids)
+    const unsigned raw = kind == 0 ? (unsigned)A.uidx[i] : (unsigned)(kind == 1 ? A.p[i] : A.q[i]);
+    if (kind == 0 ? raw >= (unsigned)A.n_user : raw > (unsigned)A.n_item) atomicAdd(A.bad, 1);
     A.keys0[e] = kind == 0 ? (int)min((unsigned)A.uidx[i], (unsigned)(A.n_user - 1))
                            : A.n_user + (int)min((unsigned)(kind == 1 ? A.p[i] : A.q[i]), (unsigned)A.n_item);
   }
@@ -187,8 +195,9 @@ __global__ __launch_bounds__(256) void bpr_chunk_kernel(BprArgs A) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) dot += dot4(ur.v[t], x[u].v[t]);
             dot = group_sum<LPR>(dot);
-            sg[u] = ok[u] ? -sigmoidf_(-dot) : 0.f;
-            if (ok[u] && gl == 0) { A.g[tri[u]] = sg[u]; A.loss[tri[u]] = -log_sigmoidf_(dot); }
+            const bool bad = (unsigned)A.uidx[tri[u]] >= (unsigned)A.n_user || (unsigned)A.p[tri[u]] > (unsigned)A.n_item || (unsigned)A.q[tri[u]] > (unsigned)A.n_item;
+            sg[u] = (ok[u] && !bad) ? -sigmoidf_(-dot) : 0.f;      // (a triple with an id outside its table moves nothing)
+            if (ok[u] && gl == 0) { A.g[tri[u]] = sg[u]; A.loss[tri[u]] = bad ? __int_as_float(0x7fc00000) : -log_sigmoidf_(dot); }
           }
         }
 #pragma unroll

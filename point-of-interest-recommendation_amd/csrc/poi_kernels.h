@@ -317,6 +317,7 @@ struct BprArgs {
   int n;
   float alpha, lambda;
   float* loss;
+  int* bad;               // device counter of out-of-range ids (poi_ctx_take_bad_ids)
   float bcap;             // batch rule cap (see SeqArgs)
   // snapshot mode (bpr.hip): 3 n table touches sorted by row
   int *keys0, *keys1, *vals0, *vals1, *hist, *cnt;

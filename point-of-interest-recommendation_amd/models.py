@@ -848,11 +848,17 @@ class MfBasic(_Base):
         rng = np.random.default_rng(seed) if seed is not None else np.random
         u = lambda *s: rng.uniform(-0.5, 0.5, s)
         init = init or {}
-        g = lambda k, v: np.asarray(init[k], np.float64) if k in init else v()
+        g = lambda k, v: (init[k] if isinstance(init[k], torch.Tensor) else np.asarray(init[k], np.float64)) if k in init else v()
         tab = (lambda a: self._dev(a).to(torch.float16)) if table_dtype == "f16" else self._dev
+        if (n_item + 1) * self.dim > (1 << 28):
+            # tables of hundreds of millions of elements (config X: 10 M x 256) are drawn ON the device, as in GruBasic: the host draw is 20 GB of float64
+            gen = torch.Generator(device=self.device).manual_seed(0 if seed is None else int(seed))
+            u_tab = lambda rows: torch.rand((rows, self.dim), generator=gen, device=self.device, dtype=torch.float32) - 0.5
+        else:
+            u_tab = lambda rows: u(rows, self.dim)
         self.ux = Shared(self._dev(g("ux", lambda: u(n_user, self.dim))))                  # BPR.py:51
-        self.lt = Shared(tab(g("lt", lambda: u(n_item + 1, self.dim))))                    # :52
-        self.trained_items = Shared(tab(u(n_item + 1, self.dim)))
+        self.lt = Shared(tab(g("lt", lambda: u_tab(n_item + 1))))                          # :52
+        self.trained_items = Shared(tab(u_tab(n_item + 1)))
         self.trained_users = Shared(self._dev(u(n_user, self.dim)))
         if table_dtype == "f16":
             self.ctx.register_f16(self.lt.t); self.ctx.register_f16(self.trained_items.t)
@@ -891,6 +897,10 @@ class OboBpr(MfBasic):
         self.ctx.check(self.lib.poi_bpr_step(self.ctx.handle, _ptr(self.ux.t), _ptr(self.lt.t), self.n_user, self.n_item, self.dim,
                                              _ptr(u), _ptr(pp), _ptr(qq), n, self.alpha_lambda[0], self.alpha_lambda[1],
                                              _ptr(loss), m, self._stream()))
+        if sync:
+            nb = self.ctx.take_bad_ids(self._stream().value if hasattr(self._stream(), "value") else None)
+            if nb:                                     # the reference's gather raises IndexError (public/BPR.py:214-218)
+                raise IndexError("%d id(s) outside the user / POI tables in this launch: those triples moved nothing, their losses are NaN" % nb)
         return loss.cpu().numpy() if sync else loss
 
     def epoch_triples(self):

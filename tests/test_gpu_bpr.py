@@ -167,3 +167,31 @@ def test_bpr_snapshot_fuzz_sizes_and_dims(pa):
         what = "fuzz %d: dim %d n %d users %d items %d cap %g" % (it, dim, n, n_user, n_item, cap)
         assert_close(got_l, el, "losses " + what)
         assert_step_close({k: getattr(m, k).get_value() for k in ("ux", "lt")}, exp, P, ("ux", "lt"), what)
+
+
+@pytest.mark.parametrize("mode", ["snapshot", "hogwild"])
+def test_out_of_range_ids_raise_like_the_reference_and_move_nothing(pa, mode):
+    """ADVICE r5 / include/poi_hip.h ABI 6: the reference's gather raises IndexError on an id outside its table (public/BPR.py:214-218).  Here the
+    triple gets no gradient and a NaN loss, nothing is written outside the tables, the device counts it and the Python mirror raises IndexError."""
+    import torch
+    n_user, n_item, D = 40, 90, 64
+    T = toy_problem(3, n_user=n_user, n_item=n_item, n_dist=10, dim=D, len_max=6)
+    m = pa.models.OboBpr(train=T["train"], test=T["test"], alpha_lambda=[0.01, 0.001], n_user=n_user, n_item=n_item, n_in=D, n_hidden=D, seed=4)
+    u, p, q = _triples(9, 300, n_user, n_item, 5, 9)
+    guard_u, guard_i = m.ux.t.clone(), m.lt.t.clone()
+    for bad in ((7, n_user, p[7], q[7]), (11, u[11], n_item + 1, q[11]), (13, u[13], p[13], -2)):
+        ub, pb, qb = u.copy(), p.copy(), q.copy()
+        ub[bad[0]], pb[bad[0]], qb[bad[0]] = bad[1], bad[2], bad[3]
+        m.ux.t.copy_(guard_u); m.lt.t.copy_(guard_i)
+        loss = m.train_batch(ub, pb, qb, mode=mode, sync=False)
+        torch.cuda.synchronize()
+        loss = loss.cpu().numpy()
+        assert np.isnan(loss[bad[0]]) and np.isfinite(np.delete(loss, bad[0])).all()
+        assert torch.isfinite(m.ux.t).all() and torch.isfinite(m.lt.t).all()
+        assert m.ctx.take_bad_ids() >= 1 and m.ctx.take_bad_ids() == 0          # counted, then cleared
+        m.ux.t.copy_(guard_u); m.lt.t.copy_(guard_i)
+        with pytest.raises(IndexError):
+            m.train_batch(ub, pb, qb, mode=mode)
+    # a clean launch afterwards is the clean result
+    m.ux.t.copy_(guard_u); m.lt.t.copy_(guard_i)
+    assert np.isfinite(m.train_batch(u, p, q, mode=mode)).all()

@@ -85,3 +85,32 @@ def test_nan_weight_propagates_through_the_exact_forward(pa, dim, n_user, where)
     else:
         assert np.isnan(out[:, 0]).all(), "losses of sequences under a NaN weight must be NaN"
     assert np.isnan(np.asarray(m.wh.get_value())).any() and np.isnan(np.asarray(m.ui.get_value())).any()
+
+
+def test_nan_flag_survives_graph_replay_with_interleaved_launch_sizes(pa):
+    """a captured launch replays the launch id it was captured with.  Two launch sizes are captured while the weights are finite; then a
+    NaN weight must poison the replays of BOTH graphs (the older graph's id is below whatever the newer launch left in the flag), and restoring
+    the weights must give finite losses again on the same context."""
+    dim = 128
+    T = toy_problem(15, n_user=96, n_item=300, n_dist=50, dim=dim, len_max=12)
+    P = spatial_params(16, T)
+    m = _model(pa, T, P, dim)
+    m.ctx.set_engine("tile")
+    m.ctx.set_graph(True)
+    try:
+        a, b = np.arange(0, 40, dtype=np.int32), np.arange(40, 96, dtype=np.int32)
+        r0 = m.ctx.graph_replays()
+        for _ in range(3):                                     # first sight eager, second sight captures, third replays - both sizes
+            assert np.isfinite(np.asarray(m.train_batch(a))).all() and np.isfinite(np.asarray(m.train_batch(b))).all()
+        assert m.ctx.graph_replays() - r0 >= 2
+        good = {k: getattr(m, k).t.clone() for k in ("wh", "ui", "lt", "di", "bi", "vs", "bs", "wd", "loss_weight")}
+        m.wh.t[1, 3, 5] = float("nan")
+        oa, ob = np.asarray(m.train_batch(a)), np.asarray(m.train_batch(b))          # replays of the OLDER and of the newer graph
+        assert np.isnan(oa[:, 0]).all() and np.isnan(ob[:, 0]).all(), "a NaN weight must poison the replayed launches"
+        for k, v in good.items():
+            getattr(m, k).t.copy_(v)
+        oa, ob = np.asarray(m.train_batch(a)), np.asarray(m.train_batch(b))
+        assert np.isfinite(oa).all() and np.isfinite(ob).all(), "restored weights: the flag must not stick to a graph"
+    finally:
+        m.ctx.set_graph(False)
+        m.ctx.set_engine("auto")

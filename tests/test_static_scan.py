@@ -13,7 +13,7 @@ scan_waits = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(scan_waits)
 
 HOT = ["te_head_kernel<128, 7, 0>",                          # float32-input MFMA head: predict, and training with split products off
-       "te_head3_kernel<128, 7>",                            # training head on split products (round 4): three workgroups per CU
+       "te_head3_kernel<128, 7, true>",                            # training head on split products (round 4): three workgroups per CU
        "te_wgrad_kernel<128, 128, false>", "te_wgrad_kernel<128, 128, true>",
        "te_rec_fwdx_kernel<128, true, false>", "te_rec_fwdx_kernel<128, false, false>",      # exact forward: table / per-step rows
        "te_rec_fwd16_kernel<128, false, true, false>",       # forward table, float32-input MFMA (exact forward off)
@@ -49,7 +49,7 @@ def test_hot_kernels_are_found_and_do_not_spill(records):
         assert kernels[name]["spill"] <= SPILL_ALLOWED.get(name, 0), "%s spills %d registers" % (name, kernels[name]["spill"])
     # three te_head workgroups per CU need <= 168 registers; two te_wgrad / GEMM workgroups <= 256
     assert kernels["te_head_kernel<128, 7, 0>"]["vgpr"] <= 168
-    assert kernels["te_head3_kernel<128, 7>"]["vgpr"] <= 168
+    assert kernels["te_head3_kernel<128, 7, true>"]["vgpr"] <= 168
 
 
 def test_wgrad_pipeline_never_waits_for_a_load_it_has_just_issued(records):

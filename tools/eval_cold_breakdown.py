@@ -23,6 +23,9 @@ m.update_trained_items(); m.update_trained_dists()
 h, s = m.predict_device(ids); m.update_trained_users(h); m.update_trained_sus(s)
 m.compute_sub_topk(ids, 20)
 KN = ["score_topk", "score_maxpass", "score_filter", "score_rescore", "pack_items", "topk_seed", "topk_merge"]
+if os.environ.get("EV_GEO"):      # bins from the N coordinates inside the kernel (poi_score_topk_geo) instead of the resident U x N bin matrix
+    m.use_bin_matrix = False
+    m.compute_sub_topk(ids, 20)
 for name in ("unseeded", "seeded", "unseeded"):
     if name == "unseeded": m.reset_topk_seeds()
     m.ctx.timing(True)
