@@ -38,7 +38,7 @@ rows = list(csv.DictReader(open(st)))
 shutil.copy(st, os.path.join(P, tag + "_kernel_stats.csv"))
 bench = None
 try:
-    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+    bench = json.load(open(os.path.join(src, "bench_full.json")))      # (the FULL record: stdout's last line is the compact one since round 6)
 except Exception:
     pass
 with open(os.path.join(P, tag + "_kernel_stats.md"), "w") as f:
@@ -61,14 +61,21 @@ with open(os.path.join(P, tag + "_kernel_stats.md"), "w") as f:
 
 
 # ---- PMC traffic --------------------------------------------------------------------------------
+BY_GRID = {}      # sub -> {(kernel, grid size): {counter: sum, "_n": dispatches}} for the BPR-MF kernels: bench.py launches them at several sizes
+
+
 def counters(sub):
     fn = find(sub, "*counter_collection.csv")
     acc = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(set)
+    byg = defaultdict(lambda: defaultdict(float)); bygc = defaultdict(set)
     for r in csv.DictReader(open(fn)):
         k = short(r["Kernel_Name"])
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k].add(r["Dispatch_Id"])
+        if k.startswith("bpr_") and "Grid_Size" in r:
+            byg[(k, r["Grid_Size"])][r["Counter_Name"]] += float(r["Counter_Value"]); bygc[(k, r["Grid_Size"])].add(r["Dispatch_Id"])
+    BY_GRID[sub] = {k: dict(v, _n=len(bygc[k])) for k, v in byg.items()}
     return acc, {k: len(v) for k, v in calls.items()}
 
 
@@ -109,6 +116,14 @@ for reg, pats in REGION.items():
     write = sum(wa[k]["WRITE_SIZE"] for k in wk)
     out["kernels"][reg] = {"launches": n_launch, "launches_write_pass": n_w, "fetch_kb_raw": fetch / n_launch, "write_kb": write / max(n_w, 1),
                            "hbm_bytes_per_launch": (2.0 * fetch / n_launch + write / max(n_w, 1)) * 1024.0}
+# BPR-MF kernels per launch size (grid = work-groups x 256 threads: 974 k-triple launches, 262144-triple launches and the epoch's remainder have different grids)
+bpr_sizes = {}
+for (k, g), c in sorted(BY_GRID.get("fetch", {}).items()):
+    w = BY_GRID.get("write", {}).get((k, g), {})
+    bpr_sizes["%s [grid %s]" % (k, g)] = {"launches": c["_n"], "fetch_kb_raw": c.get("FETCH_SIZE", 0.0) / max(c["_n"], 1), "write_kb": w.get("WRITE_SIZE", 0.0) / max(w.get("_n", 1), 1),
+                                          "hbm_bytes_per_launch": (2.0 * c.get("FETCH_SIZE", 0.0) / max(c["_n"], 1) + w.get("WRITE_SIZE", 0.0) / max(w.get("_n", 1), 1)) * 1024.0}
+if bpr_sizes:
+    out["bpr_by_launch_size"] = bpr_sizes
 json.dump(out, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
 
 # ---- SQ counters --------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python bench.py --steps 2 --warmup 1 --eval-steps 2 --no-cpu-baseline --no-quality --no-secondary --no-exact --no-x1"
+CMD="python bench.py --full-out /tmp/bench_prof_full.json --steps 2 --warmup 1 --eval-steps 2 --no-cpu-baseline --no-quality --no-secondary --no-exact --no-x1"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o k -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1
@@ -17,5 +17,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 [ -x tools/micro/mfma_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_calib.hip -o tools/micro/mfma_calib > $OUT/calib_build.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS \
   -f csv -d $OUT/calib -o c -- tools/micro/mfma_calib > $OUT/calib.log 2>&1
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --full-out $OUT/bench_full.json > $OUT/bench.json 2> $OUT/bench.err
 ls -R $OUT | head -30
