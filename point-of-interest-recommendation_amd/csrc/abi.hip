@@ -36,6 +36,8 @@ struct poi_ctx {
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   DevBuf g_wd, mult_wd, nseq_wd, ca_ws, ca_slab, ca_scr, ca2;      // CA-RNN (ca2: workspace of the outer-product path)
   int carnn_fast = 1;       // POI_CARNN_FAST=0: the per-sequence kernel with float atomics on the interval matrices (A/B)
+  hipStream_t side2 = nullptr; hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr, ev_h2 = nullptr, ev_h3 = nullptr;      // hybrid recurrences of mid-size launches (TeArgs.hyb)
+  int hybrid = 1, hyb_min = 1150, hyb_max = 2300, hyb_force = 0;      // POI_TE_HYBRID=0 / option "hybrid"; launches of hyb_min .. hyb_max sequences (POI_TE_HYB_MIN / _MAX; measured: below ~1200 the per-sequence kernels alone are faster, above ~2600 the tiles alone - the fork / join costs ~15 us)
   hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr, ev_start = nullptr, ev_pack = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
   DevBuf seg_s, seg_e;      // per table row [start, end) of the sorted scatter (te_scatter.hip); seg_e is all-zero between launches
   DevBuf xc;                // exact forward over the step-input POIs only: rank tables + per-step table rows (TeArgs.xcomp)
@@ -153,6 +155,10 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_PPOI")) c->ppoi = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_EARLY_BINS")) c->early_bins = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_HOTBINS")) c->hot_bins = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_HYBRID")) c->hybrid = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_HYB_MIN")) c->hyb_min = atoi(e);
+  if (const char* e = getenv("POI_TE_HYB_MAX")) c->hyb_max = atoi(e);
+  if (const char* e = getenv("POI_TE_HYB_FORCE")) c->hyb_force = atoi(e);
   if (const char* e = getenv("POI_TE_EARLY_MIN")) c->early_min = atoi(e);
   if (const char* e = getenv("POI_TE_FWDTAB")) c->fwd_tab = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_SPLIT")) c->rec_split = atoi(e) != 0;
@@ -183,6 +189,12 @@ int poi_ctx_create(poi_ctx** out, int device) {
       (void)hipGetLastError();
       c->side = nullptr;                     // fall back to the inline sort
     }
+    if (c->side && (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_h0, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_h1, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_h2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_h3, hipEventDisableTiming) != hipSuccess)) {
+      (void)hipGetLastError();
+      c->side2 = nullptr;                    // no hybrid recurrences
+    }
   }
   if (c->graph_mode && hipStreamCreateWithFlags(&c->cap, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->cap = nullptr; c->graph_mode = 0; }
   *out = c;
@@ -203,6 +215,7 @@ int poi_ctx_destroy(poi_ctx* c) {
   c->tm.clear();
   drop_graphs(c);
   if (c->cap) (void)hipStreamDestroy(c->cap);
+  if (c->side2) { (void)hipStreamDestroy(c->side2); (void)hipEventDestroy(c->ev_h0); (void)hipEventDestroy(c->ev_h1); (void)hipEventDestroy(c->ev_h2); (void)hipEventDestroy(c->ev_h3); }
   if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); (void)hipEventDestroy(c->ev_start); (void)hipEventDestroy(c->ev_pack); }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c;
@@ -250,6 +263,12 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.head_split = (c->rec_split && A.spatial && (P->n_dist + 1 > 256 || (c->head3 && !predict))) ? 1 : 0;      // (<= 256 bins: te_head3, training launches only)
   A.efuse = (c->efuse && A.head_split && !predict && P->n_dist + 1 <= 256 && D == 128) ? 1 : 0;      // (the one-sequence path clears it: te_one_in writes E)
   A.rec1 = (!A.rec32 && n <= c->rec1_max) ? 1 : 0;
+  // hybrid recurrences (poi_kernels.h TeArgs.hyb): training launches of hyb_min .. hyb_max sequences on the exact forward, dim 128.  (NOT dim 64: there a
+  // workgroup of each kernel fits the same CU, and with the two backward kernels co-resident identical launches differed in the last bits of DA in 5 - 20 % of
+  // the runs - inside every parity bar, but not bitwise reproducible; serialised, or at dim 128 where each workgroup fills its CU, 0 of 240: tools/repro_check.py)
+  A.hyb = (c->hybrid && c->side2 && !predict && !A.rec32 && D == 128 && c->xfwd && poi::te_xfwd_supported(D) && c->rec_split && n >= c->hyb_min && n <= c->hyb_max && n <= TE_HYB_NMAX && n > 1) ? 1 : 0;
+  A.hyb_force = c->hyb_force;
+  if (A.hyb) A.rec1 = 0;                    // (the tile kernels' weight packs; the per-sequence backward kernel gets its transposes in pWhc1 / pWhzr1)
   A.ppoi = (A.bintab && !predict && c->ppoi) ? 1 : 0;
   A.off = T->off; A.p = T->p; A.q = T->q; A.dp = T->dp; A.dq = T->dq; A.len_max = T->len_max;
   A.uidx = uidx; A.n_seq = n; A.predict = predict ? 1 : 0;
@@ -257,12 +276,12 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.dl = poi::dense_layout(D, A.xw, n_dist + 1);
   const size_t Tcap = (size_t)n * (size_t)(predict ? T->max_len : (T->max_len > 1 ? T->max_len - 1 : 1)) + 192;   // + spare rows: row T and the rest of the last 128-row tile
   // uiT 6 + uiP 3 + pWhT16 4.5 + pWhc16 1.5 + pWhzr16 3 + pUiP3 4.5 (x D^2) + spare, pVsT + pVs 2 x 1.5 NBP D, + the rounding of each carve
-  const size_t pk = (size_t)27 * D * D + (size_t)3 * NBP * D + 64;
+  const size_t pk = (size_t)30 * D * D + (size_t)3 * NBP * D + 128;      // (+ 3 D^2: pWhc1 / pWhzr1 of the hybrid recurrences)
   // sorted scatter (training): 3 slots per sequence position
   const bool sorted = !predict;
   const size_t Ncap = sorted ? 3 * (Tcap + (size_t)n) : 0;
   const size_t n_hot = Ncap / (TE_COLD_MAX + 1) + 2, n_chunk = Ncap / TE_HOT_CHUNK + n_hot + 2;
-  const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)(n <= c->rec1_max ? n : (n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
+  const size_t sfl = sorted ? Tcap + n_chunk * D + Tcap * (size_t)NBP + (size_t)((n <= c->rec1_max || n <= c->hyb_max) ? n : (n + 15) / 16) * 3 * D + (size_t)2 * ((n + 255) / 256) + 128 : 0;
   const int Rrows = P->n_item + 1 + n_dist + 1;
   const bool listed = sorted && (size_t)Rrows > 4 * Ncap;      // table much larger than the launch's footprint: touched-row list
   const size_t sin = sorted ? 7 * Ncap + (listed ? Ncap : 0) + (size_t)RS_HIST_INTS + RS_MAXBIN + 16 + 4 * n_hot + 3 * n_chunk + 64 : 0;
@@ -274,7 +293,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   const size_t n_prange = Tcap / 64 + 4;
   const size_t pfl = A.ppoi ? Tcap * (size_t)(3 * D) + 2 * n_prange * (size_t)(3 * D) + 64 : 0;
   const size_t nfl = Tcap * (size_t)(9 * D + 2) + pk + 64 + sfl + bfl + pfl;
-  const size_t nin = Tcap * 7 + (size_t)n + 32 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 4 * NBt + 64 : 0) + 3 * NBt + 48 + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
+  const size_t nin = Tcap * 7 + (size_t)n + 48 + sin + 512 + (A.bintab && sorted ? n_dchunk + n_dsuper + 4 * NBt + 64 : 0) + 3 * NBt + 48 + (A.ppoi ? 4 * Tcap + 2 * 1024 + 128 : 0);
   int rc = ensure(c, c->te_ws, nfl * 4 + nin * 4 + 1024, st);
   if (rc) return rc;
   const int R = P->n_item + 1 + n_dist + 1;
@@ -287,7 +306,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.xfwd = (c->xfwd && (!A.rec32 || D == 256) && poi::te_xfwd_supported(D)) ? 1 : 0;      // (training launches and predict alike)
   const bool want_ft = c->fwd_tab && !A.rec32 && 2 * (size_t)(P->n_item + 1) <= Tcap;
   A.fwd_tab = (!A.xfwd && want_ft && A.bintab && !A.rec1) ? 1 : 0;      // (the per-sequence kernels read G)
-  A.xrec1 = (A.xfwd && D <= 128 && n <= c->xrec1_max) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
+  A.xrec1 = (A.xfwd && D <= 128 && n <= c->xrec1_max && !A.hyb) ? 1 : 0;      // one workgroup per sequence, float64 on the vector ALUs (te_rec_fwd1x)
   // (the table over the launch's step-input POIs only - te_slots marks them for the per-POI regrouping - never has more rows than the launch has steps)
   const bool want_xc = c->xcomp && A.ppoi && P->n_item + 1 <= (1 << 22) && n >= c->xcomp_min;
   A.xft = (A.xfwd && (want_ft || want_xc) && n > 1) ? 1 : 0;      // (n == 1: the one-sequence path writes gx itself, te_one_in; the per-sequence kernel has a table variant too)
@@ -333,6 +352,7 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   A.pVsT = (float4*)take((size_t)NBP * D * 3 / 2); A.pVs = (float4*)take((size_t)NBP * D * 3 / 2);      // (x 1.5: te_head_big3 reads bf16 x 3 planes)
   // (x 1.5: the split-operand recurrent kernels keep every weight as three bf16 planes)
   A.pWhT16 = (float4*)take((size_t)9 * D * D / 2); A.pWhc16 = (float4*)take((size_t)3 * D * D / 2); A.pWhzr16 = (float4*)take((size_t)3 * D * D);
+  if (A.hyb) { A.pWhc1 = (float4*)take((size_t)D * D); A.pWhzr1 = (float4*)take((size_t)2 * D * D); } else { A.pWhc1 = A.pWhc16; A.pWhzr1 = A.pWhzr16; }
   if (A.bintab) {
     A.ztab = take(NBt * 3 * D); A.dsum = take(NBt * 3 * D); A.dgd = take(NBt * D);
     if (sorted) { A.dpart = take(n_dchunk * (size_t)(3 * D)); A.dpart2 = take(n_dsuper * (size_t)(3 * D)); }
@@ -340,10 +360,11 @@ static int te_setup(poi_ctx* c, poi::TeArgs& A, const poi_gru_params* P, const p
   if (A.ppoi) { A.S = take(Tcap * (size_t)(3 * D)); A.pfirst = take(n_prange * (size_t)(3 * D)); A.plast = take(n_prange * (size_t)(3 * D)); }
   if (sorted) {
     A.gcoef = take(Tcap); A.hot_part = take(n_chunk * D); A.DL = take(Tcap * (size_t)NBP);
-    A.bi_part = take((size_t)(A.rec1 ? n : (n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);
+    A.bi_part = take((size_t)((A.rec1 || A.hyb) ? n : (n + 15) / 16) * 3 * D); A.fin_part = take((size_t)2 * ((n + 255) / 256) + 8);
   }
   int* ip = (int*)f;
   auto itake = [&](size_t cnt) { int* r = ip; ip += (cnt + 3) & ~(size_t)3; return r; };
+  A.hyb_dev = itake(8);
   A.soff = itake(n + 1); A.row_src = itake(Tcap); A.row_t = itake(Tcap); A.row_p = itake(Tcap); A.row_dp = itake(Tcap); A.row_ab = itake(Tcap); A.row_pq = (int2*)itake(2 * Tcap);
   if (sorted) {
     int bits = 1; while ((1 << bits) <= R) ++bits;      // keys 0..R (R = sentinel)
@@ -490,6 +511,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.out = out; E.bcap = bcap; E.slab = A.slab; E.n_slab = n_slab; E.n_head = n_head; E.n_kc = n_kc; E.wg_slots = c->num_cu * c->wgrad_rounds;
     E.kc_dev = (E.bintab && c->ppoi) ? (int*)c->kc_dev.p : nullptr;
     E.hslab = (float*)c->hslab.p; E.hstride = (NB + 4) & ~3;
+    E.side2 = c->side2; E.ev_h0 = c->ev_h0; E.ev_h1 = c->ev_h1; E.ev_h2 = c->ev_h2; E.ev_h3 = c->ev_h3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin; E.ev_start = c->ev_start; E.ev_pack = c->ev_pack;
     E.early_bins = (c->early_bins && E.bintab && c->side && n >= c->early_min) ? 1 : 0; E.bin_alpha = alpha; E.bin_lambda = lambda;
     E.dhot_on = (E.early_bins && E.ppoi && c->hot_bins) ? 1 : 0;      // (te_dprep - the selection - must have run before te_psum: the early chain)
@@ -539,7 +561,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       // word they overlapped and early_min was missing), plus what te_setup derived from them for THIS launch
       const uint64_t sw[] = {(uint64_t)c->fwd_tab, (uint64_t)c->rec_split, (uint64_t)c->one_path, (uint64_t)(unsigned)c->rec1_max, (uint64_t)(unsigned)c->bintab_min,
                              (uint64_t)c->early_bins, (uint64_t)(unsigned)c->early_min, (uint64_t)c->xfwd, (uint64_t)E.early_bins, (uint64_t)E.bintab, (uint64_t)E.rec1,
-                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.xcomp, (uint64_t)(unsigned)c->xcomp_min, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one};
+                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.xcomp, (uint64_t)(unsigned)c->xcomp_min, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one, (uint64_t)E.hyb, (uint64_t)E.efuse};
       add(sw, sizeof sw);
     }
     poi_ctx::StepGraph* g = nullptr;
@@ -1120,7 +1142,7 @@ int poi_ctx_set_option(poi_ctx* c, const char* name, int value) {
   if (!c || !name) return fail(c, POI_EINVAL, "poi_ctx_set_option: null argument");
   struct Opt { const char* name; int* p; int lo, hi; };
   const Opt opts[] = {{"forward_table_compact", &c->xcomp, 0, 1}, {"forward_table_compact_min", &c->xcomp_min, 0, 1 << 30}, {"head_split", &c->head3, 0, 1},
-                      {"early_bins", &c->early_bins, 0, 1}, {"hot_bins", &c->hot_bins, 0, 1}};
+                      {"early_bins", &c->early_bins, 0, 1}, {"hot_bins", &c->hot_bins, 0, 1}, {"hybrid", &c->hybrid, 0, 1}, {"hybrid_min", &c->hyb_min, 0, 1 << 30}, {"hybrid_max", &c->hyb_max, 0, 1 << 30}, {"hybrid_force", &c->hyb_force, 0, 1 << 30}};
   for (const Opt& o : opts)
     if (!strcmp(name, o.name)) {
       if (value < o.lo || value > o.hi) return fail(c, POI_EINVAL, "poi_ctx_set_option: %s must be in [%d, %d] (got %d)", name, o.lo, o.hi, value);

@@ -153,6 +153,15 @@ struct TeArgs {
   hipStream_t side; hipEvent_t ev_slots, ev_sorted;       // side == nullptr: inline on the main stream
   hipEvent_t ev_start, ev_pack;                           // the weight packs of a launch run on the side stream next to its index preparation
   hipEvent_t ev_bwd, ev_fin;                              // te_finalize / te_parts run on the side stream next to te_wgrad / te_gemm_dx
+  // (round 6) HYBRID recurrences of mid-size launches (hyb != 0; poi_ctx option "hybrid"): a 1563-sequence launch is 98 tiles of 16 - its two recurrences
+  // are the 49-step chains of the longest tile on 98 CUs while 158 CUs idle.  The leading hyb_dev[0] (forward) / hyb_dev[2] (backward) sequences of the
+  // launch - the longest ones of a length-sorted launch - run on the per-sequence kernels (te_rec_fwd1x / te_rec_bwd1: 2.0 / 1.0 us per step, persistent
+  // grids of hyb_dev[1] / hyb_dev[3] workgroups on stream side2) WHILE the shorter rest runs in 16-sequence tiles (4.5 / 2.9 us per step) on the other CUs;
+  // the split is chosen per launch ON THE DEVICE from the launch's own lengths (te_hybrid_kernel: min over the tile boundaries of max(chain of the
+  // tiles' longest sequence, steps of the leading sequences / free CUs)).  pWhc1 / pWhzr1: the plain transposes te_rec_bwd1 reads (its own buffers: the
+  // tile kernel's bf16 x 3 fragments live in pWhc16 / pWhzr16 at the same time)
+  int hyb, hyb_force; int* hyb_dev; float4 *pWhc1, *pWhzr1;      // hyb_force > 0 (option "hybrid_force", tests): that many leading sequences, whatever the cost model says
+  hipStream_t side2; hipEvent_t ev_h0, ev_h1, ev_h2, ev_h3;      // (forward fork / join, backward fork / join: an event is never re-recorded inside a launch)
   float *bi_part, *fin_part;           // per recurrent tile d bi partials (n_tile x 3D); per te_finalize block loss sums
   float* hslab; int hstride;          // te_head's per-workgroup d bs | d wd partials (n_head x hstride)
   DenseLayout dl;
@@ -206,6 +215,7 @@ struct TeArgs {
 #define TE_ENT_GH 0x20000000      // + g[row-1] * h[row-1]
 #define TE_ENT_NEG 0x40000000     // the g*h term enters with a minus sign (negative sample)
 #define TE_ENT_FIRST 0x80000000u  // first entry of its sequence within the row segment
+#define TE_HYB_NMAX 4096          // hybrid recurrences: te_scan keeps the launch's step counts in LDS for the split
 #define TE_PSUM_WG 1024          // workgroups of te_psum = chunk partials of a hot bin: device-independent (was num_cu * 4)
 #define TE_HB 4                   // hot distance bins summed by te_psum (TeArgs.dhot)
 #define TE_HOT_BIN_MIN 4096       // ... when they hold at least this many steps of the launch

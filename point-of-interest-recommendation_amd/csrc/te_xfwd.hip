@@ -379,8 +379,10 @@ __global__ __launch_bounds__(D * 4) void te_rec_fwdx_kernel(TeArgs A) {
   const int lane = lane_id(), w = wave_id(), tid = threadIdx.x, i = lane & 15;
   const int u0 = 16 * w + 4 * (lane >> 4);           // this lane: hidden units u0 .. u0 + 3 of sequence i
   const int tile = blockIdx.x;
+  const int k_lo = (!PRED && A.hyb) ? A.hyb_dev[0] : 0;      // hybrid recurrences (TeArgs.hyb): the tiles start behind the sequences of te_rec_fwd1x
+  if (k_lo + tile * 16 >= A.n_seq) return;                   // (uniform; the grid is sized for k_lo == 0)
   if (tid < 16) {
-    const int k = tile * 16 + tid;
+    const int k = k_lo + tile * 16 + tid;
     int r0 = 0, ns = 0;
     if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
@@ -592,6 +594,9 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
   __shared__ __align__(16) double hs[D], rhs[D], zs[D];
   __shared__ double s_t64[64];
   const int tid = threadIdx.x;
+  // hybrid recurrences (TeArgs.hyb, training): the leading hyb_dev[0] sequences on hyb_dev[1] workgroups, the rest in tiles (te_rec_fwdx) at the same time
+  const int n1 = (!PRED && A.hyb) ? A.hyb_dev[0] : A.n_seq, G = (!PRED && A.hyb) ? A.hyb_dev[1] : (int)gridDim.x, bq = blockIdx.x;
+  if (bq >= G) return;
   const int gz = tid >> 3, sz = tid & 7, gc = tid >> 4, sc = tid & 15;
   const int jz = 4 * gz + (sz & 3), jc = 4 * gc + (sc & 3);        // the output this lane finishes (lanes sz / sc < 4)
   const bool isr = jz >= D;
@@ -627,10 +632,9 @@ __global__ __launch_bounds__(4 * D) void te_rec_fwd1x_kernel(TeArgs A) {
       ozr = A.ptabx[p1 + jz] + A.ztabx[z1 + jz]; oc = A.ptabx[p1 + 2 * D + jc] + A.ztabx[z1 + 2 * D + jc];
     } else { ozr = A.gx[rr * 3 * D + jz]; oc = A.gx[rr * 3 * D + 2 * D + jc]; }
   };
-  const int G = gridDim.x, bq = blockIdx.x;
   for (int j = 0;; ++j) {
     const int k = j * G + ((j & 1) ? G - 1 - bq : bq);
-    if (k >= A.n_seq) break;                 // (workgroup-uniform; the snake's odd legs run downwards: a later even leg may still exist)
+    if (k >= n1) break;                      // (workgroup-uniform; the snake's odd legs run downwards: a later even leg may still exist)
     if (tid < D) hs[tid] = 0.0;
     const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
     __syncthreads();
@@ -996,6 +1000,16 @@ static hipError_t te_xfwd_t(const TeArgs& A, int num_cu, hipStream_t st, Timing*
   tm->begin("te_rec_fwd", st);
   bool done = false;
   if constexpr (!XRec<D>::F64) {
+    if (A.hyb) {        // hybrid recurrences: the leading sequences per sequence on side2 WHILE the rest runs in tiles here (the split: te_hybrid_kernel)
+      if (hipEventRecord(A.ev_h0, st) != hipSuccess || hipStreamWaitEvent(A.side2, A.ev_h0, 0) != hipSuccess) return hipGetLastError();
+      if (A.xft) hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, false, true>), dim3(min(n, num_cu)), dim3(4 * D), 0, A.side2, A);
+      else hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, false, false>), dim3(min(n, num_cu)), dim3(4 * D), 0, A.side2, A);
+      if (hipEventRecord(A.ev_h1, A.side2) != hipSuccess) return hipGetLastError();
+      if (A.xft) XRec<D>::template launch<true, false>(A, st);
+      else XRec<D>::template launch<false, false>(A, st);
+      if (hipStreamWaitEvent(st, A.ev_h1, 0) != hipSuccess) return hipGetLastError();
+      done = true;
+    } else
     if (A.xrec1) {      // persistent: one workgroup per CU walks the launch's sequences
       if (A.xft) hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, false, true>), dim3(min(n, num_cu * (D <= 64 ? 3 : 1))), dim3(4 * D), 0, st, A);
       else hipLaunchKernelGGL((te_rec_fwd1x_kernel<D, false, false>), dim3(min(n, num_cu * (D <= 64 ? 3 : 1))), dim3(4 * D), 0, st, A);

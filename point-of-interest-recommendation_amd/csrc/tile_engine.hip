@@ -527,13 +527,73 @@ __global__ __launch_bounds__(256) void te_len_kernel(TeArgs A) {
   const int L = A.off[u + 1] - A.off[u];
   A.soff[k] = A.predict ? L : (L > 0 ? L - 1 : 0);
 }
-__global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
+// Hybrid recurrences (TeArgs.hyb): the split of the launch between the per-sequence kernels (leading sequences) and the 16-sequence tiles (the rest),
+// chosen from the launch's own lengths at the end of te_scan (a thread of the scan holds exactly one tile: its 16 step counts and the steps in front
+// of it).  Candidates are the tile boundaries hyb = 16 j: cost(j) = max(c_tile x longest sequence among k >= hyb, c_seq x (steps of the sequences
+// k < hyb / workgroups left for them + a quarter of the longest)) with num_cu - tiles workgroups for the per-sequence kernel (each kernel's workgroup
+// holds a CU).  Step costs measured under both kernels at once (1563-user launches, forced splits): forward 4.5 us per tile step,
+// 2.6 us per sequence step; backward 2.9 / 1.35.  Ties go to the smaller j.  hyb_dev = {hyb_fwd, grid_fwd, hyb_bwd, grid_bwd}.
+__device__ __forceinline__ void te_hybrid_choose(const TeArgs& A, int num_cu, int my_max, int my_pre, int total, int* s_max, int* s_pre, float* s_cost, int* s_arg,
+                                                 const unsigned short* s_len) {
+  const int n = A.n_seq, nt = (n + 15) / 16, tid = threadIdx.x;
+  s_max[tid] = tid < nt ? my_max : 0; s_pre[tid] = tid < nt ? my_pre : total;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {            // suffix maxima over the tiles
+    const int v = (tid + o < 1024) ? s_max[tid + o] : 0;
+    __syncthreads();
+    s_max[tid] = max(s_max[tid], v);
+    __syncthreads();
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    const float c_tile = pass ? 2.9f : 4.5f, c_seq = pass ? 1.35f : 2.6f;
+    float cost = 3.0e38f;
+    if (tid <= nt) {
+      const int hyb = min(16 * tid, n), ntile = nt - min(tid, nt);
+      const int g = min(num_cu - ntile, hyb);
+      const float t_tile = ntile > 0 ? c_tile * (float)s_max[min(tid, 1023)] : 0.f;
+      if (hyb == 0) cost = t_tile;
+      else if (g >= 1) {
+        // the per-sequence kernel walks the leading sequences in snake order over g workgroups (k = j g + b on even legs, j g + g - 1 - b on odd ones):
+        // its time is the heaviest workgroup's - the first, the last and the middle one are evaluated exactly from the step counts
+        int worst = 0;
+        const int bs[3] = {0, g - 1, g / 2};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          int load = 0;
+          for (int j = 0;; ++j) {
+            const int k = j * g + ((j & 1) ? g - 1 - bs[q] : bs[q]);
+            if (k >= hyb) break;
+            load += s_len[k];
+          }
+          worst = max(worst, load);
+        }
+        cost = fmaxf(t_tile, c_seq * (float)worst);
+      }
+    }
+    s_cost[tid] = cost; s_arg[tid] = tid;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (tid < o && (s_cost[tid + o] < s_cost[tid] || (s_cost[tid + o] == s_cost[tid] && s_arg[tid + o] < s_arg[tid]))) { s_cost[tid] = s_cost[tid + o]; s_arg[tid] = s_arg[tid + o]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int j = A.hyb_force > 0 ? min((A.hyb_force + 15) / 16, nt) : s_arg[0], hyb = min(16 * j, n), ntile = nt - min(j, nt);
+      A.hyb_dev[2 * pass] = hyb; A.hyb_dev[2 * pass + 1] = max(1, min(num_cu - ntile, hyb));
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A, int num_cu) {
   __shared__ int wtot[16];
+  __shared__ int s_hmax[1024], s_hpre[1024], s_harg[1024];
+  __shared__ float s_hcost[1024];
+  __shared__ unsigned short s_hlen[TE_HYB_NMAX];      // step counts of the launch's sequences (hybrid recurrences)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = A.n_seq;
   // exclusive scan of the step counts, 16384 sequences per pass: a thread holds 16 consecutive counts in registers (independent
   // loads; a load - store - load loop over soff serialised on the possible aliasing: 22 us for 12500 sequences), then a shuffle scan
   // inside each wave and over the 16 wave totals (two barriers instead of the twenty of a Hillis-Steele pass over LDS)
-  int carry = 0;
+  int carry = 0, my_max = 0, my_pre = 0;
   for (int base = 0; base < n; base += 16384) {
     const int i0 = base + tid * 16;
     int v[16];
@@ -541,7 +601,11 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
     for (int u = 0; u < 16; ++u) v[u] = i0 + u < n ? A.soff[i0 + u] : 0;
     int s = 0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { const int t = v[u]; v[u] = s; s += t; }
+    for (int u = 0; u < 16; ++u) {
+      const int t = v[u];
+      if (base == 0) { my_max = max(my_max, t); if (A.hyb && i0 + u < TE_HYB_NMAX) s_hlen[i0 + u] = (unsigned short)min(t, 65535); }
+      v[u] = s; s += t;
+    }
     int inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); inc += lane >= o ? t : 0; }
@@ -555,6 +619,7 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
     }
     __syncthreads();
     const int run = carry + inc - s + (w > 0 ? wtot[w - 1] : 0);
+    if (base == 0) my_pre = run;                 // steps in front of this thread's 16 sequences (hybrid recurrences: one tile per thread)
 #pragma unroll
     for (int u = 0; u < 16; ++u) if (i0 + u < n) A.soff[i0 + u] = run + v[u];
     carry += wtot[15];
@@ -565,6 +630,7 @@ __global__ __launch_bounds__(1024) void te_scan_kernel(TeArgs A) {
     A.soff[n] = total;
     if (A.cnt) { A.cnt[0] = (A.spatial ? 3 : 2) * (total + n); A.cnt[1] = 0; A.cnt[2] = 0; A.cnt[3] = 0; A.cnt[4] = 0; A.cnt[5] = 0; }   // slots, hot rows, hot chunks, touched rows, S rows, dx entries of the POI rows
   }
+  if (A.hyb && n <= TE_HYB_NMAX) te_hybrid_choose(A, num_cu, my_max, my_pre, carry, s_hmax, s_hpre, s_hcost, s_harg, s_hlen);      // (uniform)
 }
 
 #ifndef TE_SEQ_PER_WAVE
@@ -1530,8 +1596,10 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16t_kernel(TeArgs A) {
   const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
   const int sq = lane & 15, u0 = 16 * w + 4 * (lane >> 4);            // this lane's sequence of the tile and its first unit
   const int tile = blockIdx.x;
+  const int k_lo = A.hyb ? A.hyb_dev[2] : 0;       // hybrid recurrences: the tiles start behind the sequences of the per-sequence kernel
+  if (k_lo + tile * 16 >= A.n_seq) return;         // (uniform; the grid is sized for k_lo == 0)
   if (tid < 16) {
-    const int k = tile * 16 + tid;
+    const int k = k_lo + tile * 16 + tid;
     int r0 = 0, ns = 0;
     if (k < A.n_seq) { r0 = A.soff[k]; ns = A.soff[k + 1] - r0; }
     s_r0[tid] = r0; s_ns[tid] = ns;
@@ -1632,7 +1700,7 @@ __global__ __launch_bounds__(D * 4) void te_rec_bwd16t_kernel(TeArgs A) {
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) { sbz[r] += __shfl_xor(sbz[r], o, 64); sbr[r] += __shfl_xor(sbr[r], o, 64); sbc[r] += __shfl_xor(sbc[r], o, 64); }
   if (sq == 0) {
-    float* bp = A.bi_part + (size_t)tile * 3 * D + u0;
+    float* bp = A.bi_part + (size_t)(k_lo + tile) * 3 * D + u0;      // (rows [0, k_lo): one per sequence of the per-sequence kernel)
     *reinterpret_cast<float4*>(bp) = make_float4(sbz[0], sbz[1], sbz[2], sbz[3]);
     *reinterpret_cast<float4*>(bp + D) = make_float4(sbr[0], sbr[1], sbr[2], sbr[3]);
     *reinterpret_cast<float4*>(bp + 2 * D) = make_float4(sbc[0], sbc[1], sbc[2], sbc[3]);
@@ -1770,14 +1838,16 @@ __global__ __launch_bounds__(4 * D) void te_rec_bwd1_kernel(TeArgs A) {
   const int g = tid >> 4, s = tid & 15;
   const int kk = 4 * g + (s & 3);          // the column this lane finishes (lanes s < 4)
   f32x2 wc[2][LC], wzr[2][LZ];
-  load_rows4<LC>(wc, reinterpret_cast<const float*>(A.pWhc16) + (size_t)4 * g * D + s * LC, D);              // Wc^T:  [k][j]
-  load_rows4<LZ>(wzr, reinterpret_cast<const float*>(A.pWhzr16) + (size_t)4 * g * 2 * D + s * LZ, 2 * D);     // Wzr^T: [k][j], j < 2D
+  // hybrid recurrences (TeArgs.hyb): the leading hyb_dev[2] sequences on hyb_dev[3] workgroups, the rest in tiles (te_rec_bwd16t) at the same time
+  const int n1 = A.hyb ? A.hyb_dev[2] : A.n_seq, NG = A.hyb ? A.hyb_dev[3] : (int)gridDim.x, bq = blockIdx.x;
+  if (bq >= NG) return;
+  load_rows4<LC>(wc, reinterpret_cast<const float*>(A.pWhc1) + (size_t)4 * g * D + s * LC, D);              // Wc^T:  [k][j]
+  load_rows4<LZ>(wzr, reinterpret_cast<const float*>(A.pWhzr1) + (size_t)4 * g * 2 * D + s * LZ, 2 * D);     // Wzr^T: [k][j], j < 2D
   const bool own = s < 4;
   float* const dG = A.G + ((size_t)A.soff[A.n_seq] + 1 + (blockIdx.x & 127)) * 3 * D + (tid % (3 * D));      // a spare packed row of its own: see te_rec_fwd1x
-  const int NG = gridDim.x, bq = blockIdx.x;
   for (int j = 0;; ++j) {
     const int k = j * NG + ((j & 1) ? NG - 1 - bq : bq);
-    if (k >= A.n_seq) break;
+    if (k >= n1) break;
     const int r0 = A.soff[k], ns = A.soff[k + 1] - r0;
     float dhn = 0.f, sbz = 0.f, sbr = 0.f, sbc = 0.f;
     // operands of step t - 1 are requested while step t computes
@@ -3339,6 +3409,7 @@ __global__ __launch_bounds__(TE_BLOCK) void te_parts_kernel(TeArgs A, int n_tile
   const int j = blockIdx.x * POI_NWAVE + wave_id(), D3 = 3 * A.dim, NB = A.n_dist + 1;
   const int lane = lane_id();
   float s = 0.f;
+  if (A.hyb) n_tile = A.hyb_dev[2] + (A.n_seq - A.hyb_dev[2] + 15) / 16;      // hybrid recurrences: one row per leading sequence + one per tile
   if (j < D3) {
     for (int k = lane; k < n_tile; k += 64) s += A.bi_part[(size_t)k * D3 + j];
     s = wave_sum(s);
@@ -3686,6 +3757,10 @@ static void te_pack_jobs(const TeArgs& A, PackJobs& J, bool train) {
     else if (A.spatial) J.j[n++] = PackJob{A.vs, D, 1, NB, D, NBP / 8, D / 32, A.pVs};
     // 16-column fragments of the recurrent kernels (16x16x4 MFMA): B[k][n] = wh[2][k][n] (K = D, N = D) and
     // B[k][n] = wh_flat[k][n], k < 2D (K = 2D, N = D)
+    if (A.hyb) {        // hybrid recurrences: the per-sequence backward kernel's transposes NEXT TO the tile kernel's fragments (below)
+      J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, 0, 0, A.pWhc1, 3};
+      J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 0, 0, A.pWhzr1, 3};
+    }
     if (A.rec1) {       // per-sequence kernels: plain transposes (the forward kernel reads wh itself)
       J.j[n++] = PackJob{A.wh + (size_t)2 * D * D, D, 1, D, D, 0, 0, A.pWhc16, 3};
       J.j[n++] = PackJob{A.wh, D, 1, 2 * D, D, 0, 0, A.pWhzr16, 3};
@@ -3909,7 +3984,7 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   tm->begin("te_prep", st);
   hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
+  hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A, num_cu);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   if (A.xcomp) {      // (behind te_rowmap's marks)
     hipLaunchKernelGGL(te_xcount_kernel, dim3(TE_XBLK), dim3(256), 0, st, A);
@@ -3989,6 +4064,15 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
   }
   if constexpr (D <= 128) {
     if (!A.rec32) {
+      if (A.hyb) {        // hybrid recurrences: the leading sequences per sequence on side2 WHILE the rest runs in tiles here (the split: te_scan)
+        const bool serial = (A.dbg & 8192) != 0;      // (POI_TE_DBG bit 8192: one after the other on the main stream, for A/B runs)
+        hipStream_t s2 = serial ? st : A.side2;
+        if (!serial && (hipEventRecord(A.ev_h2, st) != hipSuccess || hipStreamWaitEvent(A.side2, A.ev_h2, 0) != hipSuccess)) return hipGetLastError();
+        hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(min(n, num_cu)), dim3(4 * D), 0, s2, A);
+        if (!serial && hipEventRecord(A.ev_h3, A.side2) != hipSuccess) return hipGetLastError();
+        hipLaunchKernelGGL((te_rec_bwd16t_kernel<D>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
+        if (!serial && hipStreamWaitEvent(st, A.ev_h3, 0) != hipSuccess) return hipGetLastError();
+      } else
       if (A.rec1) hipLaunchKernelGGL(te_rec_bwd1_kernel<D>, dim3(min(n, num_cu * (D <= 64 ? 4 : 1))), dim3(4 * D), 0, st, A);      // persistent: the workgroups one CU holds at a time
       else if (A.rec_split && !(A.dbg & 128)) hipLaunchKernelGGL((te_rec_bwd16t_kernel<D>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);
       else if (A.rec_split) hipLaunchKernelGGL((te_rec_bwd16_kernel<D, true>), dim3((n + 15) / 16), dim3(D * 4), sizeof(short) * (3 * 16 * (3 * D + 16) + 3 * D * D), st, A);      // (POI_TE_DBG bit 128: one unit of four sequences per lane, for A/B runs)
@@ -4132,7 +4216,7 @@ static hipError_t te_predict_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm
   PackJobs J; te_pack_jobs(A, J, false);
   tm->begin("te_predict", st);
   hipLaunchKernelGGL(te_len_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A);
+  hipLaunchKernelGGL(te_scan_kernel, dim3(1), dim3(1024), 0, st, A, num_cu);
   hipLaunchKernelGGL(te_rowmap_kernel, dim3((n + POI_NWAVE * TE_SEQ_PER_WAVE - 1) / (POI_NWAVE * TE_SEQ_PER_WAVE)), dim3(TE_BLOCK), 0, st, A);
   if (J.n) hipLaunchKernelGGL(te_pack_kernel, dim3(64, J.n), dim3(TE_BLOCK), 0, st, J);
   if (A.xfwd) {      // exact forward (te_xfwd.hip): the same input product and recurrence as the training launches, final state -> hts

@@ -748,3 +748,37 @@ def test_stream_placements_and_transposed_bptt_are_bitwise_invisible(pa):
         else:
             os.environ["POI_TE_DBG"] = old
         ctx.set_engine("auto")
+
+
+@pytest.mark.parametrize("dim,force", [(128, 0), (128, 48), (128, 16), (128, 80), (64, 80), (128, 150)])      # (dim 64: the hybrid is off there - the option must be harmless)
+def test_hybrid_recurrences_match_the_oracle_and_the_plain_tiles(pa, dim, force):
+    """Round 6, TeArgs.hyb: the leading sequences of a launch run on the per-sequence recurrent kernels (te_rec_fwd1x / te_rec_bwd1) WHILE the rest
+    runs in 16-sequence tiles (te_rec_fwdx / te_rec_bwd16t) on another stream.  Forced splits (option "hybrid_force": 16, 48, 80 leading
+    sequences, all 150 = no tile at all; 0 = the device's own cost model) against the float64 oracle's batch and against the launch without
+    the hybrid - same bars as every other engine test; launches are repeated to check reproducibility across the two streams."""
+    T = toy_problem(700 + dim + force, n_user=160, n_item=220, n_dist=60, dim=dim, len_max=14, hot=40)
+    P = spatial_params(701 + dim, T)
+    lens = np.asarray(T["train"][1]).sum(axis=1)
+    users = np.random.default_rng(3).permutation(160)[:150].astype(np.int32)
+    users = users[np.argsort(-lens[users], kind="stable")]                # a length-sorted launch, as bench.py / the harness build them
+    exp, outs = _oracle_batch(P, T, users)
+    got = {}
+    for mode in ("hybrid", "hybrid again", "tiles"):
+        model = _model(pa, T, P)
+        model.ctx.set_engine("tile")
+        model.ctx.set_option("hybrid_min", 2); model.ctx.set_option("hybrid_force", force)
+        model.ctx.set_option("hybrid", 0 if mode == "tiles" else 1)
+        model.ctx.set_small_launch(0); model.ctx.set_exact_forward(True, 0)      # (no all-per-sequence launch: tiles unless the hybrid says otherwise)
+        try:
+            out = np.asarray(model.train_batch(users))
+            got[mode] = (_get(model), out)
+        finally:
+            model.ctx.set_option("hybrid", 1); model.ctx.set_option("hybrid_min", 1150); model.ctx.set_option("hybrid_force", 0)
+            model.ctx.set_small_launch(1800); model.ctx.set_exact_forward(True, 1100); model.ctx.set_engine("auto")
+    for mode in ("hybrid", "tiles"):
+        for k, out in enumerate(outs):
+            assert_close(got[mode][1][k][:3], out[:3], "%s losses[%d]" % (mode, k), rtol=2e-5)
+        assert_step_close(got[mode][0], exp, P, SP_NAMES, mode)
+    for k in SP_NAMES:          # two streams, one result
+        assert np.array_equal(np.asarray(got["hybrid"][0][k]), np.asarray(got["hybrid again"][0][k])), k
+    assert np.array_equal(got["hybrid"][1], got["hybrid again"][1])
