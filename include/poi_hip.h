@@ -169,7 +169,14 @@ int poi_ctx_set_exact_forward(poi_ctx* ctx, int on, int per_sequence_max);
  *   "early_bins" 0|1 (default 1): the distance-bin rows' write-back chain starts next to the d x product instead of at the tail;
  *   "hot_bins" 0|1 (default 1; ABI 5): the per-POI pass over DA also sums the rows of the (<= 4) most frequent step-input distance bins of the
  *       launch - on check-in data a few bins hold most steps - so the per-bin pass reads only the rows of the others; reproducible,
- *       another fixed summation order than 0. */
+ *       another fixed summation order than 0;
+ *   "hybrid" 0|1 (default 1; ABI 6), "hybrid_min" / "hybrid_max" n (defaults 1150 / 2300): training launches of hybrid_min .. hybrid_max sequences at
+ *       dim 128 run their two recurrences (public/GRU_Spatial.py:170-178 and its BPTT) on BOTH kernel families at once - the longest sequences of the
+ *       launch one per workgroup (float64 / float32 FMAs: 2.6 / 1.35 us per step) on a second stream while the shorter rest runs in 16-sequence matrix-core
+ *       tiles (4.5 / 2.9 us per step) on the other CUs; the split is chosen on the device from the launch's own lengths.  A 1563-sequence launch is 98
+ *       tiles - 158 CUs idle behind the longest tile's 49-step chain: 678 -> 632 us.  Every sequence still goes through one of the two kernel
+ *       families that hold it to the oracle on their own; a sequence's values depend on which one (inside the bars), identical launches are bitwise
+ *       identical.  "hybrid_force" n (tests): n leading sequences per workgroup whatever the cost model says. */
 int poi_ctx_set_option(poi_ctx* ctx, const char* name, int value);
 /* Small launches: launches of at most max_sequences sequences (default 1800; 0 disables; dim 64 / 128) run the recurrence of every
  * sequence per workgroup on the vector ALUs (te_rec_fwd1 / bwd1, weights resident in registers; persistent since round 5: one workgroup per

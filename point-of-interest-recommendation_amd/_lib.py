@@ -223,7 +223,7 @@ class Context:
 
     def set_option(self, name, value):
         """Named tuning switch of the tile engine (poi_ctx_set_option: "forward_table_compact", "forward_table_compact_min", "head_split",
-        "early_bins")."""
+        "early_bins", "hot_bins", "hybrid", "hybrid_min", "hybrid_max", "hybrid_force")."""
         self.check(self.lib.poi_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def set_small_launch(self, max_sequences=1800):
