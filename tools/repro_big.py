@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Bitwise reproducibility of a real mid-size launch (Gowalla shape, 1563 / 2048 users: the hybrid recurrences' home) repeated from the same parameters.
-    python tools/repro_big.py [users] [reps]"""
+    python tools/repro_big.py [users] [reps] [shape]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +8,8 @@ import poi_amd
 from poi_amd import data as pdata
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1563
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-n_item, n_user, max_len, D = pdata.SHAPES["gowalla"]
+shape = sys.argv[3] if len(sys.argv) > 3 else "gowalla"
+n_item, n_user, max_len, D = pdata.SHAPES[shape]
 ds = pdata.make_synthetic(n_user, n_item, max_len, seed=20260928 + 2, local=0.8)
 tab = ds.shard(0, n_user)
 lens = np.diff(tab.off.astype(np.int64))
@@ -29,4 +30,4 @@ for r in range(reps):
     else:
         for k in got:
             if not torch.equal(ref[k], got[k]): bad[k] = bad.get(k, 0) + 1
-print("gowalla shape, %d-user launch, %d repetitions from the same parameters: tensors that differed from the first run: %s" % (B, reps, bad or "none"))
+print(shape + " shape, %d-user launch, %d repetitions from the same parameters: tensors that differed from the first run: %s" % (B, reps, bad or "none"))
