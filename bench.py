@@ -10,7 +10,11 @@ A "step" is one training epoch over the rank's user shard: ceil(users/B) launche
 (B users per launch, batch rule of include/poi_hip.h with --batch-cap) plus, for N > 1, the per-epoch replica
 reconciliation (one RCCL all-reduce of the parameter deltas through the library's own communicator).  Users are
 sharded across ranks (total work fixed: strong scaling); every rank holds the full parameter replica.  Inputs are
-resident in HBM before the timed region.  One JSON line is printed by rank 0.  Besides the contract fields it carries
+resident in HBM before the timed region.  Rank 0 prints ONE compact JSON line (emit(): the contract fields, roofline,
+roofline_gather_scatter, cpu_baseline, headline - under 6 KB) as the last line of stdout and writes the FULL record to --full-out
+(default gpurun_out/bench_full.json).  Map of main(): setup + timed region -> exact_mode -> evaluation -> per-kernel work model and
+roofline blocks -> quality / reference schedule -> secondary shapes (foursquare, dd25, x1 subprocess, BPR-MF) -> launch_sweep ->
+multi_gpu.projection -> cpu_baseline -> emit.  Besides the contract fields the full record carries
   roofline / roofline_gather_scatter / kernels   live HIP-event timings of the timed region against gfx950 peaks
   reference_schedule                             the reference's own schedule (one user per step) on the same GPU
   quality                                        recall@20 / AUC after a fixed training wall time: headline mode vs the
