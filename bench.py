@@ -116,8 +116,9 @@ def emit(a, out):
         "bound": "hbm", "kernels": g["kernels"], "ms_per_epoch": g["ms_per_epoch"], "achieved": g["achieved"], "peak": g["peak"], "unit": g["unit"], "frac": g["frac"],
         "frac_survey_8d": (g.get("survey_8d") or {}).get("frac"), "frac_bytes_moved": (g.get("implementation") or {}).get("frac"),
         "frac_embedding_rows_only": (g.get("embedding_rows_only") or {}).get("frac"), "bytes_per_epoch_survey_8d": (g.get("survey_8d") or {}).get("bytes_per_epoch"),
-        "traffic": g.get("traffic"), "sort_ms_hidden": g.get("sort_ms_hidden"),
-        "frac_survey_8d_with_fused_gather_charged": (g.get("fused_gather") or {}).get("frac_survey_8d_with_it"), "x1": g.get("x1")}
+        "traffic": g.get("traffic"), "sort_ms_hidden": g.get("sort_ms_hidden"), "hot_reduce_ms_hidden": g.get("hot_reduce_ms_hidden"),
+        "frac_survey_8d_with_fused_gather_charged": (g.get("fused_gather") or {}).get("frac_survey_8d_with_it"),
+        "frac_survey_8d_with_fused_gather_and_hidden_hot_rows_charged": g.get("frac_survey_8d_with_fused_gather_and_hidden_hot_rows_charged"), "x1": g.get("x1")}
     if c:
         compact["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "sample": c["sample"][:160],
                                    "all_cores": sub(c.get("all_cores"), ("value", "cores"))}
@@ -302,7 +303,7 @@ def main():
     barrier()
     dt = rank_max(time.perf_counter() - t0)
     KN = ["seq_train", "te_prep", "te_gather", "te_gemm_ax", "te_rec_fwd", "te_head", "te_rec_bwd", "te_psum", "te_wgrad", "te_gemm_dx",
-          "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "te_tail", "rows_apply", "dense_apply", "te_sort"]
+          "te_finalize", "te_dsum", "te_bin_gemm", "te_scatter", "te_tail", "rows_apply", "dense_apply", "te_sort", "te_hot_early"]
     kt = {k: ctx.timing_get(k) for k in KN}
     ctx.timing(False)
     seq_per_s = (n_user if not a.emulate_world else n_local) * a.steps / dt
@@ -599,6 +600,9 @@ def main():
             ent["note"] = ("the distance-bin chain (te_dsum, te_bin_gemm) runs on the side stream from the end of te_wgrad on, next to te_gemm_dx and "
                            "te_scatter (POI rows): the spans overlap and stretch each other (stand-alone: 0.37 / 0.14 / 0.44 ms per epoch, POI_TE_DBG=1) - "
                            "te_tail, te_scatter's start to the join, is the span that counts")
+        if k == "te_hot_early":
+            ent["note"] = ("side stream, beside te_rec_bwd: the chunk sums of the write-back's hot rows (te_hot_reduce; they need the sorted entries, gcoef and H - nothing later) - part "
+                           "of the scatter, off the main stream's chain since round 6 (roofline_gather_scatter.hot_reduce_ms_hidden; same-box A/B at 12500 users: te_tail -13 us, te_rec_bwd +10 us)")
         if k == "te_sort":
             ent["note"] = ("side stream, beside te_rec_fwd: stable radix sort of the table-touch slots + segment bounds + S-row assignment + the bin chain's chunk offsets - part "
                            "of the scatter, hidden from the main stream's chain (roofline_gather_scatter.sort_ms_hidden); the span stretches with what runs beside it")
@@ -649,10 +653,13 @@ def main():
                                  "dx sums in, DA rows read once for the per-bin and once for the per-POI sums, S rows out, touched rows read + written)",
                "embedding_rows_only": "table rows only: the two rows of E per step + every touched row read and written once per launch"}}
     hbm["sort_ms_hidden"] = kernels["te_sort"]["ms_per_step"] if "te_sort" in kernels else None
+    hbm["hot_reduce_ms_hidden"] = kernels["te_hot_early"]["ms_per_step"] if "te_hot_early" in kernels else None
     if efuse:
         # the two table rows of E are gathered inside te_head3 (an MFMA-bound kernel): A/B on one box (profiles/r06, POI_TE_EFUSE=0 / 1, 12500-user launches):
         # te_gather 71.0 -> 6.7 us, te_head 217.6 -> 228.4 us per launch - the 10.8 us are charged here
         fused_ms = 10.8e-3 * n_launches
+        hot_ms = (kernels["te_hot_early"]["ms_per_step"] if "te_hot_early" in kernels else 0.0)
+        hbm["frac_survey_8d_with_fused_gather_and_hidden_hot_rows_charged"] = (survey_bytes / ((gs_ms + fused_ms + hot_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS) if survey_bytes else None
         hbm["fused_gather"] = {"what": "E = lt[p'] - lt[q'] is gathered inside te_head3 (no E rows in HBM): te_gather 71.0 -> 6.7 us, te_head +10.8 us per 12500-user launch (same-box A/B)",
                                "ms_per_epoch_charged": fused_ms,
                                "frac_survey_8d_with_it": (survey_bytes / ((gs_ms + fused_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS) if survey_bytes else None}

@@ -36,6 +36,8 @@ struct poi_ctx {
   DevBuf g_lt, mult_lt, nseq_lt, g_di, mult_di, nseq_di;
   DevBuf g_wd, mult_wd, nseq_wd, ca_ws, ca_slab, ca_scr, ca2;      // CA-RNN (ca2: workspace of the outer-product path)
   int carnn_fast = 1;       // POI_CARNN_FAST=0: the per-sequence kernel with float atomics on the interval matrices (A/B)
+  hipEvent_t ev_hr0 = nullptr, ev_hr1 = nullptr;      // early chunk sums of the write-back's hot rows (TeArgs.hot_early)
+  int hot_early = 1;        // POI_TE_HOT_EARLY=0: in the tail, as up to round 5 (A/B)
   hipStream_t side2 = nullptr; hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr, ev_h2 = nullptr, ev_h3 = nullptr;      // hybrid recurrences of mid-size launches (TeArgs.hyb)
   int hybrid = 1, hyb_min = 1150, hyb_max = 2300, hyb_force = 0;      // POI_TE_HYBRID=0 / option "hybrid"; launches of hyb_min .. hyb_max sequences (POI_TE_HYB_MIN / _MAX; measured: below ~1200 the per-sequence kernels alone are faster, above ~2600 the tiles alone - the fork / join costs ~15 us)
   hipStream_t side = nullptr; hipEvent_t ev_slots = nullptr, ev_sorted = nullptr, ev_bwd = nullptr, ev_fin = nullptr, ev_start = nullptr, ev_pack = nullptr;   // slot sort next to the GEMMs (POI_TE_SIDE=0: inline)
@@ -156,6 +158,7 @@ int poi_ctx_create(poi_ctx** out, int device) {
   if (const char* e = getenv("POI_TE_EARLY_BINS")) c->early_bins = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_HOTBINS")) c->hot_bins = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_HYBRID")) c->hybrid = atoi(e) != 0;
+  if (const char* e = getenv("POI_TE_HOT_EARLY")) c->hot_early = atoi(e) != 0;
   if (const char* e = getenv("POI_TE_HYB_MIN")) c->hyb_min = atoi(e);
   if (const char* e = getenv("POI_TE_HYB_MAX")) c->hyb_max = atoi(e);
   if (const char* e = getenv("POI_TE_HYB_FORCE")) c->hyb_force = atoi(e);
@@ -185,7 +188,8 @@ int poi_ctx_create(poi_ctx** out, int device) {
         hipEventCreateWithFlags(&c->ev_bwd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_hr0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_hr1, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       c->side = nullptr;                     // fall back to the inline sort
     }
@@ -216,7 +220,7 @@ int poi_ctx_destroy(poi_ctx* c) {
   drop_graphs(c);
   if (c->cap) (void)hipStreamDestroy(c->cap);
   if (c->side2) { (void)hipStreamDestroy(c->side2); (void)hipEventDestroy(c->ev_h0); (void)hipEventDestroy(c->ev_h1); (void)hipEventDestroy(c->ev_h2); (void)hipEventDestroy(c->ev_h3); }
-  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); (void)hipEventDestroy(c->ev_start); (void)hipEventDestroy(c->ev_pack); }
+  if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_slots); (void)hipEventDestroy(c->ev_sorted); (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_fin); (void)hipEventDestroy(c->ev_start); (void)hipEventDestroy(c->ev_pack); (void)hipEventDestroy(c->ev_hr0); (void)hipEventDestroy(c->ev_hr1); }
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   delete c;
   return POI_OK;
@@ -514,7 +518,8 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
     E.side2 = c->side2; E.ev_h0 = c->ev_h0; E.ev_h1 = c->ev_h1; E.ev_h2 = c->ev_h2; E.ev_h3 = c->ev_h3;
     E.side = c->side; E.ev_slots = c->ev_slots; E.ev_sorted = c->ev_sorted; E.ev_bwd = c->ev_bwd; E.ev_fin = c->ev_fin; E.ev_start = c->ev_start; E.ev_pack = c->ev_pack;
     E.early_bins = (c->early_bins && E.bintab && c->side && n >= c->early_min) ? 1 : 0; E.bin_alpha = alpha; E.bin_lambda = lambda;
-    E.dhot_on = (E.early_bins && E.ppoi && c->hot_bins) ? 1 : 0;      // (te_dprep - the selection - must have run before te_psum: the early chain)
+    E.dhot_on = (E.early_bins && E.ppoi && c->hot_bins) ? 1 : 0;
+    E.hot_early = (c->hot_early && E.side && E.ppoi) ? 1 : 0; E.ev_hr0 = c->ev_hr0; E.ev_hr1 = c->ev_hr1;      // (ppoi: the hot rows' entries carry no per-entry dx rows - nothing te_gemm_dx produces is read)      // (te_dprep - the selection - must have run before te_psum: the early chain)
     E.mult_lt = A.mult_lt; E.nseq_lt = A.nseq_lt; E.mult_di = A.mult_di; E.nseq_di = A.nseq_di;
     A.kc_dev = E.kc_dev;                 // (dense_apply reads te_wgrad's K-chunk counts from the device)
     // one sequence (the reference schedule): the whole step in five kernels (tile_engine.hip, te_one_*)
@@ -561,7 +566,7 @@ static int seq_step(poi_ctx* c, const poi_gru_params* P, const poi_seq_tables* T
       // word they overlapped and early_min was missing), plus what te_setup derived from them for THIS launch
       const uint64_t sw[] = {(uint64_t)c->fwd_tab, (uint64_t)c->rec_split, (uint64_t)c->one_path, (uint64_t)(unsigned)c->rec1_max, (uint64_t)(unsigned)c->bintab_min,
                              (uint64_t)c->early_bins, (uint64_t)(unsigned)c->early_min, (uint64_t)c->xfwd, (uint64_t)E.early_bins, (uint64_t)E.bintab, (uint64_t)E.rec1,
-                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.xcomp, (uint64_t)(unsigned)c->xcomp_min, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one, (uint64_t)E.hyb, (uint64_t)E.efuse};
+                             (uint64_t)E.fwd_tab, (uint64_t)E.xfwd, (uint64_t)E.xft, (uint64_t)E.xrec1, (uint64_t)E.xcomp, (uint64_t)(unsigned)c->xcomp_min, (uint64_t)E.head_split, (uint64_t)(unsigned)c->xrec1_max, (uint64_t)E.ppoi, (uint64_t)one, (uint64_t)E.hyb, (uint64_t)E.efuse, (uint64_t)E.hot_early};
       add(sw, sizeof sw);
     }
     poi_ctx::StepGraph* g = nullptr;

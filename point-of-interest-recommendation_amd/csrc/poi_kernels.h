@@ -153,6 +153,9 @@ struct TeArgs {
   hipStream_t side; hipEvent_t ev_slots, ev_sorted;       // side == nullptr: inline on the main stream
   hipEvent_t ev_start, ev_pack;                           // the weight packs of a launch run on the side stream next to its index preparation
   hipEvent_t ev_bwd, ev_fin;                              // te_finalize / te_parts run on the side stream next to te_wgrad / te_gemm_dx
+  // (round 6) hot_early: the hot rows' g*h chunk sums (te_hot_reduce: needs the sorted entries, gcoef and H - nothing later) run on the side stream right behind te_head,
+  // beside te_rec_bwd, instead of in the tail; the hot-row list is built behind te_segment (te_hotlist) instead of by te_reduce.  Per-POI regrouping only (no per-entry dx rows)
+  int hot_early; hipEvent_t ev_hr0, ev_hr1;
   // (round 6) HYBRID recurrences of mid-size launches (hyb != 0; poi_ctx option "hybrid"): a 1563-sequence launch is 98 tiles of 16 - its two recurrences
   // are the 49-step chains of the longest tile on 98 CUs while 158 CUs idle.  The leading hyb_dev[0] (forward) / hyb_dev[2] (backward) sequences of the
   // launch - the longest ones of a length-sorted launch - run on the per-sequence kernels (te_rec_fwd1x / te_rec_bwd1: 2.0 / 1.0 us per step, persistent
@@ -235,6 +238,7 @@ int te_wgrad_jobs(int D, int n_dist, bool spatial, bool bintab);
 hipError_t launch_te_sort(TeArgs& A, hipStream_t st);
 hipError_t launch_te_psum(TeArgs& A, int num_cu, hipStream_t st);
 hipError_t launch_te_passign(TeArgs& A, hipStream_t st);
+hipError_t launch_te_hot_reduce(TeArgs& A, int num_cu, hipStream_t st);      // chunk sums of the hot rows (te_scatter.hip); early on the side stream when TeArgs.hot_early
 hipError_t launch_te_dprep(TeArgs& A, hipStream_t st);        // chunk offsets of the distance-bin chain (behind the slot sort; launch_te_bins expects them)      // S rows of the per-POI regrouping (behind the slot sort)
 int te_wgrad_ui_jobs(int D, int n_dist, bool spatial, bool bintab);
 hipError_t launch_te_scatter(TeArgs& A, float alpha, float lambda, int num_cu, hipStream_t st, Timing* tm);

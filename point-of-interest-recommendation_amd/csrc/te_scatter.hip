@@ -155,6 +155,33 @@ __global__ __launch_bounds__(256) void te_segment_kernel(TeArgs A, const int* __
   }
 }
 
+// (round 6) The hot rows of the write-back - more than TE_COLD_MAX entries - and their 64-entry chunks, listed right behind te_segment (te_reduce used to build
+// the list with atomics while it walked the rows: the chunk sums could not start before it).  One wave per 64 rows; a hot row's chunk list is written by the
+// whole wave.  The order of the list depends on scheduling; every row is reduced on its own, in chunk order: the result does not.
+__global__ __launch_bounds__(256) void te_hotlist_kernel(TeArgs A) {
+  const int RT = A.bintab ? A.n_item + 1 : A.n_item + 1 + A.n_dist + 1;      // bintab: the distance-bin rows are written by te_dapply
+  const int R = A.urow ? A.cnt[3] : RT;
+  const int lane = lane_id();
+  for (int i0 = (blockIdx.x * 4 + wave_id()) * 64; i0 < R; i0 += gridDim.x * 256) {
+    const int i = i0 + lane;
+    int row = -1, start = 0, cnt = 0;
+    if (i < R) {
+      row = A.urow ? A.urow[i] : i;
+      if (row >= 0 && row < RT) { const int e = A.seg_end[row]; if (e) { start = A.seg_start[row]; cnt = e - start; } }
+    }
+    unsigned long long m = __ballot(cnt > TE_COLD_MAX);
+    while (m) {
+      const int src = __builtin_ctzll(m); m &= m - 1;
+      const int r = __shfl(row, src, 64), st = __shfl(start, src, 64), c = __shfl(cnt, src, 64);
+      const int nch = (c + TE_HOT_CHUNK - 1) / TE_HOT_CHUNK;
+      int h = 0, c0 = 0;
+      if (lane == 0) { h = atomicAdd(&A.cnt[1], 1); c0 = atomicAdd(&A.cnt[2], nch); A.hot_rows[h] = make_int4(r, st, c, c0); }
+      h = __shfl(h, 0, 64); c0 = __shfl(c0, 0, 64);
+      for (int k = lane; k < nch; k += 64) A.hot_chunks[c0 + k] = make_int2(h, k);
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // per-POI regrouping (TeArgs.ppoi): S[r] = sum of DA over the steps whose input POI is row r.
 //   te_pcount / te_passign  one exclusive scan over the sorted slots (per-block counts, then block prefix + ballot ranks inside
@@ -352,6 +379,7 @@ hipError_t launch_te_sort(TeArgs& A, hipStream_t st) {
     if (kout == A.keys1) { kout = A.keys0; vout = A.vals0; } else { kout = A.keys1; vout = A.vals1; }
   }
   hipLaunchKernelGGL(te_segment_kernel, dim3(1024), dim3(256), 0, st, A, kin, vin);
+  hipLaunchKernelGGL(te_hotlist_kernel, dim3(256), dim3(256), 0, st, A);
   A.ks = kin;
   return hipGetLastError();
 }
@@ -490,18 +518,7 @@ __global__ __launch_bounds__(256) void te_reduce_kernel(TeArgs A, float alpha, f
     const int am = (in && ri.pm) ? *ri.pm : 0, an = (in && ri.pn) ? *ri.pn : 0;
     const int start = end ? (A.urow ? A.seg_start[row] : start_pre) : 0, cnt = end - start;
     const bool hot = cnt > TE_COLD_MAX;
-    if (hot) {
-      const int nch = (cnt + TE_HOT_CHUNK - 1) / TE_HOT_CHUNK;
-      int h = 0, c0 = 0;
-      if (lane == lead) {
-        h = atomicAdd(&A.cnt[1], 1);
-        c0 = atomicAdd(&A.cnt[2], nch);
-        A.hot_rows[h] = make_int4(row, start, cnt, c0);
-      }
-      h = __shfl(h, lead, 64); c0 = __shfl(c0, lead, 64);
-      for (int k = lane - lead; k < nch; k += LPR) A.hot_chunks[c0 + k] = make_int2(h, k);
-    }
-    const int n_e = hot ? 0 : cnt;
+    const int n_e = hot ? 0 : cnt;       // (hot rows: te_hotlist listed them behind te_segment; te_hot_reduce / te_hot_apply take them)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int nf = 0;
     for (int i0 = 0; i0 < n_e; i0 += 8) {
@@ -917,12 +934,21 @@ static hipError_t te_scatter_t(TeArgs& A, float alpha, float lambda, int num_cu,
   tm->begin("te_scatter", st);
   if (A.ppoi) hipLaunchKernelGGL((te_reduce_kernel<D, true>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
   else hipLaunchKernelGGL((te_reduce_kernel<D, false>), dim3(grid), dim3(256), 0, st, A, alpha, lambda);
-  hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
+  if (A.hot_early) { if (hipStreamWaitEvent(st, A.ev_hr1, 0) != hipSuccess) return hipGetLastError(); }      // (the chunk sums ran beside te_rec_bwd: launch_te_train)
+  else hipLaunchKernelGGL(te_hot_reduce_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A);
   hipLaunchKernelGGL(te_hot_apply_kernel<D>, dim3(num_cu * 8), dim3(256), 0, st, A, alpha, lambda);
   tm->end(st);
   if (fork && hipStreamWaitEvent(st, A.ev_fin, 0) != hipSuccess) return hipGetLastError();       // join: dense_apply reads te_dui's slab
   if (early && hipStreamWaitEvent(st, A.ev_slots, 0) != hipSuccess) return hipGetLastError();     // (recorded behind the chain by launch_te_train)
   tm->span_end(tail, st);
+  return hipGetLastError();
+}
+
+hipError_t launch_te_hot_reduce(TeArgs& A, int num_cu, hipStream_t st) {
+  if (A.dim == 64) hipLaunchKernelGGL(te_hot_reduce_kernel<64>, dim3(num_cu * 8), dim3(256), 0, st, A);
+  else if (A.dim == 128) hipLaunchKernelGGL(te_hot_reduce_kernel<128>, dim3(num_cu * 8), dim3(256), 0, st, A);
+  else if (A.dim == 256) hipLaunchKernelGGL(te_hot_reduce_kernel<256>, dim3(num_cu * 8), dim3(256), 0, st, A);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

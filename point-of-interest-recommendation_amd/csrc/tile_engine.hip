@@ -4057,6 +4057,13 @@ static hipError_t te_train_t(TeArgs& A, int num_cu, hipStream_t st, Timing* tm) 
     hipLaunchKernelGGL(te_bpr_head_kernel<D>, dim3(num_cu * 8), dim3(TE_BLOCK), 0, st, A);
   }
   tm->end(st);
+  if (A.hot_early) {      // the hot rows' chunk sums need the sorted entries (side stream, long done), gcoef and H: beside te_rec_bwd instead of in the tail
+    if (hipEventRecord(A.ev_hr0, st) != hipSuccess || hipStreamWaitEvent(A.side, A.ev_hr0, 0) != hipSuccess) return hipGetLastError();
+    const long sp = tm->span_begin("te_hot_early", A.side);
+    hipError_t he = launch_te_hot_reduce(A, num_cu, A.side); if (he != hipSuccess) return he;
+    tm->span_end(sp, A.side);
+    if (hipEventRecord(A.ev_hr1, A.side) != hipSuccess) return hipGetLastError();
+  }
   tm->begin("te_rec_bwd", st);
   if constexpr (D >= 128) {
     if (A.rec32 && A.rec_split) hipLaunchKernelGGL((te_rec_bwd32_kernel<D, D / 32, true>), dim3((n + 31) / 32), dim3(D * 2), sizeof(short) * 3 * 32 * (3 * D + 16), st, A);
