@@ -658,7 +658,9 @@ def main():
         # the two table rows of E are gathered inside te_head3 (an MFMA-bound kernel): A/B on one box (profiles/r06, POI_TE_EFUSE=0 / 1, 12500-user launches):
         # te_gather 71.0 -> 6.7 us, te_head 217.6 -> 228.4 us per launch - the 10.8 us are charged here
         fused_ms = 10.8e-3 * n_launches
-        hot_ms = (kernels["te_hot_early"]["ms_per_step"] if "te_hot_early" in kernels else 0.0)
+        # ... and the hot rows' chunk sums, which run beside te_rec_bwd since round 6 (te_hot_early: a SPAN on the side stream, stretched by the kernel it hides behind),
+        # at their stand-alone cost: 19.5 us per 12500-user launch (profiles/r06 notes: te_hot_reduce in the tail, rocprofv3)
+        hot_ms = 19.5e-3 * n_launches if "te_hot_early" in kernels else 0.0
         hbm["frac_survey_8d_with_fused_gather_and_hidden_hot_rows_charged"] = (survey_bytes / ((gs_ms + fused_ms + hot_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS) if survey_bytes else None
         hbm["fused_gather"] = {"what": "E = lt[p'] - lt[q'] is gathered inside te_head3 (no E rows in HBM): te_gather 71.0 -> 6.7 us, te_head +10.8 us per 12500-user launch (same-box A/B)",
                                "ms_per_epoch_charged": fused_ms,
